@@ -1,0 +1,311 @@
+#!/usr/bin/env python
+"""ORACLE — test infrastructure.  Generates ``tests/golden/*.npz`` by running the REAL reference.
+
+Runs only in the build container, where the read-only reference checkout is
+mounted at /root/reference; the GPU box never sees the reference, only the
+vectors written here.  Nothing from the reference is copied: its modules are
+imported (with stub modules for the absent third-party packages ``timm``,
+``torchvision`` and ``omegaconf`` that unrelated files import at module load)
+and called on seeded synthetic inputs; inputs and outputs are saved.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+Vectors (all float32 unless noted; inputs that are feature maps are stored as
+float16-exact values to halve the files):
+  state_dict_shapes.json   key -> shape of StageNet.state_dict() for both regularizer kinds
+  warp_kat.npz             hand-checkable known-answer case of homo_warping_3D_with_mask
+  warp_general.npz         general poses, [B,D] and [B,D,H,W] hypotheses, behind-camera / off-frustum samples
+  heads.npz                depth_regression, conf_regression, init/schedule_inverse_range
+  costreg.npz              CostRegNet / CostRegNet3D alone, eval BN, odd sizes
+  stage_costregnet.npz     StageNet with ndepth=16 (CostRegNet), eval + train, intermediate taps
+  stage_costregnet3d.npz   StageNet with ndepth=4 (CostRegNet3D), eval + train, intermediate taps
+  cascade_v3.npz, cascade_v5.npz   4-stage inverse-depth cascade, 64x64, tmp=[5,5,5,1]
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+
+def _stub(name, **kw):
+    m = types.ModuleType(name)
+    m.__dict__.update(kw)
+    sys.modules[name] = m
+
+
+_stub("timm")
+_stub("timm.models")
+_stub("timm.models.layers", DropPath=nn.Identity, to_2tuple=lambda x: (x, x), trunc_normal_=nn.init.trunc_normal_)
+_stub("timm.models.vision_transformer", Block=nn.Module)
+_stub("torchvision")
+_stub("torchvision.utils")
+_stub("omegaconf", OmegaConf=object)
+
+import warnings  # noqa: E402
+
+warnings.filterwarnings("ignore")
+import models.mvsformer_model as ref_mm  # noqa: E402
+from models.module import (CostRegNet, CostRegNet3D, conf_regression, depth_regression,  # noqa: E402
+                           init_inverse_range, schedule_inverse_range)
+from models.warping import homo_warping_3D, homo_warping_3D_with_mask  # noqa: E402
+
+from mvsformer_amd import synth  # noqa: E402
+from oracle.weights import make_state_dict  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+ARGS = dict(base_ch=8, fusion_type="cnn", depth_type="ce", model_th=8)
+
+
+def np32(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def f16exact(t):
+    return t.to(torch.float16).to(torch.float32)
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrs)
+    print("%-28s %8.1f kB" % (name, os.path.getsize(path) / 1e3))
+
+
+# ---------------------------------------------------------------------------------------------
+def dump_shapes():
+    shapes = {}
+    for kind, nd in (("stage_costregnet", 16), ("stage_costregnet3d", 4)):
+        net = ref_mm.StageNet(dict(ARGS), nd, 0)
+        shapes[kind] = {k: list(v.shape) for k, v in net.state_dict().items()}
+    with open(os.path.join(OUT, "state_dict_shapes.json"), "w") as f:
+        json.dump(shapes, f, indent=0)
+    return shapes
+
+
+def gen_warp_kat():
+    K = torch.tensor([[100.0, 0, 2.5, 0], [0, 100.0, 1.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    E_ref = torch.eye(4)
+    E_src = torch.eye(4)
+    E_src[0, 3] = 1.0
+    ref_proj = (K @ E_ref).unsqueeze(0)
+    src_proj = (K @ E_src).unsqueeze(0)
+    src = torch.arange(2 * 4 * 6, dtype=torch.float32).view(1, 2, 4, 6)
+    depth = torch.tensor([[100.0, 200.0, 50.0, -10.0]])
+    warped, mask = homo_warping_3D_with_mask(src, src_proj, ref_proj, depth)
+    ident, imask = homo_warping_3D_with_mask(src, ref_proj, ref_proj, depth[:, :1])
+    save("warp_kat.npz", src=np32(src), src_proj=np32(src_proj), ref_proj=np32(ref_proj), depth=np32(depth),
+         warped=np32(warped), mask=mask.numpy(), ident=np32(ident), ident_mask=imask.numpy())
+
+
+def _general_projs(B, g):
+    """World->image 4x4 projections with generic rotations/translations (scene ~ 2-6 units deep)."""
+    Ps = []
+    for _ in range(2):
+        P = torch.zeros(B, 4, 4)
+        for b in range(B):
+            a = 0.25 * (torch.rand(3, generator=g) - 0.5)
+            Rm = synth._rot_xyz(float(a[0]), float(a[1]), float(a[2])).float()
+            t = 0.6 * (torch.rand(3, generator=g) - 0.5)
+            K = torch.tensor([[22.0, 0, 9.5], [0, 21.0, 5.5], [0, 0, 1]])
+            P[b, :3, :3] = K @ Rm
+            P[b, :3, 3] = K @ t
+            P[b, 3, 3] = 1
+        Ps.append(P)
+    return Ps
+
+
+def gen_warp_general():
+    g = torch.Generator().manual_seed(11)
+    B, C, H, W, D = 2, 16, 12, 20, 6
+    src = f16exact(torch.randn(B, C, H, W, generator=g))
+    ref_proj, src_proj = _general_projs(B, g)
+    depth_bd = torch.tensor([[1.5, 2.5, 4.0, 7.0, -1.0, 0.05]]).repeat(B, 1)
+    depth_bd[1] *= 1.3
+    depth_map = depth_bd.view(B, D, 1, 1) * (1.0 + 0.2 * torch.rand(B, D, H, W, generator=g))
+    w1, m1 = homo_warping_3D_with_mask(src, src_proj, ref_proj, depth_bd)
+    w2, m2 = homo_warping_3D_with_mask(src, src_proj, ref_proj, depth_map)
+    w3 = homo_warping_3D(src, src_proj, ref_proj, depth_map)
+    assert torch.equal(w2, w3)
+    save("warp_general.npz", src=np32(src), src_proj=np32(src_proj), ref_proj=np32(ref_proj),
+         depth_bd=np32(depth_bd), depth_map=np32(depth_map), warped_bd=np32(w1), mask_bd=m1.numpy(),
+         warped_map=np32(w2), mask_map=m2.numpy())
+
+
+def gen_heads():
+    g = torch.Generator().manual_seed(5)
+    B, D, H, W = 2, 8, 6, 10
+    logits = 3.0 * torch.randn(B, D, H, W, generator=g)
+    p = F.softmax(logits, dim=1)
+    dv_map = 400.0 + 500.0 * torch.rand(B, D, H, W, generator=g)
+    dv_bd = 400.0 + 60.0 * torch.arange(D, dtype=torch.float32).view(1, D).repeat(B, 1)
+    out = dict(logits=np32(logits), p=np32(p), dv_map=np32(dv_map), dv_bd=np32(dv_bd),
+               reg_map=np32(depth_regression(p, dv_map)), reg_bd=np32(depth_regression(p, dv_bd)))
+    for n in (2, 3, 4):
+        out["conf_n%d" % n] = np32(conf_regression(p, n=n))
+    # schedulers
+    cur = synth.depth_range(batch=B)
+    cur[1] = cur[1] * 1.1
+    init = init_inverse_range(cur, 32, "cpu", torch.float32, 8, 12)
+    prev_depth = 500.0 + 300.0 * torch.rand(B, 8, 12, generator=g)
+    sched = schedule_inverse_range(prev_depth, init, 16, 2.67, 16, 24)
+    out.update(cur_depth=np32(cur), init_inv=np32(init), prev_depth=np32(prev_depth), sched_inv=np32(sched))
+    save("heads.npz", **out)
+
+
+def gen_costreg(shapes):
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    for kind, cls, seed, shp in (("costregnet", CostRegNet, 101, (1, 8, 16, 8, 24)),
+                                 ("costregnet3d", CostRegNet3D, 102, (2, 8, 3, 16, 40))):
+        sd_stage = make_state_dict(shapes["stage_" + kind], seed)
+        sd = {k[len("cost_reg."):]: v for k, v in sd_stage.items() if k.startswith("cost_reg.")}
+        net = cls(8, 8)
+        net.load_state_dict(sd, strict=True)
+        net.eval()
+        x = torch.randn(shp, generator=g)
+        with torch.no_grad():
+            y = net(x)
+        out[kind + "_x"] = np32(x)
+        out[kind + "_y"] = np32(y)
+        out[kind + "_seed"] = np.int64(seed)
+    save("costreg.npz", **out)
+
+
+def _stage_case(kind, ndepth, C, seed, shapes):
+    """One StageNet golden: small photo-consistent scene rendered at 1/8 of a 128x192 image."""
+    V, Hf, Wf, scale = 4, 128, 192, 8
+    scene = synth.make_scene(V, Hf, Wf, seed=seed)
+    feats = f16exact(synth.render_features(scene, scale, C, noise=0.05))
+    proj = synth.proj_matrices(scene, (scale,))["stage1"]
+    H, W = Hf // scale, Wf // scale
+    if ndepth > 8:
+        hyp = init_inverse_range(synth.depth_range(1), ndepth, "cpu", torch.float32, H, W)
+    else:
+        # narrow per-pixel hypotheses around the true plane, as a later cascade stage sees them
+        g = torch.Generator().manual_seed(seed + 77)
+        z = synth.plane_depth(scene, scale)
+        centre = (z * (1.0 + 0.01 * torch.randn(z.shape, generator=g))).unsqueeze(0)
+        inv = 1.0 / centre.unsqueeze(1) + torch.linspace(-1, 1, ndepth).view(1, -1, 1, 1) * 4e-5
+        hyp = 1.0 / inv
+    sd = make_state_dict(shapes["stage_" + kind], 1000 + seed)
+    net = ref_mm.StageNet(dict(ARGS), ndepth, 1)
+    net.load_state_dict(sd, strict=True)
+    out = dict(features=feats.numpy().astype(np.float16), proj=np32(proj), depth_values=np32(hyp),
+               weight_seed=np.int64(1000 + seed), ndepth=np.int64(ndepth), tmp=np.float32(5.0))
+
+    # taps: re-run the reference's own building blocks the way StageNet.forward chains them
+    net.eval()
+    with torch.no_grad():
+        o = net(feats, proj, hyp, tmp=5.0)
+        for k in ("depth", "prob_volume", "photometric_confidence", "prob_volume_pre", "sim_depth"):
+            out["eval_" + k] = np32(o[k])
+        ref_feat = feats[:, 0]
+        ref_pair = proj[:, 0]
+        ref_new = ref_pair[:, 0].clone()
+        ref_new[:, :3, :4] = torch.matmul(ref_pair[:, 1, :3, :3], ref_pair[:, 0, :3, :4])
+        ents, ws, vol, wsum, sims = [], [], 0.0, 0.0, 0.0
+        for v in range(1, V):
+            sp = proj[:, v]
+            src_new = sp[:, 0].clone()
+            src_new[:, :3, :4] = torch.matmul(sp[:, 1, :3, :3], sp[:, 0, :3, :4])
+            warped, _ = homo_warping_3D_with_mask(feats[:, v], src_new, ref_new, hyp)
+            B, Cc, D, Hh, Ww = warped.shape
+            wv = warped.view(B, 8, Cc // 8, D, Hh, Ww)
+            rv = ref_feat.view(B, 8, Cc // 8, 1, Hh, Ww).repeat(1, 1, 1, D, 1, 1)
+            ip = (rv * wv).mean(dim=2)
+            sims = sims + (F.normalize(rv, dim=1) * F.normalize(wv, dim=1)).mean(dim=2).sum(dim=1)
+            sn = F.softmax(ip.sum(dim=1), dim=1)
+            ent = (-sn * torch.log(sn + 1e-7)).sum(dim=1, keepdim=True)
+            w = net.vis(ent)
+            if v == 1:
+                out["tap_in_prod_v1"] = np32(ip)
+            ents.append(ent)
+            ws.append(w)
+            vol = vol + ip * w.unsqueeze(1)
+            wsum = wsum + w
+        vm = vol / (wsum.unsqueeze(1) + 1e-6)
+        chk = net.cost_reg(vm).squeeze(1)
+        assert torch.allclose(chk, o["prob_volume_pre"], atol=1e-5), "tap chain diverged from StageNet.forward"
+        out["tap_entropy"] = np32(torch.cat(ents, dim=1))
+        out["tap_vis_weight"] = np32(torch.cat(ws, dim=1))
+        out["tap_volume_mean"] = np32(vm)
+        out["tap_similarity_sum"] = np32(sims)
+    # training-mode forward (batch-stat BN, argmax depth, no similarity branch); BN buffers restored afterwards
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    with torch.no_grad():
+        o = net(feats, proj, hyp, tmp=5.0)
+        for k in ("depth", "photometric_confidence", "prob_volume_pre"):
+            out["train_" + k] = np32(o[k])
+        assert "sim_depth" not in o
+    save("stage_%s.npz" % kind, **out)
+
+
+def gen_cascade(V, shapes, seed):
+    ndepths, ratios, tmps = [32, 16, 8, 4], [4.0, 2.67, 1.5, 1.0], [5.0, 5.0, 5.0, 1.0]
+    Hf = Wf = 64
+    feats, proj, dv, scene = synth.make_inputs(V, Hf, Wf, seed=seed)
+    feats = {k: f16exact(v) for k, v in feats.items()}
+    nets, seeds = [], []
+    for i, nd in enumerate(ndepths):
+        kind = "stage_costregnet3d" if nd <= 8 else "stage_costregnet"
+        s = 2000 + 10 * seed + i
+        net = ref_mm.StageNet(dict(ARGS), nd, i)
+        net.load_state_dict(make_state_dict(shapes[kind], s), strict=True)
+        net.eval()
+        nets.append(net)
+        seeds.append(s)
+    out = dict(depth_range=np32(dv), weight_seeds=np.array(seeds, dtype=np.int64), ndepths=np.array(ndepths),
+               ratios=np.array(ratios, dtype=np.float32), tmps=np.array(tmps, dtype=np.float32), scene_seed=np.int64(seed))
+    for k, v in feats.items():
+        out["features_" + k] = v.numpy().astype(np.float16)
+    for k, v in proj.items():
+        out["proj_" + k] = np32(v)
+    # the cascade loop of DINOMVSNet/TwinMVSNet.forward, driven with the reference's own functions
+    B = 1
+    prob_maps = torch.zeros(B, Hf, Wf)
+    prev = None
+    with torch.no_grad():
+        for i, nd in enumerate(ndepths):
+            f = feats["stage%d" % (i + 1)]
+            H, W = f.shape[-2:]
+            if i == 0:
+                hyp = init_inverse_range(dv, nd, "cpu", torch.float32, H, W)
+            else:
+                hyp = schedule_inverse_range(prev["depth"].detach(), prev["depth_values"], nd, ratios[i], H, W)
+            prev = nets[i].forward(f, proj["stage%d" % (i + 1)], hyp, tmp=tmps)
+            conf = prev["photometric_confidence"]
+            if conf.shape[1] != Hf or conf.shape[2] != Wf:
+                conf = F.interpolate(conf.unsqueeze(1), [Hf, Wf], mode="nearest").squeeze(1)
+            prob_maps += conf
+            for k in ("depth", "photometric_confidence", "prob_volume_pre", "depth_values", "sim_depth"):
+                out["s%d_%s" % (i + 1, k)] = np32(prev[k])
+    out["refined_depth"] = np32(prev["depth"])
+    out["photometric_confidence"] = np32(prob_maps / len(ndepths))
+    out["true_depth"] = np32(synth.plane_depth(scene, 1))
+    save("cascade_v%d.npz" % V, **out)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    shapes = dump_shapes()
+    gen_warp_kat()
+    gen_warp_general()
+    gen_heads()
+    gen_costreg(shapes)
+    _stage_case("costregnet", 16, 16, 3, shapes)
+    _stage_case("costregnet3d", 4, 8, 4, shapes)
+    gen_cascade(3, shapes, 6)
+    gen_cascade(5, shapes, 7)

@@ -1,0 +1,56 @@
+"""ORACLE — test infrastructure, not product code.
+
+Deterministic StageNet weights for the golden vectors.  The golden files do
+not store the ~291k regularizer parameters; they store a seed, and both
+``oracle/gen_golden.py`` (feeding the real reference modules) and the tests
+(feeding the oracle and the HIP modules) rebuild the same ``state_dict`` from
+it here.  Key names and shapes come from ``tests/golden/state_dict_shapes.json``,
+which ``gen_golden.py`` dumped from the reference's own modules
+(``StageNet(...).state_dict()``), so a drift in either side's parameter
+layout fails ``tests/test_state_dict.py``.
+
+BatchNorm running statistics and affine parameters are randomized on purpose:
+PyTorch's default BN init makes eval-mode BN the identity and would hide
+epilogue bugs.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from typing import Dict
+
+import torch
+
+_SHAPES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "state_dict_shapes.json")
+
+
+def load_shapes(kind: str) -> Dict[str, list]:
+    """``kind`` in {'stage_costregnet', 'stage_costregnet3d'} -> ``{key: shape}`` in the reference's order."""
+    with open(_SHAPES) as f:
+        return json.load(f)[kind]
+
+
+def make_state_dict(shapes: Dict[str, list], seed: int) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for key in shapes:                      # json preserves the reference's registration order
+        shp = tuple(shapes[key])
+        if key.endswith("num_batches_tracked"):
+            sd[key] = torch.zeros(shp, dtype=torch.int64)
+        elif key.endswith("running_var"):
+            sd[key] = 0.5 + torch.rand(shp, generator=g)
+        elif key.endswith("running_mean"):
+            sd[key] = 0.2 * torch.randn(shp, generator=g)
+        elif len(shp) == 1 and key.endswith("weight"):
+            sd[key] = 0.5 + torch.rand(shp, generator=g)            # only BN gammas are 1-D weights
+        elif len(shp) == 1:
+            sd[key] = 0.2 * torch.randn(shp, generator=g)           # conv biases, BN betas
+        else:
+            # conv / deconv kernels: He-style scale on the receptive field so activations stay O(1)
+            if ".conv7" in key or ".conv9" in key or ".conv11" in key:
+                fan = shp[0] * math.prod(shp[2:]) / 4.0              # transposed conv: ~27/4..27/8 taps per output
+            else:
+                fan = shp[1] * math.prod(shp[2:])
+            sd[key] = torch.randn(shp, generator=g) * math.sqrt(2.0 / max(fan, 1.0))
+    return sd

@@ -1,0 +1,111 @@
+"""Pins the oracle (oracle/ref_torch.py, oracle/ref_numpy.py) to the golden vectors that
+oracle/gen_golden.py produced by running the real reference (/root/reference) in the build container."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, max_abs, rel_err, t
+from oracle import ref_numpy, ref_torch
+from oracle.weights import load_shapes, make_state_dict
+
+TOL = 2e-5   # oracle and reference run the same ATen CPU kernels; only op grouping differs
+
+
+def test_warp_kat_literals():
+    """SURVEY.md §8(a1) known-answer case, checked against hand-derived rows, the golden file and both oracles."""
+    g = load_golden("warp_kat.npz")
+    w = g["warped"]
+    np.testing.assert_allclose(w[0, 0, 0, 0], [1, 2, 3, 4, 5, 0], atol=1e-4)          # d=100: +1 px
+    np.testing.assert_allclose(w[0, 0, 1, 0], [0.5, 1.5, 2.5, 3.5, 4.5, 2.5], atol=1e-4)  # d=200: +0.5 px
+    np.testing.assert_allclose(w[0, 0, 2, 0, :3], [2, 3, 4], atol=1e-4)               # d=50: +2 px
+    assert np.all(w[0, :, 3] == 0) and g["mask"][0, 3].all()                           # d<0: behind camera
+    assert g["mask"][0, 2, 0].tolist() == [False, False, False, True, True, True]
+    assert max_abs(g["ident"][0, :, 0], g["src"][0]) < 1e-5
+    wt, mt = ref_torch.homo_warping_3D_with_mask(t(g["src"]), t(g["src_proj"]), t(g["ref_proj"]), t(g["depth"]))
+    assert max_abs(wt, w) < 1e-6 and np.array_equal(mt.numpy(), g["mask"])
+    wn, mn = ref_numpy.plane_sweep_warp(g["src"], g["src_proj"], g["ref_proj"], g["depth"])
+    # pixel 3 of the d=50 row lands on x=W-1 to rounding: sampled but value is rounding sensitive
+    assert np.abs(wn - w).max() < 1e-4
+    assert (mn != g["mask"]).sum() <= 4
+
+
+@pytest.mark.parametrize("which", ["bd", "map"])
+def test_warp_general(which):
+    g = load_golden("warp_general.npz")
+    depth = g["depth_" + which]
+    wt, mt = ref_torch.homo_warping_3D_with_mask(t(g["src"]), t(g["src_proj"]), t(g["ref_proj"]), t(depth))
+    assert max_abs(wt, g["warped_" + which]) < TOL
+    assert np.array_equal(mt.numpy(), g["mask_" + which])
+    wn, mn = ref_numpy.plane_sweep_warp(g["src"], g["src_proj"], g["ref_proj"], depth)
+    # numpy inverse/matmul round differently from ATen -> compare away from tap-switch discontinuities
+    err = np.abs(wn - g["warped_" + which])
+    assert np.quantile(err, 0.999) < 1e-3 and (mn != g["mask_" + which]).mean() < 2e-3
+    assert g["mask_" + which].any() and not g["mask_" + which].all()
+
+
+def test_heads_and_schedulers():
+    g = load_golden("heads.npz")
+    p = t(g["p"])
+    assert max_abs(ref_torch.depth_regression(p, t(g["dv_map"])), g["reg_map"]) < 1e-3
+    assert max_abs(ref_torch.depth_regression(p, t(g["dv_bd"])), g["reg_bd"]) < 1e-3
+    for n in (2, 3, 4):
+        assert max_abs(ref_torch.conf_regression(p, n), g["conf_n%d" % n]) < 1e-6
+    init = ref_torch.init_inverse_range(t(g["cur_depth"]), 32, 8, 12)
+    assert rel_err(init, g["init_inv"]) < 1e-6
+    sched = ref_torch.schedule_inverse_range(t(g["prev_depth"]), t(g["init_inv"]), 16, 2.67, 16, 24)
+    assert rel_err(sched, g["sched_inv"]) < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["costregnet", "costregnet3d"])
+def test_regularizers(kind):
+    g = load_golden("costreg.npz")
+    sd = make_state_dict(load_shapes("stage_" + kind), int(g[kind + "_seed"]))
+    fn = ref_torch.cost_reg_net if kind == "costregnet" else ref_torch.cost_reg_net_3d
+    with torch.no_grad():
+        y = fn(t(g[kind + "_x"]), sd, "cost_reg")
+    assert max_abs(y, g[kind + "_y"]) < 1e-4 * max(1.0, float(np.abs(g[kind + "_y"]).max()))
+
+
+@pytest.mark.parametrize("kind", ["costregnet", "costregnet3d"])
+def test_stage(kind):
+    g = load_golden("stage_%s.npz" % kind)
+    sd = make_state_dict(load_shapes("stage_" + kind), int(g["weight_seed"]))
+    nd = int(g["ndepth"])
+    taps = {}
+    with torch.no_grad():
+        o = ref_torch.stage_forward(t(g["features"]), t(g["proj"]), t(g["depth_values"]), sd, ndepth=nd, tmp=5.0,
+                                    training=False, taps=taps)
+    assert max_abs(taps["in_prod"][0], g["tap_in_prod_v1"]) < TOL
+    assert max_abs(torch.cat(taps["entropy"], 1), g["tap_entropy"]) < TOL
+    assert max_abs(torch.cat(taps["vis_weight"], 1), g["tap_vis_weight"]) < TOL
+    assert max_abs(taps["volume_mean"], g["tap_volume_mean"]) < TOL
+    assert max_abs(taps["similarity_sum"], g["tap_similarity_sum"]) < TOL
+    assert max_abs(o["prob_volume_pre"], g["eval_prob_volume_pre"]) < 1e-4
+    assert rel_err(o["depth"], g["eval_depth"]) < 1e-5
+    assert max_abs(o["photometric_confidence"], g["eval_photometric_confidence"]) < 1e-5
+    assert (o["sim_depth"].numpy() != g["eval_sim_depth"]).mean() < 0.01
+    with torch.no_grad():
+        o = ref_torch.stage_forward(t(g["features"]), t(g["proj"]), t(g["depth_values"]), sd, ndepth=nd, tmp=5.0,
+                                    training=True)
+    assert max_abs(o["prob_volume_pre"], g["train_prob_volume_pre"]) < 1e-4
+    assert (o["depth"].numpy() != g["train_depth"]).mean() < 0.01
+    assert "sim_depth" not in o
+
+
+@pytest.mark.parametrize("V", [3, 5])
+def test_cascade(V):
+    g = load_golden("cascade_v%d.npz" % V)
+    nds = [int(x) for x in g["ndepths"]]
+    sds = [make_state_dict(load_shapes("stage_costregnet3d" if nd <= 8 else "stage_costregnet"), int(s))
+           for nd, s in zip(nds, g["weight_seeds"])]
+    feats = {"stage%d" % i: t(g["features_stage%d" % i]) for i in range(1, 5)}
+    proj = {"stage%d" % i: t(g["proj_stage%d" % i]) for i in range(1, 5)}
+    with torch.no_grad():
+        out = ref_torch.cascade_forward(feats, proj, t(g["depth_range"]), sds, ndepths=nds,
+                                        depth_interals_ratio=[float(x) for x in g["ratios"]],
+                                        tmp=[float(x) for x in g["tmps"]])
+    for i in range(1, 5):
+        assert rel_err(out["stage%d" % i]["depth"], g["s%d_depth" % i]) < 1e-5
+        assert rel_err(out["stage%d" % i]["depth_values"], g["s%d_depth_values" % i]) < 1e-5
+    assert rel_err(out["refined_depth"], g["refined_depth"]) < 1e-5
+    assert max_abs(out["photometric_confidence"], g["photometric_confidence"]) < 1e-5
