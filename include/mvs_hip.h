@@ -1,0 +1,155 @@
+/*
+ * mvs_hip.h — C ABI of libmvs_hip.so, the MI355X (gfx950) plane-sweep cost-volume path.
+ *
+ * The reference (ewrfcas/MVSFormer) has no FFI: its "operator interface" for this path is the set of
+ * Python symbols models/mvsformer_model.py looks up.  Each entry point below replaces the
+ * ATen launches behind one of those symbols; the reference file:line it stands in for is cited on every
+ * declaration, and INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, MVS_EINVAL (-22) for a shape/argument violation, -(1000+hipError_t) for a HIP
+ *     runtime error; never throw, never exit.  mvs_last_error() returns a thread-local message.
+ *   - every pointer is a DEVICE pointer owned by the caller (fp32 unless stated, dense, row-major, the
+ *     layout given in brackets).  Nothing is allocated or freed; scratch comes in as a caller workspace.
+ *   - launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream); the
+ *     device is the caller's current HIP device.  No global mutable state: re-entrant across streams,
+ *     threads and devices.
+ *   - arithmetic is IEEE fp32 (the reference forces fp32 for the cost volume, mvsformer_model.py:65-78).
+ */
+#ifndef MVS_HIP_H
+#define MVS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVS_OK 0
+#define MVS_EINVAL (-22)
+#define MVS_ABI_VERSION 1
+
+typedef void* mvs_stream_t;
+
+/* ABI version (MVS_ABI_VERSION) and the last error message of the calling thread. */
+int mvs_version(void);
+const char* mvs_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Projection prep.  Replaces the per-source-view clone + 2 matmul + torch.inverse + matmul of
+ * models/mvsformer_model.py:69-72 and models/warping.py:80-82 (one launch per stage instead of 5 per view,
+ * no host sync).
+ *   proj [B,V,2,4,4]  proj[b,v,0] = extrinsic 4x4, proj[b,v,1,:3,:3] = stage intrinsic
+ *   rt   [B,V-1,12]   for source view v>=1: rows of M[:3,:3] (9 floats) then M[:3,3] (3 floats),
+ *                     M = P_v * inverse(P_0), P = [[K*E[:3,:4]],[E[3,:]]]
+ * ------------------------------------------------------------------------------------------------------- */
+int mvs_proj_prepare(const float* proj, int B, int V, float* rt, mvs_stream_t stream);
+
+/* Same for already composed projections (the op-level warp API, models/warping.py:80-82):
+ *   src_proj, ref_proj [B,4,4] -> rt [B,12] */
+int mvs_proj_relative(const float* src_proj, const float* ref_proj, int B, float* rt, mvs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Unfused plane-sweep warp = homo_warping_3D_with_mask / homo_warping_3D, models/warping.py:69-109,155-189.
+ *   src    [B,C,H,W]
+ *   rt     [B,12]            from mvs_proj_relative
+ *   depth  [B,D,H,W] if depth_per_pixel else [B,D]
+ *   warped [B,C,D,H,W]
+ *   mask   [B,D,H,W] uint8 (1 = outside the source frustum), may be NULL
+ * ------------------------------------------------------------------------------------------------------- */
+int mvs_warp_fwd(const float* src, const float* rt, const float* depth, int depth_per_pixel,
+                 int B, int C, int D, int H, int W, float* warped, uint8_t* mask, mvs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Fused cost-volume build, fusion_type='cnn' (models/mvsformer_model.py:62-105 inline in StageNet.forward).
+ * The warped volume, the repeated reference volume, the products and the normalized copies are never
+ * materialized.  Two sweeps because the visibility weight needs the full-D entropy plus a 3x3 CNN halo:
+ *
+ * sweep A  mvs_cv_entropy_fwd: per source view, warp + group correlation -> softmax_d entropy
+ *          (mvsformer_model.py:73-79,88-90)
+ *   feat    [B,V,C,H,W]  view 0 = reference            rt [B,V-1,12]       depth [B,D,H,W]
+ *   entropy [B,V-1,H,W]
+ * vis CNN  mvs_vis_fwd: ConvBnReLU(1,16)->ConvBnReLU(16,16)->ConvBnReLU(16,8)->Conv2d(8,1,1)->Sigmoid in one
+ *          LDS-tiled launch (mvsformer_model.py:37,91; module.py:168-197), eval-mode BN folded to scale/shift
+ *   entropy [N,H,W] -> weight [N,H,W];  params: MVS_VIS_PARAM_FLOATS floats, layout in vis_net.hip
+ * sweep B  mvs_cv_aggregate_fwd: recompute warp + correlation for all views, accumulate
+ *          sum_v w_v*corr_v / (sum_v w_v + 1e-6)  (mvsformer_model.py:101-105) and, if sim_depth != NULL, the
+ *          eval-only similarity arg-max depth (mvsformer_model.py:81-85,151-158)
+ *   weight  [B,V-1,H,W]   volume [B,G,D,H,W]   sim_depth [B,H,W] or NULL
+ * Constraints: G == 8, C in {8,16,32,64} (C/G channels per group), D*64*4 bytes of LDS <= 64 KiB.
+ * ------------------------------------------------------------------------------------------------------- */
+int mvs_cv_entropy_fwd(const float* feat, const float* rt, const float* depth,
+                       int B, int V, int C, int G, int D, int H, int W, float* entropy, mvs_stream_t stream);
+#define MVS_VIS_PARAM_FLOATS 3689
+int mvs_vis_fwd(const float* entropy, const float* params, int N, int H, int W, float* weight, mvs_stream_t stream);
+int mvs_cv_aggregate_fwd(const float* feat, const float* rt, const float* depth, const float* weight,
+                         int B, int V, int C, int G, int D, int H, int W,
+                         float* volume, float* sim_depth, mvs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * 3-D regularizer layers on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), implicit GEMM with the input
+ * tile + weights staged through LDS and a fused epilogue  y = [relu](acc*scale + shift) [+ residual].
+ * Replaces Conv3d / Deconv3d (conv -> BatchNorm3d -> ReLU, models/module.py:83-165) and the residual adds
+ * of CostRegNet.forward / CostRegNet3D.forward (module.py:495-505,584-594).  Kernel 3x3x3, padding 1.
+ *   x [B,Cin,Di,Hi,Wi]   y [B,Cout,Do,Ho,Wo]   residual [B,Cout,Do,Ho,Wo] or NULL (added after the ReLU)
+ *   scale, shift [Cout]  (eval BN folded; scale==NULL means 1, shift==NULL means 0)
+ *   wpacked: weights re-laid by mvs_conv3d_pack_weights (size from mvs_conv3d_packed_floats)
+ *   conv:   stride (sd,shw,shw) in {(1,1,1),(2,2,2),(1,2,2)};  Do = (Di-1)/sd+1 etc.
+ *   deconv: ConvTranspose3d stride (sd,2,2), output_padding (sd-1,1,1):  Do = Di*sd, Ho = 2*Hi, Wo = 2*Wi
+ * Constraints: Cin % 4 == 0, Cout % 8 == 0, Cout <= 64.
+ * ------------------------------------------------------------------------------------------------------- */
+int64_t mvs_conv3d_packed_floats(int Cin, int Cout);
+/* w: Conv3d weight [Cout,Cin,3,3,3] (transposed=0) or ConvTranspose3d weight [Cin,Cout,3,3,3] (transposed=1) */
+int mvs_conv3d_pack_weights(const float* w, int Cin, int Cout, int transposed, float* wpacked, mvs_stream_t stream);
+int mvs_conv3d_fwd(const float* x, const float* wpacked, const float* scale, const float* shift,
+                   const float* residual, float* y, int B, int Cin, int Cout, int Di, int Hi, int Wi,
+                   int sd, int shw, int relu, mvs_stream_t stream);
+int mvs_deconv3d_fwd(const float* x, const float* wpacked, const float* scale, const float* shift,
+                     const float* residual, float* y, int B, int Cin, int Cout, int Di, int Hi, int Wi,
+                     int sd, int relu, mvs_stream_t stream);
+
+/* CostRegNet.prob: Conv3d(C -> 1, k=3, padding=1, bias=False), models/module.py:493,503.
+ *   x [B,C,D,H,W], w [1,C,3,3,3] (PyTorch layout) -> logits [B,D,H,W] */
+int mvs_prob3_fwd(const float* x, const float* w, int B, int C, int D, int H, int W, float* logits, mvs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Depth head, depth_type 'ce' (models/mvsformer_model.py:110-125, module.py:597-603), one per-pixel D sweep:
+ *   prob_volume_pre = logits                      (or the fused CostRegNet3D.prob 1x1x1 conv, module.py:581,592:
+ *                                                  x8 [B,C,D,H,W], w1 [C], b1 [1] device pointers, C = x8_channels)
+ *   prob_volume     = softmax_d(prob_volume_pre)
+ *   eval:  depth = sum_d softmax_d(pre*tmp) * depth_values      train: depth = depth_values[argmax_d prob_volume]
+ *   photometric_confidence = max_d prob_volume
+ * Exactly one of (logits) / (x8,w1,b1) is given.  prob_volume_pre is written only in the fused-conv form
+ * (may be NULL otherwise).  depth_values [B,D,H,W].
+ * ------------------------------------------------------------------------------------------------------- */
+int mvs_head_fwd(const float* logits, const float* x8, const float* w1, const float* b1, int x8_channels,
+                 const float* depth_values, float tmp, int training, int B, int D, int H, int W,
+                 float* prob_volume_pre, float* prob_volume, float* depth, float* conf, mvs_stream_t stream);
+
+/* Stand-alone heads for callers that use the ops directly.
+ *   mvs_depth_regression: module.py:597-603, depth = sum_d p*depth_values; depth_values [B,D,H,W] or [B,D]
+ *   mvs_conf_regression:  module.py:606-619, sum of the n probabilities around floor(sum_d p*d)
+ *   mvs_prob1_fwd:        CostRegNet3D.prob alone (module.py:581,592): 1x1x1 conv C->1, x [B,C,N] -> logits [B,N],
+ *                         w [C], bias [1] or NULL */
+int mvs_depth_regression(const float* p, const float* depth_values, int depth_per_pixel, int B, int D, int H, int W,
+                         float* depth, mvs_stream_t stream);
+int mvs_conf_regression(const float* p, int n, int B, int D, int H, int W, float* conf, mvs_stream_t stream);
+int mvs_prob1_fwd(const float* x, const float* w, const float* bias, int B, int C, int64_t N, float* logits,
+                  mvs_stream_t stream);
+
+/* Hypothesis schedulers, models/module.py:633-653.
+ *   init:     depth_range [B,N] (only [:,0] and [:,N-1] are read) -> hyp [B,D,H,W], index 0 = far
+ *   schedule: prev_depth [B,H/2,W/2], prev_hyp [B,Dp,H/2,W/2] (planes 1 and 2 are read) -> hyp [B,D,H,W]
+ *             (trilinear x2 upsampling, align_corners=True, of the inverse-depth samples, then reciprocal) */
+int mvs_init_inverse_range(const float* depth_range, int N, int B, int D, int H, int W, float* hyp, mvs_stream_t stream);
+int mvs_schedule_inverse_range(const float* prev_depth, const float* prev_hyp, int Dp, float split_itv,
+                               int B, int D, int H, int W, float* hyp, mvs_stream_t stream);
+
+/* Nearest-neighbour upsample + accumulate of the per-stage confidences (mvsformer_model.py:297-301):
+ *   acc [B,Hf,Wf] += nearest(conf [B,H,W]) * weight */
+int mvs_conf_accumulate(const float* conf, int B, int H, int W, float* acc, int Hf, int Wf, float weight, mvs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVS_HIP_H */

@@ -1,0 +1,79 @@
+"""ctypes binding of libmvs_hip.so (the C ABI declared in include/mvs_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C mvsformer_amd/csrc`` and is the ONLY
+compute path of this package: there is no PyTorch or CPU fallback, so a missing library is a hard error.
+
+``import torch`` must precede the ``CDLL`` call: torch's wheel bundles its own HIP runtime under the same
+SONAME (libamdhip64.so.7) and the dynamic loader then binds our library to that already-loaded runtime, so the
+``hipStream_t`` handles torch hands us belong to the runtime that launches our kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+import torch  # noqa: F401  (load order, see above)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvs_hip.so")
+ABI_VERSION = 1
+
+P, I, F, L = c_void_p, c_int, c_float, c_int64
+
+# name -> (restype, argtypes); mirrors include/mvs_hip.h one to one (tests/test_abi.py cross-checks the header)
+SIGNATURES = {
+    "mvs_version": (I, []),
+    "mvs_last_error": (c_char_p, []),
+    "mvs_proj_prepare": (I, [P, I, I, P, P]),
+    "mvs_proj_relative": (I, [P, P, I, P, P]),
+    "mvs_warp_fwd": (I, [P, P, P, I, I, I, I, I, I, P, P, P]),
+    "mvs_cv_entropy_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P]),
+    "mvs_vis_fwd": (I, [P, P, I, I, I, P, P]),
+    "mvs_cv_aggregate_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, P]),
+    "mvs_conv3d_packed_floats": (L, [I, I]),
+    "mvs_conv3d_pack_weights": (I, [P, I, I, I, P, P]),
+    "mvs_conv3d_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "mvs_deconv3d_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "mvs_prob3_fwd": (I, [P, P, I, I, I, I, I, P, P]),
+    "mvs_head_fwd": (I, [P, P, P, P, I, P, F, I, I, I, I, I, P, P, P, P, P]),
+    "mvs_depth_regression": (I, [P, P, I, I, I, I, I, P, P]),
+    "mvs_conf_regression": (I, [P, I, I, I, I, I, P, P]),
+    "mvs_prob1_fwd": (I, [P, P, P, I, I, L, P, P]),
+    "mvs_init_inverse_range": (I, [P, I, I, I, I, I, P, P]),
+    "mvs_schedule_inverse_range": (I, [P, P, I, F, I, I, I, I, P, P]),
+    "mvs_conf_accumulate": (I, [P, I, I, I, P, I, I, F, P]),
+}
+
+_lib = None
+
+
+class MvsHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and return the library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MvsHipError(
+            "%s is missing: the HIP path has not been built (run `python -c \"import __graft_entry__ as g; g.build()\"` "
+            "or `make -C mvsformer_amd/csrc`).  mvsformer_amd has no CPU/PyTorch fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library drift
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.mvs_version()
+    if got != ABI_VERSION:
+        raise MvsHipError("libmvs_hip.so ABI version %d, binding expects %d — rebuild" % (got, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().mvs_last_error()
+        raise MvsHipError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))

@@ -1,0 +1,35 @@
+// Shared host/device helpers for libmvs_hip.so (gfx950 only; no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/mvs_hip.h"
+
+namespace mvs {
+
+void set_error(const char* fmt, ...);
+
+inline int finish_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return -(1000 + (int)e);
+    }
+    return MVS_OK;
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace mvs
+
+#define MVS_REQUIRE(cond, ...)               \
+    do {                                     \
+        if (!(cond)) {                       \
+            mvs::set_error(__VA_ARGS__);     \
+            return MVS_EINVAL;               \
+        }                                    \
+    } while (0)
+
+#define MVS_STREAM(s) reinterpret_cast<hipStream_t>(s)

@@ -1,0 +1,480 @@
+// 3-D regularizer layers (models/module.py:83-165 Conv3d/Deconv3d = conv -> BatchNorm3d -> ReLU, and the
+// residual adds of CostRegNet.forward / CostRegNet3D.forward, module.py:495-505,584-594) as implicit GEMMs on
+// the fp32 matrix cores of gfx950: v_mfma_f32_16x16x4_f32 (exact fp32 = an fmaf chain, 64 FLOP/clk/SIMD).
+//
+// GEMM view: M = output voxels (16 consecutive voxels along W per MFMA tile), N = output channels (16 per
+// tile), K = 27 taps x Cin (4 input channels per MFMA).  Layout stays NCDHW: for one (tap, cin) the A operand
+// of a tile is 16 consecutive floats of an input row, so both the global->LDS staging and the LDS->register
+// fragment reads are unit-stride.  Per input-channel chunk a block stages (a) the input tile with its halo and
+// (b) the matching slice of the pre-packed weights into LDS; channel strides are padded so the two k-halves
+// of a 32-lane LDS access group fall on disjoint banks.  Epilogue (fused): y = relu(acc*scale + shift) +
+// residual, written as 16-byte row segments.
+//
+// Transposed convolutions are computed as gathers over the stride-2 output parities (no zero-stuffing, no
+// scatter): an even output index has one contributing tap per strided dimension, an odd one two, and a
+// wavefront always owns an even+odd pair in each strided dimension so that all wavefronts do equal work.
+//
+// Algorithmic FLOPs per layer: 2*27*Cin*Cout per output voxel (conv) / per input voxel (deconv).
+#include "common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int NWAVES = 4;
+
+constexpr int np_of(int NT) { return NT == 1 ? 16 : (NT == 2 ? 48 : 80); }   // packed cout row, == 16 (mod 32)
+constexpr int pad_cs(int raw, int shw) {
+    // channel stride of the LDS input tile: == 16 (mod 32) for unit-stride fragment reads, odd for stride-2 reads
+    return shw == 1 ? raw + ((16 - raw % 32) + 32) % 32 : raw + ((raw % 2 == 0) ? 1 : 0);
+}
+constexpr int CC_DECONV = 8;                                                  // input channels per LDS chunk
+constexpr int cc_conv(int NT, int SHW) { return (SHW == 1 && NT == 1) ? 8 : 4; }
+
+__host__ __device__ inline int nt_of(int Cout) { int nt = (Cout + 15) / 16; return nt == 3 ? 4 : nt; }
+
+// --------------------------------------------------------------------------------------------------------
+// weight packing: one zero-padded image per layer, [cin/4 slabs][tap 27][c 4][NP].  A kernel that stages CC
+// input channels per chunk copies CC/4 consecutive slabs; the slab count is padded to an even number so CC=8
+// kernels always read whole slabs.
+// --------------------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ w, int Cin, int Cout, int transposed, int NP, int n4,
+                                    float* __restrict__ out) {
+    const int64_t total = (int64_t)n4 * 27 * 4 * NP;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx % NP);
+        const int c = (int)((idx / NP) % 4);
+        const int tap = (int)((idx / (NP * 4)) % 27);
+        const int ch = (int)(idx / ((int64_t)NP * 4 * 27));
+        const int cin = ch * 4 + c;
+        float v = 0.0f;
+        if (cin < Cin && n < Cout)
+            v = transposed ? w[((size_t)cin * Cout + n) * 27 + tap] : w[((size_t)n * Cin + cin) * 27 + tap];
+        out[idx] = v;
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// fused epilogue for one lane's 4 consecutive output voxels of one channel
+__device__ __forceinline__ f32x4 bn_act(f32x4 a, float sc, float sh, int relu) {
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = fmaf(a[r], sc, sh);
+        o[r] = relu ? fmaxf(v, 0.0f) : v;
+    }
+    return o;
+}
+
+// --------------------------------------------------------------------------------------------------------
+// forward convolution, stride (SD, SHW, SHW), kernel 3, padding 1.
+// block = 4 wavefronts = 2 (d) x 2 (h) output rows x 64 voxels along W; wavefront = one row, 4 M-tiles.
+// --------------------------------------------------------------------------------------------------------
+template <int NT, int SD, int SHW>
+__global__ __launch_bounds__(256) void conv3d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     const float* __restrict__ res, float* __restrict__ y, int CIN, int COUT,
+                                                     int Di, int Hi, int Wi, int Do, int Ho, int Wo, int relu) {
+    constexpr int TD = 2, TH = 2, MT = 4;
+    constexpr int CC = cc_conv(NT, SHW);
+    constexpr int NP = np_of(NT);
+    constexpr int ID = (TD - 1) * SD + 3, IH = (TH - 1) * SHW + 3, IW = (64 - 1) * SHW + 3;
+    constexpr int CS = pad_cs(ID * IH * IW, SHW);
+    constexpr int WSLAB = 27 * 4 * NP;                       // one packed cin/4 slab
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_in = smem;                                      // [CC][CS]
+    float* s_w = smem + CC * CS;                             // [CC/4][27][4][NP]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kk = lane >> 4;
+    const int ndt = (Do + TD - 1) / TD;
+    const int b = blockIdx.z / ndt, d0 = (blockIdx.z % ndt) * TD, h0 = blockIdx.y * TH, w0 = blockIdx.x * 64;
+    const int dl = wave / TH, hl = wave % TH;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = (CIN + CC - 1) / CC;
+    const size_t plane = (size_t)Hi * Wi;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();
+        // ---- stage the input tile (zero-filled halo / padding) ----
+        for (int r = wave; r < CC * ID * IH; r += NWAVES) {
+            const int c = r / (ID * IH), rem = r % (ID * IH), dz = rem / IH, hy = rem % IH;
+            const int cin = ch * CC + c, gd = d0 * SD - 1 + dz, gh = h0 * SHW - 1 + hy;
+            const bool rowok = cin < CIN && gd >= 0 && gd < Di && gh >= 0 && gh < Hi;
+            const float* grow = x + ((size_t)(b * CIN + cin) * Di + gd) * plane + (size_t)gh * Wi;
+            float* lrow = s_in + c * CS + (dz * IH + hy) * IW;
+            for (int wx = lane; wx < IW; wx += 64) {
+                const int gw = w0 * SHW - 1 + wx;
+                lrow[wx] = (rowok && gw >= 0 && gw < Wi) ? grow[gw] : 0.0f;
+            }
+        }
+        // ---- stage the weight slabs of this chunk (linear copy, 16 B per lane) ----
+        {
+            const float4* src = reinterpret_cast<const float4*>(wp + (size_t)ch * (CC / 4) * WSLAB);
+            float4* dst = reinterpret_cast<float4*>(s_w);
+            for (int i = tid; i < (CC / 4) * WSLAB / 4; i += 256) dst[i] = src[i];
+        }
+        __syncthreads();
+        // ---- 27 taps x CC/4 k-steps of MFMA ----
+        const float* abase = s_in + kk * CS + ((dl * SD) * IH + hl * SHW) * IW + i16 * SHW;
+        const float* bbase = s_w + kk * NP + i16;
+#pragma unroll
+        for (int ks = 0; ks < CC / 4; ++ks) {
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int tap = (kd * 3 + kh) * 3 + kw;
+                        float a[MT], bf[NT];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) a[m] = abase[ks * 4 * CS + (kd * IH + kh) * IW + kw + m * 16 * SHW];
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) bf[n] = bbase[ks * WSLAB + tap * 4 * NP + n * 16];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) acc[m][n] = mfma4(a[m], bf[n], acc[m][n]);
+                    }
+        }
+    }
+
+    // ---- epilogue ----
+    const int od = d0 + dl, oh = h0 + hl;
+    if (od >= Do || oh >= Ho) return;
+    const bool vec_ok = (Wo % 4) == 0;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n * 16 + i16;
+        if (co >= COUT) continue;
+        const float sc = scale ? scale[co] : 1.0f, sh = shift ? shift[co] : 0.0f;
+        const size_t rowoff = (((size_t)(b * COUT + co) * Do + od) * Ho + oh) * Wo;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int ow = w0 + m * 16 + kk * 4;
+            if (ow >= Wo) continue;
+            f32x4 o = bn_act(acc[m][n], sc, sh, relu);
+            if (vec_ok) {
+                if (res) { const f32x4 rr = *reinterpret_cast<const f32x4*>(res + rowoff + ow); o += rr; }
+                *reinterpret_cast<f32x4*>(y + rowoff + ow) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ow + r < Wo) y[rowoff + ow + r] = o[r] + (res ? res[rowoff + ow + r] : 0.0f);
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------
+// transposed convolution, stride (SD,2,2), kernel 3, padding 1, output_padding (SD-1,1,1): out = 2x in along
+// every strided dim.  Gather form: out[o] = sum over taps k with o = 2*i - 1 + k:
+//   o even: (k=1, i=o/2)          o odd: (k=2, i=(o-1)/2), (k=0, i=(o+1)/2)        (stride-1 dim: i = o+1-k)
+// SD==1: wavefront = 1 output depth x 2 output rows (even+odd) x 64 output columns  (8 M-tiles)
+//        block     = 2 depths x 2 row pairs x 64 columns
+// SD==2: wavefront = 2 depths (even+odd) x 2 rows x 32 columns                      (8 M-tiles)
+//        block     = 2 depths x 2 row pairs x 64 columns
+// --------------------------------------------------------------------------------------------------------
+template <int NT, int SD>
+__global__ __launch_bounds__(256) void deconv3d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ res, float* __restrict__ y, int CIN, int COUT,
+                                                       int Di, int Hi, int Wi, int relu) {
+    constexpr int CC = CC_DECONV;
+    constexpr int NP = np_of(NT);
+    constexpr int ID = (SD == 1) ? 4 : 2;                    // input depths staged per block
+    constexpr int IH = 3;                                    // input rows: 2 row pairs + 1
+    constexpr int IWI = 32;                                  // input columns per block (excluding the +1 halo)
+    constexpr int IW = IWI + 1;
+    constexpr int CS = pad_cs(ID * IH * IW, 1);
+    constexpr int WSLAB = 27 * 4 * NP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_in = smem;
+    float* s_w = smem + CC * CS;
+
+    const int Do = Di * SD, Ho = Hi * 2, Wo = Wi * 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kk = lane >> 4;
+    // block origin in INPUT coordinates
+    const int ndt = (SD == 1) ? (Di + 1) / 2 : Di;
+    const int b = blockIdx.z / ndt;
+    const int di0 = (SD == 1) ? (blockIdx.z % ndt) * 2 : (blockIdx.z % ndt);   // SD==1: first output depth; SD==2: input depth
+    const int hi0 = blockIdx.y * 2, wi0 = blockIdx.x * IWI;
+    // wavefront role
+    const int hp = wave & 1;                                 // row pair within the block
+    const int wsel = wave >> 1;                              // SD==1: output depth within the block; SD==2: 16-column half
+    const int dl = (SD == 1) ? wsel : 0;
+    const int wq0 = (SD == 1) ? 0 : wsel * 16;               // first input column (relative) of this wavefront
+
+    // 8 M-tiles of 16 input columns: SD==1: t = (hh, pw, q), q = column half;  SD==2: t = (dd, hh, pw)
+    f32x4 acc[8][NT];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = (CIN + CC - 1) / CC;
+    const size_t plane = (size_t)Hi * Wi;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();
+        for (int r = wave; r < CC * ID * IH; r += NWAVES) {
+            const int c = r / (ID * IH), rem = r % (ID * IH), dz = rem / IH, hy = rem % IH;
+            const int cin = ch * CC + c;
+            const int gd = (SD == 1) ? di0 - 1 + dz : di0 + dz;
+            const int gh = hi0 + hy;
+            const bool rowok = cin < CIN && gd >= 0 && gd < Di && gh < Hi;
+            const float* grow = x + ((size_t)(b * CIN + cin) * Di + gd) * plane + (size_t)gh * Wi;
+            float* lrow = s_in + c * CS + (dz * IH + hy) * IW;
+            for (int wx = lane; wx < IW; wx += 64) {
+                const int gw = wi0 + wx;
+                lrow[wx] = (rowok && gw < Wi) ? grow[gw] : 0.0f;
+            }
+        }
+        {
+            const float4* src = reinterpret_cast<const float4*>(wp + (size_t)ch * (CC / 4) * WSLAB);
+            float4* dst = reinterpret_cast<float4*>(s_w);
+            for (int i = tid; i < (CC / 4) * WSLAB / 4; i += 256) dst[i] = src[i];
+        }
+        __syncthreads();
+
+        const float* bbase = s_w + kk * NP + i16;
+#pragma unroll
+        for (int ks = 0; ks < CC / 4; ++ks) {
+            const float* abase = s_in + (ks * 4 + kk) * CS + i16;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                // decode tile -> parities / offsets
+                const int dd = (SD == 1) ? 0 : (t >> 2);
+                const int hh = (SD == 1) ? (t >> 2) : ((t >> 1) & 1);
+                const int pw = (SD == 1) ? ((t >> 1) & 1) : (t & 1);
+                const int q = (SD == 1) ? (t & 1) : 0;
+                const int col = wq0 + q * 16;
+                const int ndtap = (SD == 1) ? 3 : (1 + dd);
+#pragma unroll
+                for (int td = 0; td < ndtap; ++td) {
+                    // stride-1 depth: kd = td, dz = dl + 2 - kd.  stride-2 depth: even -> (k=1,off 0); odd -> (k=2,off 0),(k=0,off 1)
+                    const int kd = (SD == 1) ? td : (dd == 0 ? 1 : (td == 0 ? 2 : 0));
+                    const int dz = (SD == 1) ? (dl + 2 - td) : ((dd == 1 && td == 1) ? 1 : 0);
+#pragma unroll
+                    for (int th = 0; th < 1 + hh; ++th) {
+                        const int kh = hh == 0 ? 1 : (th == 0 ? 2 : 0);
+                        const int hy = hp + ((hh == 1 && th == 1) ? 1 : 0);
+#pragma unroll
+                        for (int tw = 0; tw < 1 + pw; ++tw) {
+                            const int kw = pw == 0 ? 1 : (tw == 0 ? 2 : 0);
+                            const int wx = col + ((pw == 1 && tw == 1) ? 1 : 0);
+                            const int tap = (kd * 3 + kh) * 3 + kw;
+                            const float a = abase[(dz * IH + hy) * IW + wx];
+#pragma unroll
+                            for (int n = 0; n < NT; ++n)
+                                acc[t][n] = mfma4(a, bbase[ks * WSLAB + tap * 4 * NP + n * 16], acc[t][n]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: interleave even/odd columns into contiguous 32-byte runs ----
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = n * 16 + i16;
+        if (co >= COUT) continue;
+        const float sc = scale ? scale[co] : 1.0f, sh = shift ? shift[co] : 0.0f;
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {                     // tile pairs (pw = 0 / 1)
+            int dd, hh, q;
+            if (SD == 1) { dd = 0; hh = tp >> 1; q = tp & 1; } else { dd = tp >> 1; hh = tp & 1; q = 0; }
+            const int te = (SD == 1) ? (hh * 4 + 0 * 2 + q) : (dd * 4 + hh * 2 + 0);
+            const int to = (SD == 1) ? (hh * 4 + 1 * 2 + q) : (dd * 4 + hh * 2 + 1);
+            const int od = (SD == 1) ? di0 + dl : di0 * 2 + dd;
+            const int oh = (hi0 + hp) * 2 + hh;
+            const int wi = wi0 + wq0 + q * 16 + kk * 4;      // first of this lane's 4 input columns
+            if (od >= Do || oh >= Ho || wi >= Wi) continue;
+            const f32x4 e = bn_act(acc[te][n], sc, sh, relu);
+            const f32x4 o = bn_act(acc[to][n], sc, sh, relu);
+            const size_t off = (((size_t)(b * COUT + co) * Do + od) * Ho + oh) * Wo + (size_t)wi * 2;
+            if ((Wi % 4) == 0) {
+                f32x4 v0 = {e[0], o[0], e[1], o[1]}, v1 = {e[2], o[2], e[3], o[3]};
+                if (res) {
+                    v0 += *reinterpret_cast<const f32x4*>(res + off);
+                    v1 += *reinterpret_cast<const f32x4*>(res + off + 4);
+                }
+                *reinterpret_cast<f32x4*>(y + off) = v0;
+                *reinterpret_cast<f32x4*>(y + off + 4) = v1;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (wi + r < Wi) {
+                        y[off + 2 * r] = e[r] + (res ? res[off + 2 * r] : 0.0f);
+                        y[off + 2 * r + 1] = o[r] + (res ? res[off + 2 * r + 1] : 0.0f);
+                    }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------
+// CostRegNet.prob: Conv3d(C -> 1, k=3, padding=1, bias=False).  N=1 is not matrix-core work: one lane per
+// output voxel, 27*C coalesced row reads served by L1, weights through the scalar cache.
+// --------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prob3_kernel(const float* __restrict__ x, const float* __restrict__ w, int C, int D, int H,
+                                                    int W, float* __restrict__ out) {
+    const int xw = blockIdx.x * 64 + threadIdx.x;
+    const int yh = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z / D, d = blockIdx.z % D;
+    if (xw >= W || yh >= H) return;
+    const size_t plane = (size_t)H * W;
+    float acc = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const float* xc = x + (size_t)(b * C + c) * D * plane;
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const int zd = d + kd - 1;
+            if (zd < 0 || zd >= D) continue;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int zh = yh + kh - 1;
+                if (zh < 0 || zh >= H) continue;
+                const float* row = xc + (size_t)zd * plane + (size_t)zh * W;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int zw = xw + kw - 1;
+                    const float v = (zw >= 0 && zw < W) ? row[zw] : 0.0f;
+                    acc = fmaf(w[c * 27 + (kd * 3 + kh) * 3 + kw], v, acc);
+                }
+            }
+        }
+    }
+    out[((size_t)(b * D + d) * H + yh) * W + xw] = acc;
+}
+
+template <int NT, int SD, int SHW>
+size_t conv_lds_bytes() {
+    constexpr int CC = cc_conv(NT, SHW);
+    constexpr int ID = (2 - 1) * SD + 3, IH = (2 - 1) * SHW + 3, IW = 63 * SHW + 3;
+    return (size_t)(CC * pad_cs(ID * IH * IW, SHW) + (CC / 4) * 27 * 4 * np_of(NT)) * sizeof(float);
+}
+template <int NT, int SD>
+size_t deconv_lds_bytes() {
+    constexpr int ID = (SD == 1) ? 4 : 2, IW = 32 + 1;
+    return (size_t)(CC_DECONV * pad_cs(ID * 3 * IW, 1) + (CC_DECONV / 4) * 27 * 4 * np_of(NT)) * sizeof(float);
+}
+
+template <int NT, int SD, int SHW>
+int launch_conv(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y, int B,
+                int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int relu, hipStream_t s) {
+    const size_t lds = conv_lds_bytes<NT, SD, SHW>();
+    static bool attr_done = false;   // idempotent; a race only repeats the call
+    if (!attr_done && lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_kernel<NT, SD, SHW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            mvs::set_error("mvs_conv3d_fwd: cannot raise dynamic LDS to %zu bytes", lds);
+            return -(1000 + (int)hipGetLastError());
+        }
+        attr_done = true;
+    }
+    dim3 grid(mvs::ceil_div(Wo, 64), mvs::ceil_div(Ho, 2), B * mvs::ceil_div(Do, 2));
+    hipLaunchKernelGGL((conv3d_kernel<NT, SD, SHW>), grid, dim3(256), lds, s, x, wp, scale, shift, res, y, Cin, Cout, Di, Hi, Wi,
+                       Do, Ho, Wo, relu);
+    return mvs::finish_launch("mvs_conv3d_fwd");
+}
+
+template <int NT, int SD>
+int launch_deconv(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y, int B,
+                  int Cin, int Cout, int Di, int Hi, int Wi, int relu, hipStream_t s) {
+    const size_t lds = deconv_lds_bytes<NT, SD>();
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(deconv3d_kernel<NT, SD>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            mvs::set_error("mvs_deconv3d_fwd: cannot raise dynamic LDS to %zu bytes", lds);
+            return -(1000 + (int)hipGetLastError());
+        }
+        attr_done = true;
+    }
+    dim3 grid(mvs::ceil_div(Wi, 32), mvs::ceil_div(Hi, 2), B * ((SD == 1) ? mvs::ceil_div(Di, 2) : Di));
+    hipLaunchKernelGGL((deconv3d_kernel<NT, SD>), grid, dim3(256), lds, s, x, wp, scale, shift, res, y, Cin, Cout, Di, Hi, Wi, relu);
+    return mvs::finish_launch("mvs_deconv3d_fwd");
+}
+
+int check_conv_args(const char* who, int B, int Cin, int Cout, int Di, int Hi, int Wi) {
+    MVS_REQUIRE(B >= 1 && Di >= 1 && Hi >= 1 && Wi >= 1, "%s: bad shape B=%d D=%d H=%d W=%d", who, B, Di, Hi, Wi);
+    MVS_REQUIRE(Cin >= 4 && Cin % 4 == 0, "%s: Cin must be a multiple of 4 (got %d)", who, Cin);
+    MVS_REQUIRE(Cout >= 8 && Cout % 8 == 0 && Cout <= 64, "%s: Cout must be a multiple of 8, <= 64 (got %d)", who, Cout);
+    return MVS_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t mvs_conv3d_packed_floats(int Cin, int Cout) {
+    if (Cin < 1 || Cout < 1 || Cout > 64) return 0;
+    // padded to a multiple of 8 input channels so CC=8 kernels can always stage two full slabs
+    const int n4 = 2 * ((Cin + 7) / 8);
+    return (int64_t)n4 * 27 * 4 * np_of(nt_of(Cout));
+}
+
+extern "C" int mvs_conv3d_pack_weights(const float* w, int Cin, int Cout, int transposed, float* wpacked, mvs_stream_t stream) {
+    MVS_REQUIRE(w && wpacked, "mvs_conv3d_pack_weights: null pointer");
+    if (int rc = check_conv_args("mvs_conv3d_pack_weights", 1, Cin, Cout, 1, 1, 1)) return rc;
+    const int n4 = 2 * ((Cin + 7) / 8), NP = np_of(nt_of(Cout));
+    const int64_t total = (int64_t)n4 * 27 * 4 * NP;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, MVS_STREAM(stream), w, Cin, Cout,
+                       transposed, NP, n4, wpacked);
+    return mvs::finish_launch("mvs_conv3d_pack_weights");
+}
+
+extern "C" int mvs_conv3d_fwd(const float* x, const float* wpacked, const float* scale, const float* shift, const float* residual,
+                              float* y, int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int shw, int relu,
+                              mvs_stream_t stream) {
+    MVS_REQUIRE(x && wpacked && y, "mvs_conv3d_fwd: null pointer");
+    if (int rc = check_conv_args("mvs_conv3d_fwd", B, Cin, Cout, Di, Hi, Wi)) return rc;
+    MVS_REQUIRE((sd == 1 && shw == 1) || (sd == 2 && shw == 2) || (sd == 1 && shw == 2),
+                "mvs_conv3d_fwd: stride (%d,%d,%d) not built", sd, shw, shw);
+    const int Do = (Di - 1) / sd + 1, Ho = (Hi - 1) / shw + 1, Wo = (Wi - 1) / shw + 1;
+    MVS_REQUIRE((int64_t)B * mvs::ceil_div(Do, 2) <= 65535, "mvs_conv3d_fwd: grid.z limit");
+    hipStream_t s = MVS_STREAM(stream);
+    const int nt = nt_of(Cout);
+#define MVS_CONV(NTV)                                                                                                          \
+    if (sd == 1 && shw == 1) return launch_conv<NTV, 1, 1>(x, wpacked, scale, shift, residual, y, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, relu, s); \
+    if (sd == 2) return launch_conv<NTV, 2, 2>(x, wpacked, scale, shift, residual, y, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, relu, s);            \
+    return launch_conv<NTV, 1, 2>(x, wpacked, scale, shift, residual, y, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, relu, s)
+    if (nt == 1) { MVS_CONV(1); }
+    if (nt == 2) { MVS_CONV(2); }
+    MVS_CONV(4);
+#undef MVS_CONV
+}
+
+extern "C" int mvs_deconv3d_fwd(const float* x, const float* wpacked, const float* scale, const float* shift, const float* residual,
+                                float* y, int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int relu, mvs_stream_t stream) {
+    MVS_REQUIRE(x && wpacked && y, "mvs_deconv3d_fwd: null pointer");
+    if (int rc = check_conv_args("mvs_deconv3d_fwd", B, Cin, Cout, Di, Hi, Wi)) return rc;
+    MVS_REQUIRE(sd == 1 || sd == 2, "mvs_deconv3d_fwd: depth stride %d not built", sd);
+    MVS_REQUIRE((int64_t)B * Di <= 65535, "mvs_deconv3d_fwd: grid.z limit");
+    hipStream_t s = MVS_STREAM(stream);
+    const int nt = nt_of(Cout);
+#define MVS_DECONV(NTV)                                                                                                     \
+    if (sd == 1) return launch_deconv<NTV, 1>(x, wpacked, scale, shift, residual, y, B, Cin, Cout, Di, Hi, Wi, relu, s);   \
+    return launch_deconv<NTV, 2>(x, wpacked, scale, shift, residual, y, B, Cin, Cout, Di, Hi, Wi, relu, s)
+    if (nt == 1) { MVS_DECONV(1); }
+    if (nt == 2) { MVS_DECONV(2); }
+    MVS_DECONV(4);
+#undef MVS_DECONV
+}
+
+extern "C" int mvs_prob3_fwd(const float* x, const float* w, int B, int C, int D, int H, int W, float* logits, mvs_stream_t stream) {
+    MVS_REQUIRE(x && w && logits, "mvs_prob3_fwd: null pointer");
+    MVS_REQUIRE(B >= 1 && C >= 1 && D >= 1 && H >= 1 && W >= 1 && (int64_t)B * D <= 65535, "mvs_prob3_fwd: bad shape");
+    dim3 grid(mvs::ceil_div(W, 64), mvs::ceil_div(H, 4), B * D), block(64, 4);
+    hipLaunchKernelGGL(prob3_kernel, grid, block, 0, MVS_STREAM(stream), x, w, C, D, H, W, logits);
+    return mvs::finish_launch("mvs_prob3_fwd");
+}

@@ -1,0 +1,78 @@
+// Plane-sweep sampling geometry shared by the unfused warp and the fused cost-volume sweeps.
+//
+// Semantics restated from the reference call chain (models/warping.py:84-106 feeding
+// F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=True)); the checklist is SURVEY.md
+// Appendix B.  The file is compiled with -ffp-contract=off, so every rounding below is explicit: products
+// and sums that the reference performs as separate tensor ops stay separate, fmaf() is used only where the
+// reference's matmul accumulates.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mvs {
+
+struct Taps {
+    int o00, o01, o10, o11;      // element offsets (y*W + x) of the 4 taps inside one H*W plane, clamped in-bounds
+    float w00, w01, w10, w11;    // bilinear weights, already 0 for taps outside the source image
+};
+
+// rt: 12 floats (3x3 row-major, then translation).  x, y: integer pixel lattice of the reference view.
+// Returns X2 (camera-space z in the source view) through *z, normalized coordinates through *un, *vn.
+__device__ __forceinline__ void sweep_project(const float* __restrict__ rt, float x, float y, float d,
+                                              float half_w, float half_h, float* un, float* vn, float* z) {
+    // rot @ (x, y, 1): k-ordered fma chain like a k=3 sgemm
+    const float rx = fmaf(rt[2], 1.0f, fmaf(rt[1], y, rt[0] * x));
+    const float ry = fmaf(rt[5], 1.0f, fmaf(rt[4], y, rt[3] * x));
+    const float rz = fmaf(rt[8], 1.0f, fmaf(rt[7], y, rt[6] * x));
+    const float X0 = rx * d + rt[9];
+    const float X1 = ry * d + rt[10];
+    const float X2 = rz * d + rt[11];
+    const float zz = X2 + 1e-6f;
+    const float u = X0 / zz;
+    const float v = X1 / zz;
+    *un = u / half_w - 1.0f;
+    *vn = v / half_h - 1.0f;
+    *z = X2;
+}
+
+// grid_sample un-normalization (align_corners=True) + the 4 zero-padded taps.
+__device__ __forceinline__ Taps sweep_taps(float un, float vn, int H, int W, float half_w, float half_h) {
+    const float ix = (un + 1.0f) * half_w;     // ((u_n + 1) / 2) * (W - 1)
+    const float iy = (vn + 1.0f) * half_h;
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float wx = ix - x0f, wy = iy - y0f;
+    const float ex = 1.0f - wx, ey = 1.0f - wy;
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    // float comparisons: NaN / +-inf coordinates fail every test and contribute zero
+    const bool vx0 = (x0f >= 0.0f) && (x0f <= wm1);
+    const bool vx1 = (x0f >= -1.0f) && (x0f <= wm1 - 1.0f);
+    const bool vy0 = (y0f >= 0.0f) && (y0f <= hm1);
+    const bool vy1 = (y0f >= -1.0f) && (y0f <= hm1 - 1.0f);
+    const int x0 = vx0 ? (int)x0f : 0;
+    const int x1 = vx1 ? (int)x0f + 1 : 0;
+    const int y0 = vy0 ? (int)y0f : 0;
+    const int y1 = vy1 ? (int)y0f + 1 : 0;
+    Taps t;
+    t.o00 = y0 * W + x0;
+    t.o01 = y0 * W + x1;
+    t.o10 = y1 * W + x0;
+    t.o11 = y1 * W + x1;
+    t.w00 = (vx0 && vy0) ? ey * ex : 0.0f;
+    t.w01 = (vx1 && vy0) ? ey * wx : 0.0f;
+    t.w10 = (vx0 && vy1) ? wy * ex : 0.0f;
+    t.w11 = (vx1 && vy1) ? wy * wx : 0.0f;
+    return t;
+}
+
+__device__ __forceinline__ float bilinear(const float* __restrict__ plane, const Taps& t) {
+    float acc = plane[t.o00] * t.w00;
+    acc = fmaf(plane[t.o01], t.w01, acc);
+    acc = fmaf(plane[t.o10], t.w10, acc);
+    acc = fmaf(plane[t.o11], t.w11, acc);
+    return acc;
+}
+
+__device__ __forceinline__ bool sweep_outside(float un, float vn, float z) {
+    return (un > 1.0f) || (un < -1.0f) || (vn > 1.0f) || (vn < -1.0f) || (z <= 0.0f);
+}
+
+}  // namespace mvs

@@ -1,0 +1,49 @@
+"""Drop the MI355X path into an unmodified reference checkout.
+
+``models/mvsformer_model.py`` binds its hot-path symbols at import time (``from models.module import *`` and
+``from models.warping import homo_warping_3D_with_mask``, reference lines 6-7) and constructs ``StageNet`` by
+name (lines 203 / 347).  ``install()`` rebinds exactly those names in the already-imported reference modules, so
+``DINOMVSNet`` / ``TwinMVSNet`` build their ``fusions`` from the HIP-backed classes and ``load_state_dict`` of a
+reference checkpoint keeps working (identical keys).  See INTEGRATION.md.
+"""
+from __future__ import annotations
+
+import importlib
+
+from . import module as _m
+from . import stagenet as _s
+from . import warping as _w
+
+_SYMBOLS = {
+    "StageNet": _s.StageNet,
+    "CostRegNet": _m.CostRegNet,
+    "CostRegNet3D": _m.CostRegNet3D,
+    "Conv3d": _m.Conv3d,
+    "Deconv3d": _m.Deconv3d,
+    "depth_regression": _m.depth_regression,
+    "conf_regression": _m.conf_regression,
+    "init_inverse_range": _m.init_inverse_range,
+    "schedule_inverse_range": _m.schedule_inverse_range,
+    "homo_warping_3D_with_mask": _w.homo_warping_3D_with_mask,
+}
+
+
+def install(model_module: str = "models.mvsformer_model", also=("models.module", "models.warping")) -> dict:
+    """Rebind the hot-path names inside the reference's modules.  Returns ``{module: [names rebound]}``."""
+    done = {}
+    for name in (model_module,) + tuple(also):
+        try:
+            mod = importlib.import_module(name)
+        except ImportError:
+            continue
+        hit = []
+        for sym, obj in _SYMBOLS.items():
+            if hasattr(mod, sym):
+                setattr(mod, sym, obj)
+                hit.append(sym)
+        for sym in ("homo_warping_3D", "diff_homo_warping_3D_with_mask"):
+            if hasattr(mod, sym):
+                setattr(mod, sym, getattr(_w, sym))
+                hit.append(sym)
+        done[name] = hit
+    return done

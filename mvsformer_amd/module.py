@@ -1,0 +1,297 @@
+"""Host-side mirror of the hot-path symbols of the reference's ``models/module.py``.
+
+Same class names, constructor signatures, forward signatures and ``state_dict`` keys as the reference
+(models/module.py:83-165 ``Conv3d``/``Deconv3d``, :168-197 ``ConvBnReLU``, :469-505 ``CostRegNet``, :550-594
+``CostRegNet3D``, :597-619 ``depth_regression``/``conf_regression``, :633-653 the inverse-depth schedulers), so a
+reference checkpoint loads with ``strict=True`` and ``models/mvsformer_model.py`` can use them unchanged.  The
+``nn.Conv3d`` / ``nn.BatchNorm3d`` children are parameter holders only (they keep ``.to()``, ``state_dict()``,
+DDP and SyncBatchNorm conversion working); every forward runs the hand-written HIP kernels of
+``libmvs_hip.so`` through :mod:`mvsformer_amd.ops`.  There is no PyTorch/CPU fallback.
+
+Eval-mode BatchNorm is folded into a per-channel ``scale``/``shift`` pair applied in the conv epilogue;
+folded parameters and the MFMA-friendly weight packing are cached and rebuilt when any parameter changes.
+Training-mode (batch-statistics BN + autograd) is not built yet and raises.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import MvsHipError
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _bn_fold(bn: nn.modules.batchnorm._BatchNorm) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Eval BatchNorm as y = x*scale + shift (fp32, on the module's device)."""
+    var = bn.running_var.detach().to(torch.float32)
+    mean = bn.running_mean.detach().to(torch.float32)
+    g = bn.weight.detach().to(torch.float32) if bn.weight is not None else torch.ones_like(var)
+    b = bn.bias.detach().to(torch.float32) if bn.bias is not None else torch.zeros_like(var)
+    scale = g / torch.sqrt(var + bn.eps)
+    return scale.contiguous(), (b - mean * scale).contiguous()
+
+
+def _versions(mod: nn.Module) -> tuple:
+    return tuple((t.data_ptr(), t._version) for t in list(mod.parameters()) + list(mod.buffers()))
+
+
+def _no_training(mod: nn.Module, what: str) -> None:
+    if mod.training:
+        raise MvsHipError(
+            "%s: training mode (batch-statistics BatchNorm + backward kernels) is not built in this round; call .eval(). "
+            "There is deliberately no PyTorch fallback." % what)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# layer holders (reference models/module.py:83-165, 168-197)
+# ---------------------------------------------------------------------------------------------------------
+class Conv3d(nn.Module):
+    """conv(bias = not bn) -> BatchNorm3d -> ReLU, as reference ``Conv3d`` (module.py:83-123)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, relu=True, bn=True, bn_momentum=0.1,
+                 init_method="xavier", **kwargs):
+        super().__init__()
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
+        self.bn = nn.BatchNorm3d(out_channels, momentum=bn_momentum) if bn else None
+        self.relu = relu
+        self._cache = None
+
+    def _prepared(self):
+        key = _versions(self)
+        if self._cache is None or self._cache[0] != key:
+            conv = self.conv
+            if tuple(conv.kernel_size) != (3, 3, 3) or tuple(conv.padding) != (1, 1, 1) or tuple(conv.dilation) != (1, 1, 1) \
+                    or conv.groups != 1:
+                raise MvsHipError("Conv3d: only kernel 3, padding 1, dilation 1, groups 1 is built (got %s)" % conv)
+            s = tuple(conv.stride)
+            if s not in ((1, 1, 1), (2, 2, 2), (1, 2, 2)):
+                raise MvsHipError("Conv3d: stride %s is not built" % (s,))
+            packed = ops.conv3d_pack(_f32c(conv.weight), transposed=False)
+            if self.bn is not None:
+                scale, shift = _bn_fold(self.bn)
+            else:
+                scale = None
+                shift = _f32c(conv.bias) if conv.bias is not None else None
+            self._cache = (key, packed, scale, shift, (s[0], s[1]))
+        return self._cache[1:]
+
+    def forward(self, x, residual: Optional[torch.Tensor] = None):
+        _no_training(self, "Conv3d")
+        packed, scale, shift, stride = self._prepared()
+        return ops.conv3d(x, packed, self.conv.in_channels, self.conv.out_channels, stride, scale, shift, residual,
+                          relu=self.relu, tag="conv3d_%dto%d_s%d%d" % (self.conv.in_channels, self.conv.out_channels, *stride))
+
+
+class Deconv3d(nn.Module):
+    """conv_transpose(bias = not bn) -> BatchNorm3d -> ReLU, as reference ``Deconv3d`` (module.py:126-165)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, relu=True, bn=True, bn_momentum=0.1,
+                 init_method="xavier", **kwargs):
+        super().__init__()
+        self.out_channels = out_channels
+        self.conv = nn.ConvTranspose3d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
+        self.bn = nn.BatchNorm3d(out_channels, momentum=bn_momentum) if bn else None
+        self.relu = relu
+        self._cache = None
+
+    def forward(self, x, residual: Optional[torch.Tensor] = None):
+        _no_training(self, "Deconv3d")
+        key = _versions(self)
+        if self._cache is None or self._cache[0] != key:
+            self._cache = (key,) + _prepare_deconv(self.conv, self.bn)
+        _, packed, scale, shift, sd = self._cache
+        return ops.deconv3d(x, packed, self.conv.in_channels, self.conv.out_channels, sd, scale, shift, residual,
+                            relu=self.relu, tag="deconv3d_%dto%d_s%d" % (self.conv.in_channels, self.conv.out_channels, sd))
+
+
+def _prepare_deconv(conv: nn.ConvTranspose3d, bn):
+    s, op = tuple(conv.stride), tuple(conv.output_padding)
+    if tuple(conv.kernel_size) != (3, 3, 3) or tuple(conv.padding) != (1, 1, 1) or conv.groups != 1:
+        raise MvsHipError("Deconv3d: only kernel 3, padding 1, groups 1 is built (got %s)" % conv)
+    if not ((s == (2, 2, 2) and op == (1, 1, 1)) or (s == (1, 2, 2) and op == (0, 1, 1))):
+        raise MvsHipError("Deconv3d: stride %s / output_padding %s is not built" % (s, op))
+    packed = ops.conv3d_pack(_f32c(conv.weight), transposed=True)
+    if bn is not None:
+        scale, shift = _bn_fold(bn)
+    else:
+        scale, shift = None, (_f32c(conv.bias) if conv.bias is not None else None)
+    return packed, scale, shift, s[0]
+
+
+class ConvBnReLU(nn.Module):
+    """2-D conv(bias=False) -> BatchNorm2d -> ReLU holder (reference module.py:168-197).  Used only inside
+    ``StageNet.vis``, whose four layers run as one fused HIP launch (:func:`pack_vis_params`)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, stride: int = 1, pad: int = 1, dilation: int = 1):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, dilation=dilation, bias=False)
+        self.bn = nn.BatchNorm2d(out_channels)
+
+    def forward(self, x):
+        raise MvsHipError("ConvBnReLU is a parameter holder; the fused visibility CNN runs through StageNet (mvs_vis_fwd)")
+
+
+def pack_vis_params(vis: nn.Sequential) -> torch.Tensor:
+    """Flatten ``StageNet.vis`` (ConvBnReLU(1,16), ConvBnReLU(16,16), ConvBnReLU(16,8), Conv2d(8,1,1), Sigmoid) into the
+    3689-float parameter block of ``mvs_vis_fwd`` (layout documented in csrc/vis_net.hip)."""
+    c0, c1, c2, c3 = vis[0], vis[1], vis[2], vis[3]
+    shapes = [tuple(c.conv.weight.shape) for c in (c0, c1, c2)] + [tuple(c3.weight.shape)]
+    if shapes != [(16, 1, 3, 3), (16, 16, 3, 3), (8, 16, 3, 3), (1, 8, 1, 1)]:
+        raise MvsHipError("vis CNN has unexpected shapes %s" % (shapes,))
+    parts = []
+    for c in (c0, c1, c2):
+        w = _f32c(c.conv.weight)                               # [cout, cin, 3, 3] -> [cin, tap, cout]
+        parts.append(w.permute(1, 2, 3, 0).reshape(-1))
+        s, b = _bn_fold(c.bn)
+        parts += [s, b]
+    parts += [_f32c(c3.weight).reshape(-1), _f32c(c3.bias).reshape(-1)]
+    out = torch.cat(parts).contiguous()
+    assert out.numel() == ops.VIS_PARAM_FLOATS
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# regularizers (reference models/module.py:469-505, 550-594)
+# ---------------------------------------------------------------------------------------------------------
+class CostRegNet(nn.Module):
+    """3-D U-Net with stride-2 down/up-sampling in D, H, W (reference ``CostRegNet``).  ``forward(x[B,Cin,D,H,W])``
+    returns ``[B,1,D,H,W]`` logits (``[B,base,D,H,W]`` features if ``last_layer=False``)."""
+
+    def __init__(self, in_channels, base_channels, last_layer=True):
+        super().__init__()
+        self.last_layer = last_layer
+        b = base_channels
+        self.conv1 = Conv3d(in_channels, b * 2, stride=2, padding=1)
+        self.conv2 = Conv3d(b * 2, b * 2, padding=1)
+        self.conv3 = Conv3d(b * 2, b * 4, stride=2, padding=1)
+        self.conv4 = Conv3d(b * 4, b * 4, padding=1)
+        self.conv5 = Conv3d(b * 4, b * 8, stride=2, padding=1)
+        self.conv6 = Conv3d(b * 8, b * 8, padding=1)
+        self.conv7 = Deconv3d(b * 8, b * 4, stride=2, padding=1, output_padding=1)
+        self.conv9 = Deconv3d(b * 4, b * 2, stride=2, padding=1, output_padding=1)
+        self.conv11 = Deconv3d(b * 2, b * 1, stride=2, padding=1, output_padding=1)
+        if in_channels != base_channels:
+            self.inner = nn.Conv3d(in_channels, base_channels, 1, 1)
+        else:
+            self.inner = nn.Identity()
+        if self.last_layer:
+            self.prob = nn.Conv3d(base_channels, 1, 3, stride=1, padding=1, bias=False)
+
+    def features(self, x: torch.Tensor) -> torch.Tensor:
+        """Everything up to (not including) ``prob``; residual adds are fused into the deconv epilogues."""
+        _no_training(self, "CostRegNet")
+        if not isinstance(self.inner, nn.Identity):
+            raise MvsHipError("CostRegNet: in_channels != base_channels (1x1x1 'inner' conv) is not built")
+        x = x.to(torch.float32).contiguous()
+        if x.shape[2] % 8 or x.shape[3] % 8 or x.shape[4] % 8:
+            raise MvsHipError("CostRegNet needs D, H, W divisible by 8 (three stride-2 levels), got %s" % (tuple(x.shape[2:]),))
+        c2 = self.conv2(self.conv1(x))
+        c4 = self.conv4(self.conv3(c2))
+        y = self.conv6(self.conv5(c4))
+        y = self.conv7(y, residual=c4)
+        y = self.conv9(y, residual=c2)
+        return self.conv11(y, residual=x)
+
+    def forward(self, x):
+        y = self.features(x)
+        if self.last_layer:
+            y = ops.prob3(y, _f32c(self.prob.weight)).unsqueeze(1)
+        return y
+
+
+def _deconv_seq(cin, cout):
+    return nn.Sequential(
+        nn.ConvTranspose3d(cin, cout, kernel_size=3, padding=1, output_padding=(0, 1, 1), stride=(1, 2, 2), bias=False),
+        nn.BatchNorm3d(cout), nn.ReLU(inplace=True))
+
+
+class CostRegNet3D(nn.Module):
+    """3-D U-Net with stride (1,2,2): depth resolution kept (reference ``CostRegNet3D``).  The decoder layers are
+    ``nn.Sequential(ConvTranspose3d, BatchNorm3d, ReLU)`` so the checkpoint keys are ``convN.0.weight`` / ``convN.1.*``."""
+
+    def __init__(self, in_channels, base_channel=8):
+        super().__init__()
+        b = base_channel
+        self.conv1 = Conv3d(in_channels, b * 2, kernel_size=3, stride=(1, 2, 2), padding=1)
+        self.conv2 = Conv3d(b * 2, b * 2, padding=1)
+        self.conv3 = Conv3d(b * 2, b * 4, kernel_size=3, stride=(1, 2, 2), padding=1)
+        self.conv4 = Conv3d(b * 4, b * 4, padding=1)
+        self.conv5 = Conv3d(b * 4, b * 8, kernel_size=3, stride=(1, 2, 2), padding=1)
+        self.conv6 = Conv3d(b * 8, b * 8, padding=1)
+        self.conv7 = _deconv_seq(b * 8, b * 4)
+        self.conv9 = _deconv_seq(b * 4, b * 2)
+        self.conv11 = _deconv_seq(b * 2, b)
+        if in_channels != base_channel:
+            self.inner = nn.Conv3d(in_channels, base_channel, 1, 1)
+        else:
+            self.inner = nn.Identity()
+        self.prob = nn.Conv3d(base_channel, 1, 1, stride=1, padding=0)
+        self._dcache: Dict[str, tuple] = {}
+
+    def _up(self, name: str, x, residual):
+        seq = getattr(self, name)
+        key = _versions(seq)
+        c = self._dcache.get(name)
+        if c is None or c[0] != key:
+            c = (key,) + _prepare_deconv(seq[0], seq[1])
+            self._dcache[name] = c
+        _, packed, scale, shift, sd = c
+        return ops.deconv3d(x, packed, seq[0].in_channels, seq[0].out_channels, sd, scale, shift, residual, relu=True,
+                            tag="deconv3d_%dto%d_s%d" % (seq[0].in_channels, seq[0].out_channels, sd))
+
+    def features(self, x: torch.Tensor) -> torch.Tensor:
+        _no_training(self, "CostRegNet3D")
+        if not isinstance(self.inner, nn.Identity):
+            raise MvsHipError("CostRegNet3D: in_channels != base_channel (1x1x1 'inner' conv) is not built")
+        x = x.to(torch.float32).contiguous()
+        if x.shape[3] % 8 or x.shape[4] % 8:
+            raise MvsHipError("CostRegNet3D needs H, W divisible by 8 (three stride-2 levels), got %s" % (tuple(x.shape[3:]),))
+        c2 = self.conv2(self.conv1(x))
+        c4 = self.conv4(self.conv3(c2))
+        y = self.conv6(self.conv5(c4))
+        y = self._up("conv7", y, c4)
+        y = self._up("conv9", y, c2)
+        return self._up("conv11", y, x)
+
+    def prob_params(self):
+        return _f32c(self.prob.weight).reshape(-1), _f32c(self.prob.bias).reshape(-1)
+
+    def forward(self, x):
+        y = self.features(x)
+        w, b = self.prob_params()
+        return ops.prob1(y, w, b)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# heads and schedulers (reference models/module.py:597-619, 633-653)
+# ---------------------------------------------------------------------------------------------------------
+def depth_regression(p, depth_values):
+    """``sum_d p * depth_values``; ``depth_values`` is ``[B,D,H,W]`` or ``[B,D]`` (reference module.py:597-603)."""
+    if depth_values.dim() > 2 and depth_values.shape != p.shape:
+        depth_values = depth_values.expand_as(p)
+    return ops.depth_regression(p.to(torch.float32).contiguous(), depth_values.to(torch.float32).contiguous())
+
+
+def conf_regression(p, n=4):
+    """Windowed probability mass around the expected index (reference module.py:606-619)."""
+    return ops.conf_regression(p.detach().to(torch.float32).contiguous(), n)
+
+
+def init_inverse_range(cur_depth, ndepths, device, dtype, H, W):
+    """Reference signature (module.py:633); ``device``/``dtype`` are accepted for compatibility, output is fp32 on
+    ``cur_depth``'s device."""
+    return ops.init_inverse_range(cur_depth.to(torch.float32).contiguous(), ndepths, H, W)
+
+
+def schedule_inverse_range(depth, depth_hypo, ndepths, split_itv, H, W):
+    """Reference signature (module.py:642)."""
+    return ops.schedule_inverse_range(depth.to(torch.float32).contiguous(), depth_hypo.to(torch.float32).contiguous(),
+                                      ndepths, float(split_itv), H, W)

@@ -1,0 +1,283 @@
+"""Tensor-level wrappers over the C ABI (include/mvs_hip.h): argument checks, output allocation, stream plumbing.
+
+PyTorch is used here for device memory (caching allocator) and the current HIP stream only; every FLOP of the
+path runs in libmvs_hip.so.  All functions require CUDA(ROCm) float32 contiguous tensors and raise otherwise —
+there is no fallback.  ``KernelTimer`` (used by bench.py) brackets each launch with HIP events recorded on the
+launch stream to get per-kernel durations live.
+"""
+from __future__ import annotations
+
+import contextlib
+from collections import defaultdict
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+VIS_PARAM_FLOATS = 3689
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.MvsHipError("%s must be a GPU tensor: the MI355X HIP path is the only implementation (no CPU fallback)" % name)
+    if t.dtype != dtype:
+        raise _lib.MvsHipError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise _lib.MvsHipError("%s must be contiguous" % name)
+    return t
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ----------------------------------------------------------------------------------------------- timing hook
+class KernelTimer:
+    """Collects (start, end) HIP events per C-ABI launch, on the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.events: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]] = defaultdict(list)
+
+    def summary(self) -> Dict[str, Dict[str, float]]:
+        torch.cuda.synchronize()
+        out = {}
+        for k, evs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[k] = {"calls": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / max(1, len(ms))}
+        return out
+
+
+_timer: Optional[KernelTimer] = None
+
+
+@contextlib.contextmanager
+def kernel_timer():
+    global _timer
+    prev, _timer = _timer, KernelTimer()
+    try:
+        yield _timer
+    finally:
+        _timer = prev
+
+
+def _call(name: str, tag: Optional[str], *args):
+    fn = getattr(_lib.load(), name)
+    if _timer is not None:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*args)
+        b.record()
+        _timer.events[tag or name].append((a, b))
+    else:
+        rc = fn(*args)
+    _lib.check(rc, name)
+
+
+# ----------------------------------------------------------------------------------------------- projection
+def proj_prepare(proj: torch.Tensor) -> torch.Tensor:
+    """``proj [B,V,2,4,4]`` -> ``rt [B,V-1,12]`` (reference mvsformer_model.py:69-72 + warping.py:80-82)."""
+    _chk(proj, "proj")
+    B, V = proj.shape[0], proj.shape[1]
+    if proj.shape[2:] != (2, 4, 4) or V < 2:
+        raise _lib.MvsHipError("proj must be [B,V>=2,2,4,4], got %s" % (tuple(proj.shape),))
+    rt = torch.empty(B, V - 1, 12, device=proj.device, dtype=torch.float32)
+    _call("mvs_proj_prepare", None, _ptr(proj), B, V, _ptr(rt), _stream())
+    return rt
+
+
+def proj_relative(src_proj: torch.Tensor, ref_proj: torch.Tensor) -> torch.Tensor:
+    _chk(src_proj, "src_proj"), _chk(ref_proj, "ref_proj")
+    B = src_proj.shape[0]
+    if src_proj.shape != (B, 4, 4) or ref_proj.shape != (B, 4, 4):
+        raise _lib.MvsHipError("src_proj/ref_proj must be [B,4,4]")
+    rt = torch.empty(B, 12, device=src_proj.device, dtype=torch.float32)
+    _call("mvs_proj_relative", None, _ptr(src_proj), _ptr(ref_proj), B, _ptr(rt), _stream())
+    return rt
+
+
+# ----------------------------------------------------------------------------------------------- warp
+def warp(src: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, with_mask: bool = True):
+    _chk(src, "src_fea"), _chk(rt, "rt"), _chk(depth, "depth_values")
+    B, C, H, W = src.shape
+    D = depth.shape[1]
+    per_pixel = depth.dim() == 4
+    if per_pixel and depth.shape != (B, D, H, W):
+        raise _lib.MvsHipError("depth_values must be [B,D,H,W] or [B,D], got %s" % (tuple(depth.shape),))
+    if not per_pixel and depth.shape != (B, D):
+        raise _lib.MvsHipError("depth_values must be [B,D,H,W] or [B,D], got %s" % (tuple(depth.shape),))
+    warped = torch.empty(B, C, D, H, W, device=src.device, dtype=torch.float32)
+    mask = torch.empty(B, D, H, W, device=src.device, dtype=torch.uint8) if with_mask else None
+    _call("mvs_warp_fwd", None, _ptr(src), _ptr(rt), _ptr(depth), int(per_pixel), B, C, D, H, W, _ptr(warped), _ptr(mask), _stream())
+    return warped, (mask.bool() if with_mask else None)
+
+
+# ----------------------------------------------------------------------------------------------- cost volume
+def cv_entropy(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, G: int) -> torch.Tensor:
+    _chk(feat, "features"), _chk(rt, "rt"), _chk(depth, "depth_values")
+    B, V, C, H, W = feat.shape
+    D = depth.shape[1]
+    if depth.shape != (B, D, H, W):
+        raise _lib.MvsHipError("depth_values must be [B,D,H,W]=%s, got %s" % ((B, D, H, W), tuple(depth.shape)))
+    ent = torch.empty(B, V - 1, H, W, device=feat.device, dtype=torch.float32)
+    _call("mvs_cv_entropy_fwd", "mvs_cv_entropy_fwd", _ptr(feat), _ptr(rt), _ptr(depth), B, V, C, G, D, H, W, _ptr(ent), _stream())
+    return ent
+
+
+def vis(entropy: torch.Tensor, params: torch.Tensor) -> torch.Tensor:
+    _chk(entropy, "entropy"), _chk(params, "vis params")
+    if params.numel() != VIS_PARAM_FLOATS:
+        raise _lib.MvsHipError("vis params must hold %d floats" % VIS_PARAM_FLOATS)
+    H, W = entropy.shape[-2:]
+    N = entropy.numel() // (H * W)
+    out = torch.empty_like(entropy)
+    _call("mvs_vis_fwd", None, _ptr(entropy), _ptr(params), N, H, W, _ptr(out), _stream())
+    return out
+
+
+def cv_aggregate(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, weight: torch.Tensor, G: int,
+                 want_sim_depth: bool):
+    _chk(feat, "features"), _chk(rt, "rt"), _chk(depth, "depth_values"), _chk(weight, "vis_weight")
+    B, V, C, H, W = feat.shape
+    D = depth.shape[1]
+    vol = torch.empty(B, G, D, H, W, device=feat.device, dtype=torch.float32)
+    sim = torch.empty(B, H, W, device=feat.device, dtype=torch.float32) if want_sim_depth else None
+    _call("mvs_cv_aggregate_fwd", "mvs_cv_aggregate_fwd", _ptr(feat), _ptr(rt), _ptr(depth), _ptr(weight), B, V, C, G, D, H, W,
+          _ptr(vol), _ptr(sim), _stream())
+    return vol, sim
+
+
+# ----------------------------------------------------------------------------------------------- 3-D convs
+def conv3d_pack(weight: torch.Tensor, transposed: bool) -> torch.Tensor:
+    _chk(weight, "conv weight")
+    if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3):
+        raise _lib.MvsHipError("conv weight must be [*,*,3,3,3], got %s" % (tuple(weight.shape),))
+    cin, cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
+    n = _lib.load().mvs_conv3d_packed_floats(cin, cout)
+    if n <= 0:
+        raise _lib.MvsHipError("unsupported conv channels Cin=%d Cout=%d" % (cin, cout))
+    packed = torch.empty(n, device=weight.device, dtype=torch.float32)
+    _call("mvs_conv3d_pack_weights", None, _ptr(weight), cin, cout, int(transposed), _ptr(packed), _stream())
+    return packed
+
+
+def conv3d(x, wpacked, cin, cout, stride, scale=None, shift=None, residual=None, relu=True, tag=None):
+    _chk(x, "x"), _chk(wpacked, "packed weights")
+    B, C, Di, Hi, Wi = x.shape
+    assert C == cin
+    sd, shw = stride
+    Do, Ho, Wo = (Di - 1) // sd + 1, (Hi - 1) // shw + 1, (Wi - 1) // shw + 1
+    y = torch.empty(B, cout, Do, Ho, Wo, device=x.device, dtype=torch.float32)
+    if residual is not None:
+        _chk(residual, "residual")
+        if residual.shape != y.shape:
+            raise _lib.MvsHipError("residual shape %s != output %s" % (tuple(residual.shape), tuple(y.shape)))
+    _call("mvs_conv3d_fwd", tag or "mvs_conv3d_fwd", _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), B, cin, cout,
+          Di, Hi, Wi, sd, shw, int(relu), _stream())
+    return y
+
+
+def deconv3d(x, wpacked, cin, cout, sd, scale=None, shift=None, residual=None, relu=True, tag=None):
+    _chk(x, "x"), _chk(wpacked, "packed weights")
+    B, C, Di, Hi, Wi = x.shape
+    assert C == cin
+    y = torch.empty(B, cout, Di * sd, Hi * 2, Wi * 2, device=x.device, dtype=torch.float32)
+    if residual is not None:
+        _chk(residual, "residual")
+        if residual.shape != y.shape:
+            raise _lib.MvsHipError("residual shape %s != output %s (stage H, W must be divisible by 8%s)" % (
+                tuple(residual.shape), tuple(y.shape), ", D by 8" if sd == 2 else ""))
+    _call("mvs_deconv3d_fwd", tag or "mvs_deconv3d_fwd", _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), B, cin,
+          cout, Di, Hi, Wi, sd, int(relu), _stream())
+    return y
+
+
+def prob3(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    _chk(x, "x"), _chk(w, "prob weight")
+    B, C, D, H, W = x.shape
+    out = torch.empty(B, D, H, W, device=x.device, dtype=torch.float32)
+    _call("mvs_prob3_fwd", None, _ptr(x), _ptr(w), B, C, D, H, W, _ptr(out), _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- head
+def head(depth_values: torch.Tensor, tmp: float, training: bool, logits: Optional[torch.Tensor] = None,
+         x8: Optional[torch.Tensor] = None, w1: Optional[torch.Tensor] = None, b1: Optional[torch.Tensor] = None):
+    _chk(depth_values, "depth_values")
+    B, D, H, W = depth_values.shape
+    dev = depth_values.device
+    prob = torch.empty(B, D, H, W, device=dev, dtype=torch.float32)
+    depth = torch.empty(B, H, W, device=dev, dtype=torch.float32)
+    conf = torch.empty(B, H, W, device=dev, dtype=torch.float32)
+    if x8 is not None:
+        _chk(x8, "x8"), _chk(w1, "prob.weight"), _chk(b1, "prob.bias")
+        if x8.shape[0] != B or tuple(x8.shape[2:]) != (D, H, W):
+            raise _lib.MvsHipError("x8 %s does not match depth_values %s" % (tuple(x8.shape), tuple(depth_values.shape)))
+        pre = torch.empty(B, D, H, W, device=dev, dtype=torch.float32)
+        _call("mvs_head_fwd", None, None, _ptr(x8), _ptr(w1), _ptr(b1), x8.shape[1], _ptr(depth_values), float(tmp), int(training),
+              B, D, H, W, _ptr(pre), _ptr(prob), _ptr(depth), _ptr(conf), _stream())
+    else:
+        _chk(logits, "logits")
+        if logits.shape != depth_values.shape:
+            raise _lib.MvsHipError("logits %s != depth_values %s" % (tuple(logits.shape), tuple(depth_values.shape)))
+        pre = logits
+        _call("mvs_head_fwd", None, _ptr(logits), None, None, None, 0, _ptr(depth_values), float(tmp), int(training), B, D, H, W,
+              None, _ptr(prob), _ptr(depth), _ptr(conf), _stream())
+    return pre, prob, depth, conf
+
+
+def depth_regression(p: torch.Tensor, depth_values: torch.Tensor) -> torch.Tensor:
+    _chk(p, "p"), _chk(depth_values, "depth_values")
+    B, D, H, W = p.shape
+    per_pixel = depth_values.dim() == 4
+    if (per_pixel and depth_values.shape != p.shape) or (not per_pixel and depth_values.shape != (B, D)):
+        raise _lib.MvsHipError("depth_values %s does not match p %s" % (tuple(depth_values.shape), tuple(p.shape)))
+    out = torch.empty(B, H, W, device=p.device, dtype=torch.float32)
+    _call("mvs_depth_regression", None, _ptr(p), _ptr(depth_values), int(per_pixel), B, D, H, W, _ptr(out), _stream())
+    return out
+
+
+def conf_regression(p: torch.Tensor, n: int) -> torch.Tensor:
+    _chk(p, "p")
+    B, D, H, W = p.shape
+    out = torch.empty(B, H, W, device=p.device, dtype=torch.float32)
+    _call("mvs_conf_regression", None, _ptr(p), int(n), B, D, H, W, _ptr(out), _stream())
+    return out
+
+
+def prob1(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    _chk(x, "x"), _chk(w, "prob.weight")
+    B, C, D, H, W = x.shape
+    out = torch.empty(B, 1, D, H, W, device=x.device, dtype=torch.float32)
+    _call("mvs_prob1_fwd", None, _ptr(x), _ptr(w), _ptr(bias), B, C, D * H * W, _ptr(out), _stream())
+    return out
+
+
+def init_inverse_range(depth_range: torch.Tensor, ndepths: int, H: int, W: int) -> torch.Tensor:
+    _chk(depth_range, "depth_values")
+    B, N = depth_range.shape
+    hyp = torch.empty(B, ndepths, H, W, device=depth_range.device, dtype=torch.float32)
+    _call("mvs_init_inverse_range", None, _ptr(depth_range), N, B, ndepths, H, W, _ptr(hyp), _stream())
+    return hyp
+
+
+def schedule_inverse_range(prev_depth: torch.Tensor, prev_hyp: torch.Tensor, ndepths: int, split_itv: float, H: int, W: int):
+    _chk(prev_depth, "depth"), _chk(prev_hyp, "depth_hypo")
+    B, Dp, Hl, Wl = prev_hyp.shape
+    if prev_depth.shape != (B, Hl, Wl) or (Hl, Wl) != (H // 2, W // 2):
+        raise _lib.MvsHipError("schedule_inverse_range: previous stage %s / %s is not half of (%d,%d)" % (
+            tuple(prev_depth.shape), tuple(prev_hyp.shape), H, W))
+    hyp = torch.empty(B, ndepths, H, W, device=prev_depth.device, dtype=torch.float32)
+    _call("mvs_schedule_inverse_range", None, _ptr(prev_depth), _ptr(prev_hyp), Dp, float(split_itv), B, ndepths, H, W, _ptr(hyp), _stream())
+    return hyp
+
+
+def conf_accumulate(conf: torch.Tensor, acc: torch.Tensor, weight: float = 1.0) -> None:
+    _chk(conf, "photometric_confidence"), _chk(acc, "prob_maps")
+    B, H, W = conf.shape
+    _, Hf, Wf = acc.shape
+    _call("mvs_conf_accumulate", None, _ptr(conf), B, H, W, _ptr(acc), Hf, Wf, float(weight), _stream())

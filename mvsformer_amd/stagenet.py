@@ -1,0 +1,85 @@
+"""``StageNet`` — one cascade stage of the plane-sweep path, drop-in for the reference class of the same name
+(models/mvsformer_model.py:26-160): same constructor ``StageNet(args, ndepth, stage_idx)``, same
+``forward(features, proj_matrices, depth_values, tmp=2.0)``, same output dict keys, same ``state_dict`` keys
+(``vis.{0,1,2}.{conv,bn}.*``, ``vis.3.*``, ``cost_reg.*``).
+
+Where the reference runs ~40 ATen launches per source view over materialized [B,C,D,H,W] temporaries, this
+forward is 5 + 10 hand-written HIP launches per stage:
+
+    mvs_proj_prepare -> mvs_cv_entropy_fwd -> mvs_vis_fwd -> mvs_cv_aggregate_fwd
+    -> 9 fused conv/deconv MFMA layers -> (mvs_prob3_fwd) -> mvs_head_fwd
+
+``DepthNet`` is the name BASELINE.json uses for the same thing.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import MvsHipError
+from .module import ConvBnReLU, CostRegNet, CostRegNet3D, _versions, pack_vis_params
+
+
+class StageNet(nn.Module):
+    def __init__(self, args, ndepth, stage_idx):
+        super().__init__()
+        self.args = args
+        self.fusion_type = args.get("fusion_type", "cnn")
+        self.ndepth = ndepth
+        self.stage_idx = stage_idx
+        in_channels = args["base_ch"]
+        if self.fusion_type != "cnn":
+            raise NotImplementedError(
+                "fusion_type=%r: only 'cnn' (every shipped reference config) is built for MI355X" % self.fusion_type)
+        model_th = args.get("model_th", 8)
+        self.vis = nn.Sequential(ConvBnReLU(1, 16), ConvBnReLU(16, 16), ConvBnReLU(16, 8), nn.Conv2d(8, 1, 1), nn.Sigmoid())
+        if ndepth <= model_th:
+            self.cost_reg = CostRegNet3D(in_channels, args["base_ch"])
+        else:
+            self.cost_reg = CostRegNet(in_channels, args["base_ch"])
+        self._vis_cache = None
+
+    def _vis_params(self) -> torch.Tensor:
+        key = _versions(self.vis)
+        if self._vis_cache is None or self._vis_cache[0] != key:
+            self._vis_cache = (key, pack_vis_params(self.vis))
+        return self._vis_cache[1]
+
+    def forward(self, features, proj_matrices, depth_values, tmp=2.0):
+        """``features [B,V,C,H,W]`` (view 0 = reference), ``proj_matrices [B,V,2,4,4]``, ``depth_values [B,D,H,W]``."""
+        if self.training:
+            raise MvsHipError("StageNet: training mode is not built in this round (eval / torch.no_grad inference only)")
+        depth_type = self.args["depth_type"]
+        if depth_type not in ("ce", "was"):
+            raise NotImplementedError("depth_type=%r: only 'ce'/'was' heads are built" % depth_type)
+        if features.shape[1] != proj_matrices.shape[1]:
+            raise AssertionError("Different number of images and projection matrices")
+        G = self.args["base_ch"]
+        feat = features.detach().to(torch.float32).contiguous()
+        proj = proj_matrices.detach().to(torch.float32).contiguous()
+        hyp = depth_values.detach().to(torch.float32).contiguous()
+        if hyp.dim() != 4:
+            raise MvsHipError("depth_values must be [B,D,H,W]")
+
+        # step 2 of the reference forward: fused warp + group correlation + visibility-weighted aggregation
+        rt = ops.proj_prepare(proj)
+        entropy = ops.cv_entropy(feat, rt, hyp, G)
+        weight = ops.vis(entropy, self._vis_params())
+        volume, sim_depth = ops.cv_aggregate(feat, rt, hyp, weight, G, want_sim_depth=True)
+
+        # step 3: regularization + head
+        if type(tmp) == list:
+            tmp = tmp[self.stage_idx]
+        x = self.cost_reg.features(volume)
+        if isinstance(self.cost_reg, CostRegNet3D):
+            w1, b1 = self.cost_reg.prob_params()
+            pre, prob, depth, conf = ops.head(hyp, float(tmp), False, x8=x, w1=w1, b1=b1)
+        else:
+            logits = ops.prob3(x, self.cost_reg.prob.weight.detach().to(torch.float32).contiguous())
+            pre, prob, depth, conf = ops.head(hyp, float(tmp), False, logits=logits)
+        return {"depth": depth, "prob_volume": prob, "photometric_confidence": conf, "depth_values": depth_values,
+                "prob_volume_pre": pre, "sim_depth": sim_depth}
+
+
+DepthNet = StageNet

@@ -1,0 +1,95 @@
+"""CPU-side checks of the C-ABI boundary: the header, the ctypes table and the built library agree, the
+package mirrors the reference's interface (names, signatures, state_dict keys), and there is no CPU fallback."""
+import inspect
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import GOLDEN, REPO
+
+HEADER = os.path.join(REPO, "include", "mvs_hip.h")
+
+
+def header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|int64_t|char\s*\*|const char\s*\*)\s+(mvs_\w+)\s*\(", src, flags=re.M)
+    protos = {}
+    for m in re.finditer(r"(mvs_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    return names, protos
+
+
+def test_header_matches_ctypes_table():
+    from mvsformer_amd import _lib
+    names, protos = header_functions()
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    for n, (_, args) in _lib.SIGNATURES.items():
+        assert protos[n] == len(args), (n, protos[n], len(args))
+
+
+def test_library_exports_every_symbol():
+    from mvsformer_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _lib.load()               # binds every symbol of SIGNATURES or raises
+    assert lib.mvs_version() == _lib.ABI_VERSION
+    names, _ = header_functions()
+    for n in names:
+        assert hasattr(lib, n)
+    assert lib.mvs_conv3d_packed_floats(8, 16) == 2 * 27 * 4 * 16
+    assert lib.mvs_conv3d_packed_floats(64, 64) == 16 * 27 * 4 * 80
+
+
+def test_state_dict_keys_match_reference():
+    import mvsformer_amd as m
+    shapes = json.load(open(os.path.join(GOLDEN, "state_dict_shapes.json")))
+    args = dict(base_ch=8, fusion_type="cnn", depth_type="ce")
+    for kind, nd in (("stage_costregnet", 16), ("stage_costregnet3d", 4)):
+        net = m.StageNet(dict(args), nd, 0)
+        mine = {k: list(v.shape) for k, v in net.state_dict().items()}
+        assert list(mine.keys()) == list(shapes[kind].keys())
+        assert mine == shapes[kind]
+    assert m.DepthNet is m.StageNet and m.homo_warping is m.homo_warping_3D
+
+
+def test_reference_signatures():
+    import mvsformer_amd as m
+    assert list(inspect.signature(m.StageNet.__init__).parameters) == ["self", "args", "ndepth", "stage_idx"]
+    assert list(inspect.signature(m.StageNet.forward).parameters) == ["self", "features", "proj_matrices", "depth_values", "tmp"]
+    assert inspect.signature(m.StageNet.forward).parameters["tmp"].default == 2.0
+    assert list(inspect.signature(m.homo_warping_3D_with_mask).parameters) == ["src_fea", "src_proj", "ref_proj", "depth_values"]
+    assert list(inspect.signature(m.CostRegNet.__init__).parameters) == ["self", "in_channels", "base_channels", "last_layer"]
+    assert list(inspect.signature(m.CostRegNet3D.__init__).parameters) == ["self", "in_channels", "base_channel"]
+    assert list(inspect.signature(m.depth_regression).parameters) == ["p", "depth_values"]
+    assert list(inspect.signature(m.schedule_inverse_range).parameters) == ["depth", "depth_hypo", "ndepths", "split_itv", "H", "W"]
+    with pytest.raises(NotImplementedError):
+        m.StageNet(dict(base_ch=8, fusion_type="epipole", depth_type="ce"), 8, 0)
+
+
+def test_no_cpu_fallback():
+    """CPU tensors must be refused loudly, not silently computed some other way."""
+    import mvsformer_amd as m
+    from mvsformer_amd._lib import MvsHipError
+    with pytest.raises(MvsHipError):
+        m.homo_warping_3D_with_mask(torch.zeros(1, 8, 4, 4), torch.eye(4)[None], torch.eye(4)[None], torch.ones(1, 2))
+    net = m.StageNet(dict(base_ch=8, fusion_type="cnn", depth_type="ce"), 4, 0).eval()
+    with pytest.raises(MvsHipError):
+        net(torch.zeros(1, 3, 8, 8, 8), torch.zeros(1, 3, 2, 4, 4), torch.ones(1, 4, 8, 8))
+    net.train()
+    with pytest.raises(MvsHipError):
+        net(torch.zeros(1, 3, 8, 8, 8), torch.zeros(1, 3, 2, 4, 4), torch.ones(1, 4, 8, 8))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(REPO, "mvsformer_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
