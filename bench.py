@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""bench.py — depth maps/s of the MI355X plane-sweep cost-volume path (BASELINE.json metric).
+
+One "step" = one full 4-stage hot-path cascade (hypotheses -> fused cost volume -> 3-D U-Net -> softmax
+regression, stages 32/16/8/4 hypotheses) for ONE reference view at BASELINE config 2: 1536x1152, 5 views,
+192-plane DTU depth range, fp32, given precomputed per-stage feature maps already resident in HBM (feature
+extraction is outside the path).  Synthetic photo-consistent DTU-shaped inputs, random-init
+weights with randomized BatchNorm statistics.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+N > 1 is inference sharding: every rank runs the cascade for its own reference views, no data-path
+collective (weak scaling); the only collectives are the timing barrier and the MAX over ranks.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, timed live with HIP events on the launch
+stream) and `cpu_baseline` (the torch-CPU oracle on a bounded sample, rank 0 / N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_16x16x4_f32)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--height", type=int, default=1152)
+    ap.add_argument("--width", type=int, default=1536)
+    ap.add_argument("--views", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-div", type=int, default=4, help="CPU baseline runs on (H/div)x(W/div)")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(net, args):
+    """The oracle (torch CPU, all host cores) on a bounded sample: same cascade, same views/depths, 1/div^2 of the pixels."""
+    from mvsformer_amd import synth
+    from oracle import ref_torch
+    div = args.cpu_sample_div
+    H, W = args.height // div, args.width // div
+    H, W = H - H % 64, W - W % 64
+    cores = min(os.cpu_count() or 1, 64)       # torch's intra-op pool stops scaling (and oversubscribes) beyond this
+    torch.set_num_threads(cores)
+    feats, proj, dv, _ = synth.make_inputs(args.views, H, W, seed=0)
+    sds = [{k: v.detach().cpu() for k, v in f.state_dict().items()} for f in net.fusions]
+    t0 = time.time()
+    with torch.no_grad():
+        ref_torch.cascade_forward(feats, proj, dv, sds, ndepths=net.ndepths, depth_interals_ratio=net.depth_interals_ratio,
+                                  tmp=[5.0, 5.0, 5.0, 1.0])
+    dt = time.time() - t0
+    scale = (args.height * args.width) / float(H * W)
+    return {"value": 1.0 / (dt * scale), "unit": "depth maps/s", "cores": cores, "kind": "port",
+            "sample": "oracle/ref_torch.cascade_forward (torch %s CPU, %d threads) on one %dx%d x %d-view cascade = 1/%.1f of the "
+                      "config-2 pixels, %.1f s; value = 1/(t*%.1f)" % (torch.__version__, cores, W, H, args.views, scale, dt, scale)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback exists)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import mvsformer_amd as m
+    from mvsformer_amd import ops, synth
+
+    torch.manual_seed(0)
+    net = m.CascadeMVS().eval()
+    m.randomize_bn_(net, seed=1)
+    net_cpu_sd = net  # state dicts are read from this module for the CPU leg before moving
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(net_cpu_sd, args)
+    net = net.to(dev)
+
+    # each rank owns its reference view(s): different scene seed per rank, inputs resident in HBM before timing
+    feats, proj, dv, _ = synth.make_inputs(args.views, args.height, args.width, seed=rank, device=dev)
+    tmp = [5.0, 5.0, 5.0, 1.0]
+
+    def step():
+        return net(feats, proj, dv, tmp=tmp)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    assert torch.isfinite(out["refined_depth"]).all()
+
+    # ---- per-kernel durations: HIP events around every launch, on the launch stream ----
+    with ops.kernel_timer() as timer:
+        for _ in range(args.profile_steps):
+            step()
+    ksum = timer.summary()
+    work = timer.work
+    kernels = []
+    for name, s in ksum.items():
+        w = work.get(name)
+        e = {"kernel": name, "calls_per_step": s["calls"] // args.profile_steps, "avg_ms": round(s["avg_ms"], 5),
+             "ms_per_step": round(s["total_ms"] / args.profile_steps, 4)}
+        if w:
+            per_launch = w["amount"] / s["calls"]
+            if w["kind"] == "bytes":
+                ach = per_launch / (s["avg_ms"] * 1e-3) / 1e9
+                e.update(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                         algorithmic_per_launch=per_launch)
+            else:
+                ach = per_launch / (s["avg_ms"] * 1e-3) / 1e12
+                e.update(bound="mfma", achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s",
+                         frac=round(ach / FP32_MFMA_PEAK_TF, 4), algorithmic_per_launch=per_launch)
+        kernels.append(e)
+    kernels.sort(key=lambda e: -e["ms_per_step"])
+    dom = next(e for e in kernels if "bound" in e)
+    traffic = None
+    pmc_path = os.path.join(REPO, "profiles", "pmc_traffic.json")     # filled from rocprofv3 --pmc passes (see profiles/README.md)
+    if os.path.exists(pmc_path):
+        traffic = json.load(open(pmc_path)).get(dom["kernel"])
+    roofline = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
+                "frac": dom["frac"], "traffic": traffic, "avg_launch_ms": dom["avg_ms"],
+                "algorithmic_per_launch": dom["algorithmic_per_launch"]}
+
+    if rank == 0:
+        total = world * args.steps
+        line = {
+            "metric": "depth maps/sec @1536x1152 N=5 D=192", "value": round(total / dt, 3), "unit": "depth maps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: DTU eval %dx%d, %d views, 192-plane range, 4-stage cascade ndepths=32/16/8/4, "
+                                   "fp32, one reference view per step per GPU, precomputed features resident in HBM"
+                                   % (args.width, args.height, args.views),
+                       "parallelism": "inference sharding of reference views, no collective" if world > 1 else "single GPU"},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels[:14],
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,9 +65,12 @@ int mvs_warp_fwd(const float* src, const float* rt, const float* depth, int dept
  * The warped volume, the repeated reference volume, the products and the normalized copies are never
  * materialized.  Two sweeps because the visibility weight needs the full-D entropy plus a 3x3 CNN halo:
  *
+ * layout   mvs_nchw_to_nhwc: the sweeps gather CHANNEL-LAST features (one tap = C contiguous floats, fetched as
+ *          16-byte loads by adjacent lanes), so the FPN decoder's [B,V,C,H,W] maps are transposed once per stage:
+ *          in [N,C,HW] -> out [N,HW,C], C in {8,16,32,64}
  * sweep A  mvs_cv_entropy_fwd: per source view, warp + group correlation -> softmax_d entropy
  *          (mvsformer_model.py:73-79,88-90)
- *   feat    [B,V,C,H,W]  view 0 = reference            rt [B,V-1,12]       depth [B,D,H,W]
+ *   feat    [B,V,H,W,C]  channel-last, view 0 = reference   rt [B,V-1,12]   depth [B,D,H,W]
  *   entropy [B,V-1,H,W]
  * vis CNN  mvs_vis_fwd: ConvBnReLU(1,16)->ConvBnReLU(16,16)->ConvBnReLU(16,8)->Conv2d(8,1,1)->Sigmoid in one
  *          LDS-tiled launch (mvsformer_model.py:37,91; module.py:168-197), eval-mode BN folded to scale/shift
@@ -76,8 +79,10 @@ int mvs_warp_fwd(const float* src, const float* rt, const float* depth, int dept
  *          sum_v w_v*corr_v / (sum_v w_v + 1e-6)  (mvsformer_model.py:101-105) and, if sim_depth != NULL, the
  *          eval-only similarity arg-max depth (mvsformer_model.py:81-85,151-158)
  *   weight  [B,V-1,H,W]   volume [B,G,D,H,W]   sim_depth [B,H,W] or NULL
- * Constraints: G == 8, C in {8,16,32,64} (C/G channels per group), D*64*4 bytes of LDS <= 64 KiB.
+ * Constraints: G == 8, C in {8,16,32,64} (C/G channels per group); sweep A needs (1024/C)*D*4 + 8192 bytes of
+ * LDS per block (<= 64 KiB).
  * ------------------------------------------------------------------------------------------------------- */
+int mvs_nchw_to_nhwc(const float* in, float* out, int N, int C, int64_t HW, mvs_stream_t stream);
 int mvs_cv_entropy_fwd(const float* feat, const float* rt, const float* depth,
                        int B, int V, int C, int G, int D, int H, int W, float* entropy, mvs_stream_t stream);
 #define MVS_VIS_PARAM_FLOATS 3689

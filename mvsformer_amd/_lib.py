@@ -28,6 +28,7 @@ SIGNATURES = {
     "mvs_proj_prepare": (I, [P, I, I, P, P]),
     "mvs_proj_relative": (I, [P, P, I, P, P]),
     "mvs_warp_fwd": (I, [P, P, P, I, I, I, I, I, I, P, P, P]),
+    "mvs_nchw_to_nhwc": (I, [P, P, I, I, L, P]),
     "mvs_cv_entropy_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P]),
     "mvs_vis_fwd": (I, [P, P, I, I, I, P, P]),
     "mvs_cv_aggregate_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, P]),

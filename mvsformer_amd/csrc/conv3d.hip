@@ -20,6 +20,16 @@
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using mvs_rsrc_t = __amdgpu_buffer_rsrc_t;
+
+// wave-uniform buffer descriptor: loads beyond `bytes` (or with the OOB marker as offset) return 0, which is how the
+// zero padding / tile halo is produced without branches
+__device__ __forceinline__ mvs_rsrc_t mvs_make_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float mvs_buf_load(mvs_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));
+}
 
 constexpr int NWAVES = 4;
 
@@ -101,27 +111,68 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const float* __restrict__ x
 
     const int nchunks = (CIN + CC - 1) / CC;
     const size_t plane = (size_t)Hi * Wi;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        __syncthreads();
-        // ---- stage the input tile (zero-filled halo / padding) ----
-        for (int r = wave; r < CC * ID * IH; r += NWAVES) {
+
+    // ---- staging registers: the NEXT chunk's input rows + weight slabs are fetched while this chunk's MFMAs run
+    //      (issue early / write late); out-of-tile and padding elements come back as 0 from the buffer bounds check
+    constexpr int RPW = (CC * ID * IH + NWAVES - 1) / NWAVES;       // input rows per wavefront
+    constexpr int LPR = (IW + 63) / 64;                             // loads per row per lane
+    constexpr int NWV = ((CC / 4) * WSLAB / 4 + 255) / 256;         // weight float4s per thread
+    constexpr unsigned OOB = 0x80000000u;
+    float sreg[RPW][LPR];
+    f32x4 wreg[NWV];
+    auto prefetch = [&](int ch) {
+        const int cleft = min(CC, CIN - ch * CC);
+        const mvs_rsrc_t xin = mvs_make_rsrc(x + (size_t)(b * CIN + ch * CC) * Di * plane, (unsigned)((size_t)cleft * Di * plane * 4));
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int r = wave + i * NWAVES;
             const int c = r / (ID * IH), rem = r % (ID * IH), dz = rem / IH, hy = rem % IH;
-            const int cin = ch * CC + c, gd = d0 * SD - 1 + dz, gh = h0 * SHW - 1 + hy;
-            const bool rowok = cin < CIN && gd >= 0 && gd < Di && gh >= 0 && gh < Hi;
-            const float* grow = x + ((size_t)(b * CIN + cin) * Di + gd) * plane + (size_t)gh * Wi;
-            float* lrow = s_in + c * CS + (dz * IH + hy) * IW;
-            for (int wx = lane; wx < IW; wx += 64) {
+            const int gd = d0 * SD - 1 + dz, gh = h0 * SHW - 1 + hy;
+            const bool rowok = (r < CC * ID * IH) && gd >= 0 && gd < Di && gh >= 0 && gh < Hi;
+            const unsigned soff = rowok ? (unsigned)((((size_t)c * Di + gd) * Hi + gh) * Wi * 4) : 0u;
+#pragma unroll
+            for (int j = 0; j < LPR; ++j) {
+                const int wx = lane + j * 64;
                 const int gw = w0 * SHW - 1 + wx;
-                lrow[wx] = (rowok && gw >= 0 && gw < Wi) ? grow[gw] : 0.0f;
+                const unsigned voff = (rowok && wx < IW && gw >= 0 && gw < Wi) ? (unsigned)gw * 4u : OOB;
+                sreg[i][j] = mvs_buf_load(xin, voff, soff);
             }
         }
-        // ---- stage the weight slabs of this chunk (linear copy, 16 B per lane) ----
-        {
-            const float4* src = reinterpret_cast<const float4*>(wp + (size_t)ch * (CC / 4) * WSLAB);
-            float4* dst = reinterpret_cast<float4*>(s_w);
-            for (int i = tid; i < (CC / 4) * WSLAB / 4; i += 256) dst[i] = src[i];
+        const f32x4* src = reinterpret_cast<const f32x4*>(wp + (size_t)ch * (CC / 4) * WSLAB);
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + i * 256;
+            wreg[i] = (idx < (CC / 4) * WSLAB / 4) ? src[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int r = wave + i * NWAVES;
+            if (r < CC * ID * IH) {
+                const int c = r / (ID * IH), rem = r % (ID * IH);
+                float* lrow = s_in + c * CS + rem * IW;
+#pragma unroll
+                for (int j = 0; j < LPR; ++j) {
+                    const int wx = lane + j * 64;
+                    if (wx < IW) lrow[wx] = sreg[i][j];
+                }
+            }
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(s_w);
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < (CC / 4) * WSLAB / 4) dst[idx] = wreg[i];
+        }
+    };
+
+    prefetch(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();                                     // everyone is done reading the previous chunk
+        commit();
         __syncthreads();
+        if (ch + 1 < nchunks) prefetch(ch + 1);
         // ---- 27 taps x CC/4 k-steps of MFMA ----
         const float* abase = s_in + kk * CS + ((dl * SD) * IH + hl * SHW) * IW + i16 * SHW;
         const float* bbase = s_w + kk * NP + i16;
@@ -224,27 +275,58 @@ __global__ __launch_bounds__(256) void deconv3d_kernel(const float* __restrict__
 
     const int nchunks = (CIN + CC - 1) / CC;
     const size_t plane = (size_t)Hi * Wi;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        __syncthreads();
-        for (int r = wave; r < CC * ID * IH; r += NWAVES) {
+
+    constexpr int RPW = (CC * ID * IH + NWAVES - 1) / NWAVES;
+    constexpr int NWV = ((CC / 4) * WSLAB / 4 + 255) / 256;
+    constexpr unsigned OOB = 0x80000000u;
+    static_assert(IW <= 64, "one load per row per lane");
+    float sreg[RPW];
+    f32x4 wreg[NWV];
+    auto prefetch = [&](int ch) {
+        const int cleft = min(CC, CIN - ch * CC);
+        const mvs_rsrc_t xin = mvs_make_rsrc(x + (size_t)(b * CIN + ch * CC) * Di * plane, (unsigned)((size_t)cleft * Di * plane * 4));
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int r = wave + i * NWAVES;
             const int c = r / (ID * IH), rem = r % (ID * IH), dz = rem / IH, hy = rem % IH;
-            const int cin = ch * CC + c;
             const int gd = (SD == 1) ? di0 - 1 + dz : di0 + dz;
             const int gh = hi0 + hy;
-            const bool rowok = cin < CIN && gd >= 0 && gd < Di && gh < Hi;
-            const float* grow = x + ((size_t)(b * CIN + cin) * Di + gd) * plane + (size_t)gh * Wi;
-            float* lrow = s_in + c * CS + (dz * IH + hy) * IW;
-            for (int wx = lane; wx < IW; wx += 64) {
-                const int gw = wi0 + wx;
-                lrow[wx] = (rowok && gw < Wi) ? grow[gw] : 0.0f;
+            const bool rowok = (r < CC * ID * IH) && gd >= 0 && gd < Di && gh < Hi;
+            const unsigned soff = rowok ? (unsigned)((((size_t)c * Di + gd) * Hi + gh) * Wi * 4) : 0u;
+            const int gw = wi0 + lane;
+            const unsigned voff = (rowok && lane < IW && gw < Wi) ? (unsigned)gw * 4u : OOB;
+            sreg[i] = mvs_buf_load(xin, voff, soff);
+        }
+        const f32x4* src = reinterpret_cast<const f32x4*>(wp + (size_t)ch * (CC / 4) * WSLAB);
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + i * 256;
+            wreg[i] = (idx < (CC / 4) * WSLAB / 4) ? src[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int r = wave + i * NWAVES;
+            if (r < CC * ID * IH && lane < IW) {
+                const int c = r / (ID * IH), rem = r % (ID * IH);
+                s_in[c * CS + rem * IW + lane] = sreg[i];
             }
         }
-        {
-            const float4* src = reinterpret_cast<const float4*>(wp + (size_t)ch * (CC / 4) * WSLAB);
-            float4* dst = reinterpret_cast<float4*>(s_w);
-            for (int i = tid; i < (CC / 4) * WSLAB / 4; i += 256) dst[i] = src[i];
+        f32x4* dst = reinterpret_cast<f32x4*>(s_w);
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < (CC / 4) * WSLAB / 4) dst[idx] = wreg[i];
         }
+    };
+
+    prefetch(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
         __syncthreads();
+        commit();
+        __syncthreads();
+        if (ch + 1 < nchunks) prefetch(ch + 1);
 
         const float* bbase = s_w + kk * NP + i16;
 #pragma unroll
@@ -411,6 +493,7 @@ int check_conv_args(const char* who, int B, int Cin, int Cout, int Di, int Hi, i
     MVS_REQUIRE(B >= 1 && Di >= 1 && Hi >= 1 && Wi >= 1, "%s: bad shape B=%d D=%d H=%d W=%d", who, B, Di, Hi, Wi);
     MVS_REQUIRE(Cin >= 4 && Cin % 4 == 0, "%s: Cin must be a multiple of 4 (got %d)", who, Cin);
     MVS_REQUIRE(Cout >= 8 && Cout % 8 == 0 && Cout <= 64, "%s: Cout must be a multiple of 8, <= 64 (got %d)", who, Cout);
+    MVS_REQUIRE((int64_t)8 * Di * Hi * Wi * 4 < ((int64_t)1 << 31), "%s: 8 input channels exceed the 2 GiB buffer window", who);
     return MVS_OK;
 }
 

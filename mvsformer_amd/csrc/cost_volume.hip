@@ -2,22 +2,27 @@
 // models/mvsformer_model.py:62-105 — without ever materializing the warped volume [B,C,D,H,W], the repeated
 // reference volume, their product or the normalized copies the reference's eval branch makes.
 //
-// Data layout: everything stays NCHW / NCDHW exactly as the FPN decoder hands it over and as the 3-D
-// regularizer consumes it, so there is no transpose pass.  One lane owns one reference pixel; the 64 lanes of
-// a wavefront are 64 consecutive pixels of one image row, so for a fixed channel the four bilinear taps of
-// the wavefront are four (nearly) contiguous row segments of the source plane — coalesced gathers that hit
-// L1/L2 (a source map is 7-57 MB; neighbouring depths/rows re-touch the same lines), and the volume store
-// is one contiguous 256-B row segment per (group, depth).  threadIdx.y splits the depth hypotheses of the same
-// 64 pixels across the wavefronts of a block (coarse stages have few pixels but many depths).
+// What bounds it: not HBM but the CU's vector-memory front end.  rocprofv3 on the first (NCHW, one dword per
+// lane) version showed TCP_TOTAL_CACHE_ACCESSES = (lane loads)/4: the texture addresser retires one 4-lane
+// quad per clock whatever the access width, i.e. 16 B/clk/CU for dword gathers but 64 B/clk/CU when every lane
+// brings 16 bytes and the 4 lanes of a quad are contiguous.  Hence the layout:
 //
-// The reference feature vector of the pixel (C <= 64 floats) lives in registers for the whole sweep; the
-// per-depth tap offsets/weights are computed once and reused over the C channels.  Group sums over the C/G
-// channels of a group are in-lane (no cross-lane traffic at all).
+//   * features are gathered CHANNEL-LAST ([B,V,H,W,C], one mvs_nchw_to_nhwc pass per stage): a bilinear tap of
+//     one pixel is C contiguous floats, fetched as C/4 dwordx4 loads by LPP = C/4 adjacent lanes
+//     (lane = pixel*LPP + channel_quad) -> every quad reads 64 contiguous bytes, independent of how coherent
+//     neighbouring pixels' sampling positions are;
+//   * a wavefront owns PPW = 64/LPP consecutive pixels of one row and ALL their depth hypotheses;
+//   * the projective geometry (homography, perspective divide, grid_sample un-normalization, zero-padding tap
+//     masks) is evaluated once per (pixel, depth) with lanes = (pixel, depth) pairs — 64 samples per pass — and
+//     handed to the gather phase through LDS (2 x ds_read_b128 per lane per sample, broadcast within a pixel);
+//   * per-voxel reductions over channels (group sums, the cross-group similarity norms, sum over groups) are
+//     DPP/shuffle butterflies over the LPP lanes of a pixel — no LDS, no atomics;
+//   * the volume is written once, NCDHW, as the 3-D regularizer reads it.
 //
-// Sweep A (cv_entropy): per source view, correlation -> sim[d] = sum_g in_prod[g,d] -> entropy of softmax_d.
+// Sweep A (cv_entropy): per source view, sim[d] = sum_g in_prod[g,d] -> entropy of softmax_d (mvsformer_model.py:88-90).
 // Sweep B (cv_aggregate): recomputes the correlation for all source views (cheaper than storing (V-1)
 //   [B,G,D,H,W] volumes for the fine stages), accumulates sum_v w_v*in_prod_v in registers, writes
-//   volume_mean once; also the eval-only similarity arg-max depth.
+//   volume_mean once; also the eval-only similarity arg-max depth (mvsformer_model.py:81-85,151-158).
 //
 // Algorithmic HBM bytes per stage: 4*H*W*(V*C + D + G*D)  (features once, hypotheses once, volume once).
 #include "common.h"
@@ -26,89 +31,176 @@
 namespace {
 
 constexpr int G = 8;
+constexpr int NW = 4;                         // wavefronts per block
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-template <int CPG>
-__global__ __launch_bounds__(512) void cv_entropy_kernel(const float* __restrict__ feat, const float* __restrict__ rt_all,
-                                                         const float* __restrict__ depth, int V, int D, int H, int W,
-                                                         float* __restrict__ entropy) {
-    constexpr int C = G * CPG;
-    extern __shared__ float sims[];                      // [D][64]
-    const int tx = threadIdx.x, ty = threadIdx.y, DS = blockDim.y;
-    const int x = blockIdx.x * 64 + tx, y = blockIdx.y;
+__device__ __forceinline__ f32x4 buf_load4(mvs::rsrc_t r, unsigned voff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, 0, 0));
+}
+
+// sum over the LPP lanes of a pixel (lanes pixel*LPP .. pixel*LPP+LPP-1); every lane gets the total
+template <int LPP>
+__device__ __forceinline__ float pixel_sum(float v) {
+#pragma unroll
+    for (int m = 1; m < LPP; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// geometry pass: lane l = (p = l % PPW, dd = l / PPW) evaluates sample (pixel x0+p, depth c0+dd) and leaves
+// {tap pixel indices, tap weights} in the wavefront's LDS slab at slot l = dd*PPW + p.
+// ---------------------------------------------------------------------------------------------------------
+template <int PPW>
+__device__ __forceinline__ void geometry_pass(const float* __restrict__ rt, const float* __restrict__ depth_row /* + d*HW */,
+                                              size_t HW, int c0, int D, int x0, int y, int H, int W, float half_w, float half_h,
+                                              int lane, u32x4* taps_o, f32x4* taps_w) {
+    const int p = lane % PPW, dd = lane / PPW;
+    const int d = min(c0 + dd, D - 1);                    // clamped duplicates are never consumed
+    const int x = min(x0 + p, W - 1);
+    const float dv = depth_row[(size_t)d * HW + x];
+    float un, vn, z;
+    mvs::sweep_project(rt, (float)x, (float)y, dv, half_w, half_h, &un, &vn, &z);
+    const mvs::Taps t = mvs::sweep_taps(un, vn, H, W, half_w, half_h);
+    taps_o[lane] = u32x4{(unsigned)t.o00, (unsigned)t.o01, (unsigned)t.o10, (unsigned)t.o11};
+    taps_w[lane] = f32x4{t.w00, t.w01, t.w10, t.w11};
+}
+
+// gather phase for one sample: 4 dwordx4 loads (this lane's 4 channels at the 4 taps) + bilinear blend
+__device__ __forceinline__ f32x4 gather4(mvs::rsrc_t src, unsigned pix_bytes, unsigned cq_bytes, u32x4 o, f32x4 w) {
+    const f32x4 a = buf_load4(src, o[0] * pix_bytes + cq_bytes);
+    const f32x4 b = buf_load4(src, o[1] * pix_bytes + cq_bytes);
+    const f32x4 c = buf_load4(src, o[2] * pix_bytes + cq_bytes);
+    const f32x4 d = buf_load4(src, o[3] * pix_bytes + cq_bytes);
+    f32x4 out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float acc = a[i] * w[0];
+        acc = fmaf(b[i], w[1], acc);
+        acc = fmaf(c[i], w[2], acc);
+        out[i] = fmaf(d[i], w[3], acc);
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// sweep A
+// ---------------------------------------------------------------------------------------------------------
+template <int LPP>
+__global__ __launch_bounds__(64 * NW) void cv_entropy_kernel(const float* __restrict__ feat /*[B,V,H,W,C]*/,
+                                                             const float* __restrict__ rt_all, const float* __restrict__ depth,
+                                                             int V, int D, int H, int W, float* __restrict__ entropy) {
+    constexpr int C = 4 * LPP, CPG = C / G, PPW = 64 / LPP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u32x4* taps_o = reinterpret_cast<u32x4*>(smem) + wave * 64;
+    f32x4* taps_w = reinterpret_cast<f32x4*>(smem + NW * 64 * 16) + wave * 64;
+    float* sims = reinterpret_cast<float*>(smem + NW * 64 * 32) + (size_t)wave * PPW * D;     // [D][PPW]
+
+    const int x0 = (blockIdx.x * NW + wave) * PPW, y = blockIdx.y;
     const int b = blockIdx.z / (V - 1), sv = blockIdx.z % (V - 1);
-    const bool active = x < W;
-    const int xc = active ? x : W - 1;
+    if (x0 >= W) return;                                   // wave-uniform; no block-wide barrier is used below
     const size_t HW = (size_t)H * W;
-    const float* ref = feat + (size_t)(b * V) * C * HW + (size_t)y * W + xc;
-    const float* src = feat + (size_t)(b * V + sv + 1) * C * HW;
+    const unsigned pix_bytes = C * 4u;
+    const int pg = lane / LPP, cq = lane % LPP;
+    const int xg = min(x0 + pg, W - 1);
+    const f32x4 r = *reinterpret_cast<const f32x4*>(feat + ((size_t)(b * V) * HW + (size_t)y * W + xg) * C + cq * 4);
+    const mvs::rsrc_t src = mvs::make_rsrc(feat + (size_t)(b * V + sv + 1) * HW * C, (unsigned)(HW * pix_bytes));
     const float* rt = rt_all + (size_t)(b * (V - 1) + sv) * 12;
+    const float* depth_row = depth + (size_t)b * D * HW + (size_t)y * W;
     const float half_w = (float)((W - 1) / 2.0), half_h = (float)((H - 1) / 2.0);
 
-    float r[C];
+    for (int c0 = 0; c0 < D; c0 += LPP) {
+        geometry_pass<PPW>(rt, depth_row, HW, c0, D, x0, y, H, W, half_w, half_h, lane, taps_o, taps_w);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int c = 0; c < C; ++c) r[c] = ref[(size_t)c * HW];
-
-    for (int d = ty; d < D; d += DS) {
-        const float dv = depth[((size_t)(b * D + d) * H + y) * W + xc];
-        float un, vn, z;
-        mvs::sweep_project(rt, (float)xc, (float)y, dv, half_w, half_h, &un, &vn, &z);
-        const mvs::Taps t = mvs::sweep_taps(un, vn, H, W, half_w, half_h);
-        float sim = 0.0f;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float s = 0.0f;
-#pragma unroll
-            for (int j = 0; j < CPG; ++j) {
-                const int c = g * CPG + j;
-                s = s + r[c] * mvs::bilinear(src + (size_t)c * HW, t);
+        for (int dd = 0; dd < LPP; ++dd) {
+            if (c0 + dd < D) {
+                const u32x4 o = taps_o[dd * PPW + pg];
+                const f32x4 w = taps_w[dd * PPW + pg];
+                const f32x4 g4 = gather4(src, pix_bytes, cq * 16u, o, w);
+                float s = r[0] * g4[0];
+                s = s + r[1] * g4[1];
+                s = s + r[2] * g4[2];
+                s = s + r[3] * g4[3];
+                s = pixel_sum<LPP>(s) * (1.0f / CPG);
+                if (cq == 0) sims[(c0 + dd) * PPW + pg] = s;
             }
-            sim = sim + s * (1.0f / CPG);
         }
-        sims[d * 64 + tx] = sim;
+        __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-    if (ty == 0 && active) {
+    // entropy of softmax_d: lane l = (p = l % PPW, k = l / PPW) takes depths k, k+LPP, ...; reductions over k are
+    // butterflies over lane strides PPW, 2*PPW, ... 32
+    {
+        const int p = lane % PPW, k = lane / PPW;
         float m = -INFINITY;
-        for (int d = 0; d < D; ++d) m = fmaxf(m, sims[d * 64 + tx]);
+        for (int d = k; d < D; d += LPP) m = fmaxf(m, sims[d * PPW + p]);
+#pragma unroll
+        for (int s = PPW; s < 64; s <<= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
         float sum = 0.0f;
-        for (int d = 0; d < D; ++d) sum += expf(sims[d * 64 + tx] - m);
+        for (int d = k; d < D; d += LPP) sum += expf(sims[d * PPW + p] - m);
+#pragma unroll
+        for (int s = PPW; s < 64; s <<= 1) sum += __shfl_xor(sum, s, 64);
         float ent = 0.0f;
-        for (int d = 0; d < D; ++d) {
-            const float p = expf(sims[d * 64 + tx] - m) / sum;
-            ent = ent + (-p) * logf(p + 1e-7f);
+        for (int d = k; d < D; d += LPP) {
+            const float pr = expf(sims[d * PPW + p] - m) / sum;
+            ent = ent + (-pr) * logf(pr + 1e-7f);
         }
-        entropy[((size_t)(b * (V - 1) + sv) * H + y) * W + x] = ent;
+#pragma unroll
+        for (int s = PPW; s < 64; s <<= 1) ent += __shfl_xor(ent, s, 64);
+        if (k == 0 && x0 + p < W) entropy[((size_t)(b * (V - 1) + sv) * H + y) * W + x0 + p] = ent;
     }
 }
 
-template <int CPG, bool SIM>
-__global__ __launch_bounds__(512) void cv_aggregate_kernel(const float* __restrict__ feat, const float* __restrict__ rt_all,
-                                                           const float* __restrict__ depth, const float* __restrict__ weight,
-                                                           int V, int D, int H, int W,
-                                                           float* __restrict__ volume, float* __restrict__ sim_depth) {
-    constexpr int C = G * CPG;
-    extern __shared__ float red[];                       // SIM: [DS][64] best value, [DS][64] best index
-    const int tx = threadIdx.x, ty = threadIdx.y, DS = blockDim.y;
-    const int x = blockIdx.x * 64 + tx, y = blockIdx.y, b = blockIdx.z;
-    const bool active = x < W;
-    const int xc = active ? x : W - 1;
+// ---------------------------------------------------------------------------------------------------------
+// sweep B
+// ---------------------------------------------------------------------------------------------------------
+template <int LPP, bool SIM>
+__global__ __launch_bounds__(64 * NW) void cv_aggregate_kernel(const float* __restrict__ feat, const float* __restrict__ rt_all,
+                                                               const float* __restrict__ depth, const float* __restrict__ weight,
+                                                               int V, int D, int H, int W, float* __restrict__ volume,
+                                                               float* __restrict__ sim_depth) {
+    constexpr int C = 4 * LPP, CPG = C / G, PPW = 64 / LPP;
+    constexpr int NG = (CPG >= 4) ? 1 : 4 / CPG;          // correlation groups whose sums live in this lane
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u32x4* taps_o = reinterpret_cast<u32x4*>(smem) + wave * 64;
+    f32x4* taps_w = reinterpret_cast<f32x4*>(smem + NW * 64 * 16) + wave * 64;
+
+    const int x0 = (blockIdx.x * NW + wave) * PPW, y = blockIdx.y, b = blockIdx.z;
+    if (x0 >= W) return;
     const size_t HW = (size_t)H * W;
-    const size_t pix = (size_t)y * W + xc;
-    const float* ref = feat + (size_t)(b * V) * C * HW + pix;
+    const unsigned pix_bytes = C * 4u;
+    const int pg = lane / LPP, cq = lane % LPP;
+    const bool active = x0 + pg < W;
+    const int xg = min(x0 + pg, W - 1);
+    const size_t pix = (size_t)y * W + xg;
+    const f32x4 r = *reinterpret_cast<const f32x4*>(feat + ((size_t)(b * V) * HW + pix) * C + cq * 4);
+    const float* depth_row = depth + (size_t)b * D * HW + (size_t)y * W;
     const float half_w = (float)((W - 1) / 2.0), half_h = (float)((H - 1) / 2.0);
 
-    float r[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) r[c] = ref[(size_t)c * HW];
-    float rinv[CPG];
+    // F.normalize(ref_volume, dim=1): per channel-in-group index j, L2 norm over the 8 groups
+    f32x4 rn = {0.f, 0.f, 0.f, 0.f};                      // this lane's 4 reference channels, normalized
     if (SIM) {
+        const f32x4 sq = {r[0] * r[0], r[1] * r[1], r[2] * r[2], r[3] * r[3]};
+        f32x4 n2 = sq;
+        if (CPG < 4) {                                    // several groups inside the lane share j = i % CPG
 #pragma unroll
-        for (int j = 0; j < CPG; ++j) {
-            float n2 = 0.0f;
+            for (int i = 0; i < 4; ++i) {
+                float t = 0.0f;
 #pragma unroll
-            for (int g = 0; g < G; ++g) n2 = fmaf(r[g * CPG + j], r[g * CPG + j], n2);
-            rinv[j] = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+                for (int k = i % CPG; k < 4; k += CPG) t += sq[k];
+                n2[i] = t;
+            }
         }
+#pragma unroll
+        for (int m = (CPG == 8 ? 2 : 1); m < LPP; m <<= 1)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) n2[i] += __shfl_xor(n2[i], m, 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rn[i] = r[i] / fmaxf(sqrtf(n2[i]), 1e-12f);
     }
     const float* wp = weight + (size_t)(b * (V - 1)) * HW + pix;
     float wsum = 0.0f;
@@ -117,72 +209,113 @@ __global__ __launch_bounds__(512) void cv_aggregate_kernel(const float* __restri
 
     float best = -INFINITY;
     int besti = 0;
-    for (int d = ty; d < D; d += DS) {
-        const float dv = depth[((size_t)(b * D + d) * H + y) * W + xc];
-        float acc[G];
+    for (int c0 = 0; c0 < D; c0 += LPP) {
+        float acc[LPP][NG];
+        float simtot[LPP];
 #pragma unroll
-        for (int g = 0; g < G; ++g) acc[g] = 0.0f;
-        float simtot = 0.0f;
+        for (int dd = 0; dd < LPP; ++dd) {
+            simtot[dd] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NG; ++k) acc[dd][k] = 0.0f;
+        }
         for (int sv = 0; sv < V - 1; ++sv) {
             const float* rt = rt_all + (size_t)(b * (V - 1) + sv) * 12;
-            const float* src = feat + (size_t)(b * V + sv + 1) * C * HW;
+            const mvs::rsrc_t src = mvs::make_rsrc(feat + (size_t)(b * V + sv + 1) * HW * C, (unsigned)(HW * pix_bytes));
             const float wv = wp[(size_t)sv * HW];
-            float un, vn, z;
-            mvs::sweep_project(rt, (float)xc, (float)y, dv, half_w, half_h, &un, &vn, &z);
-            const mvs::Taps t = mvs::sweep_taps(un, vn, H, W, half_w, half_h);
-            float dotj[CPG], nrm[CPG];
+            __builtin_amdgcn_wave_barrier();
+            geometry_pass<PPW>(rt, depth_row, HW, c0, D, x0, y, H, W, half_w, half_h, lane, taps_o, taps_w);
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < CPG; ++j) { dotj[j] = 0.0f; nrm[j] = 0.0f; }
+            for (int dd = 0; dd < LPP; ++dd) {
+                if (c0 + dd < D) {
+                    const u32x4 o = taps_o[dd * PPW + pg];
+                    const f32x4 w = taps_w[dd * PPW + pg];
+                    const f32x4 g4 = gather4(src, pix_bytes, cq * 16u, o, w);
+                    const f32x4 p = {r[0] * g4[0], r[1] * g4[1], r[2] * g4[2], r[3] * g4[3]};
+                    // group means held by this lane
+                    if (CPG == 1) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                float s = 0.0f;
-#pragma unroll
-                for (int j = 0; j < CPG; ++j) {
-                    const int c = g * CPG + j;
-                    const float w = mvs::bilinear(src + (size_t)c * HW, t);
-                    const float p = r[c] * w;
-                    s = s + p;
+                        for (int k = 0; k < 4; ++k) acc[dd][k] = acc[dd][k] + p[k] * wv;
+                    } else if (CPG == 2) {
+                        acc[dd][0] = acc[dd][0] + ((p[0] + p[1]) * 0.5f) * wv;
+                        acc[dd][1] = acc[dd][1] + ((p[2] + p[3]) * 0.5f) * wv;
+                    } else if (CPG == 4) {
+                        acc[dd][0] = acc[dd][0] + ((((p[0] + p[1]) + p[2]) + p[3]) * 0.25f) * wv;
+                    } else {
+                        float h = ((p[0] + p[1]) + p[2]) + p[3];
+                        const float o2 = __shfl_xor(h, 1, 64);
+                        h = (cq & 1) ? o2 + h : h + o2;       // same association in both lanes: low half first
+                        acc[dd][0] = acc[dd][0] + (h * 0.125f) * wv;
+                    }
                     if (SIM) {
-                        dotj[j] = dotj[j] + p;
-                        nrm[j] = fmaf(w, w, nrm[j]);
+                        // similarity: sum_j (sum_g refn[g,j]*warp[g,j]) / max(||warp[:,j]||, eps), mean over j
+                        f32x4 q = {rn[0] * g4[0], rn[1] * g4[1], rn[2] * g4[2], rn[3] * g4[3]};
+                        f32x4 n2 = {g4[0] * g4[0], g4[1] * g4[1], g4[2] * g4[2], g4[3] * g4[3]};
+                        if (CPG < 4) {
+#pragma unroll
+                            for (int i = 0; i < CPG; ++i) {
+#pragma unroll
+                                for (int k = i + CPG; k < 4; k += CPG) { q[i] += q[k]; n2[i] += n2[k]; }
+                            }
+                        }
+                        constexpr int NJ = (CPG < 4) ? CPG : 4;      // distinct j held by this lane
+#pragma unroll
+                        for (int m = (CPG == 8 ? 2 : 1); m < LPP; m <<= 1)
+#pragma unroll
+                            for (int i = 0; i < NJ; ++i) {
+                                q[i] += __shfl_xor(q[i], m, 64);
+                                n2[i] += __shfl_xor(n2[i], m, 64);
+                            }
+                        float s = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < NJ; ++i) s += q[i] / fmaxf(sqrtf(n2[i]), 1e-12f);
+                        if (CPG == 8) s += __shfl_xor(s, 1, 64);      // the other 4 j's live in the neighbour lane
+                        simtot[dd] = simtot[dd] + s * (1.0f / CPG);
                     }
                 }
-                acc[g] = acc[g] + (s * (1.0f / CPG)) * wv;
-            }
-            if (SIM) {
-                float ssum = 0.0f;
-#pragma unroll
-                for (int j = 0; j < CPG; ++j) ssum = ssum + (dotj[j] * rinv[j]) / fmaxf(sqrtf(nrm[j]), 1e-12f);
-                simtot = simtot + ssum * (1.0f / CPG);
             }
         }
-        if (active) {
-            float* vp = volume + ((size_t)(b * G) * D + d) * HW + pix;
+        // write volume_mean for this depth chunk, track the similarity arg-max
 #pragma unroll
-            for (int g = 0; g < G; ++g) vp[(size_t)g * D * HW] = acc[g] / denom;
-        }
-        if (SIM && simtot > best) { best = simtot; besti = d; }
-    }
-    if (SIM) {
-        red[ty * 64 + tx] = best;
-        red[(DS + ty) * 64 + tx] = __int_as_float(besti);
-        __syncthreads();
-        if (ty == 0 && active) {
-            for (int s = 1; s < DS; ++s) {
-                const float v = red[s * 64 + tx];
-                const int i = __float_as_int(red[(DS + s) * 64 + tx]);
-                if (v > best || (v == best && i < besti)) { best = v; besti = i; }
+        for (int dd = 0; dd < LPP; ++dd) {
+            const int d = c0 + dd;
+            if (d < D) {
+                if (active && (CPG < 8 || (cq & 1) == 0)) {
+#pragma unroll
+                    for (int k = 0; k < NG; ++k) {
+                        const int g = (CPG == 8) ? (cq >> 1) : cq * NG + k;
+                        volume[((size_t)(b * G + g) * D + d) * HW + pix] = acc[dd][k] / denom;
+                    }
+                }
+                if (SIM && simtot[dd] > best) { best = simtot[dd]; besti = d; }
             }
-            sim_depth[(size_t)b * HW + pix] = depth[((size_t)(b * D + besti) * H + y) * W + x];
         }
     }
+    if (SIM && active && cq == 0) sim_depth[(size_t)b * HW + pix] = depth_row[(size_t)besti * HW + xg];
 }
 
-int pick_depth_slices(int D) {
-    int ds = D / 2;
-    if (ds < 1) ds = 1;
-    if (ds > 8) ds = 8;
-    return ds;
+// ---------------------------------------------------------------------------------------------------------
+// NCHW -> NHWC feature transpose ([N,C,HW] -> [N,HW,C]) through an LDS tile: reads are 256-B row segments per
+// channel, writes are one contiguous 64*C-float run per block (dwordx4 per lane).
+// ---------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, size_t HW) {
+    __shared__ float tile[C][65];
+    const int tid = threadIdx.x;
+    const size_t p0 = (size_t)blockIdx.x * 64;
+    const size_t n = blockIdx.y;
+    const int npix = (int)min((size_t)64, HW - p0);
+    for (int i = tid; i < C * 64; i += 256) {
+        const int c = i >> 6, p = i & 63;
+        tile[c][p] = (p < npix) ? in[(n * C + c) * HW + p0 + p] : 0.0f;
+    }
+    __syncthreads();
+    float* o = out + (n * HW + p0) * C;
+    for (int i = tid; i < npix * C / 4; i += 256) {
+        const int p = (i * 4) / C, c = (i * 4) % C;
+        const f32x4 v = {tile[c][p], tile[c + 1][p], tile[c + 2][p], tile[c + 3][p]};
+        *reinterpret_cast<f32x4*>(o + (size_t)i * 4) = v;
+    }
 }
 
 int check_shapes(const char* who, int B, int V, int C, int Gin, int D, int H, int W) {
@@ -190,25 +323,41 @@ int check_shapes(const char* who, int B, int V, int C, int Gin, int D, int H, in
     MVS_REQUIRE(Gin == G, "%s: only G=8 correlation groups are built (got %d)", who, Gin);
     MVS_REQUIRE(C == 8 || C == 16 || C == 32 || C == 64, "%s: C must be 8, 16, 32 or 64 (got %d)", who, C);
     MVS_REQUIRE((int64_t)B * (V - 1) <= 65535 && H <= 65535, "%s: grid limits exceeded", who);
-    MVS_REQUIRE((int64_t)D * 64 * 4 <= 64 * 1024, "%s: D=%d needs more than 64 KiB of LDS", who, D);
+    MVS_REQUIRE((int64_t)C * H * W * 4 < ((int64_t)1 << 32), "%s: one view's feature block exceeds the 4 GiB buffer range", who);
     return MVS_OK;
 }
 
 }  // namespace
 
+extern "C" int mvs_nchw_to_nhwc(const float* in, float* out, int N, int C, int64_t HW, mvs_stream_t stream) {
+    MVS_REQUIRE(in && out, "mvs_nchw_to_nhwc: null pointer");
+    MVS_REQUIRE(N >= 1 && N <= 65535 && HW >= 1, "mvs_nchw_to_nhwc: bad shape N=%d HW=%lld", N, (long long)HW);
+    MVS_REQUIRE(C == 8 || C == 16 || C == 32 || C == 64, "mvs_nchw_to_nhwc: C must be 8, 16, 32 or 64 (got %d)", C);
+    dim3 grid((unsigned)((HW + 63) / 64), N);
+    hipStream_t s = MVS_STREAM(stream);
+    switch (C) {
+        case 8: hipLaunchKernelGGL(nchw_to_nhwc_kernel<8>, grid, dim3(256), 0, s, in, out, (size_t)HW); break;
+        case 16: hipLaunchKernelGGL(nchw_to_nhwc_kernel<16>, grid, dim3(256), 0, s, in, out, (size_t)HW); break;
+        case 32: hipLaunchKernelGGL(nchw_to_nhwc_kernel<32>, grid, dim3(256), 0, s, in, out, (size_t)HW); break;
+        default: hipLaunchKernelGGL(nchw_to_nhwc_kernel<64>, grid, dim3(256), 0, s, in, out, (size_t)HW); break;
+    }
+    return mvs::finish_launch("mvs_nchw_to_nhwc");
+}
+
 extern "C" int mvs_cv_entropy_fwd(const float* feat, const float* rt, const float* depth, int B, int V, int C, int Gin, int D,
                                   int H, int W, float* entropy, mvs_stream_t stream) {
     MVS_REQUIRE(feat && rt && depth && entropy, "mvs_cv_entropy_fwd: null pointer");
     if (int rc = check_shapes("mvs_cv_entropy_fwd", B, V, C, Gin, D, H, W)) return rc;
-    const int DS = pick_depth_slices(D);
-    dim3 grid(mvs::ceil_div(W, 64), H, B * (V - 1)), block(64, DS);
-    const size_t lds = (size_t)D * 64 * sizeof(float);
+    const int LPP = C / 4, PPW = 64 / LPP;
+    const size_t lds = (size_t)NW * 64 * 32 + (size_t)NW * PPW * D * sizeof(float);
+    MVS_REQUIRE(lds <= 64 * 1024, "mvs_cv_entropy_fwd: D=%d with C=%d needs %zu bytes of LDS (> 64 KiB)", D, C, lds);
+    dim3 grid(mvs::ceil_div(W, NW * PPW), H, B * (V - 1)), block(64 * NW);
     hipStream_t s = MVS_STREAM(stream);
-    switch (C / G) {
-        case 1: hipLaunchKernelGGL(cv_entropy_kernel<1>, grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy); break;
+    switch (LPP) {
         case 2: hipLaunchKernelGGL(cv_entropy_kernel<2>, grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy); break;
         case 4: hipLaunchKernelGGL(cv_entropy_kernel<4>, grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy); break;
-        default: hipLaunchKernelGGL(cv_entropy_kernel<8>, grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy); break;
+        case 8: hipLaunchKernelGGL(cv_entropy_kernel<8>, grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy); break;
+        default: hipLaunchKernelGGL(cv_entropy_kernel<16>, grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy); break;
     }
     return mvs::finish_launch("mvs_cv_entropy_fwd");
 }
@@ -218,22 +367,22 @@ extern "C" int mvs_cv_aggregate_fwd(const float* feat, const float* rt, const fl
                                     mvs_stream_t stream) {
     MVS_REQUIRE(feat && rt && depth && weight && volume, "mvs_cv_aggregate_fwd: null pointer");
     if (int rc = check_shapes("mvs_cv_aggregate_fwd", B, V, C, Gin, D, H, W)) return rc;
-    const int DS = pick_depth_slices(D);
-    dim3 grid(mvs::ceil_div(W, 64), H, B), block(64, DS);
+    const int LPP = C / 4, PPW = 64 / LPP;
+    dim3 grid(mvs::ceil_div(W, NW * PPW), H, B), block(64 * NW);
     hipStream_t s = MVS_STREAM(stream);
-    const size_t lds = sim_depth ? (size_t)2 * DS * 64 * sizeof(float) : 0;
-#define MVS_LAUNCH_AGG(CPG)                                                                                              \
-    if (sim_depth)                                                                                                       \
-        hipLaunchKernelGGL((cv_aggregate_kernel<CPG, true>), grid, block, lds, s, feat, rt, depth, weight, V, D, H, W,  \
-                           volume, sim_depth);                                                                           \
-    else                                                                                                                 \
-        hipLaunchKernelGGL((cv_aggregate_kernel<CPG, false>), grid, block, lds, s, feat, rt, depth, weight, V, D, H, W, \
+    const size_t lds = (size_t)NW * 64 * 32;
+#define MVS_LAUNCH_AGG(L)                                                                                               \
+    if (sim_depth)                                                                                                      \
+        hipLaunchKernelGGL((cv_aggregate_kernel<L, true>), grid, block, lds, s, feat, rt, depth, weight, V, D, H, W,    \
+                           volume, sim_depth);                                                                          \
+    else                                                                                                                \
+        hipLaunchKernelGGL((cv_aggregate_kernel<L, false>), grid, block, lds, s, feat, rt, depth, weight, V, D, H, W,   \
                            volume, sim_depth)
-    switch (C / G) {
-        case 1: MVS_LAUNCH_AGG(1); break;
+    switch (LPP) {
         case 2: MVS_LAUNCH_AGG(2); break;
         case 4: MVS_LAUNCH_AGG(4); break;
-        default: MVS_LAUNCH_AGG(8); break;
+        case 8: MVS_LAUNCH_AGG(8); break;
+        default: MVS_LAUNCH_AGG(16); break;
     }
 #undef MVS_LAUNCH_AGG
     return mvs::finish_launch("mvs_cv_aggregate_fwd");

