@@ -15,33 +15,14 @@
 // wavefront always owns an even+odd pair in each strided dimension so that all wavefronts do equal work.
 //
 // Algorithmic FLOPs per layer: 2*27*Cin*Cout per output voxel (conv) / per input voxel (deconv).
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-using mvs_rsrc_t = __amdgpu_buffer_rsrc_t;
-
-// wave-uniform buffer descriptor: loads beyond `bytes` (or with the OOB marker as offset) return 0, which is how the
-// zero padding / tile halo is produced without branches
-__device__ __forceinline__ mvs_rsrc_t mvs_make_rsrc(const float* base, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float mvs_buf_load(mvs_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, 0));
-}
-
-constexpr int NWAVES = 4;
-
-constexpr int np_of(int NT) { return NT == 1 ? 16 : (NT == 2 ? 48 : 80); }   // packed cout row, == 16 (mod 32)
-constexpr int pad_cs(int raw, int shw) {
-    // channel stride of the LDS input tile: == 16 (mod 32) for unit-stride fragment reads, odd for stride-2 reads
-    return shw == 1 ? raw + ((16 - raw % 32) + 32) % 32 : raw + ((raw % 2 == 0) ? 1 : 0);
-}
+using namespace mvsconv;
+using mvs_rsrc_t = rsrc_t;
+__device__ __forceinline__ mvs_rsrc_t mvs_make_rsrc(const float* b, unsigned n) { return make_rsrc(b, n); }
+__device__ __forceinline__ float mvs_buf_load(mvs_rsrc_t r, unsigned v, unsigned s) { return buf_load(r, v, s); }
 constexpr int CC_DECONV = 8;                                                  // input channels per LDS chunk
-constexpr int cc_conv(int NT, int SHW) { return (SHW == 1 && NT == 1) ? 8 : 4; }
-
-__host__ __device__ inline int nt_of(int Cout) { int nt = (Cout + 15) / 16; return nt == 3 ? 4 : nt; }
 
 // --------------------------------------------------------------------------------------------------------
 // weight packing: one zero-padded image per layer, [cin/4 slabs][tap 27][c 4][NP].  A kernel that stages CC
@@ -61,167 +42,6 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int Cin, int Co
         if (cin < Cin && n < Cout)
             v = transposed ? w[((size_t)cin * Cout + n) * 27 + tap] : w[((size_t)n * Cin + cin) * 27 + tap];
         out[idx] = v;
-    }
-}
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-
-// fused epilogue for one lane's 4 consecutive output voxels of one channel
-__device__ __forceinline__ f32x4 bn_act(f32x4 a, float sc, float sh, int relu) {
-    f32x4 o;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float v = fmaf(a[r], sc, sh);
-        o[r] = relu ? fmaxf(v, 0.0f) : v;
-    }
-    return o;
-}
-
-// --------------------------------------------------------------------------------------------------------
-// forward convolution, stride (SD, SHW, SHW), kernel 3, padding 1.
-// block = 4 wavefronts = 2 (d) x 2 (h) output rows x 64 voxels along W; wavefront = one row, 4 M-tiles.
-// --------------------------------------------------------------------------------------------------------
-template <int NT, int SD, int SHW>
-__global__ __launch_bounds__(256) void conv3d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
-                                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                                     const float* __restrict__ res, float* __restrict__ y, int CIN, int COUT,
-                                                     int Di, int Hi, int Wi, int Do, int Ho, int Wo, int relu) {
-    constexpr int TD = 2, TH = 2, MT = 4;
-    constexpr int CC = cc_conv(NT, SHW);
-    constexpr int NP = np_of(NT);
-    constexpr int ID = (TD - 1) * SD + 3, IH = (TH - 1) * SHW + 3, IW = (64 - 1) * SHW + 3;
-    constexpr int CS = pad_cs(ID * IH * IW, SHW);
-    constexpr int WSLAB = 27 * 4 * NP;                       // one packed cin/4 slab
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_in = smem;                                      // [CC][CS]
-    float* s_w = smem + CC * CS;                             // [CC/4][27][4][NP]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i16 = lane & 15, kk = lane >> 4;
-    const int ndt = (Do + TD - 1) / TD;
-    const int b = blockIdx.z / ndt, d0 = (blockIdx.z % ndt) * TD, h0 = blockIdx.y * TH, w0 = blockIdx.x * 64;
-    const int dl = wave / TH, hl = wave % TH;
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nchunks = (CIN + CC - 1) / CC;
-    const size_t plane = (size_t)Hi * Wi;
-
-    // ---- staging registers: the NEXT chunk's input rows + weight slabs are fetched while this chunk's MFMAs run
-    //      (issue early / write late); out-of-tile and padding elements come back as 0 from the buffer bounds check
-    constexpr int RPW = (CC * ID * IH + NWAVES - 1) / NWAVES;       // input rows per wavefront
-    constexpr int LPR = (IW + 63) / 64;                             // loads per row per lane
-    constexpr int NWV = ((CC / 4) * WSLAB / 4 + 255) / 256;         // weight float4s per thread
-    constexpr unsigned OOB = 0x80000000u;
-    float sreg[RPW][LPR];
-    f32x4 wreg[NWV];
-    auto prefetch = [&](int ch) {
-        const int cleft = min(CC, CIN - ch * CC);
-        const mvs_rsrc_t xin = mvs_make_rsrc(x + (size_t)(b * CIN + ch * CC) * Di * plane, (unsigned)((size_t)cleft * Di * plane * 4));
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int r = wave + i * NWAVES;
-            const int c = r / (ID * IH), rem = r % (ID * IH), dz = rem / IH, hy = rem % IH;
-            const int gd = d0 * SD - 1 + dz, gh = h0 * SHW - 1 + hy;
-            const bool rowok = (r < CC * ID * IH) && gd >= 0 && gd < Di && gh >= 0 && gh < Hi;
-            const unsigned soff = rowok ? (unsigned)((((size_t)c * Di + gd) * Hi + gh) * Wi * 4) : 0u;
-#pragma unroll
-            for (int j = 0; j < LPR; ++j) {
-                const int wx = lane + j * 64;
-                const int gw = w0 * SHW - 1 + wx;
-                const unsigned voff = (rowok && wx < IW && gw >= 0 && gw < Wi) ? (unsigned)gw * 4u : OOB;
-                sreg[i][j] = mvs_buf_load(xin, voff, soff);
-            }
-        }
-        const f32x4* src = reinterpret_cast<const f32x4*>(wp + (size_t)ch * (CC / 4) * WSLAB);
-#pragma unroll
-        for (int i = 0; i < NWV; ++i) {
-            const int idx = tid + i * 256;
-            wreg[i] = (idx < (CC / 4) * WSLAB / 4) ? src[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int r = wave + i * NWAVES;
-            if (r < CC * ID * IH) {
-                const int c = r / (ID * IH), rem = r % (ID * IH);
-                float* lrow = s_in + c * CS + rem * IW;
-#pragma unroll
-                for (int j = 0; j < LPR; ++j) {
-                    const int wx = lane + j * 64;
-                    if (wx < IW) lrow[wx] = sreg[i][j];
-                }
-            }
-        }
-        f32x4* dst = reinterpret_cast<f32x4*>(s_w);
-#pragma unroll
-        for (int i = 0; i < NWV; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < (CC / 4) * WSLAB / 4) dst[idx] = wreg[i];
-        }
-    };
-
-    prefetch(0);
-    for (int ch = 0; ch < nchunks; ++ch) {
-        __syncthreads();                                     // everyone is done reading the previous chunk
-        commit();
-        __syncthreads();
-        if (ch + 1 < nchunks) prefetch(ch + 1);
-        // ---- 27 taps x CC/4 k-steps of MFMA ----
-        const float* abase = s_in + kk * CS + ((dl * SD) * IH + hl * SHW) * IW + i16 * SHW;
-        const float* bbase = s_w + kk * NP + i16;
-#pragma unroll
-        for (int ks = 0; ks < CC / 4; ++ks) {
-#pragma unroll
-            for (int kd = 0; kd < 3; ++kd)
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const int tap = (kd * 3 + kh) * 3 + kw;
-                        float a[MT], bf[NT];
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) a[m] = abase[ks * 4 * CS + (kd * IH + kh) * IW + kw + m * 16 * SHW];
-#pragma unroll
-                        for (int n = 0; n < NT; ++n) bf[n] = bbase[ks * WSLAB + tap * 4 * NP + n * 16];
-#pragma unroll
-                        for (int m = 0; m < MT; ++m)
-#pragma unroll
-                            for (int n = 0; n < NT; ++n) acc[m][n] = mfma4(a[m], bf[n], acc[m][n]);
-                    }
-        }
-    }
-
-    // ---- epilogue ----
-    const int od = d0 + dl, oh = h0 + hl;
-    if (od >= Do || oh >= Ho) return;
-    const bool vec_ok = (Wo % 4) == 0;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int co = n * 16 + i16;
-        if (co >= COUT) continue;
-        const float sc = scale ? scale[co] : 1.0f, sh = shift ? shift[co] : 0.0f;
-        const size_t rowoff = (((size_t)(b * COUT + co) * Do + od) * Ho + oh) * Wo;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int ow = w0 + m * 16 + kk * 4;
-            if (ow >= Wo) continue;
-            f32x4 o = bn_act(acc[m][n], sc, sh, relu);
-            if (vec_ok) {
-                if (res) { const f32x4 rr = *reinterpret_cast<const f32x4*>(res + rowoff + ow); o += rr; }
-                *reinterpret_cast<f32x4*>(y + rowoff + ow) = o;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (ow + r < Wo) y[rowoff + ow + r] = o[r] + (res ? res[rowoff + ow + r] : 0.0f);
-            }
-        }
     }
 }
 
@@ -440,35 +260,10 @@ __global__ __launch_bounds__(256) void prob3_kernel(const float* __restrict__ x,
     out[((size_t)(b * D + d) * H + yh) * W + xw] = acc;
 }
 
-template <int NT, int SD, int SHW>
-size_t conv_lds_bytes() {
-    constexpr int CC = cc_conv(NT, SHW);
-    constexpr int ID = (2 - 1) * SD + 3, IH = (2 - 1) * SHW + 3, IW = 63 * SHW + 3;
-    return (size_t)(CC * pad_cs(ID * IH * IW, SHW) + (CC / 4) * 27 * 4 * np_of(NT)) * sizeof(float);
-}
 template <int NT, int SD>
 size_t deconv_lds_bytes() {
     constexpr int ID = (SD == 1) ? 4 : 2, IW = 32 + 1;
     return (size_t)(CC_DECONV * pad_cs(ID * 3 * IW, 1) + (CC_DECONV / 4) * 27 * 4 * np_of(NT)) * sizeof(float);
-}
-
-template <int NT, int SD, int SHW>
-int launch_conv(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y, int B,
-                int Cin, int Cout, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int relu, hipStream_t s) {
-    const size_t lds = conv_lds_bytes<NT, SD, SHW>();
-    static bool attr_done = false;   // idempotent; a race only repeats the call
-    if (!attr_done && lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_kernel<NT, SD, SHW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            mvs::set_error("mvs_conv3d_fwd: cannot raise dynamic LDS to %zu bytes", lds);
-            return -(1000 + (int)hipGetLastError());
-        }
-        attr_done = true;
-    }
-    dim3 grid(mvs::ceil_div(Wo, 64), mvs::ceil_div(Ho, 2), B * mvs::ceil_div(Do, 2));
-    hipLaunchKernelGGL((conv3d_kernel<NT, SD, SHW>), grid, dim3(256), lds, s, x, wp, scale, shift, res, y, Cin, Cout, Di, Hi, Wi,
-                       Do, Ho, Wo, relu);
-    return mvs::finish_launch("mvs_conv3d_fwd");
 }
 
 template <int NT, int SD>
@@ -489,14 +284,6 @@ int launch_deconv(const float* x, const float* wp, const float* scale, const flo
     return mvs::finish_launch("mvs_deconv3d_fwd");
 }
 
-int check_conv_args(const char* who, int B, int Cin, int Cout, int Di, int Hi, int Wi) {
-    MVS_REQUIRE(B >= 1 && Di >= 1 && Hi >= 1 && Wi >= 1, "%s: bad shape B=%d D=%d H=%d W=%d", who, B, Di, Hi, Wi);
-    MVS_REQUIRE(Cin >= 4 && Cin % 4 == 0, "%s: Cin must be a multiple of 4 (got %d)", who, Cin);
-    MVS_REQUIRE(Cout >= 8 && Cout % 8 == 0 && Cout <= 64, "%s: Cout must be a multiple of 8, <= 64 (got %d)", who, Cout);
-    MVS_REQUIRE((int64_t)8 * Di * Hi * Wi * 4 < ((int64_t)1 << 31), "%s: 8 input channels exceed the 2 GiB buffer window", who);
-    return MVS_OK;
-}
-
 }  // namespace
 
 extern "C" int64_t mvs_conv3d_packed_floats(int Cin, int Cout) {
@@ -514,27 +301,6 @@ extern "C" int mvs_conv3d_pack_weights(const float* w, int Cin, int Cout, int tr
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, MVS_STREAM(stream), w, Cin, Cout,
                        transposed, NP, n4, wpacked);
     return mvs::finish_launch("mvs_conv3d_pack_weights");
-}
-
-extern "C" int mvs_conv3d_fwd(const float* x, const float* wpacked, const float* scale, const float* shift, const float* residual,
-                              float* y, int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int shw, int relu,
-                              mvs_stream_t stream) {
-    MVS_REQUIRE(x && wpacked && y, "mvs_conv3d_fwd: null pointer");
-    if (int rc = check_conv_args("mvs_conv3d_fwd", B, Cin, Cout, Di, Hi, Wi)) return rc;
-    MVS_REQUIRE((sd == 1 && shw == 1) || (sd == 2 && shw == 2) || (sd == 1 && shw == 2),
-                "mvs_conv3d_fwd: stride (%d,%d,%d) not built", sd, shw, shw);
-    const int Do = (Di - 1) / sd + 1, Ho = (Hi - 1) / shw + 1, Wo = (Wi - 1) / shw + 1;
-    MVS_REQUIRE((int64_t)B * mvs::ceil_div(Do, 2) <= 65535, "mvs_conv3d_fwd: grid.z limit");
-    hipStream_t s = MVS_STREAM(stream);
-    const int nt = nt_of(Cout);
-#define MVS_CONV(NTV)                                                                                                          \
-    if (sd == 1 && shw == 1) return launch_conv<NTV, 1, 1>(x, wpacked, scale, shift, residual, y, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, relu, s); \
-    if (sd == 2) return launch_conv<NTV, 2, 2>(x, wpacked, scale, shift, residual, y, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, relu, s);            \
-    return launch_conv<NTV, 1, 2>(x, wpacked, scale, shift, residual, y, B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, relu, s)
-    if (nt == 1) { MVS_CONV(1); }
-    if (nt == 2) { MVS_CONV(2); }
-    MVS_CONV(4);
-#undef MVS_CONV
 }
 
 extern "C" int mvs_deconv3d_fwd(const float* x, const float* wpacked, const float* scale, const float* shift, const float* residual,
