@@ -103,9 +103,10 @@ int mvs_cv_aggregate_fwd(const float* feat, const float* rt, const float* depth,
  *   deconv: ConvTranspose3d stride (sd,2,2), output_padding (sd-1,1,1):  Do = Di*sd, Ho = 2*Hi, Wo = 2*Wi
  * Constraints: Cin % 4 == 0, Cout % 8 == 0, Cout <= 64.
  * ------------------------------------------------------------------------------------------------------- */
-int64_t mvs_conv3d_packed_floats(int Cin, int Cout);
-/* w: Conv3d weight [Cout,Cin,3,3,3] (transposed=0) or ConvTranspose3d weight [Cin,Cout,3,3,3] (transposed=1) */
-int mvs_conv3d_pack_weights(const float* w, int Cin, int Cout, int transposed, float* wpacked, mvs_stream_t stream);
+/* mode 0: Conv3d weight [Cout,Cin,3,3,3];  mode 1 / 2: ConvTranspose3d weight [Cin,Cout,3,3,3] for depth stride
+ * sd = 2 / sd = 1 (the two transposed kernels use different weight images; pass the same mode to both calls) */
+int64_t mvs_conv3d_packed_floats(int Cin, int Cout, int mode);
+int mvs_conv3d_pack_weights(const float* w, int Cin, int Cout, int mode, float* wpacked, mvs_stream_t stream);
 int mvs_conv3d_fwd(const float* x, const float* wpacked, const float* scale, const float* shift,
                    const float* residual, float* y, int B, int Cin, int Cout, int Di, int Hi, int Wi,
                    int sd, int shw, int relu, mvs_stream_t stream);

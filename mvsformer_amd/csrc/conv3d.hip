@@ -286,16 +286,20 @@ int launch_deconv(const float* x, const float* wp, const float* scale, const flo
 
 }  // namespace
 
-extern "C" int64_t mvs_conv3d_packed_floats(int Cin, int Cout) {
-    if (Cin < 1 || Cout < 1 || Cout > 64) return 0;
+extern "C" int64_t mvs_conv3d_packed_floats(int Cin, int Cout, int mode) {
+    if (Cin < 1 || Cout < 1 || Cout > 64 || mode < 0 || mode > 2) return 0;
+    if (mode == 2 && deconv_s1_supported(Cout)) return deconv_s1_packed_floats(Cin, Cout);
     // padded to a multiple of 8 input channels so CC=8 kernels can always stage two full slabs
     const int n4 = 2 * ((Cin + 7) / 8);
     return (int64_t)n4 * 27 * 4 * np_of(nt_of(Cout));
 }
 
-extern "C" int mvs_conv3d_pack_weights(const float* w, int Cin, int Cout, int transposed, float* wpacked, mvs_stream_t stream) {
+extern "C" int mvs_conv3d_pack_weights(const float* w, int Cin, int Cout, int mode, float* wpacked, mvs_stream_t stream) {
     MVS_REQUIRE(w && wpacked, "mvs_conv3d_pack_weights: null pointer");
+    MVS_REQUIRE(mode >= 0 && mode <= 2, "mvs_conv3d_pack_weights: mode %d", mode);
     if (int rc = check_conv_args("mvs_conv3d_pack_weights", 1, Cin, Cout, 1, 1, 1)) return rc;
+    if (mode == 2 && deconv_s1_supported(Cout)) return deconv_s1_pack(w, Cin, Cout, wpacked, MVS_STREAM(stream));
+    const int transposed = mode != 0;
     const int n4 = 2 * ((Cin + 7) / 8), NP = np_of(nt_of(Cout));
     const int64_t total = (int64_t)n4 * 27 * 4 * NP;
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, MVS_STREAM(stream), w, Cin, Cout,
@@ -310,6 +314,8 @@ extern "C" int mvs_deconv3d_fwd(const float* x, const float* wpacked, const floa
     MVS_REQUIRE(sd == 1 || sd == 2, "mvs_deconv3d_fwd: depth stride %d not built", sd);
     MVS_REQUIRE((int64_t)B * Di <= 65535, "mvs_deconv3d_fwd: grid.z limit");
     hipStream_t s = MVS_STREAM(stream);
+    if (sd == 1 && deconv_s1_supported(Cout))
+        return deconv_s1_launch(x, wpacked, scale, shift, residual, y, B, Cin, Cout, Di, Hi, Wi, relu, s);
     const int nt = nt_of(Cout);
 #define MVS_DECONV(NTV)                                                                                                     \
     if (sd == 1) return launch_deconv<NTV, 1>(x, wpacked, scale, shift, residual, y, B, Cin, Cout, Di, Hi, Wi, relu, s);   \

@@ -47,4 +47,11 @@ inline int check_conv_args(const char* who, int B, int Cin, int Cout, int Di, in
     return MVS_OK;
 }
 
+// grouped stride-(1,2,2) transposed convolution (deconv3d_s1.hip)
+bool deconv_s1_supported(int Cout);
+int64_t deconv_s1_packed_floats(int Cin, int Cout);
+int deconv_s1_pack(const float* w, int Cin, int Cout, float* out, hipStream_t s);
+int deconv_s1_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y, int B,
+                     int Cin, int Cout, int Di, int Hi, int Wi, int relu, hipStream_t s);
+
 }  // namespace mvsconv

@@ -118,7 +118,7 @@ def _prepare_deconv(conv: nn.ConvTranspose3d, bn):
         raise MvsHipError("Deconv3d: only kernel 3, padding 1, groups 1 is built (got %s)" % conv)
     if not ((s == (2, 2, 2) and op == (1, 1, 1)) or (s == (1, 2, 2) and op == (0, 1, 1))):
         raise MvsHipError("Deconv3d: stride %s / output_padding %s is not built" % (s, op))
-    packed = ops.conv3d_pack(_f32c(conv.weight), transposed=True)
+    packed = ops.conv3d_pack(_f32c(conv.weight), transposed=True, sd=s[0])
     if bn is not None:
         scale, shift = _bn_fold(bn)
     else:

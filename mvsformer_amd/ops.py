@@ -187,16 +187,18 @@ def cv_aggregate(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, weig
 
 
 # ----------------------------------------------------------------------------------------------- 3-D convs
-def conv3d_pack(weight: torch.Tensor, transposed: bool) -> torch.Tensor:
+def conv3d_pack(weight: torch.Tensor, transposed: bool, sd: int = 2) -> torch.Tensor:
+    """Re-lay a Conv3d (``[Cout,Cin,3,3,3]``) or ConvTranspose3d (``[Cin,Cout,3,3,3]``, ``sd`` = its depth stride) weight."""
     _chk(weight, "conv weight")
+    mode = 0 if not transposed else (2 if sd == 1 else 1)
     if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3):
         raise _lib.MvsHipError("conv weight must be [*,*,3,3,3], got %s" % (tuple(weight.shape),))
     cin, cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
-    n = _lib.load().mvs_conv3d_packed_floats(cin, cout)
+    n = _lib.load().mvs_conv3d_packed_floats(cin, cout, mode)
     if n <= 0:
         raise _lib.MvsHipError("unsupported conv channels Cin=%d Cout=%d" % (cin, cout))
     packed = torch.empty(n, device=weight.device, dtype=torch.float32)
-    _call("mvs_conv3d_pack_weights", None, _ptr(weight), cin, cout, int(transposed), _ptr(packed), _stream())
+    _call("mvs_conv3d_pack_weights", None, _ptr(weight), cin, cout, mode, _ptr(packed), _stream())
     return packed
 
 
@@ -227,7 +229,8 @@ def deconv3d(x, wpacked, cin, cout, sd, scale=None, shift=None, residual=None, r
         if residual.shape != y.shape:
             raise _lib.MvsHipError("residual shape %s != output %s (stage H, W must be divisible by 8%s)" % (
                 tuple(residual.shape), tuple(y.shape), ", D by 8" if sd == 2 else ""))
-    tag = ("deconv3d_kernel<%d,%d>" % (_nt(cout), sd), "flops", 2.0 * 27 * cin * cout * B * Di * Hi * Wi)
+    name = "deconv3d_s1_kernel<%d>" % cout if (sd == 1 and cout == 8) else "deconv3d_kernel<%d,%d>" % (_nt(cout), sd)
+    tag = (name, "flops", 2.0 * 27 * cin * cout * B * Di * Hi * Wi)
     _call("mvs_deconv3d_fwd", tag, _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), B, cin,
           cout, Di, Hi, Wi, sd, int(relu), _stream())
     return y

@@ -186,7 +186,7 @@ def test_deconv3d_layer(dev, cin, cout, sd, D, H, W):
     y0 = F.conv_transpose3d(x, w, None, stride=(sd, 2, 2), padding=1, output_padding=(sd - 1, 1, 1))
     res = torch.randn(y0.shape, generator=gen)
     want = F.relu(y0 * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)) + res
-    packed = ops.conv3d_pack(w.to(dev), transposed=True)
+    packed = ops.conv3d_pack(w.to(dev), transposed=True, sd=sd)
     got = ops.deconv3d(x.to(dev), packed, cin, cout, sd, scale.to(dev), shift.to(dev), res.to(dev), relu=True)
     assert got.shape == want.shape
     assert max_abs(got.cpu(), want) < 2e-5 * max(1.0, want.abs().max().item())

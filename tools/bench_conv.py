@@ -55,7 +55,7 @@ for st in [int(s) for s in args.stages.split(",")]:
             vox = (d // stride[0]) * (h // stride[1]) * (w // stride[1])
         else:
             wt = torch.randn(cin, cout, 3, 3, 3, device=dev) * 0.05
-            pk = ops.conv3d_pack(wt, True)
+            pk = ops.conv3d_pack(wt, True, sd)
             fn = lambda: ops.deconv3d(x, pk, cin, cout, sd, scale, shift, None, True)
             vox = d * h * w
         ms = timeit(fn)
