@@ -83,6 +83,30 @@ __device__ __forceinline__ f32x4 gather4(mvs::rsrc_t src, unsigned pix_bytes, un
     return out;
 }
 
+// split form for the software-pipelined sweeps: issue the 4 tap loads now, blend later
+__device__ __forceinline__ void load_taps4(mvs::rsrc_t src, unsigned pix_bytes, unsigned cq_bytes, u32x4 o, f32x4 (&t)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = buf_load4(src, o[k] * pix_bytes + cq_bytes);
+}
+__device__ __forceinline__ f32x4 blend4(const f32x4 (&t)[4], f32x4 w) {
+    f32x4 out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float acc = t[0][i] * w[0];
+        acc = fmaf(t[1][i], w[1], acc);
+        acc = fmaf(t[2][i], w[2], acc);
+        out[i] = fmaf(t[3][i], w[3], acc);
+    }
+    return out;
+}
+
+// Fine stages (LPP <= 4: few channels, few depths, many pixels) are software-pipelined inside the wavefront: a pass
+// issues the tap loads of all its LPP steps, THEN evaluates the next pass's geometry (~130 VALU ops that need no
+// memory) while those loads are in flight, then blends/accumulates.  Coarse stages (LPP >= 8) keep one step's loads
+// in flight per wavefront and rely on 4 wavefronts per SIMD instead (hoisting all steps there costs 2x the registers
+// and measured 1.6x slower).
+constexpr bool pipelined(int LPP) { return LPP <= 4; }
+
 // ---------------------------------------------------------------------------------------------------------
 // sweep A
 // ---------------------------------------------------------------------------------------------------------
@@ -94,9 +118,10 @@ __global__ __launch_bounds__(64 * NW) void cv_entropy_kernel(const float* __rest
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    u32x4* taps_o = reinterpret_cast<u32x4*>(smem) + wave * 64;
-    f32x4* taps_w = reinterpret_cast<f32x4*>(smem + NW * 64 * 16) + wave * 64;
-    float* sims = reinterpret_cast<float*>(smem + NW * 64 * 32) + (size_t)wave * PPW * D;     // [D][PPW]
+    // per wavefront: 2 x 64 tap slots (double buffer for the pipelined schedule), then the sims[D][PPW] slab
+    u32x4* taps_o = reinterpret_cast<u32x4*>(smem) + wave * 128;
+    f32x4* taps_w = reinterpret_cast<f32x4*>(smem + NW * 128 * 16) + wave * 128;
+    float* sims = reinterpret_cast<float*>(smem + NW * 128 * 32) + (size_t)wave * PPW * D;     // [D][PPW]
 
     const int x0 = (blockIdx.x * NW + wave) * PPW, y = blockIdx.y;
     const int b = blockIdx.z / (V - 1), sv = blockIdx.z % (V - 1);
@@ -124,6 +149,33 @@ __global__ __launch_bounds__(64 * NW) void cv_entropy_kernel(const float* __rest
         s = pixel_sum<LPP>(s) * (1.0f / CPG);
         if (valid && cq == 0) sims[(c0 + dd) * PPW + pg] = s;
     };
+    if constexpr (pipelined(LPP)) {
+        geometry_pass<PPW>(rt, depth_row, HW, 0, D, x0, y, H, W, half_w, half_h, lane, taps_o, taps_w);
+        int buf = 0;
+        for (int c0 = 0; c0 < D; c0 += LPP, buf ^= 1) {
+            __builtin_amdgcn_wave_barrier();
+            f32x4 w[LPP], t[LPP][4];
+#pragma unroll
+            for (int dd = 0; dd < LPP; ++dd) {
+                w[dd] = taps_w[buf * 64 + dd * PPW + pg];
+                load_taps4(src, pix_bytes, cq * 16u, taps_o[buf * 64 + dd * PPW + pg], t[dd]);
+            }
+            if (c0 + LPP < D)
+                geometry_pass<PPW>(rt, depth_row, HW, c0 + LPP, D, x0, y, H, W, half_w, half_h, lane, taps_o + (buf ^ 1) * 64,
+                                   taps_w + (buf ^ 1) * 64);
+#pragma unroll
+            for (int dd = 0; dd < LPP; ++dd) {
+                const f32x4 g4 = blend4(t[dd], w[dd]);
+                float s = r[0] * g4[0];
+                s = s + r[1] * g4[1];
+                s = s + r[2] * g4[2];
+                s = s + r[3] * g4[3];
+                s = pixel_sum<LPP>(s) * (1.0f / CPG);
+                if (c0 + dd < D && cq == 0) sims[(c0 + dd) * PPW + pg] = s;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else
     for (int c0 = 0; c0 < D; c0 += LPP) {
         geometry_pass<PPW>(rt, depth_row, HW, c0, D, x0, y, H, W, half_w, half_h, lane, taps_o, taps_w);
         __builtin_amdgcn_wave_barrier();
@@ -172,8 +224,8 @@ __global__ __launch_bounds__(64 * NW) void cv_aggregate_kernel(const float* __re
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    u32x4* taps_o = reinterpret_cast<u32x4*>(smem) + wave * 64;
-    f32x4* taps_w = reinterpret_cast<f32x4*>(smem + NW * 64 * 16) + wave * 64;
+    u32x4* taps_o = reinterpret_cast<u32x4*>(smem) + wave * 128;
+    f32x4* taps_w = reinterpret_cast<f32x4*>(smem + NW * 128 * 16) + wave * 128;
 
     const int x0 = (blockIdx.x * NW + wave) * PPW, y = blockIdx.y, b = blockIdx.z;
     if (x0 >= W) return;
@@ -215,6 +267,85 @@ __global__ __launch_bounds__(64 * NW) void cv_aggregate_kernel(const float* __re
 
     float best = -INFINITY;
     int besti = 0;
+    if constexpr (pipelined(LPP)) {
+        // flattened (depth chunk, source view) passes, geometry of pass i+1 overlapped with the loads of pass i
+        const int nviews = V - 1, npass = ((D + LPP - 1) / LPP) * nviews;
+        float acc[LPP][NG];
+        float simtot[LPP];
+        geometry_pass<PPW>(rt_all + (size_t)(b * nviews) * 12, depth_row, HW, 0, D, x0, y, H, W, half_w, half_h, lane, taps_o, taps_w);
+        int c0 = 0, sv = 0, buf = 0;
+        for (int i = 0; i < npass; ++i, buf ^= 1) {
+            if (sv == 0) {
+#pragma unroll
+                for (int dd = 0; dd < LPP; ++dd) {
+                    simtot[dd] = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < NG; ++k) acc[dd][k] = 0.0f;
+                }
+            }
+            const mvs::rsrc_t src = mvs::make_rsrc(feat + (size_t)(b * V + sv + 1) * HW * C, (unsigned)(HW * pix_bytes));
+            const float wv = wp[(size_t)sv * HW];
+            __builtin_amdgcn_wave_barrier();
+            f32x4 w[LPP], t[LPP][4];
+#pragma unroll
+            for (int dd = 0; dd < LPP; ++dd) {
+                w[dd] = taps_w[buf * 64 + dd * PPW + pg];
+                load_taps4(src, pix_bytes, cq * 16u, taps_o[buf * 64 + dd * PPW + pg], t[dd]);
+            }
+            const int nsv = (sv + 1 == nviews) ? 0 : sv + 1, nc0 = (sv + 1 == nviews) ? c0 + LPP : c0;
+            if (i + 1 < npass)
+                geometry_pass<PPW>(rt_all + (size_t)(b * nviews + nsv) * 12, depth_row, HW, nc0, D, x0, y, H, W, half_w, half_h, lane,
+                                   taps_o + (buf ^ 1) * 64, taps_w + (buf ^ 1) * 64);
+#pragma unroll
+            for (int dd = 0; dd < LPP; ++dd) {
+                const f32x4 g4 = blend4(t[dd], w[dd]);
+                const f32x4 p = {r[0] * g4[0], r[1] * g4[1], r[2] * g4[2], r[3] * g4[3]};
+                if (CPG == 1) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[dd][k] = acc[dd][k] + p[k] * wv;
+                } else {                                      // CPG == 2 (LPP == 4)
+                    acc[dd][0] = acc[dd][0] + ((p[0] + p[1]) * 0.5f) * wv;
+                    acc[dd][1] = acc[dd][1] + ((p[2] + p[3]) * 0.5f) * wv;
+                }
+                if (SIM) {
+                    f32x4 q = {rn[0] * g4[0], rn[1] * g4[1], rn[2] * g4[2], rn[3] * g4[3]};
+                    f32x4 n2 = {g4[0] * g4[0], g4[1] * g4[1], g4[2] * g4[2], g4[3] * g4[3]};
+#pragma unroll
+                    for (int ii = 0; ii < CPG; ++ii) {
+#pragma unroll
+                        for (int k = ii + CPG; k < 4; k += CPG) { q[ii] += q[k]; n2[ii] += n2[k]; }
+                    }
+#pragma unroll
+                    for (int m = 1; m < LPP; m <<= 1)
+#pragma unroll
+                        for (int ii = 0; ii < CPG; ++ii) {
+                            q[ii] += __shfl_xor(q[ii], m, 64);
+                            n2[ii] += __shfl_xor(n2[ii], m, 64);
+                        }
+                    float ssum = 0.0f;
+#pragma unroll
+                    for (int ii = 0; ii < CPG; ++ii) ssum += q[ii] * __builtin_amdgcn_rsqf(fmaxf(n2[ii], 1e-24f));
+                    simtot[dd] = simtot[dd] + ssum * (1.0f / CPG);
+                }
+            }
+            if (sv + 1 == nviews) {
+#pragma unroll
+                for (int dd = 0; dd < LPP; ++dd) {
+                    const int d = c0 + dd;
+                    if (d < D) {
+                        if (active) {
+#pragma unroll
+                            for (int k = 0; k < NG; ++k)
+                                volume[((size_t)(b * G + cq * NG + k) * D + d) * HW + pix] = acc[dd][k] / denom;
+                        }
+                        if (SIM && simtot[dd] > best) { best = simtot[dd]; besti = d; }
+                    }
+                }
+            }
+            sv = nsv;
+            c0 = nc0;
+        }
+    } else
     for (int c0 = 0; c0 < D; c0 += LPP) {
         float acc[LPP][NG];
         float simtot[LPP];
@@ -357,7 +488,7 @@ extern "C" int mvs_cv_entropy_fwd(const float* feat, const float* rt, const floa
     MVS_REQUIRE(feat && rt && depth && entropy, "mvs_cv_entropy_fwd: null pointer");
     if (int rc = check_shapes("mvs_cv_entropy_fwd", B, V, C, Gin, D, H, W)) return rc;
     const int LPP = C / 4, PPW = 64 / LPP;
-    const size_t lds = (size_t)NW * 64 * 32 + (size_t)NW * PPW * D * sizeof(float);
+    const size_t lds = (size_t)NW * 128 * 32 + (size_t)NW * PPW * D * sizeof(float);
     MVS_REQUIRE(lds <= 64 * 1024, "mvs_cv_entropy_fwd: D=%d with C=%d needs %zu bytes of LDS (> 64 KiB)", D, C, lds);
     dim3 grid(mvs::ceil_div(W, NW * PPW), H, B * (V - 1)), block(64 * NW);
     hipStream_t s = MVS_STREAM(stream);
@@ -378,7 +509,7 @@ extern "C" int mvs_cv_aggregate_fwd(const float* feat, const float* rt, const fl
     const int LPP = C / 4, PPW = 64 / LPP;
     dim3 grid(mvs::ceil_div(W, NW * PPW), H, B), block(64 * NW);
     hipStream_t s = MVS_STREAM(stream);
-    const size_t lds = (size_t)NW * 64 * 32;
+    const size_t lds = (size_t)NW * 128 * 32;
 #define MVS_LAUNCH_AGG(L)                                                                                               \
     if (sim_depth)                                                                                                      \
         hipLaunchKernelGGL((cv_aggregate_kernel<L, true>), grid, block, lds, s, feat, rt, depth, weight, V, D, H, W,    \
