@@ -104,7 +104,10 @@ int mvs_cv_aggregate_fwd(const float* feat, const float* rt, const float* depth,
  * Constraints: Cin % 4 == 0, Cout % 8 == 0, Cout <= 64.
  * ------------------------------------------------------------------------------------------------------- */
 /* mode 0: Conv3d weight [Cout,Cin,3,3,3];  mode 1 / 2: ConvTranspose3d weight [Cin,Cout,3,3,3] for depth stride
- * sd = 2 / sd = 1 (the two transposed kernels use different weight images; pass the same mode to both calls) */
+ * sd = 2 / sd = 1 (the two transposed kernels use different weight images; pass the same mode to both calls);
+ * mode 3: w is a Conv3d weight [Cin,Cout,3,3,3] in the roles of the DATA-GRADIENT conv of a stride-1 layer
+ * (channels swapped, taps mirrored) — feeds mvs_conv3d_fwd(dY) -> dX.  The other data gradients need no extra mode:
+ * strided Conv3d -> mvs_deconv3d_fwd with mode 1/2 of the same weight, ConvTranspose3d -> mvs_conv3d_fwd with mode 0. */
 int64_t mvs_conv3d_packed_floats(int Cin, int Cout, int mode);
 int mvs_conv3d_pack_weights(const float* w, int Cin, int Cout, int mode, float* wpacked, mvs_stream_t stream);
 int mvs_conv3d_fwd(const float* x, const float* wpacked, const float* scale, const float* shift,
@@ -131,6 +134,48 @@ int mvs_prob3_fwd(const float* x, const float* w, int B, int C, int D, int H, in
 int mvs_head_fwd(const float* logits, const float* x8, const float* w1, const float* b1, int x8_channels,
                  const float* depth_values, float tmp, int training, int B, int D, int H, int W,
                  float* prob_volume_pre, float* prob_volume, float* depth, float* conf, mvs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Training.  The reference trains StageNet with batch-statistics BatchNorm (module.py:111-117,
+ * 153-159,195-197) and autograd through every op; here the forward is  raw conv (mvs_conv3d_fwd / mvs_deconv3d_fwd with
+ * scale = shift = NULL, relu = 0) -> mvs_bn_stats -> [all-reduce of sums across ranks = SyncBatchNorm] -> mvs_bn_finalize
+ * -> mvs_affine_act, and the backward is mvs_bn_bwd_reduce -> [all-reduce] -> mvs_bn_bwd_apply -> data gradient through
+ * the same MFMA conv kernels with re-packed weights -> mvs_conv3d_wgrad.  Tensors are [B,C,N], N = D*H*W or H*W.
+ *   mvs_bn_stats:      sums[c] += sum x, sums[C+c] += sum x^2   (sums zeroed by the caller)
+ *   mvs_bn_finalize:   mean/var from sums and count -> scale = gamma*invstd, shift = beta - mean*scale, mean, invstd;
+ *                      running stats updated with momentum (unbiased variance), as nn.BatchNorm does; NULL to skip
+ *   mvs_affine_act:    y = [relu](x*scale[c] + shift[c]) [+ residual]
+ *   mvs_bn_bwd_reduce: g = dy*[x*scale+shift > 0 or !relu]; sums[c] += sum g, sums[C+c] += sum g*xhat
+ *   mvs_bn_bwd_apply:  dx = gamma*invstd*(g - sums[c]/count - xhat*sums[C+c]/count);  dgamma = sums[C+c], dbeta = sums[c]
+ *   mvs_conv3d_wgrad:  dW[a][b][k] += sum_{batch,p} A[a,p] * Bt[b, p*s - 1 + k]  (dW zeroed by the caller); Conv3d:
+ *                      A = dY, Bt = X, dW = [Cout,Cin,27]; ConvTranspose3d: A = X, Bt = dY, dW = [Cin,Cout,27];
+ *                      (Dp,Hp,Wp) is the grid the stride divides (conv output / deconv input), (Db,Hb,Wb) the other
+ *   mvs_cv_aggregate_bwd: gradient of mvs_cv_aggregate_fwd w.r.t. the channel-last features (dfeat [B,V,H,W,C], zeroed by
+ *                      the caller; source views are accumulated with fp32 atomics) and the visibility weights
+ *   mvs_softmax_bwd, mvs_prob1_bwd (dwb[C+1] zeroed by the caller: dW then dbias), mvs_sigmoid_fwd/bwd, mvs_nhwc_to_nchw
+ * ------------------------------------------------------------------------------------------------------- */
+int mvs_bn_stats(const float* x, int B, int C, int64_t N, float* sums, mvs_stream_t stream);
+int mvs_bn_finalize(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float momentum, float eps, double count, int C, float* scale, float* shift, float* mean, float* invstd,
+                    mvs_stream_t stream);
+int mvs_affine_act(const float* x, const float* scale, const float* shift, const float* residual, int relu, int B, int C,
+                   int64_t N, float* y, mvs_stream_t stream);
+int mvs_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
+                      const float* invstd, int relu, int B, int C, int64_t N, float* sums, mvs_stream_t stream);
+int mvs_bn_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
+                     const float* invstd, const float* gamma, const float* sums, double count, int relu, int B, int C,
+                     int64_t N, float* dx, mvs_stream_t stream);
+int mvs_conv3d_wgrad(const float* A, const float* Bt, float* dW, int nbatch, int CA, int CB, int Dp, int Hp, int Wp, int Db,
+                     int Hb, int Wb, int sd, int shw, mvs_stream_t stream);
+int mvs_cv_aggregate_bwd(const float* feat, const float* rt, const float* depth, const float* weight, const float* volume,
+                         const float* gvolume, int B, int V, int C, int G, int D, int H, int W, float* dfeat, float* dweight,
+                         mvs_stream_t stream);
+int mvs_softmax_bwd(const float* p, const float* dp, int B, int D, int64_t HW, float* dpre, mvs_stream_t stream);
+int mvs_prob1_bwd(const float* x, const float* w, const float* dlogits, int B, int C, int64_t N, float* dx, float* dwb,
+                  mvs_stream_t stream);
+int mvs_sigmoid_fwd(const float* x, int64_t n, float* y, mvs_stream_t stream);
+int mvs_sigmoid_bwd(const float* y, const float* dy, int64_t n, float* dx, mvs_stream_t stream);
+int mvs_nhwc_to_nchw(const float* in, float* out, int N, int C, int64_t HW, mvs_stream_t stream);
 
 /* Stand-alone heads for callers that use the ops directly.
  *   mvs_depth_regression: module.py:597-603, depth = sum_d p*depth_values; depth_values [B,D,H,W] or [B,D]

@@ -19,7 +19,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvs_hip.so")
 ABI_VERSION = 1
 
-P, I, F, L = c_void_p, c_int, c_float, c_int64
+from ctypes import c_double  # noqa: E402
+
+P, I, F, L, Dbl = c_void_p, c_int, c_float, c_int64, c_double
 
 # name -> (restype, argtypes); mirrors include/mvs_hip.h one to one (tests/test_abi.py cross-checks the header)
 SIGNATURES = {
@@ -38,6 +40,18 @@ SIGNATURES = {
     "mvs_deconv3d_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "mvs_prob3_fwd": (I, [P, P, I, I, I, I, I, P, P]),
     "mvs_head_fwd": (I, [P, P, P, P, I, P, F, I, I, I, I, I, P, P, P, P, P]),
+    "mvs_bn_stats": (I, [P, I, I, L, P, P]),
+    "mvs_bn_finalize": (I, [P, P, P, P, P, F, F, Dbl, I, P, P, P, P, P]),
+    "mvs_affine_act": (I, [P, P, P, P, I, I, I, L, P, P]),
+    "mvs_bn_bwd_reduce": (I, [P, P, P, P, P, P, I, I, I, L, P, P]),
+    "mvs_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, Dbl, I, I, I, L, P, P]),
+    "mvs_conv3d_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "mvs_cv_aggregate_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P]),
+    "mvs_softmax_bwd": (I, [P, P, I, I, L, P, P]),
+    "mvs_prob1_bwd": (I, [P, P, P, I, I, L, P, P, P]),
+    "mvs_sigmoid_fwd": (I, [P, L, P, P]),
+    "mvs_sigmoid_bwd": (I, [P, P, L, P, P]),
+    "mvs_nhwc_to_nchw": (I, [P, P, I, I, L, P]),
     "mvs_depth_regression": (I, [P, P, I, I, I, I, I, P, P]),
     "mvs_conf_regression": (I, [P, I, I, I, I, I, P, P]),
     "mvs_prob1_fwd": (I, [P, P, P, I, I, L, P, P]),

@@ -1,0 +1,222 @@
+"""torch.autograd glue for training mode: every forward AND backward op is a hand-written HIP
+kernel of libmvs_hip.so; PyTorch only sequences them (autograd graph, parameter .grad accumulation, DDP hooks,
+SyncBatchNorm's all-reduce of the per-channel sums).
+
+Gradient contract restated from the reference: the sampling grid is built under ``no_grad`` and hypotheses are detached
+(models/warping.py:79-97, mvsformer_model.py:290,430), the entropy that feeds ``self.vis`` is detached
+(mvsformer_model.py:89) — so gradients reach the feature maps, the ``vis`` CNN parameters and the regularizer
+parameters; ``depth`` (arg-max gather) and ``photometric_confidence`` are not differentiable.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _sync_sums(sums: torch.Tensor, count: float, bn) -> float:
+    """SyncBatchNorm: all-reduce [sum, sumsq] (and the element count) over the process group."""
+    if isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        packed = torch.cat([sums, sums.new_tensor([count])])
+        dist.all_reduce(packed, group=bn.process_group)
+        sums.copy_(packed[:-1])
+        return float(packed[-1].item())
+    return count
+
+
+class ConvFn(torch.autograd.Function):
+    """Raw 3x3x3 convolution, padding 1, stride (sd, shw, shw); weight is the layer's ``nn.Conv3d.weight``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride):
+        x = x.contiguous()
+        w = weight.detach().to(torch.float32).contiguous()
+        cout, cin = w.shape[0], w.shape[1]
+        y = ops.conv3d(x, ops.conv3d_pack(w, False), cin, cout, stride, None, None, None, relu=False)
+        ctx.save_for_backward(x, w)
+        ctx.stride = stride
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        cout, cin = w.shape[0], w.shape[1]
+        sd, shw = ctx.stride
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if shw == 1:
+                dx = ops.conv3d(dy, ops.conv3d_pack(w, "dgrad"), cout, cin, (1, 1), None, None, None, relu=False)
+            else:       # strided conv: the data gradient is the transposed conv with the same weight
+                dx = ops.deconv3d(dy, ops.conv3d_pack(w, True, sd), cout, cin, sd, None, None, None, relu=False)
+            if dx.shape != x.shape:
+                raise ops._lib.MvsHipError("conv backward: input %s is not 2x the output grid %s" % (tuple(x.shape), tuple(dy.shape)))
+        dw = ops.conv3d_wgrad(dy, x, (sd, shw)) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
+class DeconvFn(torch.autograd.Function):
+    """Raw ConvTranspose3d k=3, stride (sd,2,2), padding 1, output_padding (sd-1,1,1); weight ``[Cin,Cout,3,3,3]``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, sd):
+        x = x.contiguous()
+        w = weight.detach().to(torch.float32).contiguous()
+        cin, cout = w.shape[0], w.shape[1]
+        y = ops.deconv3d(x, ops.conv3d_pack(w, True, sd), cin, cout, sd, None, None, None, relu=False)
+        ctx.save_for_backward(x, w)
+        ctx.sd = sd
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        cin, cout = w.shape[0], w.shape[1]
+        sd = ctx.sd
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dX[ci] = sum_{co,k} dY[co, i*s-1+k] * W[ci,co,k]  ==  strided conv of dY with W read as [out=ci, in=co]
+            dx = ops.conv3d(dy, ops.conv3d_pack(w, False), cout, cin, (sd, 2), None, None, None, relu=False)
+        dw = ops.conv3d_wgrad(x, dy, (sd, 2)) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
+class BnActFn(torch.autograd.Function):
+    """Training-mode BatchNorm (batch statistics, running-stat update) + optional ReLU + optional residual add."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, bn, relu):
+        x = x.contiguous()
+        B, C = x.shape[0], x.shape[1]
+        count = float(x.numel() // C)
+        sums = ops.bn_stats(x)
+        count = _sync_sums(sums, count, bn)
+        g = gamma.detach().to(torch.float32).contiguous() if gamma is not None else None
+        b = beta.detach().to(torch.float32).contiguous() if beta is not None else None
+        momentum = 0.1 if bn.momentum is None else bn.momentum
+        track = bn.track_running_stats and bn.running_mean is not None
+        scale, shift, mean, invstd = ops.bn_finalize(sums, g, b, bn.running_mean if track else None,
+                                                     bn.running_var if track else None, momentum, bn.eps, count)
+        if track and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        res = residual.contiguous() if residual is not None else None
+        y = ops.affine_act(x, scale, shift, res, relu)
+        ctx.save_for_backward(x, scale, shift, mean, invstd, g if g is not None else scale.new_ones(C))
+        ctx.relu, ctx.count, ctx.bn, ctx.has_res = relu, count, bn, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, shift, mean, invstd, g = ctx.saved_tensors
+        dy = dy.contiguous()
+        sums = ops.bn_bwd_reduce(dy, x, scale, shift, mean, invstd, ctx.relu)
+        C = x.shape[1]
+        local = sums.clone()                       # dgamma / dbeta stay per-rank (DDP averages parameter grads itself)
+        _sync_sums(sums, 0.0, ctx.bn)
+        dx = ops.bn_bwd_apply(dy, x, scale, shift, mean, invstd, g, sums, ctx.count, ctx.relu)
+        dgamma = local[C:].clone() if ctx.needs_input_grad[1] else None
+        dbeta = local[:C].clone() if ctx.needs_input_grad[2] else None
+        dres = dy if ctx.has_res else None
+        return dx, dgamma, dbeta, dres, None, None
+
+
+class Prob1Fn(torch.autograd.Function):
+    """1x1x1 (or 1x1) convolution C -> 1 with bias."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        w = weight.detach().to(torch.float32).reshape(-1).contiguous()
+        b = bias.detach().to(torch.float32).reshape(-1).contiguous()
+        B, C = x.shape[0], x.shape[1]
+        x5 = x.reshape(B, C, 1, 1, -1)
+        y = ops.prob1(x5, w, b).reshape(B, 1, *x.shape[2:])
+        ctx.save_for_backward(x, w)
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx, dwb = ops.prob1_bwd(x, w, dy.contiguous().reshape(x.shape[0], -1))
+        C = x.shape[1]
+        return dx, dwb[:C].reshape(ctx.wshape).clone(), dwb[C:].clone()
+
+
+class SigmoidFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.sigmoid(x.contiguous())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.sigmoid_bwd(y, dy.contiguous())
+
+
+class AggregateFn(torch.autograd.Function):
+    """volume_mean = sum_v w_v * corr(ref, warp(src_v)) / (sum_v w_v + 1e-6); grads to features and to w."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, rt, hyp, G):
+        feat_cl = ops.to_channels_last(feat.detach().to(torch.float32).contiguous())
+        weight = weight.contiguous()
+        vol, _ = ops.cv_aggregate(feat_cl, rt, hyp, weight, G, want_sim_depth=False)
+        ctx.save_for_backward(feat_cl, rt, hyp, weight, vol)
+        ctx.G, ctx.dtype = G, feat.dtype
+        return vol
+
+    @staticmethod
+    def backward(ctx, gvol):
+        feat_cl, rt, hyp, weight, vol = ctx.saved_tensors
+        dfeat_cl, dw = ops.cv_aggregate_bwd(feat_cl, rt, hyp, weight, vol, gvol.contiguous(), ctx.G)
+        dfeat = ops.to_channels_first(dfeat_cl).to(ctx.dtype) if ctx.needs_input_grad[0] else None
+        return dfeat, (dw if ctx.needs_input_grad[1] else None), None, None, None
+
+
+class HeadFn(torch.autograd.Function):
+    """softmax over depth + arg-max depth + max-prob confidence (training branch of mvsformer_model.py:110-125)."""
+
+    @staticmethod
+    def forward(ctx, pre, hyp, tmp):
+        pre = pre.contiguous()
+        _, prob, depth, conf = ops.head(hyp, float(tmp), True, logits=pre)
+        ctx.save_for_backward(prob)
+        ctx.mark_non_differentiable(depth, conf)
+        return prob, depth, conf
+
+    @staticmethod
+    def backward(ctx, dprob, _dd, _dc):
+        (prob,) = ctx.saved_tensors
+        return ops.softmax_bwd(prob, dprob.contiguous()), None, None
+
+
+# ---------------------------------------------------------------------------------------------------------
+def embed_conv2d_weight(w2d: torch.Tensor, cin_pad: int) -> torch.Tensor:
+    """``[Cout,Cin,3,3]`` -> ``[Cout,cin_pad,3,3,3]`` with the 2-D kernel in the centre depth tap (so the 2-D convs of
+    ``StageNet.vis`` run, forward and backward, on the same MFMA conv3d kernels at D = 1).  Pure padding: differentiable."""
+    w = F.pad(w2d.unsqueeze(2), (0, 0, 0, 0, 1, 1))                      # kd = 0, 2 are zero
+    if cin_pad > w.shape[1]:
+        w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, cin_pad - w.shape[1]))
+    return w
+
+
+def vis_train(entropy: torch.Tensor, vis: nn.Sequential) -> torch.Tensor:
+    """``self.vis(entropy)`` in training mode for ONE source view: ``entropy [B,1,H,W]`` -> ``[B,1,H,W]``.  The reference
+    calls the CNN once per view (mvsformer_model.py:91), so batch statistics are per view; keep that."""
+    B, _, H, W = entropy.shape
+    x = torch.zeros(B, 4, 1, H, W, device=entropy.device, dtype=torch.float32)
+    x[:, 0, 0] = entropy[:, 0]
+    for i in range(3):
+        blk = vis[i]
+        cin_pad = 4 if i == 0 else blk.conv.in_channels
+        x = ConvFn.apply(x, embed_conv2d_weight(blk.conv.weight, cin_pad), (1, 1))
+        x = BnActFn.apply(x, blk.bn.weight, blk.bn.bias, None, blk.bn, True)
+    y = Prob1Fn.apply(x, vis[3].weight, vis[3].bias)                    # [B,1,1,H,W]
+    return SigmoidFn.apply(y).reshape(B, 1, H, W)

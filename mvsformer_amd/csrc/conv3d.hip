@@ -39,8 +39,10 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int Cin, int Co
         const int ch = (int)(idx / ((int64_t)NP * 4 * 27));
         const int cin = ch * 4 + c;
         float v = 0.0f;
+        // transposed == 2: data gradient of a stride-1 Conv3d = conv with swapped channels and the taps mirrored
         if (cin < Cin && n < Cout)
-            v = transposed ? w[((size_t)cin * Cout + n) * 27 + tap] : w[((size_t)n * Cin + cin) * 27 + tap];
+            v = transposed == 2 ? w[((size_t)cin * Cout + n) * 27 + (26 - tap)]
+                                : (transposed ? w[((size_t)cin * Cout + n) * 27 + tap] : w[((size_t)n * Cin + cin) * 27 + tap]);
         out[idx] = v;
     }
 }
@@ -287,7 +289,7 @@ int launch_deconv(const float* x, const float* wp, const float* scale, const flo
 }  // namespace
 
 extern "C" int64_t mvs_conv3d_packed_floats(int Cin, int Cout, int mode) {
-    if (Cin < 1 || Cout < 1 || Cout > 64 || mode < 0 || mode > 2) return 0;
+    if (Cin < 1 || Cout < 1 || Cout > 64 || mode < 0 || mode > 3) return 0;
     if (mode == 2 && deconv_s1_supported(Cout)) return deconv_s1_packed_floats(Cin, Cout);
     // padded to a multiple of 8 input channels so CC=8 kernels can always stage two full slabs
     const int n4 = 2 * ((Cin + 7) / 8);
@@ -296,10 +298,10 @@ extern "C" int64_t mvs_conv3d_packed_floats(int Cin, int Cout, int mode) {
 
 extern "C" int mvs_conv3d_pack_weights(const float* w, int Cin, int Cout, int mode, float* wpacked, mvs_stream_t stream) {
     MVS_REQUIRE(w && wpacked, "mvs_conv3d_pack_weights: null pointer");
-    MVS_REQUIRE(mode >= 0 && mode <= 2, "mvs_conv3d_pack_weights: mode %d", mode);
+    MVS_REQUIRE(mode >= 0 && mode <= 3, "mvs_conv3d_pack_weights: mode %d", mode);
     if (int rc = check_conv_args("mvs_conv3d_pack_weights", 1, Cin, Cout, 1, 1, 1)) return rc;
     if (mode == 2 && deconv_s1_supported(Cout)) return deconv_s1_pack(w, Cin, Cout, wpacked, MVS_STREAM(stream));
-    const int transposed = mode != 0;
+    const int transposed = mode == 3 ? 2 : (mode != 0);
     const int n4 = 2 * ((Cin + 7) / 8), NP = np_of(nt_of(Cout));
     const int64_t total = (int64_t)n4 * 27 * 4 * NP;
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, MVS_STREAM(stream), w, Cin, Cout,

@@ -1,0 +1,276 @@
+// Training-mode pieces of the path: batch-statistics BatchNorm forward/backward around the raw
+// MFMA convolutions (reference Conv3d/Deconv3d/ConvBnReLU in train mode, models/module.py:111-117,153-159,195-197;
+// SyncBatchNorm hooks in here: the per-channel sums are what ranks all-reduce), softmax / 1x1x1-prob / sigmoid
+// backward, and the NHWC->NCHW transpose of the feature gradient.  All bandwidth-bound elementwise / reduction kernels:
+// tensors are [B, C, N] with N = D*H*W (or H*W), one block per (chunk of N, channel, batch) so every access is a
+// coalesced 16-byte-per-lane stream; per-channel sums are block-reduced in LDS and combined with fp32 atomics.
+#include "common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int CHUNK = 4096;            // elements of one (b, c) row handled by a block (256 threads x 4 x 4)
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.0f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}
+
+// sums[c] += sum x, sums[C + c] += sum x^2
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int C, size_t N, float* __restrict__ sums) {
+    __shared__ float red[8];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float* row = x + ((size_t)b * C + c) * N;
+    const size_t i0 = (size_t)blockIdx.x * CHUNK, i1 = min(i0 + CHUNK, N);
+    float s = 0.0f, q = 0.0f;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float v = row[i];
+        s += v;
+        q = fmaf(v, v, q);
+    }
+    s = block_sum(s, red);
+    q = block_sum(q, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[c], s);
+        atomicAdd(&sums[C + c], q);
+    }
+}
+
+// mean/var from the (possibly all-reduced) sums; eval-style scale/shift for the apply kernel; running-stat update
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+                                   double count, int C, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = (double)sums[c] / count;
+    double var = (double)sums[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
+    scale[c] = g * invstd;
+    shift[c] = bt - (float)mean * g * invstd;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = invstd;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// y = [relu](x*scale[c] + shift[c]) [+ residual]
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const float* __restrict__ res, int relu,
+                                                         int C, size_t N, float* __restrict__ y) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const size_t base = ((size_t)b * C + c) * N;
+    const float sc = scale[c], sh = shift[c];
+    const size_t i0 = (size_t)blockIdx.x * CHUNK, i1 = min(i0 + CHUNK, N);
+    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        float v = fmaf(x[base + i], sc, sh);
+        if (relu) v = fmaxf(v, 0.0f);
+        if (res) v += res[base + i];
+        y[base + i] = v;
+    }
+}
+
+// backward of y = relu(bn(x)): g = dy * [x*scale+shift > 0];  sums[c] += sum g, sums[C+c] += sum g * xhat
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                            int C, size_t N, float* __restrict__ sums) {
+    __shared__ float red[8];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const size_t base = ((size_t)b * C + c) * N;
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    const size_t i0 = (size_t)blockIdx.x * CHUNK, i1 = min(i0 + CHUNK, N);
+    float s1 = 0.0f, s2 = 0.0f;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float xv = x[base + i];
+        float g = dy[base + i];
+        if (relu && !(fmaf(xv, sc, sh) > 0.0f)) g = 0.0f;
+        s1 += g;
+        s2 = fmaf(g, (xv - mu) * is, s2);
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[c], s1);
+        atomicAdd(&sums[C + c], s2);
+    }
+}
+
+// dx = gamma*invstd*(g - s1/n - xhat*s2/n)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                           double count, int relu, int C, size_t N, float* __restrict__ dx) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const size_t base = ((size_t)b * C + c) * N;
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    const float gi = (gamma ? gamma[c] : 1.0f) * is;
+    const float m1 = (float)((double)sums[c] / count), m2 = (float)((double)sums[C + c] / count);
+    const size_t i0 = (size_t)blockIdx.x * CHUNK, i1 = min(i0 + CHUNK, N);
+    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float xv = x[base + i];
+        float g = dy[base + i];
+        if (relu && !(fmaf(xv, sc, sh) > 0.0f)) g = 0.0f;
+        dx[base + i] = gi * (g - m1 - (xv - mu) * is * m2);
+    }
+}
+
+// dpre = p * (dp - sum_d dp*p)   over [B,D,HW]
+__global__ void softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp, int D, size_t HW, float* __restrict__ dpre) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= HW) return;
+    const size_t base = (size_t)b * D * HW + i;
+    float dot = 0.0f;
+    for (int d = 0; d < D; ++d) dot = fmaf(dp[base + d * HW], p[base + d * HW], dot);
+    for (int d = 0; d < D; ++d) dpre[base + d * HW] = p[base + d * HW] * (dp[base + d * HW] - dot);
+}
+
+// backward of logits[b,v] = sum_c w[c]*x[b,c,v] + bias:  dx[b,c,v] = w[c]*dl[b,v];  dwb[c] += sum dl*x[c], dwb[C] += sum dl
+__global__ __launch_bounds__(256) void prob1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dl,
+                                                        int C, size_t N, float* __restrict__ dx, float* __restrict__ dwb) {
+    __shared__ float red[8];
+    const int b = blockIdx.y;
+    const size_t i0 = (size_t)blockIdx.x * CHUNK, i1 = min(i0 + CHUNK, N);
+    float sb = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const float wc = w[c];
+        const size_t base = ((size_t)b * C + c) * N;
+        float s = 0.0f;
+        for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
+            const float g = dl[(size_t)b * N + i];
+            dx[base + i] = wc * g;
+            s = fmaf(g, x[base + i], s);
+            if (c == 0) sb += g;
+        }
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) atomicAdd(&dwb[c], s);
+    }
+    sb = block_sum(sb, red);
+    if (threadIdx.x == 0) atomicAdd(&dwb[C], sb);
+}
+
+__global__ void sigmoid_kernel(const float* __restrict__ x, size_t n, float* __restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = 1.0f / (1.0f + expf(-x[i]));
+}
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, size_t n, float* __restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dx[i] = dy[i] * y[i] * (1.0f - y[i]);
+}
+
+// [N,HW,C] -> [N,C,HW]
+template <int C>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, size_t HW) {
+    __shared__ float tile[C][65];
+    const int tid = threadIdx.x;
+    const size_t p0 = (size_t)blockIdx.x * 64, n = blockIdx.y;
+    const int npix = (int)min((size_t)64, HW - p0);
+    const float* src = in + (n * HW + p0) * C;
+    for (int i = tid; i < npix * C; i += 256) tile[i % C][i / C] = src[i];
+    __syncthreads();
+    for (int i = tid; i < C * 64; i += 256) {
+        const int c = i >> 6, p = i & 63;
+        if (p < npix) out[(n * C + c) * HW + p0 + p] = tile[c][p];
+    }
+}
+
+dim3 row_grid(int B, int C, size_t N) { return dim3((unsigned)((N + CHUNK - 1) / CHUNK), C, B); }
+
+}  // namespace
+
+extern "C" int mvs_bn_stats(const float* x, int B, int C, int64_t N, float* sums, mvs_stream_t stream) {
+    MVS_REQUIRE(x && sums && B >= 1 && C >= 1 && C <= 65535 && B <= 65535 && N >= 1, "mvs_bn_stats: bad arguments");
+    hipLaunchKernelGGL(bn_stats_kernel, row_grid(B, C, N), dim3(256), 0, MVS_STREAM(stream), x, C, (size_t)N, sums);
+    return mvs::finish_launch("mvs_bn_stats");
+}
+
+extern "C" int mvs_bn_finalize(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                               float momentum, float eps, double count, int C, float* scale, float* shift, float* mean, float* invstd,
+                               mvs_stream_t stream) {
+    MVS_REQUIRE(sums && scale && shift && mean && invstd && C >= 1 && count >= 1.0, "mvs_bn_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, MVS_STREAM(stream), sums, gamma, beta, running_mean,
+                       running_var, momentum, eps, count, C, scale, shift, mean, invstd);
+    return mvs::finish_launch("mvs_bn_finalize");
+}
+
+extern "C" int mvs_affine_act(const float* x, const float* scale, const float* shift, const float* residual, int relu, int B, int C,
+                              int64_t N, float* y, mvs_stream_t stream) {
+    MVS_REQUIRE(x && scale && shift && y && B >= 1 && C >= 1 && C <= 65535 && B <= 65535 && N >= 1, "mvs_affine_act: bad arguments");
+    hipLaunchKernelGGL(affine_act_kernel, row_grid(B, C, N), dim3(256), 0, MVS_STREAM(stream), x, scale, shift, residual, relu, C,
+                       (size_t)N, y);
+    return mvs::finish_launch("mvs_affine_act");
+}
+
+extern "C" int mvs_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
+                                 const float* invstd, int relu, int B, int C, int64_t N, float* sums, mvs_stream_t stream) {
+    MVS_REQUIRE(dy && x && scale && shift && mean && invstd && sums && B >= 1 && C >= 1 && C <= 65535 && B <= 65535 && N >= 1,
+                "mvs_bn_bwd_reduce: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, row_grid(B, C, N), dim3(256), 0, MVS_STREAM(stream), dy, x, scale, shift, mean, invstd, relu,
+                       C, (size_t)N, sums);
+    return mvs::finish_launch("mvs_bn_bwd_reduce");
+}
+
+extern "C" int mvs_bn_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, const float* gamma, const float* sums, double count, int relu, int B, int C,
+                                int64_t N, float* dx, mvs_stream_t stream) {
+    MVS_REQUIRE(dy && x && scale && shift && mean && invstd && sums && dx && B >= 1 && C >= 1 && C <= 65535 && B <= 65535 && N >= 1,
+                "mvs_bn_bwd_apply: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, row_grid(B, C, N), dim3(256), 0, MVS_STREAM(stream), dy, x, scale, shift, mean, invstd, gamma,
+                       sums, count, relu, C, (size_t)N, dx);
+    return mvs::finish_launch("mvs_bn_bwd_apply");
+}
+
+extern "C" int mvs_softmax_bwd(const float* p, const float* dp, int B, int D, int64_t HW, float* dpre, mvs_stream_t stream) {
+    MVS_REQUIRE(p && dp && dpre && B >= 1 && B <= 65535 && D >= 1 && HW >= 1, "mvs_softmax_bwd: bad arguments");
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, MVS_STREAM(stream), p, dp, D, (size_t)HW,
+                       dpre);
+    return mvs::finish_launch("mvs_softmax_bwd");
+}
+
+extern "C" int mvs_prob1_bwd(const float* x, const float* w, const float* dlogits, int B, int C, int64_t N, float* dx, float* dwb,
+                             mvs_stream_t stream) {
+    MVS_REQUIRE(x && w && dlogits && dx && dwb && B >= 1 && B <= 65535 && C >= 1 && N >= 1, "mvs_prob1_bwd: bad arguments");
+    hipLaunchKernelGGL(prob1_bwd_kernel, dim3((unsigned)((N + CHUNK - 1) / CHUNK), B), dim3(256), 0, MVS_STREAM(stream), x, w, dlogits, C,
+                       (size_t)N, dx, dwb);
+    return mvs::finish_launch("mvs_prob1_bwd");
+}
+
+extern "C" int mvs_sigmoid_fwd(const float* x, int64_t n, float* y, mvs_stream_t stream) {
+    MVS_REQUIRE(x && y && n >= 1, "mvs_sigmoid_fwd: bad arguments");
+    hipLaunchKernelGGL(sigmoid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, MVS_STREAM(stream), x, (size_t)n, y);
+    return mvs::finish_launch("mvs_sigmoid_fwd");
+}
+
+extern "C" int mvs_sigmoid_bwd(const float* y, const float* dy, int64_t n, float* dx, mvs_stream_t stream) {
+    MVS_REQUIRE(y && dy && dx && n >= 1, "mvs_sigmoid_bwd: bad arguments");
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, MVS_STREAM(stream), y, dy, (size_t)n, dx);
+    return mvs::finish_launch("mvs_sigmoid_bwd");
+}
+
+extern "C" int mvs_nhwc_to_nchw(const float* in, float* out, int N, int C, int64_t HW, mvs_stream_t stream) {
+    MVS_REQUIRE(in && out && N >= 1 && N <= 65535 && HW >= 1, "mvs_nhwc_to_nchw: bad shape");
+    MVS_REQUIRE(C == 8 || C == 16 || C == 32 || C == 64, "mvs_nhwc_to_nchw: C must be 8, 16, 32 or 64 (got %d)", C);
+    dim3 grid((unsigned)((HW + 63) / 64), N);
+    hipStream_t s = MVS_STREAM(stream);
+    switch (C) {
+        case 8: hipLaunchKernelGGL(nhwc_to_nchw_kernel<8>, grid, dim3(256), 0, s, in, out, (size_t)HW); break;
+        case 16: hipLaunchKernelGGL(nhwc_to_nchw_kernel<16>, grid, dim3(256), 0, s, in, out, (size_t)HW); break;
+        case 32: hipLaunchKernelGGL(nhwc_to_nchw_kernel<32>, grid, dim3(256), 0, s, in, out, (size_t)HW); break;
+        default: hipLaunchKernelGGL(nhwc_to_nchw_kernel<64>, grid, dim3(256), 0, s, in, out, (size_t)HW); break;
+    }
+    return mvs::finish_launch("mvs_nhwc_to_nchw");
+}

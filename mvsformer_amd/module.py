@@ -10,7 +10,8 @@ DDP and SyncBatchNorm conversion working); every forward runs the hand-written H
 
 Eval-mode BatchNorm is folded into a per-channel ``scale``/``shift`` pair applied in the conv epilogue;
 folded parameters and the MFMA-friendly weight packing are cached and rebuilt when any parameter changes.
-Training-mode (batch-statistics BN + autograd) is not built yet and raises.
+Training mode (``module.train()``) runs raw conv -> batch-statistics BatchNorm -> ReLU (+ skip) through the autograd
+functions of :mod:`mvsformer_amd.autograd`, whose forward and backward are HIP kernels as well.
 """
 from __future__ import annotations
 
@@ -41,11 +42,19 @@ def _versions(mod: nn.Module) -> tuple:
     return tuple((t.data_ptr(), t._version) for t in list(mod.parameters()) + list(mod.buffers()))
 
 
-def _no_training(mod: nn.Module, what: str) -> None:
-    if mod.training:
-        raise MvsHipError(
-            "%s: training mode (batch-statistics BatchNorm + backward kernels) is not built in this round; call .eval(). "
-            "There is deliberately no PyTorch fallback." % what)
+def _train_conv_bn_act(x, conv, bn, relu, residual, transposed_sd=None):
+    """Training-mode layer: raw (transposed) conv -> batch-stat BN -> ReLU (+ residual), all autograd-tracked HIP ops."""
+    from . import autograd as ag
+    if transposed_sd is None:
+        s = tuple(conv.stride)
+        y = ag.ConvFn.apply(x, conv.weight, (s[0], s[1]))
+    else:
+        y = ag.DeconvFn.apply(x, conv.weight, transposed_sd)
+    if conv.bias is not None:
+        raise MvsHipError("training-mode conv with bias (bn=False) is not built")
+    if bn is None:
+        raise MvsHipError("training-mode layer without BatchNorm is not built")
+    return ag.BnActFn.apply(y, bn.weight, bn.bias, residual, bn, bool(relu))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -84,7 +93,8 @@ class Conv3d(nn.Module):
         return self._cache[1:]
 
     def forward(self, x, residual: Optional[torch.Tensor] = None):
-        _no_training(self, "Conv3d")
+        if self.training:
+            return _train_conv_bn_act(x, self.conv, self.bn, self.relu, residual)
         packed, scale, shift, stride = self._prepared()
         return ops.conv3d(x, packed, self.conv.in_channels, self.conv.out_channels, stride, scale, shift, residual,
                           relu=self.relu, tag="conv3d_%dto%d_s%d%d" % (self.conv.in_channels, self.conv.out_channels, *stride))
@@ -103,7 +113,9 @@ class Deconv3d(nn.Module):
         self._cache = None
 
     def forward(self, x, residual: Optional[torch.Tensor] = None):
-        _no_training(self, "Deconv3d")
+        if self.training:
+            _prepare_deconv_check(self.conv)
+            return _train_conv_bn_act(x, self.conv, self.bn, self.relu, residual, transposed_sd=self.conv.stride[0])
         key = _versions(self)
         if self._cache is None or self._cache[0] != key:
             self._cache = (key,) + _prepare_deconv(self.conv, self.bn)
@@ -112,12 +124,17 @@ class Deconv3d(nn.Module):
                             relu=self.relu, tag="deconv3d_%dto%d_s%d" % (self.conv.in_channels, self.conv.out_channels, sd))
 
 
-def _prepare_deconv(conv: nn.ConvTranspose3d, bn):
+def _prepare_deconv_check(conv: nn.ConvTranspose3d):
     s, op = tuple(conv.stride), tuple(conv.output_padding)
     if tuple(conv.kernel_size) != (3, 3, 3) or tuple(conv.padding) != (1, 1, 1) or conv.groups != 1:
         raise MvsHipError("Deconv3d: only kernel 3, padding 1, groups 1 is built (got %s)" % conv)
     if not ((s == (2, 2, 2) and op == (1, 1, 1)) or (s == (1, 2, 2) and op == (0, 1, 1))):
         raise MvsHipError("Deconv3d: stride %s / output_padding %s is not built" % (s, op))
+    return s
+
+
+def _prepare_deconv(conv: nn.ConvTranspose3d, bn):
+    s = _prepare_deconv_check(conv)
     packed = ops.conv3d_pack(_f32c(conv.weight), transposed=True, sd=s[0])
     if bn is not None:
         scale, shift = _bn_fold(bn)
@@ -187,10 +204,10 @@ class CostRegNet(nn.Module):
 
     def features(self, x: torch.Tensor) -> torch.Tensor:
         """Everything up to (not including) ``prob``; residual adds are fused into the deconv epilogues."""
-        _no_training(self, "CostRegNet")
         if not isinstance(self.inner, nn.Identity):
             raise MvsHipError("CostRegNet: in_channels != base_channels (1x1x1 'inner' conv) is not built")
-        x = x.to(torch.float32).contiguous()
+        x = x.to(torch.float32)
+        x = x if x.is_contiguous() else x.contiguous()
         if x.shape[2] % 8 or x.shape[3] % 8 or x.shape[4] % 8:
             raise MvsHipError("CostRegNet needs D, H, W divisible by 8 (three stride-2 levels), got %s" % (tuple(x.shape[2:]),))
         c2 = self.conv2(self.conv1(x))
@@ -203,7 +220,13 @@ class CostRegNet(nn.Module):
     def forward(self, x):
         y = self.features(x)
         if self.last_layer:
-            y = ops.prob3(y, _f32c(self.prob.weight)).unsqueeze(1)
+            if self.training:
+                from . import autograd as ag
+                # N = 1 conv embedded in an 8-channel MFMA conv (zero rows) so forward, dgrad and wgrad reuse the conv kernels
+                w8 = torch.nn.functional.pad(self.prob.weight, (0, 0, 0, 0, 0, 0, 0, 0, 0, 7))
+                y = ag.ConvFn.apply(y, w8, (1, 1))[:, :1]
+            else:
+                y = ops.prob3(y, _f32c(self.prob.weight)).unsqueeze(1)
         return y
 
 
@@ -238,6 +261,9 @@ class CostRegNet3D(nn.Module):
 
     def _up(self, name: str, x, residual):
         seq = getattr(self, name)
+        if self.training:
+            _prepare_deconv_check(seq[0])
+            return _train_conv_bn_act(x, seq[0], seq[1], True, residual, transposed_sd=seq[0].stride[0])
         key = _versions(seq)
         c = self._dcache.get(name)
         if c is None or c[0] != key:
@@ -248,10 +274,10 @@ class CostRegNet3D(nn.Module):
                             tag="deconv3d_%dto%d_s%d" % (seq[0].in_channels, seq[0].out_channels, sd))
 
     def features(self, x: torch.Tensor) -> torch.Tensor:
-        _no_training(self, "CostRegNet3D")
         if not isinstance(self.inner, nn.Identity):
             raise MvsHipError("CostRegNet3D: in_channels != base_channel (1x1x1 'inner' conv) is not built")
-        x = x.to(torch.float32).contiguous()
+        x = x.to(torch.float32)
+        x = x if x.is_contiguous() else x.contiguous()
         if x.shape[3] % 8 or x.shape[4] % 8:
             raise MvsHipError("CostRegNet3D needs H, W divisible by 8 (three stride-2 levels), got %s" % (tuple(x.shape[3:]),))
         c2 = self.conv2(self.conv1(x))
@@ -266,6 +292,9 @@ class CostRegNet3D(nn.Module):
 
     def forward(self, x):
         y = self.features(x)
+        if self.training:
+            from . import autograd as ag
+            return ag.Prob1Fn.apply(y, self.prob.weight, self.prob.bias)
         w, b = self.prob_params()
         return ops.prob1(y, w, b)
 

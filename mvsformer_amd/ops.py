@@ -191,6 +191,8 @@ def conv3d_pack(weight: torch.Tensor, transposed: bool, sd: int = 2) -> torch.Te
     """Re-lay a Conv3d (``[Cout,Cin,3,3,3]``) or ConvTranspose3d (``[Cin,Cout,3,3,3]``, ``sd`` = its depth stride) weight."""
     _chk(weight, "conv weight")
     mode = 0 if not transposed else (2 if sd == 1 else 1)
+    if transposed == "dgrad":                      # data gradient of a stride-1 Conv3d: weight stays [Cout,Cin,...] of the layer
+        mode = 3
     if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3):
         raise _lib.MvsHipError("conv weight must be [*,*,3,3,3], got %s" % (tuple(weight.shape),))
     cin, cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
@@ -321,3 +323,109 @@ def conf_accumulate(conf: torch.Tensor, acc: torch.Tensor, weight: float = 1.0) 
     B, H, W = conf.shape
     _, Hf, Wf = acc.shape
     _call("mvs_conf_accumulate", None, _ptr(conf), B, H, W, _ptr(acc), Hf, Wf, float(weight), _stream())
+
+
+# ----------------------------------------------------------------------------------------------- training kernels
+def bn_stats(x: torch.Tensor) -> torch.Tensor:
+    """``x [B,C,...]`` -> ``sums [2C]`` (sum, sum of squares per channel)."""
+    _chk(x, "x")
+    B, C = x.shape[0], x.shape[1]
+    sums = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
+    _call("mvs_bn_stats", None, _ptr(x), B, C, x.numel() // (B * C), _ptr(sums), _stream())
+    return sums
+
+
+def bn_finalize(sums, gamma, beta, running_mean, running_var, momentum, eps, count):
+    C = sums.numel() // 2
+    dev = sums.device
+    scale, shift, mean, invstd = (torch.empty(C, device=dev, dtype=torch.float32) for _ in range(4))
+    _call("mvs_bn_finalize", None, _ptr(sums), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), float(momentum),
+          float(eps), float(count), C, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _stream())
+    return scale, shift, mean, invstd
+
+
+def affine_act(x, scale, shift, residual, relu):
+    _chk(x, "x")
+    B, C = x.shape[0], x.shape[1]
+    y = torch.empty_like(x)
+    _call("mvs_affine_act", None, _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), int(relu), B, C, x.numel() // (B * C), _ptr(y), _stream())
+    return y
+
+
+def bn_bwd_reduce(dy, x, scale, shift, mean, invstd, relu):
+    _chk(dy, "dy"), _chk(x, "x")
+    B, C = x.shape[0], x.shape[1]
+    sums = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
+    _call("mvs_bn_bwd_reduce", None, _ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), int(relu), B, C,
+          x.numel() // (B * C), _ptr(sums), _stream())
+    return sums
+
+
+def bn_bwd_apply(dy, x, scale, shift, mean, invstd, gamma, sums, count, relu):
+    B, C = x.shape[0], x.shape[1]
+    dx = torch.empty_like(x)
+    _call("mvs_bn_bwd_apply", None, _ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums),
+          float(count), int(relu), B, C, x.numel() // (B * C), _ptr(dx), _stream())
+    return dx
+
+
+def conv3d_wgrad(A: torch.Tensor, Bt: torch.Tensor, stride) -> torch.Tensor:
+    """``dW[a][b][27] = sum A[a,p] * Bt[b, p*s-1+k]``; ``A [N,CA,Dp,Hp,Wp]`` lives on the grid the stride divides."""
+    _chk(A, "A"), _chk(Bt, "Bt")
+    N, CA, Dp, Hp, Wp = A.shape
+    _, CB, Db, Hb, Wb = Bt.shape
+    dW = torch.zeros(CA, CB, 3, 3, 3, device=A.device, dtype=torch.float32)
+    tag = ("wgrad_kernel<%d>" % ((CA + 15) // 16), "flops", 2.0 * 27 * CA * CB * N * Dp * Hp * Wp)
+    _call("mvs_conv3d_wgrad", tag, _ptr(A), _ptr(Bt), _ptr(dW), N, CA, CB, Dp, Hp, Wp, Db, Hb, Wb, stride[0], stride[1], _stream())
+    return dW
+
+
+def cv_aggregate_bwd(feat_cl, rt, depth, weight, volume, gvolume, G: int):
+    for t, n in ((feat_cl, "features"), (rt, "rt"), (depth, "depth_values"), (weight, "vis_weight"), (volume, "volume"), (gvolume, "grad")):
+        _chk(t, n)
+    B, V, H, W, C = feat_cl.shape
+    D = depth.shape[1]
+    dfeat = torch.zeros_like(feat_cl)
+    dw = torch.empty_like(weight)
+    _call("mvs_cv_aggregate_bwd", "cv_aggregate_bwd_kernel<%d>" % (C // 4), _ptr(feat_cl), _ptr(rt), _ptr(depth), _ptr(weight), _ptr(volume),
+          _ptr(gvolume), B, V, C, G, D, H, W, _ptr(dfeat), _ptr(dw), _stream())
+    return dfeat, dw
+
+
+def to_channels_first(feat_cl: torch.Tensor) -> torch.Tensor:
+    _chk(feat_cl, "features")
+    B, V, H, W, C = feat_cl.shape
+    out = torch.empty(B, V, C, H, W, device=feat_cl.device, dtype=torch.float32)
+    _call("mvs_nhwc_to_nchw", None, _ptr(feat_cl), _ptr(out), B * V, C, H * W, _stream())
+    return out
+
+
+def softmax_bwd(p, dp):
+    _chk(p, "p"), _chk(dp, "dp")
+    B, D = p.shape[0], p.shape[1]
+    out = torch.empty_like(p)
+    _call("mvs_softmax_bwd", None, _ptr(p), _ptr(dp), B, D, p.numel() // (B * D), _ptr(out), _stream())
+    return out
+
+
+def prob1_bwd(x, w, dlogits):
+    _chk(x, "x"), _chk(w, "w"), _chk(dlogits, "dlogits")
+    B, C = x.shape[0], x.shape[1]
+    dx = torch.empty_like(x)
+    dwb = torch.zeros(C + 1, device=x.device, dtype=torch.float32)
+    _call("mvs_prob1_bwd", None, _ptr(x), _ptr(w), _ptr(dlogits), B, C, x.numel() // (B * C), _ptr(dx), _ptr(dwb), _stream())
+    return dx, dwb
+
+
+def sigmoid(x):
+    _chk(x, "x")
+    y = torch.empty_like(x)
+    _call("mvs_sigmoid_fwd", None, _ptr(x), x.numel(), _ptr(y), _stream())
+    return y
+
+
+def sigmoid_bwd(y, dy):
+    _chk(y, "y"), _chk(dy, "dy")
+    dx = torch.empty_like(y)
+    _call("mvs_sigmoid_bwd", None, _ptr(y), _ptr(dy), y.numel(), _ptr(dx), _stream())
+    return dx

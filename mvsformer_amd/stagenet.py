@@ -48,14 +48,14 @@ class StageNet(nn.Module):
 
     def forward(self, features, proj_matrices, depth_values, tmp=2.0):
         """``features [B,V,C,H,W]`` (view 0 = reference), ``proj_matrices [B,V,2,4,4]``, ``depth_values [B,D,H,W]``."""
-        if self.training:
-            raise MvsHipError("StageNet: training mode is not built in this round (eval / torch.no_grad inference only)")
         depth_type = self.args["depth_type"]
         if depth_type not in ("ce", "was"):
             raise NotImplementedError("depth_type=%r: only 'ce'/'was' heads are built" % depth_type)
         if features.shape[1] != proj_matrices.shape[1]:
             raise AssertionError("Different number of images and projection matrices")
         G = self.args["base_ch"]
+        if self.training:
+            return self._forward_train(features, proj_matrices, depth_values, tmp, G)
         feat = features.detach().to(torch.float32).contiguous()
         proj = proj_matrices.detach().to(torch.float32).contiguous()
         hyp = depth_values.detach().to(torch.float32).contiguous()
@@ -81,6 +81,26 @@ class StageNet(nn.Module):
             pre, prob, depth, conf = ops.head(hyp, float(tmp), False, logits=logits)
         return {"depth": depth, "prob_volume": prob, "photometric_confidence": conf, "depth_values": depth_values,
                 "prob_volume_pre": pre, "sim_depth": sim_depth}
+
+
+    def _forward_train(self, features, proj_matrices, depth_values, tmp, G):
+        """Training branch (reference mvsformer_model.py:62-125 with ``self.training``): no similarity branch, batch-statistics
+        BatchNorm everywhere, depth = hypothesis at the arg-max probability; gradients via :mod:`mvsformer_amd.autograd`."""
+        from . import autograd as ag
+        proj = proj_matrices.detach().to(torch.float32).contiguous()
+        hyp = depth_values.detach().to(torch.float32).contiguous()
+        rt = ops.proj_prepare(proj)
+        feat_cl = ops.to_channels_last(features.detach().to(torch.float32).contiguous())
+        entropy = ops.cv_entropy(feat_cl, rt, hyp, G)                       # sim_vol.detach() in the reference
+        V = features.shape[1]
+        weight = torch.cat([ag.vis_train(entropy[:, v:v + 1], self.vis) for v in range(V - 1)], dim=1)
+        volume = ag.AggregateFn.apply(features, weight, rt, hyp, G)
+        if type(tmp) == list:
+            tmp = tmp[self.stage_idx]
+        pre = self.cost_reg(volume).squeeze(1)
+        prob, depth, conf = ag.HeadFn.apply(pre, hyp, float(tmp))
+        return {"depth": depth, "prob_volume": prob, "photometric_confidence": conf.detach(), "depth_values": depth_values,
+                "prob_volume_pre": pre}
 
 
 DepthNet = StageNet

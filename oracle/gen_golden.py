@@ -20,6 +20,7 @@ float16-exact values to halve the files):
   stage_costregnet.npz     StageNet with ndepth=16 (CostRegNet), eval + train, intermediate taps
   stage_costregnet3d.npz   StageNet with ndepth=4 (CostRegNet3D), eval + train, intermediate taps
   cascade_v3.npz, cascade_v5.npz   4-stage inverse-depth cascade, 64x64, tmp=[5,5,5,1]
+  train_costregnet.npz, train_costregnet3d.npz   train-mode StageNet (B=2): forward, loss=sum(pre*R), all gradients
 """
 import json
 import os
@@ -297,7 +298,7 @@ def gen_cascade(V, shapes, seed):
     save("cascade_v%d.npz" % V, **out)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and os.environ.get("GEN_EVAL", "1") == "1":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     shapes = dump_shapes()
@@ -309,3 +310,54 @@ if __name__ == "__main__":
     _stage_case("costregnet3d", 4, 8, 4, shapes)
     gen_cascade(3, shapes, 6)
     gen_cascade(5, shapes, 7)
+
+
+# ---------------------------------------------------------------------------------------------
+# training / autograd goldens: forward in train mode (batch-statistics BN, argmax depth),
+# loss = sum(prob_volume_pre * R) with a fixed random R, gradients w.r.t. features and every parameter.
+# ---------------------------------------------------------------------------------------------
+def gen_train_grads(kind, ndepth, C, seed, shapes, B=2):
+    V, Hf, Wf, scale = 3, 128, 192, 8
+    feats_l, proj_l, hyp_l = [], [], []
+    for bi in range(B):
+        scene = synth.make_scene(V, Hf, Wf, seed=seed + 31 * bi)
+        feats_l.append(f16exact(synth.render_features(scene, scale, C, noise=0.05)))
+        proj_l.append(synth.proj_matrices(scene, (scale,))["stage1"])
+        H, W = Hf // scale, Wf // scale
+        if ndepth > 8:
+            hyp_l.append(init_inverse_range(synth.depth_range(1), ndepth, "cpu", torch.float32, H, W))
+        else:
+            z = synth.plane_depth(scene, scale)
+            inv = 1.0 / z[None, None] + torch.linspace(-1, 1, ndepth).view(1, -1, 1, 1) * 4e-5
+            hyp_l.append(1.0 / inv)
+    feats = torch.cat(feats_l, 0).requires_grad_(True)
+    proj, hyp = torch.cat(proj_l, 0), torch.cat(hyp_l, 0)
+    sd = make_state_dict(shapes["stage_" + kind], 3000 + seed)
+    net = ref_mm.StageNet(dict(ARGS), ndepth, 0)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    o = net(feats, proj, hyp, tmp=5.0)
+    g = torch.Generator().manual_seed(99 + seed)
+    R = torch.randn(o["prob_volume_pre"].shape, generator=g)
+    loss = (o["prob_volume_pre"] * R).sum()
+    loss.backward()
+    out = dict(features=feats.detach().numpy().astype(np.float16), proj=np32(proj), depth_values=np32(hyp), R=np32(R),
+               weight_seed=np.int64(3000 + seed), ndepth=np.int64(ndepth), loss=np.float64(loss.item()),
+               prob_volume_pre=np32(o["prob_volume_pre"]), depth=np32(o["depth"]), grad_features=np32(feats.grad))
+    full = ("vis.", "cost_reg.prob", "cost_reg.conv1.", "cost_reg.conv11.", ".bn.", ".1.weight", ".1.bias")
+    for name, p in net.named_parameters():
+        gr = p.grad
+        out["gsum_" + name] = np.float64(gr.double().sum().item())
+        out["gabs_" + name] = np.float64(gr.double().abs().sum().item())
+        if any(t in name for t in full) and gr.numel() <= 4096:
+            out["grad_" + name] = np32(gr)
+    for name, buf in net.named_buffers():
+        if "running" in name and ("conv1." in name or "conv7" in name or "vis.0" in name):
+            out["buf_" + name] = np32(buf)
+    save("train_%s.npz" % kind, **out)
+
+
+if __name__ == "__main__" and os.environ.get("GEN_TRAIN", "1") == "1":
+    shapes = json.load(open(os.path.join(OUT, "state_dict_shapes.json")))
+    gen_train_grads("costregnet", 16, 16, 13, shapes)
+    gen_train_grads("costregnet3d", 4, 8, 14, shapes)
