@@ -31,9 +31,16 @@ class CascadeMVS(nn.Module):
             raise NotImplementedError("only inverse_depth=True (every shipped reference config) is built")
         self.fusions = nn.ModuleList([StageNet(self.args, self.ndepths[i], i) for i in range(len(self.ndepths))])
 
-    @torch.no_grad()
     def forward(self, features: Dict[str, torch.Tensor], proj_matrices: Dict[str, torch.Tensor], depth_values: torch.Tensor,
                 tmp=2.0) -> Dict[str, object]:
+        """Eval: no autograd graph (as ``test.py`` runs the reference under ``torch.no_grad``).  Train: every stage keeps
+        its graph; hypotheses come from the previous stage's detached depth (mvsformer_model.py:290,430)."""
+        if not self.training:
+            with torch.no_grad():
+                return self._forward(features, proj_matrices, depth_values, tmp)
+        return self._forward(features, proj_matrices, depth_values, tmp)
+
+    def _forward(self, features, proj_matrices, depth_values, tmp):
         n = len(self.ndepths)
         last = features["stage%d" % n]
         B, Hf, Wf = last.shape[0], last.shape[-2], last.shape[-1]
@@ -46,11 +53,11 @@ class CascadeMVS(nn.Module):
             if i == 0:
                 hyp = init_inverse_range(depth_values, self.ndepths[0], f.device, torch.float32, H, W)
             else:
-                hyp = schedule_inverse_range(stage_out["depth"], stage_out["depth_values"], self.ndepths[i],
+                hyp = schedule_inverse_range(stage_out["depth"].detach(), stage_out["depth_values"].detach(), self.ndepths[i],
                                              self.depth_interals_ratio[i], H, W)
             stage_out = self.fusions[i](f, proj_matrices["stage%d" % (i + 1)], hyp, tmp=tmp)
             # nearest-upsampled confidences averaged over the stages (mvsformer_model.py:297-301,305)
-            ops.conf_accumulate(stage_out["photometric_confidence"], prob_maps, 1.0 / n)
+            ops.conf_accumulate(stage_out["photometric_confidence"].detach().contiguous(), prob_maps, 1.0 / n)
             outputs["stage%d" % (i + 1)] = stage_out
             outputs.update(stage_out)
         outputs["refined_depth"] = stage_out["depth"]

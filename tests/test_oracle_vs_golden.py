@@ -109,3 +109,22 @@ def test_cascade(V):
         assert rel_err(out["stage%d" % i]["depth_values"], g["s%d_depth_values" % i]) < 1e-5
     assert rel_err(out["refined_depth"], g["refined_depth"]) < 1e-5
     assert max_abs(out["photometric_confidence"], g["photometric_confidence"]) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["costregnet", "costregnet3d"])
+def test_stage_train_gradients(kind):
+    """The oracle in train mode (batch-statistics BN) under torch autograd reproduces the reference's gradients."""
+    g = load_golden("train_%s.npz" % kind)
+    sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone())
+          for k, v in make_state_dict(load_shapes("stage_" + kind), int(g["weight_seed"])).items()}
+    feats = t(g["features"]).requires_grad_(True)
+    o = ref_torch.stage_forward(feats, t(g["proj"]), t(g["depth_values"]), sd, ndepth=int(g["ndepth"]), tmp=5.0, training=True)
+    (o["prob_volume_pre"] * t(g["R"])).sum().backward()
+    assert max_abs(o["prob_volume_pre"].detach(), g["prob_volume_pre"]) < 1e-4
+    scale = float(np.abs(g["grad_features"]).max())
+    assert max_abs(feats.grad, g["grad_features"]) < 1e-4 * scale
+    for k, v in sd.items():
+        if "grad_" + k in g:
+            assert max_abs(v.grad, g["grad_" + k]) < 2e-4 * max(1e-6, float(np.abs(g["grad_" + k]).max())), k
+        if "buf_" + k in g:
+            assert max_abs(v, g["buf_" + k]) < 1e-5, k
