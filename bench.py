@@ -161,7 +161,8 @@ def main():
                                    "fp32, one reference view per step per GPU, precomputed features resident in HBM"
                                    % (args.width, args.height, args.views),
                        "parallelism": "inference sharding of reference views, no collective" if world > 1 else "single GPU"},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels[:14],
+            "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_sum": round(sum(e["ms_per_step"] for e in kernels), 3),
+            "kernels": kernels,
         }
         print(json.dumps(line))
     if world > 1:

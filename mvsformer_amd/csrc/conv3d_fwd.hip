@@ -64,8 +64,10 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const float* __restrict__ x
     const int i16 = lane & 15, kk = lane >> 4;
     const int ndt = (Do + TD - 1) / TD;
     const int wblocks = (Wo + TW - 1) / TW;
-    const int nbase = (blockIdx.x / wblocks) * NT * 16;      // first output channel of this block (N split)
-    const int b = blockIdx.z / ndt, d0 = (blockIdx.z % ndt) * TD, h0 = blockIdx.y * TH, w0 = (blockIdx.x % wblocks) * TW;
+    unsigned bxi, byi, bzi;
+    xcd_block_coords(bxi, byi, bzi);
+    const int nbase = (bxi / wblocks) * NT * 16;             // first output channel of this block (N split)
+    const int b = bzi / ndt, d0 = (bzi % ndt) * TD, h0 = byi * TH, w0 = (bxi % wblocks) * TW;
     const size_t plane = (size_t)Hi * Wi;
 
     // ---- per-thread staging map (chunk-invariant): element e = tid + 256*i of the [CC][ID][IH][IW] tile ----

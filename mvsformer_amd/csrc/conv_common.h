@@ -39,6 +39,19 @@ __device__ __forceinline__ f32x4 bn_act(f32x4 a, float sc, float sh, int relu) {
     return o;
 }
 
+// XCD-aware block order (cdna_hip_programming.md T1): the dispatcher sends consecutive workgroup ids round-robin to the 8
+// XCDs, each with its own L2; remap so every XCD works on one contiguous slab of the (x, y, z) block grid and the halo
+// rows shared by neighbouring tiles hit in the same L2.  Bijective for any grid size.  Speed only, never correctness.
+__device__ __forceinline__ void xcd_block_coords(unsigned& bx, unsigned& by, unsigned& bz) {
+    const unsigned gx = gridDim.x, gy = gridDim.y, nb = gx * gy * gridDim.z;
+    const unsigned id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned q = nb / 8, r = nb % 8, xcd = id % 8, loc = id / 8;
+    const unsigned nid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    bx = nid % gx;
+    by = (nid / gx) % gy;
+    bz = nid / (gx * gy);
+}
+
 inline int check_conv_args(const char* who, int B, int Cin, int Cout, int Di, int Hi, int Wi) {
     MVS_REQUIRE(B >= 1 && Di >= 1 && Hi >= 1 && Wi >= 1, "%s: bad shape B=%d D=%d H=%d W=%d", who, B, Di, Hi, Wi);
     MVS_REQUIRE(Cin >= 4 && Cin % 4 == 0, "%s: Cin must be a multiple of 4 (got %d)", who, Cin);
