@@ -72,7 +72,6 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const float* __restrict__ x
 
     // ---- per-thread staging map (chunk-invariant): element e = tid + 256*i of the [CC][ID][IH][IW] tile ----
     unsigned voff[EPT];                                      // byte offset inside the chunk's channel block, or OOB
-    unsigned short loff[EPT];                                // word offset inside s_in
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         const int e = tid + i * 256;
@@ -81,7 +80,6 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const float* __restrict__ x
         const int gd = d0 * SD - 1 + dz, gh = h0 * SHW - 1 + hy, gw = w0 * SHW - 1 + wx;
         const bool ok = e < NEL && gd >= 0 && gd < Di && gh >= 0 && gh < Hi && gw >= 0 && gw < Wi;
         voff[i] = ok ? (unsigned)((((size_t)c * Di + gd) * Hi + gh) * Wi + gw) * 4u : OOB;
-        loff[i] = (unsigned short)(c * CS + rem);
     }
 
     float sreg[EPT];
@@ -100,8 +98,10 @@ __global__ __launch_bounds__(256) void conv3d_kernel(const float* __restrict__ x
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int i = 0; i < EPT; ++i)
-            if (tid + i * 256 < NEL) s_in[loff[i]] = sreg[i];
+        for (int i = 0; i < EPT; ++i) {
+            const int e = tid + i * 256;                     // LDS word = e + (e / RAW) * (CS - RAW): recomputed, not kept in
+            if (e < NEL) s_in[e + (e / RAW) * (CS - RAW)] = sreg[i];   // registers (a third of the staging registers otherwise)
+        }
         f32x4* dst = reinterpret_cast<f32x4*>(s_w);
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {

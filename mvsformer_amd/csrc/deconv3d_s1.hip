@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void deconv3d_s1_kernel(const float* __restric
     constexpr int NPD = npd_of(NC), NTL = ntiles_of(NC);
     constexpr int K16 = (NC >= 16) ? NC / 16 : 1;            // 16-channel tiles per class
     constexpr int NACC = (NC == 8) ? 5 : 4 * K16;            // accumulator tiles per M tile
-    constexpr int CC = (NC == 32) ? 8 : 16;                  // input channels per chunk
+    constexpr int CC = 8;                                    // input channels per chunk (2 blocks per CU: 75 staging regs, 33 KB LDS)
     constexpr int ID = 4, IH = 3, IW = 65;
     constexpr int RAW = ID * IH * IW;
     constexpr int CS = pad_cs(RAW, 1);
@@ -83,7 +83,6 @@ __global__ __launch_bounds__(256) void deconv3d_s1_kernel(const float* __restric
     const size_t plane = (size_t)Hi * Wi;
 
     unsigned voff[EPT];
-    unsigned short loff[EPT];
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         const int e = tid + i * 256;
@@ -92,7 +91,6 @@ __global__ __launch_bounds__(256) void deconv3d_s1_kernel(const float* __restric
         const int gd = d0 - 1 + dz, gh = hi0 + hy, gw = wi0 + wx;
         const bool ok = e < NEL && gd >= 0 && gd < Di && gh < Hi && gw < Wi;
         voff[i] = ok ? (unsigned)((((size_t)c * Di + gd) * Hi + gh) * Wi + gw) * 4u : OOB;
-        loff[i] = (unsigned short)(c * CS + rem);
     }
     float sreg[EPT];
     f32x4 wreg[NWV];
@@ -110,8 +108,10 @@ __global__ __launch_bounds__(256) void deconv3d_s1_kernel(const float* __restric
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int i = 0; i < EPT; ++i)
-            if (tid + i * 256 < NEL) s_in[loff[i]] = sreg[i];
+        for (int i = 0; i < EPT; ++i) {
+            const int e = tid + i * 256;
+            if (e < NEL) s_in[e + (e / RAW) * (CS - RAW)] = sreg[i];
+        }
         f32x4* dst = reinterpret_cast<f32x4*>(s_w);
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void deconv3d_s1_kernel(const float* __restric
 template <int NC>
 int launch_s1(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y, int B, int Cin,
               int Di, int Hi, int Wi, int relu, hipStream_t s) {
-    constexpr int CC = (NC == 32) ? 8 : 16;
+    constexpr int CC = 8;
     constexpr size_t lds = (size_t)(CC * pad_cs(4 * 3 * 65, 1) + (CC / 4) * 3 * 4 * npd_of(NC)) * 4;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
@@ -250,15 +250,15 @@ int launch_s1(const float* x, const float* wp, const float* scale, const float* 
 namespace mvsconv {
 
 // measured (tools/bench_conv.py): the grouped form wins only where the plain form wastes half of every N tile
-bool deconv_s1_supported(int Cout) { return Cout == 8; }
+bool deconv_s1_supported(int Cout) { return Cout == 8 || Cout == 16; }
 
 int64_t deconv_s1_packed_floats(int Cin, int Cout) {
-    const int n4 = 4 * ((Cin + 15) / 16);                    // whole 16-channel chunks
+    const int n4 = 2 * ((Cin + 7) / 8);                      // whole 8-channel chunks
     return (int64_t)n4 * 3 * 4 * npd_of(Cout);
 }
 
 int deconv_s1_pack(const float* w, int Cin, int Cout, float* out, hipStream_t s) {
-    const int n4 = 4 * ((Cin + 15) / 16), NPD = npd_of(Cout);
+    const int n4 = 2 * ((Cin + 7) / 8), NPD = npd_of(Cout);
     const int64_t total = (int64_t)n4 * 3 * 4 * NPD;
     hipLaunchKernelGGL(pack_deconv_s1_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, Cin, Cout, NPD, n4, out);
     return mvs::finish_launch("mvs_conv3d_pack_weights");

@@ -231,7 +231,7 @@ def deconv3d(x, wpacked, cin, cout, sd, scale=None, shift=None, residual=None, r
         if residual.shape != y.shape:
             raise _lib.MvsHipError("residual shape %s != output %s (stage H, W must be divisible by 8%s)" % (
                 tuple(residual.shape), tuple(y.shape), ", D by 8" if sd == 2 else ""))
-    name = "deconv3d_s1_kernel<%d>" % cout if (sd == 1 and cout == 8) else "deconv3d_kernel<%d,%d>" % (_nt(cout), sd)
+    name = "deconv3d_s1_kernel<%d>" % cout if (sd == 1 and cout in (8, 16)) else "deconv3d_kernel<%d,%d>" % (_nt(cout), sd)
     tag = (name, "flops", 2.0 * 27 * cin * cout * B * Di * Hi * Wi)
     _call("mvs_deconv3d_fwd", tag, _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), B, cin,
           cout, Di, Hi, Wi, sd, int(relu), _stream())

@@ -44,7 +44,7 @@ def test_library_exports_every_symbol():
         assert hasattr(lib, n)
     assert lib.mvs_conv3d_packed_floats(8, 16, 0) == 2 * 27 * 4 * 16
     assert lib.mvs_conv3d_packed_floats(64, 64, 0) == 16 * 27 * 4 * 80
-    assert lib.mvs_conv3d_packed_floats(16, 8, 2) == 4 * 3 * 4 * 80
+    assert lib.mvs_conv3d_packed_floats(16, 8, 2) == 4 * 3 * 4 * 80    # 2 chunks of 8 channels = 4 slabs
 
 
 def test_state_dict_keys_match_reference():
