@@ -39,12 +39,32 @@ __device__ __forceinline__ f32x4 buf_load4(mvs::rsrc_t r, unsigned voff_bytes) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, 0, 0));
 }
 
+// Cross-lane sums over the LPP lanes of a pixel as DPP row operations (full-rate VALU, no LDS crossbar traffic; the
+// ds_bpermute form of __shfl_xor was ~25 LDS-path instructions per gather step in the similarity branch).
+//   quad_perm xor 1 / xor 2, then row_half_mirror (i <-> 7-i) and row_mirror (i <-> 15-i): valid as "xor 4 / xor 8"
+//   partners because after the quad steps all 4 lanes of a quad already hold the same partial sum.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+    return v + __builtin_bit_cast(float, o);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_ROR4 = 0x124, DPP_ROR8 = 0x128;
+
 // sum over the LPP lanes of a pixel (lanes pixel*LPP .. pixel*LPP+LPP-1); every lane gets the total
 template <int LPP>
 __device__ __forceinline__ float pixel_sum(float v) {
-#pragma unroll
-    for (int m = 1; m < LPP; m <<= 1) v += __shfl_xor(v, m, 64);
+    v = dpp_add<DPP_XOR1>(v);
+    if (LPP >= 4) v = dpp_add<DPP_XOR2>(v);
+    if (LPP >= 8) v = dpp_add<DPP_HALF_MIRROR>(v);
+    if (LPP >= 16) v = dpp_add<DPP_MIRROR>(v);
     return v;
+}
+// LPP == 16 only: sum over the 8 lanes of a pixel with the same parity (lanes 2k or 2k+1) - row rotations by 4 and 8
+// keep the parity, the quad step pairs i with i^2
+__device__ __forceinline__ float parity_sum16(float v) {
+    v = dpp_add<DPP_XOR2>(v);
+    v = dpp_add<DPP_ROR4>(v);
+    return dpp_add<DPP_ROR8>(v);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -254,9 +274,7 @@ __global__ __launch_bounds__(64 * NW) void cv_aggregate_kernel(const float* __re
             }
         }
 #pragma unroll
-        for (int m = (CPG == 8 ? 2 : 1); m < LPP; m <<= 1)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) n2[i] += __shfl_xor(n2[i], m, 64);
+        for (int i = 0; i < 4; ++i) n2[i] = (CPG == 8) ? parity_sum16(n2[i]) : pixel_sum<LPP>(n2[i]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) rn[i] = r[i] / fmaxf(sqrtf(n2[i]), 1e-12f);
     }
@@ -316,12 +334,10 @@ __global__ __launch_bounds__(64 * NW) void cv_aggregate_kernel(const float* __re
                         for (int k = ii + CPG; k < 4; k += CPG) { q[ii] += q[k]; n2[ii] += n2[k]; }
                     }
 #pragma unroll
-                    for (int m = 1; m < LPP; m <<= 1)
-#pragma unroll
-                        for (int ii = 0; ii < CPG; ++ii) {
-                            q[ii] += __shfl_xor(q[ii], m, 64);
-                            n2[ii] += __shfl_xor(n2[ii], m, 64);
-                        }
+                    for (int ii = 0; ii < CPG; ++ii) {
+                        q[ii] = pixel_sum<LPP>(q[ii]);
+                        n2[ii] = pixel_sum<LPP>(n2[ii]);
+                    }
                     float ssum = 0.0f;
 #pragma unroll
                     for (int ii = 0; ii < CPG; ++ii) ssum += q[ii] * __builtin_amdgcn_rsqf(fmaxf(n2[ii], 1e-24f));
@@ -382,8 +398,7 @@ __global__ __launch_bounds__(64 * NW) void cv_aggregate_kernel(const float* __re
                         acc[dd][0] = acc[dd][0] + ((((p[0] + p[1]) + p[2]) + p[3]) * 0.25f) * wv;
                     } else {
                         float h = ((p[0] + p[1]) + p[2]) + p[3];
-                        const float o2 = __shfl_xor(h, 1, 64);
-                        h = (cq & 1) ? o2 + h : h + o2;       // same association in both lanes: low half first
+                        h = dpp_add<DPP_XOR1>(h);             // the other half of the group lives in the neighbour lane
                         acc[dd][0] = acc[dd][0] + (h * 0.125f) * wv;
                     }
                     if (SIM) {
@@ -399,16 +414,14 @@ __global__ __launch_bounds__(64 * NW) void cv_aggregate_kernel(const float* __re
                         }
                         constexpr int NJ = (CPG < 4) ? CPG : 4;      // distinct j held by this lane
 #pragma unroll
-                        for (int m = (CPG == 8 ? 2 : 1); m < LPP; m <<= 1)
-#pragma unroll
-                            for (int i = 0; i < NJ; ++i) {
-                                q[i] += __shfl_xor(q[i], m, 64);
-                                n2[i] += __shfl_xor(n2[i], m, 64);
-                            }
+                        for (int i = 0; i < NJ; ++i) {
+                            q[i] = (CPG == 8) ? parity_sum16(q[i]) : pixel_sum<LPP>(q[i]);
+                            n2[i] = (CPG == 8) ? parity_sum16(n2[i]) : pixel_sum<LPP>(n2[i]);
+                        }
                         float s = 0.0f;
 #pragma unroll
                         for (int i = 0; i < NJ; ++i) s += q[i] * __builtin_amdgcn_rsqf(fmaxf(n2[i], 1e-24f));   // q / max(||w||, 1e-12)
-                        if (CPG == 8) s += __shfl_xor(s, 1, 64);      // the other 4 j's live in the neighbour lane
+                        if (CPG == 8) s = dpp_add<DPP_XOR1>(s);       // the other 4 j's live in the neighbour lane
                         simtot[dd] = simtot[dd] + s * (1.0f / CPG);
                     }
                 }
