@@ -94,3 +94,32 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="reference checkout only exists in the build container")
+def test_install_rebinds_reference_symbols():
+    """install() swaps the hot-path names inside the unmodified reference modules (import side effects of unrelated
+    files stubbed exactly as oracle/gen_golden.py does)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, types, torch.nn as nn
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference"); sys.path.insert(0, %r)
+def stub(name, **kw):
+    m = types.ModuleType(name); m.__dict__.update(kw); sys.modules[name] = m
+stub("timm"); stub("timm.models")
+stub("timm.models.layers", DropPath=nn.Identity, to_2tuple=lambda x: (x, x), trunc_normal_=nn.init.trunc_normal_)
+stub("timm.models.vision_transformer", Block=nn.Module)
+stub("torchvision"); stub("torchvision.utils"); stub("omegaconf", OmegaConf=object)
+import models.mvsformer_model as mm
+import mvsformer_amd
+done = mvsformer_amd.install()
+assert mm.StageNet is mvsformer_amd.StageNet and mm.homo_warping_3D_with_mask is mvsformer_amd.homo_warping_3D_with_mask
+assert mm.CostRegNet is mvsformer_amd.CostRegNet and mm.CostRegNet3D is mvsformer_amd.CostRegNet3D
+net = mm.StageNet(dict(base_ch=8, fusion_type="cnn", depth_type="ce"), 4, 0)
+assert type(net.cost_reg).__module__.startswith("mvsformer_amd")
+print("OK", sorted(done))
+''' % REPO
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
