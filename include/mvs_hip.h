@@ -200,6 +200,29 @@ int mvs_schedule_inverse_range(const float* prev_depth, const float* prev_hyp, i
  *   acc [B,Hf,Wf] += nearest(conf [B,H,W]) * weight */
 int mvs_conf_accumulate(const float* conf, int B, int H, int W, float* acc, int Hf, int Wf, float weight, mvs_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Next row after the path: geometric consistency filtering of the depth maps, misc/fusion.py:79-122
+ * (get_reproj / project_img, vis_filter, ave_fusion) as driven by test.py:404-438, in one pass per reference pixel.
+ *   ref_depth [n,1,H,W]   src_depths [n,v,1,H,W]   ref_cam [n,2,4,4]   src_cams [n,v,2,4,4]  (cam[0]=extrinsic, cam[1][:3,:3]=K)
+ *   workspace: mvs_geo_filter_workspace_bytes(n, v) bytes of device scratch (per-view camera algebra)
+ * outputs (each may be NULL): reproj_xyd [n,v,3,H,W], in_range [n,v,1,H,W], masks [n,v,1,H,W] (float 0/1),
+ *   mask [n,1,H,W] uint8 (sum_v masks >= vthresh - 1.1), ref_depth_ave [n,1,H,W], points [n,3,H,W] (world xyz of ave depth)
+ * ------------------------------------------------------------------------------------------------------- */
+int64_t mvs_geo_filter_workspace_bytes(int n, int v);
+int mvs_geo_filter_fwd(const float* ref_depth, const float* src_depths, const float* ref_cam, const float* src_cams, int n, int v,
+                       int H, int W, float img_dist_thresh, float depth_thresh, float vthresh, void* workspace, float* reproj_xyd,
+                       float* in_range, float* masks, uint8_t* mask, float* ref_depth_ave, float* points, mvs_stream_t stream);
+/* op-level forms for callers that keep the reference's three calls: vis_filter (fusion.py:101-109) and ave_fusion
+ * (fusion.py:112-114) on a materialized reproj_xyd.  masks_in != NULL: averaged depth from given masks (ave_fusion);
+ * else masks are computed from in_range and the thresholds.  Outputs may be NULL. */
+int mvs_vis_filter_fwd(const float* ref_depth, const float* reproj_xyd, const float* in_range, const float* masks_in, int n, int v,
+                       int H, int W, float img_dist_thresh, float depth_thresh, float vthresh, float* masks, uint8_t* mask,
+                       float* ref_depth_ave, mvs_stream_t stream);
+/* prob_filter (fusion.py:69-77): mask = AND_c (conf[:, c] > thresh[c]), conf [n,C,HW], C <= 4, thresh in HOST memory;
+ * depth_inplace (may be NULL) [n,HW] is multiplied by the mask (test.py:414-418). */
+int mvs_prob_filter(const float* conf, int n, int C, int64_t HW, const float* thresh_host, uint8_t* mask, float* depth_inplace,
+                    mvs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,7 @@ inline int finish_launch(const char* what) {
 }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline long long ceil_div(long long a, long long b) { return (a + b - 1) / b; }
 
 }  // namespace mvs
 

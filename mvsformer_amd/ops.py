@@ -429,3 +429,63 @@ def sigmoid_bwd(y, dy):
     dx = torch.empty_like(y)
     _call("mvs_sigmoid_bwd", None, _ptr(y), _ptr(dy), y.numel(), _ptr(dx), _stream())
     return dx
+
+
+# ------------------------------------------------------------------------- depth-map consistency filtering (§8 f2)
+def geo_filter(ref_depth, srcs_depth, ref_cam, srcs_cam, img_dist_thresh: float = 1.0, depth_thresh: float = 0.01,
+               vthresh: float = 2.0, want=("mask", "ref_depth_ave", "points")) -> Dict[str, torch.Tensor]:
+    _chk(ref_depth, "ref_depth"), _chk(srcs_depth, "srcs_depth"), _chk(ref_cam, "ref_cam"), _chk(srcs_cam, "srcs_cam")
+    n, v, _, h, w = srcs_depth.shape
+    if ref_depth.shape != (n, 1, h, w) or ref_cam.shape != (n, 2, 4, 4) or srcs_cam.shape != (n, v, 2, 4, 4):
+        raise _lib.MvsHipError("geo_filter: inconsistent shapes %s %s %s %s" % (tuple(ref_depth.shape), tuple(srcs_depth.shape),
+                                                                              tuple(ref_cam.shape), tuple(srcs_cam.shape)))
+    dev = ref_depth.device
+    shapes = dict(reproj_xyd=(n, v, 3, h, w), in_range=(n, v, 1, h, w), masks=(n, v, 1, h, w), mask=(n, 1, h, w),
+                  ref_depth_ave=(n, 1, h, w), points=(n, 3, h, w))
+    out = {k: torch.empty(shapes[k], device=dev, dtype=torch.uint8 if k == "mask" else torch.float32) for k in want}
+    ws = torch.empty(_lib.load().mvs_geo_filter_workspace_bytes(n, v), device=dev, dtype=torch.uint8)
+    algo = 4.0 * n * h * w * (1 + v + sum({"reproj_xyd": 3 * v, "in_range": v, "masks": v, "mask": 0.25, "ref_depth_ave": 1,
+                                            "points": 3}[k] for k in want))
+    _call("mvs_geo_filter_fwd", ("geo_filter", "bytes", algo), _ptr(ref_depth), _ptr(srcs_depth), _ptr(ref_cam), _ptr(srcs_cam), n, v, h,
+          w, float(img_dist_thresh), float(depth_thresh), float(vthresh), _ptr(ws), *[_ptr(out.get(k)) for k in
+                                                                                      ("reproj_xyd", "in_range", "masks", "mask",
+                                                                                       "ref_depth_ave", "points")], _stream())
+    if "mask" in out:
+        out["mask"] = out["mask"].view(torch.bool)
+    return out
+
+
+def vis_filter(ref_depth, reproj_xyd, in_range, masks_in, img_dist_thresh, depth_thresh, vthresh, want_masks=True, want_ave=True):
+    _chk(ref_depth, "ref_depth"), _chk(reproj_xyd, "reproj_xyd")
+    n, v, _, h, w = reproj_xyd.shape
+    for t, name in ((in_range, "in_range"), (masks_in, "masks")):
+        if t is not None:
+            _chk(t, name)
+    dev = ref_depth.device
+    masks = torch.empty(n, v, 1, h, w, device=dev, dtype=torch.float32) if (want_masks and masks_in is None) else None
+    mask = torch.empty(n, 1, h, w, device=dev, dtype=torch.uint8) if masks_in is None else None
+    ave = torch.empty(n, 1, h, w, device=dev, dtype=torch.float32) if want_ave else None
+    _call("mvs_vis_filter_fwd", "vis_filter", _ptr(ref_depth), _ptr(reproj_xyd), _ptr(in_range), _ptr(masks_in), n, v, h, w,
+          float(img_dist_thresh), float(depth_thresh), float(vthresh), _ptr(masks), _ptr(mask), _ptr(ave), _stream())
+    return masks, (mask.view(torch.bool) if mask is not None else None), ave
+
+
+def prob_filter(conf: torch.Tensor, thresh, depth_inplace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``conf [n,C,...]`` (C = len(thresh) <= 4) -> bool ``[n,1,...]`` (the reference's ``ref_prob[:, [i]]`` shape); ``depth_inplace`` (same trailing shape) is zeroed where False."""
+    import ctypes
+    _chk(conf, "conf")
+    n, C = conf.shape[0], len(thresh)
+    if conf.shape[1] < C:
+        raise _lib.MvsHipError("prob_filter: %d thresholds for %d confidence channels" % (C, conf.shape[1]))
+    if conf.shape[1] != C:
+        conf = conf[:, :C].contiguous()
+    HW = conf.numel() // (n * C)
+    mask = torch.empty((n, 1) + tuple(conf.shape[2:]), device=conf.device, dtype=torch.uint8)
+    if depth_inplace is not None:
+        _chk(depth_inplace, "depth")
+        if depth_inplace.numel() != n * HW:
+            raise _lib.MvsHipError("prob_filter: depth has %d elements, expected %d" % (depth_inplace.numel(), n * HW))
+    th = (ctypes.c_float * C)(*[float(t) for t in thresh])
+    _call("mvs_prob_filter", "prob_filter", _ptr(conf), n, C, HW, ctypes.cast(th, ctypes.c_void_p), _ptr(mask), _ptr(depth_inplace),
+          _stream())
+    return mask.view(torch.bool)

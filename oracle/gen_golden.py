@@ -361,3 +361,38 @@ if __name__ == "__main__" and os.environ.get("GEN_TRAIN", "1") == "1":
     shapes = json.load(open(os.path.join(OUT, "state_dict_shapes.json")))
     gen_train_grads("costregnet", 16, 16, 13, shapes)
     gen_train_grads("costregnet3d", 4, 8, 14, shapes)
+
+
+def gen_fusion():
+    """fusion.npz: misc/fusion.py get_reproj / vis_filter / ave_fusion + the point back-projection of test.py:425-434,
+    run from the real reference on CPU (its get_pixel_grids hard-codes .cuda(); Tensor.cuda is made a no-op here)."""
+    from oracle import ref_fusion
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import misc.fusion as rf
+    out = {}
+    for tag, kw, thr in (("a", dict(n=1, v=4, h=48, w=64, seed=0), (1.0, 0.01, 3)),
+                         ("b", dict(n=2, v=3, h=40, w=56, seed=1, noise=0.008), (0.5, 0.02, 2))):
+        case = ref_fusion.make_fusion_case(**kw)
+        for k, t in case.items():
+            out["%s_%s" % (tag, k)] = np32(t)
+        reproj, in_range = rf.get_reproj(case["ref_depth"], case["src_depths"], case["ref_cam"], case["src_cams"])
+        masks, mask = rf.vis_filter(case["ref_depth"], reproj, in_range, *thr)
+        ave = rf.ave_fusion(case["ref_depth"], reproj, masks)
+        idx_img = rf.get_pixel_grids(*ave.size()[-2:]).unsqueeze(0)
+        points = rf.idx_cam2world(rf.idx_img2cam(idx_img, ave, case["ref_cam"]), case["ref_cam"])[..., :3, 0].permute(0, 3, 1, 2)
+        out[tag + "_thresholds"] = np.asarray(thr, np.float32)
+        out[tag + "_reproj_xyd"] = np32(reproj)
+        out[tag + "_in_range"] = np32(in_range)
+        out[tag + "_masks"] = np32(masks)
+        out[tag + "_mask"] = mask.numpy()
+        out[tag + "_ref_depth_ave"] = np32(ave)
+        out[tag + "_points"] = np32(points)
+        conf = torch.rand(kw["n"], 3, 1, kw["h"], kw["w"], generator=torch.Generator().manual_seed(5))
+        out[tag + "_conf"] = np32(conf)
+        out[tag + "_prob_mask"] = rf.prob_filter(conf, [0.3, 0.5, 0.2]).numpy()
+        print(tag, "kept", float(mask.float().mean()), "masks", float(masks.mean()))
+    save("fusion.npz", **out)
+
+
+if __name__ == "__main__" and os.environ.get("GEN_FUSION", "1") == "1":
+    gen_fusion()

@@ -128,3 +128,25 @@ def test_stage_train_gradients(kind):
             assert max_abs(v.grad, g["grad_" + k]) < 2e-4 * max(1e-6, float(np.abs(g["grad_" + k]).max())), k
         if "buf_" + k in g:
             assert max_abs(v, g["buf_" + k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_fusion_oracle_vs_reference(tag):
+    """oracle/ref_fusion.py against misc/fusion.py outputs (tests/golden/fusion.npz)."""
+    from oracle import ref_fusion
+    g = load_golden("fusion.npz")
+    case = {k: t(g["%s_%s" % (tag, k)]) for k in ("ref_depth", "src_depths", "ref_cam", "src_cams")}
+    thr = [float(x) for x in g[tag + "_thresholds"]]
+    out = ref_fusion.filter_depth_maps(case["ref_depth"], case["src_depths"], case["ref_cam"], case["src_cams"], *thr)
+    assert max_abs(out["reproj_xyd"], g[tag + "_reproj_xyd"]) < 1e-3
+    assert np.array_equal(out["in_range"].numpy(), g[tag + "_in_range"])
+    assert (out["masks"].numpy() != g[tag + "_masks"]).mean() < 1e-4
+    assert (out["mask"].numpy() != g[tag + "_mask"]).mean() < 1e-4
+    assert rel_err(out["ref_depth_ave"], g[tag + "_ref_depth_ave"]) < 1e-5
+    assert rel_err(out["points"], g[tag + "_points"]) < 1e-5
+    pm = ref_fusion.prob_filter(t(g[tag + "_conf"]), [0.3, 0.5, 0.2])
+    assert np.array_equal(pm.numpy(), g[tag + "_prob_mask"])
+    # the synthetic generator itself is deterministic: regenerating gives the stored inputs
+    kw = dict(a=dict(n=1, v=4, h=48, w=64, seed=0), b=dict(n=2, v=3, h=40, w=56, seed=1, noise=0.008))[tag]
+    again = ref_fusion.make_fusion_case(**kw)
+    assert max_abs(again["src_depths"], g[tag + "_src_depths"]) < 1e-2
