@@ -218,6 +218,19 @@ int mvs_geo_filter_fwd(const float* ref_depth, const float* src_depths, const fl
 int mvs_vis_filter_fwd(const float* ref_depth, const float* reproj_xyd, const float* in_range, const float* masks_in, int n, int v,
                        int H, int W, float img_dist_thresh, float depth_thresh, float vthresh, float* masks, uint8_t* mask,
                        float* ref_depth_ave, mvs_stream_t stream);
+/* Dynamic consistency check: get_reproj_dynamic + vis_filter_dynamic (fusion.py:116-165) + the reduction of
+ * test.py:503-514, one pass.  2 <= v <= 16.  A view passes level k (k = 2..v) when dist < k/dist_base and
+ * |d_ref - d|/d_ref < k/rel_diff_base.  Outputs (each may be NULL): reproj_xyd [n,v,3,H,W]; masks [n,v,v-1,H,W] uint8
+ * (level k at index k-2); vis_mask [n,v,1,H,W] uint8 (= level v); geo_mask [n,1,H,W] uint8 (exists k: #views passing
+ * level k >= k); ref_depth_ave [n,1,H,W] over the views in vis_mask; points [n,3,H,W].
+ * mvs_vis_filter_dynamic_fwd is the op-level form on a materialized reproj_xyd. */
+int mvs_geo_filter_dynamic_fwd(const float* ref_depth, const float* src_depths, const float* ref_cam, const float* src_cams, int n,
+                               int v, int H, int W, float dist_base, float rel_diff_base, void* workspace, float* reproj_xyd,
+                               uint8_t* masks, uint8_t* vis_mask, uint8_t* geo_mask, float* ref_depth_ave, float* points,
+                               mvs_stream_t stream);
+int mvs_vis_filter_dynamic_fwd(const float* ref_depth, const float* reproj_xyd, int n, int v, int H, int W, float dist_base,
+                               float rel_diff_base, uint8_t* masks, uint8_t* vis_mask, uint8_t* geo_mask, float* ref_depth_ave,
+                               mvs_stream_t stream);
 /* prob_filter (fusion.py:69-77): mask = AND_c (conf[:, c] > thresh[c]), conf [n,C,HW], C <= 4, thresh in HOST memory;
  * depth_inplace (may be NULL) [n,HW] is multiplied by the mask (test.py:414-418). */
 int mvs_prob_filter(const float* conf, int n, int C, int64_t HW, const float* thresh_host, uint8_t* mask, float* depth_inplace,

@@ -58,6 +58,8 @@ SIGNATURES = {
     "mvs_geo_filter_workspace_bytes": (L, [I, I]),
     "mvs_geo_filter_fwd": (I, [P, P, P, P, I, I, I, I, F, F, F, P, P, P, P, P, P, P, P]),
     "mvs_vis_filter_fwd": (I, [P, P, P, P, I, I, I, I, F, F, F, P, P, P, P]),
+    "mvs_geo_filter_dynamic_fwd": (I, [P, P, P, P, I, I, I, I, F, F, P, P, P, P, P, P, P, P]),
+    "mvs_vis_filter_dynamic_fwd": (I, [P, P, I, I, I, I, F, F, P, P, P, P, P]),
     "mvs_prob_filter": (I, [P, I, I, L, P, P, P, P]),
     "mvs_init_inverse_range": (I, [P, I, I, I, I, I, P, P]),
     "mvs_schedule_inverse_range": (I, [P, P, I, F, I, I, I, I, P, P]),

@@ -218,6 +218,135 @@ __global__ __launch_bounds__(256) void vis_filter_kernel(const float* __restrict
     if (ave_out) ave_out[(size_t)n * HW + pix] = (dsum + dref) / (msum + 1.0f);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Dynamic consistency (fusion.py:116-165 get_reproj_dynamic / vis_filter_dynamic, test.py:475-514): the reference pixel
+// is projected into the source view, the SOURCE depth is sampled there (index = pixel coordinate, align_corners=True,
+// no clamp), that sample is back-projected into the reference camera.  A view passes at level k in [2, v] when
+// dist < k/dist_base and |d_ref - d|/d_ref < k/rel_diff_base; the pixel is kept if for some k at least k views pass.
+// Thresholds grow with k, so a view is summarized by the first level it passes (kmin) and the [n,v,v-1,h,w] mask stack
+// of the reference is only written on request.
+constexpr int kMaxDynViews = 16;
+
+__device__ __forceinline__ int first_level(float rx, float ry, float rd, float px, float py, float dref, int V, float dist_base,
+                                           float rel_base) {
+    const float ddx = rx - px, ddy = ry - py;
+    const float cd = sqrtf(ddx * ddx + ddy * ddy);
+    const float dd = fabsf(dref - rd) / dref;
+    int kmin = V + 1;
+    for (int k = V; k >= 2; --k) {
+        const bool ok = (cd < (float)k / dist_base) && (dd < (float)k / rel_base);
+        kmin = ok ? k : kmin;
+    }
+    return kmin;
+}
+
+struct DynAcc {
+    int cnt[kMaxDynViews + 1];
+    float msum, dsum;
+    __device__ void init() {
+#pragma unroll
+        for (int k = 0; k <= kMaxDynViews; ++k) cnt[k] = 0;
+        msum = 0.0f;
+        dsum = 0.0f;
+    }
+    __device__ void add(int kmin, float rd, int V) {
+#pragma unroll
+        for (int k = 2; k <= kMaxDynViews; ++k) cnt[k] += (k >= kmin) ? 1 : 0;
+        if (kmin <= V) { msum += 1.0f; dsum += rd; }
+    }
+    __device__ bool keep(int V) const {
+        bool g = false;
+#pragma unroll
+        for (int k = 2; k <= kMaxDynViews; ++k) g = g || (k <= V && cnt[k] >= k);
+        return g;
+    }
+};
+
+__device__ __forceinline__ void write_levels(uint8_t* masks_out, uint8_t* vis_out, size_t nv, size_t HW, size_t pix, int kmin, int V) {
+    if (masks_out)
+        for (int k = 2; k <= V; ++k) masks_out[(nv * (V - 1) + (k - 2)) * HW + pix] = (k >= kmin) ? 1 : 0;
+    if (vis_out) vis_out[nv * HW + pix] = (kmin <= V) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void geo_filter_dynamic_kernel(const float* __restrict__ ref_depth, const float* __restrict__ src_depth,
+                                                                 const ViewXf* __restrict__ xf, int V, int H, int W, float dist_base,
+                                                                 float rel_base, float* __restrict__ reproj, uint8_t* __restrict__ masks_out,
+                                                                 uint8_t* __restrict__ vis_out, uint8_t* __restrict__ geo_out,
+                                                                 float* __restrict__ ave_out, float* __restrict__ points_out) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, n = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const size_t HW = (size_t)H * W, pix = (size_t)y * W + x;
+    const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+    const float dref = ref_depth[(size_t)n * HW + pix];
+    const float hx = (float)(W - 1) / 2.0f, hy = (float)(H - 1) / 2.0f;
+    DynAcc acc;
+    acc.init();
+    for (int v = 0; v < V; ++v) {
+        const ViewXf& t = xf[n * V + v];
+        const float* sd = src_depth + (size_t)(n * V + v) * HW;
+        const V3 q = cam_to_img(t.Ks, pix_to_cam(t.Kri, t.r2s, px, py, dref));
+        // grid = q/((w-1)/2) - 1, unnormalized by ATen as ((g+1)/2)*(w-1): the sample index is q itself (up to rounding)
+        const float ix = ((q.x / hx - 1.0f + 1.0f) / 2.0f) * (float)(W - 1), iy = ((q.y / hy - 1.0f + 1.0f) / 2.0f) * (float)(H - 1);
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        const float fx1 = ix - x0f, fx0 = (x0f + 1.0f) - ix, fy1 = iy - y0f, fy0 = (y0f + 1.0f) - iy;
+        float ds = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xs = x0f + (float)(k & 1), ys = y0f + (float)(k >> 1);
+            if (xs >= 0.0f && xs <= (float)(W - 1) && ys >= 0.0f && ys <= (float)(H - 1))
+                ds = fmaf(sd[(size_t)ys * W + (size_t)xs], ((k & 1) ? fx1 : fx0) * ((k >> 1) ? fy1 : fy0), ds);
+        }
+        const V3 cr = pix_to_cam(t.Ksi, t.s2r, q.x, q.y, ds);
+        const V3 im = cam_to_img(t.Kr, cr);
+        if (reproj) {
+            const size_t o3 = ((size_t)(n * V + v) * 3) * HW + pix;
+            reproj[o3] = im.x; reproj[o3 + HW] = im.y; reproj[o3 + 2 * HW] = cr.z;
+        }
+        const int kmin = first_level(im.x, im.y, cr.z, px, py, dref, V, dist_base, rel_base);
+        write_levels(masks_out, vis_out, (size_t)(n * V + v), HW, pix, kmin, V);
+        acc.add(kmin, cr.z, V);
+    }
+    const float ave = (acc.dsum + dref) / (acc.msum + 1.0f);
+    if (geo_out) geo_out[(size_t)n * HW + pix] = acc.keep(V) ? 1 : 0;
+    if (ave_out) ave_out[(size_t)n * HW + pix] = ave;
+    if (points_out) {
+        const ViewXf& t = xf[n * V];
+        float cx = t.Kri[0] * px + t.Kri[1] * py + t.Kri[2], cy = t.Kri[3] * px + t.Kri[4] * py + t.Kri[5];
+        float cz = t.Kri[6] * px + t.Kri[7] * py + t.Kri[8];
+        const float sc = recip(cz + 1e-9f) * ave;
+        cx *= sc; cy *= sc; cz *= sc;
+        const float* M = t.Eri;
+        const float wh = recip(M[12] * cx + M[13] * cy + M[14] * cz + M[15] + 1e-9f);
+        points_out[((size_t)n * 3 + 0) * HW + pix] = (M[0] * cx + M[1] * cy + M[2] * cz + M[3]) * wh;
+        points_out[((size_t)n * 3 + 1) * HW + pix] = (M[4] * cx + M[5] * cy + M[6] * cz + M[7]) * wh;
+        points_out[((size_t)n * 3 + 2) * HW + pix] = (M[8] * cx + M[9] * cy + M[10] * cz + M[11]) * wh;
+    }
+}
+
+// op-level vis_filter_dynamic (fusion.py:153-165) on a materialized reproj_xyd, plus the reduction of test.py:503-511
+__global__ __launch_bounds__(256) void vis_filter_dynamic_kernel(const float* __restrict__ ref_depth, const float* __restrict__ reproj, int V,
+                                                                 int H, int W, float dist_base, float rel_base,
+                                                                 uint8_t* __restrict__ masks_out, uint8_t* __restrict__ vis_out,
+                                                                 uint8_t* __restrict__ geo_out, float* __restrict__ ave_out) {
+    const size_t HW = (size_t)H * W;
+    const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    if (pix >= HW) return;
+    const float px = (float)(pix % W) + 0.5f, py = (float)(pix / W) + 0.5f;
+    const float dref = ref_depth[(size_t)n * HW + pix];
+    DynAcc acc;
+    acc.init();
+    for (int v = 0; v < V; ++v) {
+        const size_t o3 = (size_t)(n * V + v) * 3 * HW + pix;
+        const float rd = reproj[o3 + 2 * HW];
+        const int kmin = first_level(reproj[o3], reproj[o3 + HW], rd, px, py, dref, V, dist_base, rel_base);
+        write_levels(masks_out, vis_out, (size_t)(n * V + v), HW, pix, kmin, V);
+        acc.add(kmin, rd, V);
+    }
+    if (geo_out) geo_out[(size_t)n * HW + pix] = acc.keep(V) ? 1 : 0;
+    if (ave_out) ave_out[(size_t)n * HW + pix] = (acc.dsum + dref) / (acc.msum + 1.0f);
+}
+
 // prob_filter, fusion.py:69-77: AND over the C confidence channels of (conf[:, i] > thresh[i]); optionally zeroes a
 // depth map in place where the test fails (test.py:414-418, `src_depths[:, ids] *= mask`).
 __global__ __launch_bounds__(256) void prob_filter_kernel(const float* __restrict__ conf, int C, size_t HW, float t0, float t1, float t2,
@@ -255,6 +384,36 @@ extern "C" int mvs_prob_filter(const float* conf, int n, int C, int64_t HW, cons
     hipLaunchKernelGGL(prob_filter_kernel, grid, dim3(256), 0, MVS_STREAM(stream), conf, C, (size_t)HW, t[0], t[1], t[2], t[3], mask,
                        depth_inplace);
     return mvs::finish_launch("mvs_prob_filter");
+}
+
+extern "C" int mvs_geo_filter_dynamic_fwd(const float* ref_depth, const float* src_depths, const float* ref_cam, const float* src_cams,
+                                          int n, int v, int H, int W, float dist_base, float rel_diff_base, void* workspace,
+                                          float* reproj_xyd, uint8_t* masks, uint8_t* vis_mask, uint8_t* geo_mask, float* ref_depth_ave,
+                                          float* points, mvs_stream_t stream) {
+    MVS_REQUIRE(ref_depth && src_depths && ref_cam && src_cams && workspace, "mvs_geo_filter_dynamic_fwd: null pointer");
+    MVS_REQUIRE(n >= 1 && n <= 65535 && v >= 2 && v <= kMaxDynViews && H >= 2 && W >= 2,
+                "mvs_geo_filter_dynamic_fwd: bad shape n=%d v=%d (2..%d) H=%d W=%d", n, v, kMaxDynViews, H, W);
+    MVS_REQUIRE(dist_base > 0.0f && rel_diff_base > 0.0f, "mvs_geo_filter_dynamic_fwd: bases must be positive");
+    hipStream_t s = MVS_STREAM(stream);
+    ViewXf* xf = reinterpret_cast<ViewXf*>(workspace);
+    hipLaunchKernelGGL(geo_prep_kernel, dim3(mvs::ceil_div(n * v, 64)), dim3(64), 0, s, ref_cam, src_cams, n, v, xf);
+    dim3 grid(mvs::ceil_div(W, 64), mvs::ceil_div(H, 4), n), block(64, 4);
+    hipLaunchKernelGGL(geo_filter_dynamic_kernel, grid, block, 0, s, ref_depth, src_depths, xf, v, H, W, dist_base, rel_diff_base,
+                       reproj_xyd, masks, vis_mask, geo_mask, ref_depth_ave, points);
+    return mvs::finish_launch("mvs_geo_filter_dynamic_fwd");
+}
+
+extern "C" int mvs_vis_filter_dynamic_fwd(const float* ref_depth, const float* reproj_xyd, int n, int v, int H, int W, float dist_base,
+                                          float rel_diff_base, uint8_t* masks, uint8_t* vis_mask, uint8_t* geo_mask, float* ref_depth_ave,
+                                          mvs_stream_t stream) {
+    MVS_REQUIRE(ref_depth && reproj_xyd, "mvs_vis_filter_dynamic_fwd: null pointer");
+    MVS_REQUIRE(n >= 1 && n <= 65535 && v >= 2 && v <= kMaxDynViews && H >= 1 && W >= 1,
+                "mvs_vis_filter_dynamic_fwd: bad shape n=%d v=%d (2..%d) H=%d W=%d", n, v, kMaxDynViews, H, W);
+    MVS_REQUIRE(dist_base > 0.0f && rel_diff_base > 0.0f, "mvs_vis_filter_dynamic_fwd: bases must be positive");
+    dim3 grid((unsigned)mvs::ceil_div((long long)H * W, 256LL), n);
+    hipLaunchKernelGGL(vis_filter_dynamic_kernel, grid, dim3(256), 0, MVS_STREAM(stream), ref_depth, reproj_xyd, v, H, W, dist_base,
+                       rel_diff_base, masks, vis_mask, geo_mask, ref_depth_ave);
+    return mvs::finish_launch("mvs_vis_filter_dynamic_fwd");
 }
 
 extern "C" int64_t mvs_geo_filter_workspace_bytes(int n, int v) { return (int64_t)n * v * (int64_t)sizeof(ViewXf); }

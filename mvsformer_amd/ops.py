@@ -489,3 +489,38 @@ def prob_filter(conf: torch.Tensor, thresh, depth_inplace: Optional[torch.Tensor
     _call("mvs_prob_filter", "prob_filter", _ptr(conf), n, C, HW, ctypes.cast(th, ctypes.c_void_p), _ptr(mask), _ptr(depth_inplace),
           _stream())
     return mask.view(torch.bool)
+
+
+def geo_filter_dynamic(ref_depth, srcs_depth, ref_cam, srcs_cam, dist_base: float = 4, rel_diff_base: float = 1300,
+                       want=("geo_mask", "ref_depth_ave", "points")) -> Dict[str, torch.Tensor]:
+    _chk(ref_depth, "ref_depth"), _chk(srcs_depth, "srcs_depth"), _chk(ref_cam, "ref_cam"), _chk(srcs_cam, "srcs_cam")
+    n, v, _, h, w = srcs_depth.shape
+    if ref_depth.shape != (n, 1, h, w) or ref_cam.shape != (n, 2, 4, 4) or srcs_cam.shape != (n, v, 2, 4, 4):
+        raise _lib.MvsHipError("geo_filter_dynamic: inconsistent shapes %s %s %s %s" % (
+            tuple(ref_depth.shape), tuple(srcs_depth.shape), tuple(ref_cam.shape), tuple(srcs_cam.shape)))
+    dev = ref_depth.device
+    shapes = dict(reproj_xyd=(n, v, 3, h, w), masks=(n, v, v - 1, h, w), vis_mask=(n, v, 1, h, w), geo_mask=(n, 1, h, w),
+                  ref_depth_ave=(n, 1, h, w), points=(n, 3, h, w))
+    isbool = ("masks", "vis_mask", "geo_mask")
+    out = {k: torch.empty(shapes[k], device=dev, dtype=torch.uint8 if k in isbool else torch.float32) for k in want}
+    ws = torch.empty(_lib.load().mvs_geo_filter_workspace_bytes(n, v), device=dev, dtype=torch.uint8)
+    algo = n * h * w * (4.0 * (1 + v) + sum({"reproj_xyd": 12 * v, "masks": v * (v - 1), "vis_mask": v, "geo_mask": 1,
+                                             "ref_depth_ave": 4, "points": 12}[k] for k in want))
+    _call("mvs_geo_filter_dynamic_fwd", ("geo_filter_dynamic", "bytes", algo), _ptr(ref_depth), _ptr(srcs_depth), _ptr(ref_cam),
+          _ptr(srcs_cam), n, v, h, w, float(dist_base), float(rel_diff_base), _ptr(ws),
+          *[_ptr(out.get(k)) for k in ("reproj_xyd", "masks", "vis_mask", "geo_mask", "ref_depth_ave", "points")], _stream())
+    for k in isbool:
+        if k in out:
+            out[k] = out[k].view(torch.bool)
+    return out
+
+
+def vis_filter_dynamic(ref_depth, reproj_xyd, dist_base, rel_diff_base, want=("masks", "vis_mask")) -> Dict[str, torch.Tensor]:
+    _chk(ref_depth, "ref_depth"), _chk(reproj_xyd, "reproj_xyd")
+    n, v, _, h, w = reproj_xyd.shape
+    dev = ref_depth.device
+    shapes = dict(masks=(n, v, v - 1, h, w), vis_mask=(n, v, 1, h, w), geo_mask=(n, 1, h, w), ref_depth_ave=(n, 1, h, w))
+    out = {k: torch.empty(shapes[k], device=dev, dtype=torch.float32 if k == "ref_depth_ave" else torch.uint8) for k in want}
+    _call("mvs_vis_filter_dynamic_fwd", "vis_filter_dynamic", _ptr(ref_depth), _ptr(reproj_xyd), n, v, h, w, float(dist_base),
+          float(rel_diff_base), *[_ptr(out.get(k)) for k in ("masks", "vis_mask", "geo_mask", "ref_depth_ave")], _stream())
+    return {k: (t if k == "ref_depth_ave" else t.view(torch.bool)) for k, t in out.items()}

@@ -391,8 +391,89 @@ def gen_fusion():
         out[tag + "_conf"] = np32(conf)
         out[tag + "_prob_mask"] = rf.prob_filter(conf, [0.3, 0.5, 0.2]).numpy()
         print(tag, "kept", float(mask.float().mean()), "masks", float(masks.mean()))
+        # dynamic variant, test.py:494-514 verbatim in effect (reference functions called, driver arithmetic restated here)
+        bases = (4, 1300) if tag == "a" else (3, 400)
+        v = kw["v"]
+        dreproj = rf.get_reproj_dynamic(case["ref_depth"], case["src_depths"], case["ref_cam"], case["src_cams"])
+        dmasks, dmask = rf.vis_filter_dynamic(case["ref_depth"], dreproj, dist_base=bases[0], rel_diff_base=bases[1])
+        out[tag + "_dyn_bases"] = np.asarray(bases, np.float32)
+        out[tag + "_dyn_reproj_xyd"] = np32(dreproj)
+        out[tag + "_dyn_masks"] = dmasks.numpy()
+        out[tag + "_dyn_vis_mask"] = dmask.numpy()
+        rdepth = dreproj[:, :, -1].clone()
+        rdepth[~dmask.squeeze(2)] = 0
+        sums, vsum = dmasks.sum(dim=1), dmask.sum(dim=1)
+        dave = (torch.sum(rdepth, dim=1, keepdim=True) + case["ref_depth"]) / (vsum + 1)
+        geo = vsum >= v + 1
+        for i in range(2, v + 1):
+            geo = torch.logical_or(geo, sums[:, i - 2] >= i)      # [n,1,h,w] | [n,h,w] broadcasts as in the reference
+        dpoints = rf.idx_cam2world(rf.idx_img2cam(idx_img, dave, case["ref_cam"]), case["ref_cam"])[..., :3, 0].permute(0, 3, 1, 2)
+        out[tag + "_dyn_geo_mask"] = geo.numpy()
+        out[tag + "_dyn_ref_depth_ave"] = np32(dave)
+        out[tag + "_dyn_points"] = np32(dpoints)
+        print(tag, "dynamic kept", float(geo.float().mean()), "level-v views", float(dmask.float().mean()))
     save("fusion.npz", **out)
 
 
 if __name__ == "__main__" and os.environ.get("GEN_FUSION", "1") == "1":
     gen_fusion()
+
+
+def gen_io():
+    """io.npz: bytes the reference's own writers produce (datasets/data_io.py save_pfm; test.py write_cam) and what its
+    readers return (read_pfm, read_camera_parameters, read_pair_file).  test.py cannot be imported (argparse and model
+    imports at module level), so the three plain functions are pulled out of its AST and executed as they stand."""
+    import ast
+    import tempfile
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_data_io", os.path.join(REF, "datasets", "data_io.py"))   # skip datasets/__init__
+    ref_io = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_io)
+    read_pfm, save_pfm = ref_io.read_pfm, ref_io.save_pfm
+    tree = ast.parse(open(os.path.join(REF, "test.py")).read())
+    ns = {"np": np}
+    wanted = ("write_cam", "read_camera_parameters", "read_pair_file")
+    mod = ast.Module(body=[n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in wanted], type_ignores=[])
+    exec(compile(mod, "test.py", "exec"), ns)
+    rng = np.random.default_rng(0)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        grey = (rng.random((5, 7)) * 900 + 100).astype(np.float32)
+        color = rng.random((4, 6, 3)).astype(np.float32)
+        for name, img, scale in (("grey", grey, 1), ("color", color, 2.5), ("grey1", grey[:, :, None], 1)):
+            p = os.path.join(d, name + ".pfm")
+            save_pfm(p, img, scale)
+            out["pfm_%s_in" % name] = img
+            out["pfm_%s_bytes" % name] = np.frombuffer(open(p, "rb").read(), np.uint8)
+            back, sc = read_pfm(p)
+            out["pfm_%s_read" % name] = np.ascontiguousarray(back)
+            out["pfm_%s_scale" % name] = np.float64(sc)
+        # a big-endian file written by hand, for the reader's other branch
+        be = os.path.join(d, "be.pfm")
+        with open(be, "wb") as f:
+            f.write(b"Pf\n7 5\n1.000000\n")
+            np.flipud(grey).astype(">f4").tofile(f)
+        out["pfm_be_bytes"] = np.frombuffer(open(be, "rb").read(), np.uint8)
+        out["pfm_be_read"] = np.ascontiguousarray(read_pfm(be)[0]).astype(np.float32)
+        cam = np.zeros((2, 4, 4), np.float32)
+        cam[0] = np.eye(4)
+        cam[0, :3, :3] = np.linalg.qr(rng.standard_normal((3, 3)))[0]
+        cam[0, :3, 3] = rng.standard_normal(3) * 100
+        cam[1, :3, :3] = [[2892.33, 0, 823.205], [0, 2883.175, 619.071], [0, 0, 1]]
+        cam[1, 3] = [425.0, 2.65, 192, 933.8]
+        p = os.path.join(d, "00000000_cam.txt")
+        ns["write_cam"](p, cam)
+        out["cam_in"] = cam
+        out["cam_text"] = np.frombuffer(open(p, "rb").read(), np.uint8)
+        K, E = ns["read_camera_parameters"](p)
+        out["cam_read_K"], out["cam_read_E"] = K, E
+        pair = "4\n0\n3 1 2036.5 2 1243.9 3 703.2\n1\n2 0 2036.5 2 845.0\n2\n0\n3\n1 0 703.2\n"
+        p = os.path.join(d, "pair.txt")
+        open(p, "w").write(pair)
+        out["pair_text"] = np.frombuffer(pair.encode(), np.uint8)
+        out["pair_read"] = np.frombuffer(json.dumps(ns["read_pair_file"](p)).encode(), np.uint8)
+    save("io.npz", **out)
+
+
+if __name__ == "__main__" and os.environ.get("GEN_IO", "1") == "1":
+    gen_io()

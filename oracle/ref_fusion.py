@@ -157,3 +157,52 @@ def make_fusion_case(n=1, v=4, h=48, w=64, seed=0, noise=0.004, outlier_frac=0.0
     cams = torch.stack([E, K], dim=2)                # [n,1+v,2,4,4]
     return dict(ref_depth=depth[:, :1].contiguous(), src_depths=depth[:, 1:].unsqueeze(2).contiguous(),
                 ref_cam=cams[:, 0].contiguous(), src_cams=cams[:, 1:].contiguous())
+
+
+def get_reproj_dynamic(ref_depth, srcs_depth, ref_cam, srcs_cam):
+    """fusion.py:116-150."""
+    n, v, _, h, w = srcs_depth.shape
+    sd = srcs_depth.reshape(n * v, 1, h, w)
+    sc = srcs_cam.reshape(n * v, 2, 4, 4)
+    rc = ref_cam.unsqueeze(1).repeat(1, v, 1, 1, 1).reshape(n * v, 2, 4, 4)
+    rd = ref_depth.unsqueeze(1).repeat(1, v, 1, 1, 1).reshape(n * v, 1, h, w)
+    grid = pixel_centres(h, w).unsqueeze(0)
+    r2s_img = cam_to_img(world_to_cam(cam_to_world(img_to_cam(grid, rd, rc), rc), sc), sc)
+    q = r2s_img[..., :2, 0]
+    gx = q[..., 0] / ((w - 1) / 2) - 1
+    gy = q[..., 1] / ((h - 1) / 2) - 1
+    warped = F.grid_sample(sd, torch.stack((gx, gy), -1), mode="bilinear", padding_mode="zeros", align_corners=True)
+    qh = torch.cat([q, torch.ones_like(q[..., -1:])], -1).unsqueeze(-1)
+    s2r_cam = world_to_cam(cam_to_world(img_to_cam(qh, warped, sc), sc), rc)
+    depth = s2r_cam[:, :, :, 2, 0].clone()
+    xy = cam_to_img(s2r_cam, rc)
+    return torch.cat([xy[..., :2, 0], depth.unsqueeze(-1)], -1).permute(0, 3, 1, 2).reshape(n, v, 3, h, w)
+
+
+def vis_filter_dynamic(ref_depth, reproj_xyd, dist_base=4, rel_diff_base=1300):
+    """fusion.py:153-165 -> (masks [n,v,v-1,h,w] bool, mask [n,v,1,h,w] bool)."""
+    n, v, _, h, w = reproj_xyd.shape
+    xy = pixel_centres(h, w).permute(3, 2, 0, 1).unsqueeze(1)[:, :, :2]
+    cd = (reproj_xyd[:, :, :2] - xy).norm(dim=2, keepdim=True)
+    dd = (ref_depth.unsqueeze(1) - reproj_xyd[:, :, 2:]).abs() / ref_depth.unsqueeze(1)
+    levels = torch.arange(2, v + 1).reshape(1, 1, -1, 1, 1).repeat(n, v, 1, 1, 1)
+    masks = torch.min(cd < levels / dist_base, dd < levels / rel_diff_base)
+    return masks, masks[:, :, -1:]
+
+
+def dynamic_filter_depth_maps(ref_depth, src_depths, ref_cam, src_cams, dist_base=4, rel_diff_base=1300):
+    """test.py:494-514 — the geometric part of dynamic_filter_depth for one batch."""
+    v = src_depths.shape[1]
+    reproj = get_reproj_dynamic(ref_depth, src_depths, ref_cam, src_cams)
+    masks, vis_mask = vis_filter_dynamic(ref_depth, reproj, dist_base, rel_diff_base)
+    rdepth = reproj[:, :, -1].clone()
+    rdepth[~vis_mask.squeeze(2)] = 0
+    sums = masks.sum(dim=1)
+    vsum = vis_mask.sum(dim=1)
+    ave = (rdepth.sum(dim=1, keepdim=True) + ref_depth) / (vsum + 1)
+    geo = vsum >= v + 1
+    for i in range(2, v + 1):
+        geo = torch.logical_or(geo, sums[:, i - 2:i - 1] >= i)
+    grid = pixel_centres(*ave.shape[-2:]).unsqueeze(0)
+    points = cam_to_world(img_to_cam(grid, ave, ref_cam), ref_cam)[..., :3, 0].permute(0, 3, 1, 2)
+    return dict(reproj_xyd=reproj, masks=masks, vis_mask=vis_mask, geo_mask=geo, ref_depth_ave=ave, points=points)

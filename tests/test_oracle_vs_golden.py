@@ -150,3 +150,21 @@ def test_fusion_oracle_vs_reference(tag):
     kw = dict(a=dict(n=1, v=4, h=48, w=64, seed=0), b=dict(n=2, v=3, h=40, w=56, seed=1, noise=0.008))[tag]
     again = ref_fusion.make_fusion_case(**kw)
     assert max_abs(again["src_depths"], g[tag + "_src_depths"]) < 1e-2
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_fusion_dynamic_oracle_vs_reference(tag):
+    """oracle get_reproj_dynamic / vis_filter_dynamic / the test.py:494-514 reduction against the reference's outputs."""
+    from oracle import ref_fusion
+    g = load_golden("fusion.npz")
+    case = {k: t(g["%s_%s" % (tag, k)]) for k in ("ref_depth", "src_depths", "ref_cam", "src_cams")}
+    bases = [float(x) for x in g[tag + "_dyn_bases"]]
+    out = ref_fusion.dynamic_filter_depth_maps(case["ref_depth"], case["src_depths"], case["ref_cam"], case["src_cams"], *bases)
+    want = torch.as_tensor(g[tag + "_dyn_reproj_xyd"])
+    assert ((out["reproj_xyd"] - want).abs() <= 1e-3 + 1e-5 * want.abs()).all()
+    assert (out["masks"].numpy() != g[tag + "_dyn_masks"]).mean() < 1e-4
+    assert (out["vis_mask"].numpy() != g[tag + "_dyn_vis_mask"]).mean() < 1e-4
+    # n > 1: the reference broadcasts [n,1,h,w] | [n,h,w] -> [n,n,h,w] with entry [i,j] = sample j's mask
+    assert (out["geo_mask"][:, 0].numpy() != g[tag + "_dyn_geo_mask"][0]).mean() < 1e-4
+    assert rel_err(out["ref_depth_ave"], g[tag + "_dyn_ref_depth_ave"]) < 1e-5
+    assert rel_err(out["points"], g[tag + "_dyn_points"]) < 1e-5
