@@ -236,6 +236,23 @@ int mvs_vis_filter_dynamic_fwd(const float* ref_depth, const float* reproj_xyd, 
 int mvs_prob_filter(const float* conf, int n, int C, int64_t HW, const float* thresh_host, uint8_t* mask, float* depth_inplace,
                     mvs_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * the classification loss fused with the head's gradient, one stage of ce_loss_stage4
+ * (models/losses.py:304-350, focal=False).
+ *   logits [B,D,HW] = prob_volume_pre (D >= 2), depth_values [B,D,HW], depth_gt [B,HW], mask [B,HW] (valid where > 0.5)
+ *   inverse_depth != 0: hypotheses run far -> near and are read in flipped order, as the reference flips them
+ * fwd: acc2[0] = sum over valid pixels of -log softmax(logits)[gt bin], acc2[1] = number of valid pixels,
+ *      loss[0] = weight * acc2[0] / acc2[1] (NaN when no pixel is valid, like F.cross_entropy on an empty selection);
+ *      grad_unscaled [B,D,HW] (may be NULL) = (softmax - onehot) on valid pixels, 0 elsewhere;
+ *      valid [B,HW] uint8 and gt_index [B,HW] int32 (index in FLIPPED order when inverse_depth) may be NULL.
+ * bwd_scale: grad_inplace *= weight * grad_out[0] / acc2[1]   (grad_out: device scalar, dL/dloss)
+ * ------------------------------------------------------------------------------------------------------- */
+int mvs_ce_loss_fwd(const float* logits, const float* depth_values, const float* depth_gt, const float* mask, int B, int D, int64_t HW,
+                    int inverse_depth, float weight, float* grad_unscaled, float* acc2, float* loss, uint8_t* valid, int* gt_index,
+                    mvs_stream_t stream);
+int mvs_ce_loss_bwd_scale(float* grad_inplace, int64_t numel, const float* acc2, const float* grad_out, float weight,
+                          mvs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

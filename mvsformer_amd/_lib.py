@@ -60,6 +60,8 @@ SIGNATURES = {
     "mvs_vis_filter_fwd": (I, [P, P, P, P, I, I, I, I, F, F, F, P, P, P, P]),
     "mvs_geo_filter_dynamic_fwd": (I, [P, P, P, P, I, I, I, I, F, F, P, P, P, P, P, P, P, P]),
     "mvs_vis_filter_dynamic_fwd": (I, [P, P, I, I, I, I, F, F, P, P, P, P, P]),
+    "mvs_ce_loss_fwd": (I, [P, P, P, P, I, I, L, I, F, P, P, P, P, P, P]),
+    "mvs_ce_loss_bwd_scale": (I, [P, L, P, P, F, P]),
     "mvs_prob_filter": (I, [P, I, I, L, P, P, P, P]),
     "mvs_init_inverse_range": (I, [P, I, I, I, I, I, P, P]),
     "mvs_schedule_inverse_range": (I, [P, P, I, F, I, I, I, I, P, P]),

@@ -1,0 +1,47 @@
+"""Training loss of the cascade on the HIP path — the reference's ``models/losses.py`` interface for ``depth_type='ce'``.
+
+``ce_loss_stage4`` (losses.py:304-350) keeps its name, arguments and return value (dict stage -> weighted scalar loss).
+Per stage ONE kernel finds every pixel's ground-truth depth bin in the (flipped) hypothesis column, applies the range
+and validity masks, evaluates the cross entropy of ``prob_volume_pre`` and leaves ``softmax - onehot`` behind as the
+gradient, so neither the flipped copies, the ``[B,D,H,W]`` interval tensors, the gathered ``[N,D]`` matrix nor a separate
+log-softmax backward are materialized.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class CeLossFn(torch.autograd.Function):
+    """``(prob_volume_pre [B,D,H,W], depth_values [B,D,H,W], depth_gt [B,H,W], mask [B,H,W]) -> scalar loss``."""
+
+    @staticmethod
+    def forward(ctx, logits, depth_values, depth_gt, mask, inverse_depth, weight):
+        need_grad = logits.requires_grad
+        loss, acc, grad = ops.ce_loss(logits.contiguous(), depth_values.contiguous(), depth_gt.contiguous(), mask.contiguous(),
+                                      bool(inverse_depth), float(weight), want_grad=need_grad)
+        ctx.weight = float(weight)
+        ctx.save_for_backward(acc, grad if need_grad else acc)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        acc, grad = ctx.saved_tensors
+        ops.ce_loss_bwd_scale(grad, acc, gout.contiguous().reshape(1), ctx.weight)      # in place: the buffer is ours
+        return grad, None, None, None, None, None
+
+
+def ce_loss_stage4(inputs, depth_gt_ms, mask_ms, dlossw, focal=False, gamma=0.0, inverse_depth=True):
+    """losses.py:304-350.  ``inputs[stage]`` holds ``depth_values`` and ``prob_volume_pre`` (the StageNet outputs);
+    ``mask_ms[stage]`` is thresholded at 0.5 inside the kernel."""
+    if focal:
+        raise NotImplementedError("focal=True is not on the HIP path (no shipped config enables it; the reference's focal "
+                                  "branch also skips the validity mask and the reduction)")
+    out = {}
+    for key in ("stage1", "stage2", "stage3", "stage4"):
+        st = inputs[key]
+        w = 1.0 if dlossw is None else float(dlossw[int(key.replace("stage", "")) - 1])
+        out[key] = CeLossFn.apply(st["prob_volume_pre"].to(torch.float32), st["depth_values"].to(torch.float32),
+                                  depth_gt_ms[key].to(torch.float32), mask_ms[key].to(torch.float32), inverse_depth, w)
+    return out

@@ -524,3 +524,31 @@ def vis_filter_dynamic(ref_depth, reproj_xyd, dist_base, rel_diff_base, want=("m
     _call("mvs_vis_filter_dynamic_fwd", "vis_filter_dynamic", _ptr(ref_depth), _ptr(reproj_xyd), n, v, h, w, float(dist_base),
           float(rel_diff_base), *[_ptr(out.get(k)) for k in ("masks", "vis_mask", "geo_mask", "ref_depth_ave")], _stream())
     return {k: (t if k == "ref_depth_ave" else t.view(torch.bool)) for k, t in out.items()}
+
+
+# ------------------------------------------------------------------------------------- fused CE loss (§8 f3)
+def ce_loss(logits, depth_values, depth_gt, mask, inverse_depth: bool, weight: float = 1.0, want_grad: bool = True,
+            want_index: bool = False):
+    """-> ``(loss [] , acc [2] = (sum, count), grad_unscaled [B,D,H,W] or None)`` (+ ``valid``, ``gt_index`` with ``want_index``)."""
+    _chk(logits, "prob_volume_pre"), _chk(depth_values, "depth_values"), _chk(depth_gt, "depth_gt"), _chk(mask, "mask")
+    B, D, H, W = logits.shape
+    if depth_values.shape != logits.shape or depth_gt.shape != (B, H, W) or mask.shape != (B, H, W):
+        raise _lib.MvsHipError("ce_loss: shapes %s %s %s %s" % (tuple(logits.shape), tuple(depth_values.shape), tuple(depth_gt.shape),
+                                                               tuple(mask.shape)))
+    dev = logits.device
+    acc = torch.empty(2, device=dev, dtype=torch.float32)
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    grad = torch.empty_like(logits) if want_grad else None
+    valid = torch.empty(B, H, W, device=dev, dtype=torch.uint8) if want_index else None
+    index = torch.empty(B, H, W, device=dev, dtype=torch.int32) if want_index else None
+    algo = 4.0 * B * H * W * (2 * D + 2 + (D if want_grad else 0))
+    _call("mvs_ce_loss_fwd", ("ce_loss", "bytes", algo), _ptr(logits), _ptr(depth_values), _ptr(depth_gt), _ptr(mask), B, D, H * W,
+          int(inverse_depth), float(weight), _ptr(grad), _ptr(acc), _ptr(loss), _ptr(valid), _ptr(index), _stream())
+    if want_index:
+        return loss, acc, grad, valid.view(torch.bool), index
+    return loss, acc, grad
+
+
+def ce_loss_bwd_scale(grad, acc, gout, weight: float) -> None:
+    _chk(grad, "grad"), _chk(acc, "acc"), _chk(gout, "grad_out")
+    _call("mvs_ce_loss_bwd_scale", "ce_loss_bwd_scale", _ptr(grad), grad.numel(), _ptr(acc), _ptr(gout), float(weight), _stream())

@@ -477,3 +477,32 @@ def gen_io():
 
 if __name__ == "__main__" and os.environ.get("GEN_IO", "1") == "1":
     gen_io()
+
+
+def gen_ce_loss():
+    """ce_loss.npz: models/losses.py ce_loss_stage4 (focal=False) values and d loss / d prob_volume_pre from the reference."""
+    from models.losses import ce_loss_stage4
+    from oracle import ref_losses
+    out = {}
+    for tag, inverse in (("inv", True), ("fwd", False)):
+        inputs, gts, masks = ref_losses.make_loss_case(seed=3 if inverse else 4, inverse_depth=inverse)
+        for k in inputs:
+            inputs[k]["prob_volume_pre"].requires_grad_(True)
+        w = [1.0, 0.5, 2.0, 1.0]
+        losses = ce_loss_stage4(inputs, gts, masks, dlossw=w, focal=False, gamma=0.0, inverse_depth=inverse)
+        sum(losses.values()).backward()
+        out[tag + "_dlossw"] = np.asarray(w, np.float32)
+        for k in inputs:
+            out["%s_%s_depth_values" % (tag, k)] = np32(inputs[k]["depth_values"])
+            out["%s_%s_logits" % (tag, k)] = np32(inputs[k]["prob_volume_pre"])
+            out["%s_%s_gt" % (tag, k)] = np32(gts[k])
+            out["%s_%s_mask" % (tag, k)] = np32(masks[k])
+            out["%s_%s_loss" % (tag, k)] = np.float64(losses[k].item())
+            out["%s_%s_grad" % (tag, k)] = np32(inputs[k]["prob_volume_pre"].grad)
+            idx, final = ref_losses.gt_bins(inputs[k]["depth_values"], gts[k], masks[k], inverse)
+            print(tag, k, "loss %.5f" % losses[k].item(), "valid %.3f" % final.float().mean().item(), "bins", int(idx.min()), int(idx.max()))
+    save("ce_loss.npz", **out)
+
+
+if __name__ == "__main__" and os.environ.get("GEN_LOSS", "1") == "1":
+    gen_ce_loss()

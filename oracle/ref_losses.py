@@ -1,0 +1,58 @@
+"""TEST INFRASTRUCTURE — CPU oracle for the training loss: restates reference
+models/losses.py:304-350 (ce_loss_stage4, focal=False) for one stage, in the order of operations the reference uses.
+Pinned by tests/golden/ce_loss.npz (values and gradients produced by the real function).  Never imported by the
+product path."""
+import torch
+import torch.nn.functional as F
+
+
+def gt_bins(depth_values, depth_gt, mask, inverse_depth=True):
+    """losses.py:309-335 -> (gt_index [B,H,W] long, final_mask [B,H,W] bool), index in flipped order when inverse."""
+    gt = depth_gt.unsqueeze(1)
+    dv = torch.flip(depth_values, dims=[1]) if inverse_depth else depth_values
+    half = (dv[:, 1:] - dv[:, :-1]).abs() / 2
+    half = torch.cat([half, half[:, -1:]], dim=1)
+    lo, hi = dv[:, 0:1] - half[:, 0:1], dv[:, -1:] + half[:, -1:]
+    outside = torch.clamp((gt < lo).float() + (gt > hi).float(), 0, 1)
+    final = ((1 - outside).squeeze(1) * (mask > 0.5).float()).bool()
+    index = ((dv + half) <= gt.expand_as(dv)).float().sum(dim=1, keepdim=True).long()
+    return torch.clamp_max(index, dv.shape[1] - 1).squeeze(1), final
+
+
+def ce_loss_stage(prob_volume_pre, depth_values, depth_gt, mask, inverse_depth=True, weight=1.0):
+    index, final = gt_bins(depth_values, depth_gt, mask, inverse_depth)
+    logits = torch.flip(prob_volume_pre, dims=[1]) if inverse_depth else prob_volume_pre
+    return weight * F.cross_entropy(logits.permute(0, 2, 3, 1)[final, :], index[final], reduction="mean")
+
+
+def ce_loss_stage4(inputs, depth_gt_ms, mask_ms, dlossw, inverse_depth=True):
+    return {k: ce_loss_stage(inputs[k]["prob_volume_pre"].float(), inputs[k]["depth_values"], depth_gt_ms[k], mask_ms[k], inverse_depth,
+                             1.0 if dlossw is None else dlossw[int(k[-1]) - 1]) for k in ("stage1", "stage2", "stage3", "stage4")}
+
+
+def make_loss_case(seed=0, B=2, sizes=((32, 8, 12), (16, 16, 24), (8, 24, 32), (4, 40, 56)), inverse_depth=True):
+    """Four stages of (D,H,W): inverse-depth hypothesis columns around a smooth surface, logits peaked near the truth plus
+    noise, ground truth partly outside the hypothesis range, partly masked out, some landing exactly on a bin edge."""
+    g = torch.Generator().manual_seed(seed)
+    inputs, gts, masks = {}, {}, {}
+    for s, (D, H, W) in enumerate(sizes):
+        ys, xs = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+        surf = (600 + 120 * xs - 80 * ys + 25 * torch.sin(6 * xs)).expand(B, H, W).clone()
+        width = 0.25 / (s + 1)
+        inv_c = 1.0 / surf * (1 + 0.02 * torch.randn(B, H, W, generator=g))
+        steps = torch.linspace(-1, 1, D).view(1, D, 1, 1)
+        inv = inv_c.unsqueeze(1) * (1 + width * steps)                     # ascending inverse depth = descending depth
+        dv = 1.0 / inv if inverse_depth else torch.flip(1.0 / inv, dims=[1])
+        gt = surf * (1 + 0.5 * width * torch.randn(B, H, W, generator=g))
+        gt[:, : H // 8] *= 1.5                                             # far out of range
+        sel = torch.rand(B, H, W, generator=g) < 0.02                      # exactly on a right edge: the <= comparison
+        dvf = torch.flip(dv, dims=[1]) if inverse_depth else dv
+        edge = dvf[:, D // 2] + (dvf[:, D // 2 + 1] - dvf[:, D // 2]).abs() / 2 if D > 2 else dvf[:, 0]
+        gt = torch.where(sel, edge, gt)
+        mask = (torch.rand(B, H, W, generator=g) > 0.2).float() * torch.rand(B, H, W, generator=g).clamp_min(0.51)
+        mask[:, :, : W // 10] = 0.3                                        # below the 0.5 threshold
+        logits = -((dv - gt.unsqueeze(1)).abs() / (surf.unsqueeze(1) * width / D * 2)) + 0.7 * torch.randn(B, D, H, W, generator=g)
+        key = "stage%d" % (s + 1)
+        inputs[key] = dict(depth_values=dv.contiguous(), prob_volume_pre=logits.contiguous())
+        gts[key], masks[key] = gt.contiguous(), mask.contiguous()
+    return inputs, gts, masks

@@ -168,3 +168,20 @@ def test_fusion_dynamic_oracle_vs_reference(tag):
     assert (out["geo_mask"][:, 0].numpy() != g[tag + "_dyn_geo_mask"][0]).mean() < 1e-4
     assert rel_err(out["ref_depth_ave"], g[tag + "_dyn_ref_depth_ave"]) < 1e-5
     assert rel_err(out["points"], g[tag + "_dyn_points"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag,inverse", [("inv", True), ("fwd", False)])
+def test_ce_loss_oracle_vs_reference(tag, inverse):
+    """oracle/ref_losses.py against models/losses.py ce_loss_stage4 values and gradients (tests/golden/ce_loss.npz)."""
+    from oracle import ref_losses
+    g = load_golden("ce_loss.npz")
+    w = [float(x) for x in g[tag + "_dlossw"]]
+    inputs, gts, masks = {}, {}, {}
+    for k in ("stage1", "stage2", "stage3", "stage4"):
+        inputs[k] = dict(depth_values=t(g["%s_%s_depth_values" % (tag, k)]), prob_volume_pre=t(g["%s_%s_logits" % (tag, k)]).requires_grad_(True))
+        gts[k], masks[k] = t(g["%s_%s_gt" % (tag, k)]), t(g["%s_%s_mask" % (tag, k)])
+    losses = ref_losses.ce_loss_stage4(inputs, gts, masks, w, inverse_depth=inverse)
+    sum(losses.values()).backward()
+    for k in inputs:
+        assert abs(losses[k].item() - float(g["%s_%s_loss" % (tag, k)])) < 1e-6
+        assert max_abs(inputs[k]["prob_volume_pre"].grad, g["%s_%s_grad" % (tag, k)]) < 1e-8
