@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-div", type=int, default=4, help="CPU baseline runs on (H/div)x(W/div)")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--features-layout", choices=["nchw", "nhwc"], default="nchw",
+                    help="nchw: what the reference's FPN decoder + torch.stack hand over (default, the BASELINE workload); nhwc: the "
+                         "same [B,V,C,H,W] tensors channel-last in memory (decoder run in torch.channels_last), consumed zero-copy")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams per GPU; step i (one reference view) runs on stream i %% streams, so independent "
                          "reference views overlap (MFMA-bound regularizer of one with the VALU/TA-bound sweeps of another)")
@@ -97,6 +100,8 @@ def main():
 
     # each rank owns its reference view(s): different scene seed per rank, inputs resident in HBM before timing
     feats, proj, dv, _ = synth.make_inputs(args.views, args.height, args.width, seed=rank, device=dev)
+    if args.features_layout == "nhwc":
+        feats = {k: v.reshape(-1, *v.shape[2:]).contiguous(memory_format=torch.channels_last).view(v.shape) for k, v in feats.items()}
     tmp = [5.0, 5.0, 5.0, 1.0]
 
     def step():
@@ -175,7 +180,7 @@ def main():
                                    "fp32, one reference view per step per GPU, precomputed features resident in HBM"
                                    % (args.width, args.height, args.views),
                        "parallelism": "inference sharding of reference views, no collective" if world > 1 else "single GPU",
-                       "streams_per_gpu": args.streams},
+                       "streams_per_gpu": args.streams, "features_layout": args.features_layout},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_sum": round(sum(e["ms_per_step"] for e in kernels), 3),
             "kernels": kernels,
         }

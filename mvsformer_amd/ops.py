@@ -137,7 +137,13 @@ def warp(src: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, with_mask: bo
 
 # ----------------------------------------------------------------------------------------------- cost volume
 def to_channels_last(feat: torch.Tensor) -> torch.Tensor:
-    """``[B,V,C,H,W]`` (FPN decoder layout) -> ``[B,V,H,W,C]`` for the gather sweeps."""
+    """``[B,V,C,H,W]`` (FPN decoder layout) -> ``[B,V,H,W,C]`` for the gather sweeps.  A tensor that already IS
+    channel-last in memory (an FPN decoder run in ``torch.channels_last`` and viewed as ``[B,V,C,H,W]``) is
+    passed through as a view: no kernel, no copy."""
+    if feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 5 and not feat.is_contiguous():
+        cl = feat.permute(0, 1, 3, 4, 2)
+        if cl.is_contiguous():
+            return cl
     _chk(feat, "features")
     B, V, C, H, W = feat.shape
     out = torch.empty(B, V, H, W, C, device=feat.device, dtype=torch.float32)

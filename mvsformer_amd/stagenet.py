@@ -56,7 +56,7 @@ class StageNet(nn.Module):
         G = self.args["base_ch"]
         if self.training:
             return self._forward_train(features, proj_matrices, depth_values, tmp, G)
-        feat = features.detach().to(torch.float32).contiguous()
+        feat = features.detach().to(torch.float32)              # layout handled by to_channels_last (zero-copy if NHWC already)
         proj = proj_matrices.detach().to(torch.float32).contiguous()
         hyp = depth_values.detach().to(torch.float32).contiguous()
         if hyp.dim() != 4:
@@ -90,7 +90,7 @@ class StageNet(nn.Module):
         proj = proj_matrices.detach().to(torch.float32).contiguous()
         hyp = depth_values.detach().to(torch.float32).contiguous()
         rt = ops.proj_prepare(proj)
-        feat_cl = ops.to_channels_last(features.detach().to(torch.float32).contiguous())
+        feat_cl = ops.to_channels_last(features.detach().to(torch.float32))
         entropy = ops.cv_entropy(feat_cl, rt, hyp, G)                       # sim_vol.detach() in the reference
         V = features.shape[1]
         weight = torch.cat([ag.vis_train(entropy[:, v:v + 1], self.vis) for v in range(V - 1)], dim=1)

@@ -330,3 +330,24 @@ def test_full_size_properties(dev):
     assert torch.equal(y2, y1 * 2.0)
     spot = F.conv3d(x[:, :, :, 100:110, 200:232].cpu(), wgt.cpu(), padding=1)[:, :, :, 1:-1, 1:-1]
     assert max_abs(y1[:, :, :, 101:109, 201:231].cpu()[:, :, 1:-1], spot[:, :, 1:-1]) < 1e-4
+
+
+def test_channel_last_features_are_zero_copy(dev):
+    """features that are already channel-last in memory (an FPN decoder run in torch.channels_last, viewed
+    as [B,V,C,H,W]) skip the transpose kernel and give bit-identical stage outputs."""
+    import mvsformer_amd as m
+    from mvsformer_amd import ops, synth
+    feats, proj, dv, _ = synth.make_inputs(3, 64, 96, seed=4, device=dev)
+    f = feats["stage3"]                                                          # [1,3,16,32,48] NCHW-contiguous
+    B, V, C, H, W = f.shape
+    nhwc = f.reshape(B * V, C, H, W).contiguous(memory_format=torch.channels_last).view(B, V, C, H, W)
+    assert not nhwc.is_contiguous() and torch.equal(nhwc, f)
+    with ops.kernel_timer() as kt:
+        cl = ops.to_channels_last(nhwc)
+    assert cl.data_ptr() == nhwc.data_ptr() and not any("nchw_to_nhwc" in k for k in kt.events)
+    assert torch.equal(cl, ops.to_channels_last(f))
+    net = m.StageNet(dict(fusion_type="cnn", depth_type="ce", base_ch=8, feat_chs=[64, 32, 16, 8]), 8, 2).to(dev).eval()
+    hyp = m.init_inverse_range(dv, 8, dev, torch.float32, H, W)
+    a = net(f, proj["stage3"], hyp, tmp=5.0)
+    b = net(nhwc, proj["stage3"], hyp, tmp=5.0)
+    assert torch.equal(a["depth"], b["depth"]) and torch.equal(a["photometric_confidence"], b["photometric_confidence"])
