@@ -135,6 +135,17 @@ int mvs_head_fwd(const float* logits, const float* x8, const float* w1, const fl
                  const float* depth_values, float tmp, int training, int B, int D, int H, int W,
                  float* prob_volume_pre, float* prob_volume, float* depth, float* conf, mvs_stream_t stream);
 
+/* Stride-1 Conv3d (kernel 3, padding 1) with the (H, W) taps in Winograd F(2x2,3x3) form: same contract as
+ * mvs_conv3d_fwd with stride (1,1,1) — y = [relu](conv(x)*scale + shift) [+ residual] — at 2.25x fewer MACs; used for
+ * CostRegNet/CostRegNet3D conv2/conv4/conv6 (module.py:475-481,554-560).  Supported: Cin % 4 == 0, Cout in
+ * {16,32,48,64}, W % 4 == 0 (query with mvs_conv3d_wino_supported, 1 = yes).  wpacked: Conv3d weight [Cout,Cin,3,3,3]
+ * transformed by mvs_conv3d_wino_pack_weights into mvs_conv3d_wino_packed_floats(Cin, Cout) floats. */
+int mvs_conv3d_wino_supported(int Cin, int Cout, int D, int H, int W);
+int64_t mvs_conv3d_wino_packed_floats(int Cin, int Cout);
+int mvs_conv3d_wino_pack_weights(const float* w, int Cin, int Cout, float* wpacked, mvs_stream_t stream);
+int mvs_conv3d_wino_fwd(const float* x, const float* wpacked, const float* scale, const float* shift, const float* residual,
+                        float* y, int B, int Cin, int Cout, int D, int H, int W, int relu, mvs_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Training.  The reference trains StageNet with batch-statistics BatchNorm (module.py:111-117,
  * 153-159,195-197) and autograd through every op; here the forward is  raw conv (mvs_conv3d_fwd / mvs_deconv3d_fwd with

@@ -62,6 +62,10 @@ SIGNATURES = {
     "mvs_vis_filter_dynamic_fwd": (I, [P, P, I, I, I, I, F, F, P, P, P, P, P]),
     "mvs_ce_loss_fwd": (I, [P, P, P, P, I, I, L, I, F, P, P, P, P, P, P]),
     "mvs_ce_loss_bwd_scale": (I, [P, L, P, P, F, P]),
+    "mvs_conv3d_wino_supported": (I, [I, I, I, I, I]),
+    "mvs_conv3d_wino_packed_floats": (L, [I, I]),
+    "mvs_conv3d_wino_pack_weights": (I, [P, I, I, P, P]),
+    "mvs_conv3d_wino_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "mvs_prob_filter": (I, [P, I, I, L, P, P, P, P]),
     "mvs_init_inverse_range": (I, [P, I, I, I, I, I, P, P]),
     "mvs_schedule_inverse_range": (I, [P, P, I, F, I, I, I, I, P, P]),

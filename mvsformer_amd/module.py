@@ -15,6 +15,7 @@ functions of :mod:`mvsformer_amd.autograd`, whose forward and backward are HIP k
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -84,18 +85,25 @@ class Conv3d(nn.Module):
             if s not in ((1, 1, 1), (2, 2, 2), (1, 2, 2)):
                 raise MvsHipError("Conv3d: stride %s is not built" % (s,))
             packed = ops.conv3d_pack(_f32c(conv.weight), transposed=False)
+            # stride-1 layers with 16/32/48/64 output channels (conv2/conv4/conv6) also get the Winograd F(2x2,3x3) image
+            wino = None
+            if s == (1, 1, 1) and conv.in_channels % 4 == 0 and conv.out_channels % 16 == 0 and conv.out_channels <= 64 \
+                    and os.environ.get("MVS_CONV_WINO", "1") != "0":
+                wino = ops.conv3d_wino_pack(_f32c(conv.weight))
             if self.bn is not None:
                 scale, shift = _bn_fold(self.bn)
             else:
                 scale = None
                 shift = _f32c(conv.bias) if conv.bias is not None else None
-            self._cache = (key, packed, scale, shift, (s[0], s[1]))
+            self._cache = (key, packed, scale, shift, (s[0], s[1]), wino)
         return self._cache[1:]
 
     def forward(self, x, residual: Optional[torch.Tensor] = None):
         if self.training:
             return _train_conv_bn_act(x, self.conv, self.bn, self.relu, residual)
-        packed, scale, shift, stride = self._prepared()
+        packed, scale, shift, stride, wino = self._prepared()
+        if wino is not None and ops.conv3d_wino_supported(self.conv.in_channels, self.conv.out_channels, *x.shape[2:]):
+            return ops.conv3d_wino(x, wino, self.conv.in_channels, self.conv.out_channels, scale, shift, residual, relu=self.relu)
         return ops.conv3d(x, packed, self.conv.in_channels, self.conv.out_channels, stride, scale, shift, residual,
                           relu=self.relu, tag="conv3d_%dto%d_s%d%d" % (self.conv.in_channels, self.conv.out_channels, *stride))
 

@@ -227,6 +227,38 @@ def conv3d(x, wpacked, cin, cout, stride, scale=None, shift=None, residual=None,
     return y
 
 
+def conv3d_wino_supported(cin: int, cout: int, D: int, H: int, W: int) -> bool:
+    return bool(_lib.load().mvs_conv3d_wino_supported(cin, cout, D, H, W))
+
+
+def conv3d_wino_pack(weight: torch.Tensor) -> torch.Tensor:
+    """Conv3d weight ``[Cout,Cin,3,3,3]`` -> Winograd F(2x2,3x3) transform-domain slabs for :func:`conv3d_wino`."""
+    _chk(weight, "conv weight")
+    cout, cin = weight.shape[0], weight.shape[1]
+    n = _lib.load().mvs_conv3d_wino_packed_floats(cin, cout)
+    if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3) or n <= 0:
+        raise _lib.MvsHipError("conv3d_wino_pack: unsupported weight %s" % (tuple(weight.shape),))
+    packed = torch.empty(n, device=weight.device, dtype=torch.float32)
+    _call("mvs_conv3d_wino_pack_weights", None, _ptr(weight), cin, cout, _ptr(packed), _stream())
+    return packed
+
+
+def conv3d_wino(x, wpacked, cin, cout, scale=None, shift=None, residual=None, relu=True):
+    _chk(x, "x"), _chk(wpacked, "packed weights")
+    B, C, D, H, W = x.shape
+    assert C == cin
+    y = torch.empty(B, cout, D, H, W, device=x.device, dtype=torch.float32)
+    if residual is not None:
+        _chk(residual, "residual")
+        if residual.shape != y.shape:
+            raise _lib.MvsHipError("residual shape %s != output %s" % (tuple(residual.shape), tuple(y.shape)))
+    # work is credited as the direct convolution's FLOPs (the algorithmic figure), not the 2.25x fewer executed
+    tag = ("wino_conv3d_kernel<%d>" % (2 if cout % 32 == 0 else 1), "flops", 2.0 * 27 * cin * cout * B * D * H * W)
+    _call("mvs_conv3d_wino_fwd", tag, _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), B, cin, cout, D, H, W,
+          int(relu), _stream())
+    return y
+
+
 def deconv3d(x, wpacked, cin, cout, sd, scale=None, shift=None, residual=None, relu=True, tag=None):
     _chk(x, "x"), _chk(wpacked, "packed weights")
     B, C, Di, Hi, Wi = x.shape

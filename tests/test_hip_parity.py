@@ -351,3 +351,26 @@ def test_channel_last_features_are_zero_copy(dev):
     a = net(f, proj["stage3"], hyp, tmp=5.0)
     b = net(nhwc, proj["stage3"], hyp, tmp=5.0)
     assert torch.equal(a["depth"], b["depth"]) and torch.equal(a["photometric_confidence"], b["photometric_confidence"])
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(16, 16, (3, 20, 36)), (32, 32, (2, 9, 64)), (64, 64, (1, 8, 8)), (8, 16, (4, 14, 28)),
+                                            (16, 48, (2, 6, 100))])
+def test_wino_conv_matches_direct(dev, cin, cout, shape):
+    """Winograd F(2x2,3x3) stride-1 conv == F.conv3d (fp64) to fp32 rounding, incl. odd H, W not a multiple of the 32-wide
+    block, BatchNorm fold, ReLU, residual; and the direct MFMA kernel on the same inputs for reference."""
+    from mvsformer_amd import ops
+    torch.manual_seed(cin * 100 + cout)
+    x = torch.randn(2, cin, *shape, device=dev)
+    w = torch.randn(cout, cin, 3, 3, 3, device=dev) * (1.0 / (27 * cin) ** 0.5)
+    scale, shift = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev)
+    res = torch.randn(2, cout, *shape, device=dev)
+    assert ops.conv3d_wino_supported(cin, cout, *shape)
+    ref = F.relu(F.conv3d(x.double(), w.double(), padding=1) * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)) + res.double()
+    got = ops.conv3d_wino(x, ops.conv3d_wino_pack(w), cin, cout, scale, shift, res, relu=True)
+    direct = ops.conv3d(x, ops.conv3d_pack(w, False), cin, cout, (1, 1), scale, shift, res, relu=True)
+    tol = 2e-6 * ref.abs().max().item() + 1e-6
+    assert (got.double() - ref).abs().max().item() < tol and (direct.double() - ref).abs().max().item() < 2 * tol
+    raw = ops.conv3d_wino(x, ops.conv3d_wino_pack(w), cin, cout, None, None, None, relu=False)
+    assert (raw.double() - F.conv3d(x.double(), w.double(), padding=1)).abs().max().item() < tol
+    assert not ops.conv3d_wino_supported(cin, cout, shape[0], shape[1], shape[2] + 2)          # W % 4 != 0 -> direct kernel
+    assert not ops.conv3d_wino_supported(cin, 8, *shape)
