@@ -262,6 +262,58 @@ __global__ __launch_bounds__(256) void prob3_kernel(const float* __restrict__ x,
     out[((size_t)(b * D + d) * H + yh) * W + xw] = acc;
 }
 
+// Register-blocked form for W % 4 == 0: a lane owns 4 consecutive voxels along W on 4 consecutive depth planes.  Each
+// input row segment (1 float4 + its two neighbours) is loaded once and feeds up to 3 planes x 4 voxels x 3 taps = 36 FMAs,
+// 8x fewer vector-memory lane requests per output than the kernel above (which is bound by exactly that rate).  Same
+// accumulation order per output (c, kd, kh, kw ascending), so results are bit-identical.
+__global__ __launch_bounds__(256) void prob3_blocked_kernel(const float* __restrict__ x, const float* __restrict__ w, int C, int D, int H,
+                                                            int W, float* __restrict__ out) {
+    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int yh = blockIdx.y * blockDim.y + threadIdx.y;
+    const int ndb = (D + 3) / 4;
+    const int b = blockIdx.z / ndb, d0 = (blockIdx.z % ndb) * 4;
+    if (x4 >= W || yh >= H) return;
+    const size_t plane = (size_t)H * W;
+    const mvsconv::rsrc_t r = mvsconv::make_rsrc(x + (size_t)b * C * D * plane, (unsigned)((size_t)C * D * plane * 4));
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const float* wc = w + c * 27;
+#pragma unroll
+        for (int pz = 0; pz < 6; ++pz) {
+            const int zd = d0 - 1 + pz;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int zh = yh + kh - 1;
+                const bool ok = zd >= 0 && zd < D && zh >= 0 && zh < H;
+                const unsigned off = (unsigned)((((size_t)c * D + zd) * plane + (size_t)zh * W + x4) * 4);
+                const mvsconv::f32x4 q = __builtin_bit_cast(mvsconv::f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, ok ? off : mvsconv::OOB, 0, 0));
+                const float lft = mvsconv::buf_load(r, (ok && x4 > 0) ? off - 4 : mvsconv::OOB, 0);
+                const float rgt = mvsconv::buf_load(r, (ok && x4 + 4 < W) ? off + 16 : mvsconv::OOB, 0);
+                const float v[6] = {lft, q[0], q[1], q[2], q[3], rgt};
+#pragma unroll
+                for (int od = 0; od < 4; ++od) {
+                    const int kd = pz - od;
+                    if (kd < 0 || kd > 2) continue;
+#pragma unroll
+                    for (int ox = 0; ox < 4; ++ox)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) acc[od][ox] = fmaf(wc[(kd * 3 + kh) * 3 + kw], v[ox + kw], acc[od][ox]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int od = 0; od < 4; ++od)
+        if (d0 + od < D) {
+            mvsconv::f32x4 o = {acc[od][0], acc[od][1], acc[od][2], acc[od][3]};
+            *reinterpret_cast<mvsconv::f32x4*>(out + ((size_t)(b * D + d0 + od) * H + yh) * W + x4) = o;
+        }
+}
+
 template <int NT, int SD>
 size_t deconv_lds_bytes() {
     constexpr int ID = (SD == 1) ? 4 : 2, IW = 32 + 1;
@@ -331,6 +383,12 @@ extern "C" int mvs_deconv3d_fwd(const float* x, const float* wpacked, const floa
 extern "C" int mvs_prob3_fwd(const float* x, const float* w, int B, int C, int D, int H, int W, float* logits, mvs_stream_t stream) {
     MVS_REQUIRE(x && w && logits, "mvs_prob3_fwd: null pointer");
     MVS_REQUIRE(B >= 1 && C >= 1 && D >= 1 && H >= 1 && W >= 1 && (int64_t)B * D <= 65535, "mvs_prob3_fwd: bad shape");
+    if (W % 4 == 0 && (int64_t)C * D * H * W * 4 < ((int64_t)1 << 31)) {
+        // one wavefront per block: the stage-1/2 volumes are small (a few hundred wavefronts), spread them over all CUs
+        dim3 grid(mvs::ceil_div(W / 4, 64), H, B * ((D + 3) / 4)), block(64, 1);
+        hipLaunchKernelGGL(prob3_blocked_kernel, grid, block, 0, MVS_STREAM(stream), x, w, C, D, H, W, logits);
+        return mvs::finish_launch("mvs_prob3_fwd");
+    }
     dim3 grid(mvs::ceil_div(W, 64), mvs::ceil_div(H, 4), B * D), block(64, 4);
     hipLaunchKernelGGL(prob3_kernel, grid, block, 0, MVS_STREAM(stream), x, w, C, D, H, W, logits);
     return mvs::finish_launch("mvs_prob3_fwd");

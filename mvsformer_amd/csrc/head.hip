@@ -78,7 +78,7 @@ __global__ void init_inverse_kernel(const float* __restrict__ range, int N, int 
 __global__ void schedule_inverse_kernel(const float* __restrict__ prev_depth, const float* __restrict__ prev_hyp, int Dp,
                                         float split_itv, int D, int H, int W, float* __restrict__ hyp) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    const int b = blockIdx.z / D, d = blockIdx.z % D;
+    const int b = blockIdx.z;
     if (x >= W || y >= H) return;
     const int Hl = H / 2, Wl = W / 2;
     const float sy = (H > 1) ? (float)(Hl - 1) / (float)(H - 1) : 0.0f;
@@ -88,23 +88,31 @@ __global__ void schedule_inverse_kernel(const float* __restrict__ prev_depth, co
     const int y1 = y0 + ((y0 < Hl - 1) ? 1 : 0), x1 = x0 + ((x0 < Wl - 1) ? 1 : 0);
     const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
     const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
-    const float itv = (float)d / (float)(D - 1);
     const size_t lplane = (size_t)Hl * Wl;
     const float* pd = prev_depth + (size_t)b * lplane;
     const float* h1 = prev_hyp + ((size_t)b * Dp + 1) * lplane;
     const float* h2 = prev_hyp + ((size_t)b * Dp + 2) * lplane;
-    auto sample = [&](int yy, int xx) {
-        const size_t o = (size_t)yy * Wl + xx;
+    // the four low-resolution neighbours' (inv_max, inv_min - inv_max): the 12 divisions happen once per pixel, not per plane
+    float lo[4], span[4];
+    const int ys[4] = {y0, y0, y1, y1}, xs[4] = {x0, x1, x0, x1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t o = (size_t)ys[k] * Wl + xs[k];
         const float last = 1.0f / h2[o] - 1.0f / h1[o];
         const float inv_d = 1.0f / pd[o];
         const float inv_min = inv_d + split_itv * last;
-        const float inv_max = inv_d - split_itv * last;
-        return inv_max + (inv_min - inv_max) * itv;
-    };
-    const float top = lx0 * sample(y0, x0) + lx1 * sample(y0, x1);
-    const float bot = lx0 * sample(y1, x0) + lx1 * sample(y1, x1);
-    const float inv = ly0 * top + ly1 * bot;
-    hyp[((size_t)(b * D + d) * H + y) * W + x] = 1.0f / inv;
+        lo[k] = inv_d - split_itv * last;
+        span[k] = inv_min - lo[k];
+    }
+    const size_t plane = (size_t)H * W;
+    float* out = hyp + (size_t)b * D * plane + (size_t)y * W + x;
+    for (int d = 0; d < D; ++d) {
+        const float itv = (float)d / (float)(D - 1);
+        const float top = lx0 * (lo[0] + span[0] * itv) + lx1 * (lo[1] + span[1] * itv);
+        const float bot = lx0 * (lo[2] + span[2] * itv) + lx1 * (lo[3] + span[3] * itv);
+        const float inv = ly0 * top + ly1 * bot;
+        out[(size_t)d * plane] = 1.0f / inv;
+    }
 }
 
 __global__ void conf_accumulate_kernel(const float* __restrict__ conf, int H, int W, float* __restrict__ acc, int Hf, int Wf,
@@ -224,7 +232,7 @@ extern "C" int mvs_schedule_inverse_range(const float* prev_depth, const float* 
     MVS_REQUIRE(Dp >= 3, "mvs_schedule_inverse_range: previous stage needs >= 3 hypotheses (got %d)", Dp);
     MVS_REQUIRE(B >= 1 && D >= 2 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && (int64_t)B * D <= 65535,
                 "mvs_schedule_inverse_range: bad shape B=%d D=%d H=%d W=%d", B, D, H, W);
-    dim3 grid(mvs::ceil_div(W, 64), mvs::ceil_div(H, 4), B * D), block(64, 4);
+    dim3 grid(mvs::ceil_div(W, 64), mvs::ceil_div(H, 4), B), block(64, 4);
     hipLaunchKernelGGL(schedule_inverse_kernel, grid, block, 0, MVS_STREAM(stream), prev_depth, prev_hyp, Dp, split_itv, D, H, W, hyp);
     return mvs::finish_launch("mvs_schedule_inverse_range");
 }

@@ -253,7 +253,7 @@ def conv3d_wino(x, wpacked, cin, cout, scale=None, shift=None, residual=None, re
         if residual.shape != y.shape:
             raise _lib.MvsHipError("residual shape %s != output %s" % (tuple(residual.shape), tuple(y.shape)))
     # work is credited as the direct convolution's FLOPs (the algorithmic figure), not the 2.25x fewer executed
-    tag = ("wino_conv3d_kernel<%d>" % (2 if cout % 32 == 0 else 1), "flops", 2.0 * 27 * cin * cout * B * D * H * W)
+    tag = ("wino_conv3d_kernel", "flops", 2.0 * 27 * cin * cout * B * D * H * W)
     _call("mvs_conv3d_wino_fwd", tag, _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), B, cin, cout, D, H, W,
           int(relu), _stream())
     return y
