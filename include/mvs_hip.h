@@ -86,6 +86,13 @@ int mvs_nchw_to_nhwc(const float* in, float* out, int N, int C, int64_t HW, mvs_
 int mvs_cv_entropy_fwd(const float* feat, const float* rt, const float* depth,
                        int B, int V, int C, int G, int D, int H, int W, float* entropy, mvs_stream_t stream);
 #define MVS_VIS_PARAM_FLOATS 3689
+/* Winograd/MFMA form of the same CNN (vis_net_wino.hip): `prepared` = MVS_VIS_WINO_FLOATS floats written once per
+ * parameter set by mvs_vis_wino_prepare(params, prepared) (the two 3x3 layers' weights in F(2x2,3x3) transform domain,
+ * laid out per MFMA lane); mvs_vis_wino_fwd computes what mvs_vis_fwd computes, to fp32 rounding. */
+#define MVS_VIS_WINO_FLOATS 8192
+int mvs_vis_wino_prepare(const float* params, float* prepared, mvs_stream_t stream);
+int mvs_vis_wino_fwd(const float* entropy, const float* params, const float* prepared, int N, int H, int W, float* weight,
+                     mvs_stream_t stream);
 int mvs_vis_fwd(const float* entropy, const float* params, int N, int H, int W, float* weight, mvs_stream_t stream);
 int mvs_cv_aggregate_fwd(const float* feat, const float* rt, const float* depth, const float* weight,
                          int B, int V, int C, int G, int D, int H, int W,

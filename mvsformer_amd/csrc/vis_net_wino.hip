@@ -1,0 +1,311 @@
+// Visibility-weight CNN of StageNet, second generation: the two 3x3 layers that carry 94 % of its FLOPs
+// (ConvBnReLU(16,16), ConvBnReLU(16,8); models/mvsformer_model.py:37,91, ConvBnReLU = module.py:168-197) run as
+// Winograd F(2x2,3x3) GEMMs on the fp32 matrix cores, still fused with layer 1 (VALU), the 1x1 conv and the sigmoid in
+// ONE launch with every intermediate in LDS.  vis_net.hip (all-VALU, 58 TFLOP/s) stays as the reference implementation.
+//
+//   per 2x2 output tile and input channel: 4x4 patch -> B^T d B (32 adds, in the lane's registers) = the B operands of
+//   16 transform-point GEMMs  Z_xi[cout, tile] += U_xi[cout, cin] X_xi[cin, tile]   (v_mfma_f32_16x16x4_f32:
+//   M = 16 output channels, N = 16 tiles of one tile row, K = 4 input channels), then A^T Z A, BatchNorm, ReLU.
+//   2.25x fewer MACs than the direct form; the transformed weights U (16 x 16 x 16 per layer) live in 2 x 64 VGPRs of
+//   every lane for the whole kernel, which is why the kernel is persistent (blocks loop over output tiles).
+//
+// Block tile = 30 x 14 outputs: layer 2 is needed on 32 x 16 = 16 x 8 tiles (two tile rows per wavefront), layer 3 on
+// 15 x 7 tiles.  LDS activations are stored per row as even columns then odd columns, so the 16 tile lanes of a patch
+// read are unit-stride, and channel planes are padded to == 16 (mod 32) words: no bank conflicts on the operand path.
+// Each conv zero-pads ITS OWN input: activations at positions outside the image are stored as 0.
+#include <stdlib.h>
+
+#include "conv_common.h"
+
+namespace {
+using namespace mvsconv;
+
+constexpr int TW = 30, TH = 14;
+constexpr int INW = TW + 6, INH = TH + 6;                  // entropy tile, halo 3
+constexpr int A1W = TW + 4, A1H = TH + 4, A1O = A1W / 2;   // layer-1 output, halo 2; row = E[17] O[17]
+constexpr int A2W = TW + 2, A2H = TH + 2, A2O = A2W / 2;   // layer-2 output, halo 1; row = E[16] O[16]
+constexpr int A1PL = 624, A2PL = 528;                      // channel plane strides, == 16 (mod 32)
+static_assert(A1PL >= A1W * A1H && A2PL >= A2W * A2H && A1PL % 32 == 16 && A2PL % 32 == 16, "plane padding");
+constexpr int T2Y = A2H / 2, T3X = TW / 2, T3Y = TH / 2;   // 8 layer-2 tile rows (16 tiles each); 15 x 7 layer-3 tiles
+static_assert(A2W / 2 == 16, "one layer-2 tile row = one MFMA N tile");
+// offsets inside the MVS_VIS_PARAM_FLOATS block (vis_net.hip)
+constexpr int OFF_W0 = 0, OFF_S0 = 144, OFF_B0 = 160, OFF_W1 = 176, OFF_S1 = 2480, OFF_B1 = 2496, OFF_W2 = 2512, OFF_S2 = 3664,
+              OFF_B2 = 3672, OFF_W3 = 3680, OFF_B3 = 3688;
+
+// prepared[layer][xi = a*4+b][j][lane]: lane = kk*16 + co holds U_xi[cin = 4j+kk][co] = sum G[a][kh] G[b][kw] w[co][cin][kh][kw]
+__global__ void vis_wino_prepare_kernel(const float* __restrict__ prm, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= MVS_VIS_WINO_FLOATS) return;
+    const float G[4][3] = {{1.0f, 0.0f, 0.0f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.0f, 0.0f, 1.0f}};
+    const int layer = idx / 4096, e = idx % 4096;
+    const int lane = e % 64, j = (e / 64) % 4, xi = e / 256;
+    const int co = lane & 15, ci = 4 * j + (lane >> 4), a = xi >> 2, b = xi & 3;
+    float v = 0.0f;
+    if (layer == 0 || co < 8)
+        for (int kh = 0; kh < 3; ++kh)
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tap = kh * 3 + kw;
+                const float w = layer == 0 ? prm[OFF_W1 + (ci * 9 + tap) * 16 + co] : prm[OFF_W2 + (ci * 9 + tap) * 8 + co];
+                v += G[a][kh] * G[b][kw] * w;
+            }
+    out[idx] = v;
+}
+
+__device__ __forceinline__ void xform(const float (&d)[4][4], float (&X)[16]) {      // X = B^T d B
+    float t[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        t[0][c] = d[0][c] - d[2][c];
+        t[1][c] = d[1][c] + d[2][c];
+        t[2][c] = d[2][c] - d[1][c];
+        t[3][c] = d[1][c] - d[3][c];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        X[a * 4 + 0] = t[a][0] - t[a][2];
+        X[a * 4 + 1] = t[a][1] + t[a][2];
+        X[a * 4 + 2] = t[a][2] - t[a][1];
+        X[a * 4 + 3] = t[a][1] - t[a][3];
+    }
+}
+
+// one tile row: Z_xi = sum_j U[xi][j] x X_xi(patch of channel 4j+kk);  RS/OO = row stride / odd-column offset of the layout
+template <int PL, int RS, int OO>
+__device__ __forceinline__ void tile_row_gemm(const float* __restrict__ act, int ty, int i16, int kk, const float (&U)[16][4],
+                                              f32x4 (&Z)[16]) {
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) Z[xi] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float* p = act + (4 * j + kk) * PL + (2 * ty) * RS + i16;
+        float d[4][4], X[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            d[q][0] = p[q * RS];
+            d[q][1] = p[q * RS + OO];
+            d[q][2] = p[q * RS + 1];
+            d[q][3] = p[q * RS + OO + 1];
+        }
+        xform(d, X);
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) Z[xi] = mfma4(U[xi][j], X[xi], Z[xi]);
+    }
+}
+
+// A^T Z A for accumulator row r: o[a][b], a = output row, b = output column inside the 2x2 tile
+__device__ __forceinline__ void out_xform(const f32x4 (&Z)[16], int r, float (&o)[2][2]) {
+    float s[2][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        s[0][b] = Z[b][r] + Z[4 + b][r] + Z[8 + b][r];
+        s[1][b] = Z[4 + b][r] - Z[8 + b][r] - Z[12 + b][r];
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        o[a][0] = s[a][0] + s[a][1] + s[a][2];
+        o[a][1] = s[a][1] - s[a][2] - s[a][3];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void vis_wino_kernel(const float* __restrict__ entropy, const float* __restrict__ prm,
+                                                          const float* __restrict__ prep, int N, int H, int W, int ntx, int nty,
+                                                          float* __restrict__ weight) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_a1 = smem;                                    // [16][A1PL]
+    float* s_a2 = smem + 16 * A1PL;                        // [16][A2PL]
+    float* s_in = smem + 16 * (A1PL + A2PL);               // [INH][INW]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kk = lane >> 4;
+
+    float U2[16][4], U3[16][4];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            U2[xi][j] = prep[(xi * 4 + j) * 64 + lane];
+            U3[xi][j] = prep[4096 + (xi * 4 + j) * 64 + lane];
+        }
+    float sc1[4], sh1[4], sc2[4], sh2[4], w3[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = 4 * kk + r;
+        sc1[r] = prm[OFF_S1 + co];
+        sh1[r] = prm[OFF_B1 + co];
+        sc2[r] = co < 8 ? prm[OFF_S2 + co] : 0.0f;
+        sh2[r] = co < 8 ? prm[OFF_B2 + co] : 0.0f;
+        w3[r] = co < 8 ? prm[OFF_W3 + co] : 0.0f;
+    }
+    const float b3 = prm[OFF_B3];
+
+    // Software pipeline over this block's tiles, two barriers per tile:
+    //   phase A: layer 2 of tile t (s_a1 -> s_a2); the entropy of tile t+1, fetched into registers before, lands in s_in
+    //   phase B: layer 3 of tile t (s_a2 -> global) and layer 1 of tile t+1 (s_in -> s_a1): matrix and vector pipes overlap
+    const int ntiles = N * ntx * nty;
+    constexpr int EPT = (INH * INW + 255) / 256;           // entropy values per thread (3)
+    float pre[EPT];
+    auto tile_origin = [&](int tile, int& n, int& x0, int& y0) {
+        n = tile / (ntx * nty);
+        y0 = ((tile / ntx) % nty) * TH;
+        x0 = (tile % ntx) * TW;
+    };
+    auto fetch_entropy = [&](int tile) {
+        int n, x0, y0;
+        tile_origin(tile, n, x0, y0);
+        const float* src = entropy + (size_t)n * H * W;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + e * 256;
+            const int gy = y0 - 3 + i / INW, gx = x0 - 3 + i % INW;
+            pre[e] = (i < INH * INW && gy >= 0 && gy < H && gx >= 0 && gx < W) ? src[(size_t)gy * W + gx] : 0.0f;
+        }
+    };
+    auto commit_entropy = [&]() {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            if (tid + e * 256 < INH * INW) s_in[tid + e * 256] = pre[e];
+    };
+    auto layer1 = [&](int tile) {                          // 1 -> 16 on the 34 x 18 region (VALU, weights via the scalar cache)
+        int n, x0, y0;
+        tile_origin(tile, n, x0, y0);
+        for (int i = tid; i < A1W * A1H; i += 256) {
+            const int py = i / A1W, px = i % A1W;
+            const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+            float acc[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float v = s_in[(py + ky) * INW + px + kx];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) acc[c] = fmaf(prm[OFF_W0 + (ky * 3 + kx) * 16 + c], v, acc[c]);
+                }
+            const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            float* dst = s_a1 + py * A1W + (px & 1) * A1O + (px >> 1);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const float o = fmaxf(fmaf(acc[c], prm[OFF_S0 + c], prm[OFF_B0 + c]), 0.0f);
+                dst[c * A1PL] = inside ? o : 0.0f;
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    fetch_entropy(tile);
+    commit_entropy();
+    __syncthreads();
+    layer1(tile);
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x) {
+        int n, x0, y0;
+        tile_origin(tile, n, x0, y0);
+        const int next = tile + gridDim.x;
+        const bool has_next = next < ntiles;                // block-uniform
+        if (has_next) fetch_entropy(next);
+
+        // ---- phase A: layer 2, 16 -> 16 on 16 x 8 tiles, two tile rows per wavefront ----
+#pragma unroll 1
+        for (int ty = wave; ty < T2Y; ty += 4) {
+            f32x4 Z[16];
+            tile_row_gemm<A1PL, A1W, A1O>(s_a1, ty, i16, kk, U2, Z);
+            bool in_img[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int gy = y0 - 1 + 2 * ty + a, gx = x0 - 1 + 2 * i16 + b;
+                    in_img[a][b] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float o[2][2];
+                out_xform(Z, r, o);
+                float* dst = s_a2 + (4 * kk + r) * A2PL + (2 * ty) * A2W + i16;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        dst[a * A2W + b * A2O] = in_img[a][b] ? fmaxf(fmaf(o[a][b], sc1[r], sh1[r]), 0.0f) : 0.0f;
+            }
+        }
+        if (has_next) commit_entropy();
+        __syncthreads();
+
+        // ---- phase B: layer 3, 16 -> 8 on 15 x 7 tiles (+ 1x1 conv + sigmoid), then layer 1 of the next tile ----
+#pragma unroll 1
+        for (int ty = wave; ty < T3Y; ty += 4) {
+            f32x4 Z[16];
+            tile_row_gemm<A2PL, A2W, A2O>(s_a2, ty, i16, kk, U3, Z);
+            float part[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float o[2][2];
+                out_xform(Z, r, o);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) part[a][b] = fmaf(w3[r], fmaxf(fmaf(o[a][b], sc2[r], sh2[r]), 0.0f), part[a][b]);
+            }
+            // channels 0-3 live in lanes kk = 0, channels 4-7 in kk = 1 (kk = 2, 3 hold the zero padding rows)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) part[a][b] += __shfl_xor(part[a][b], 16, 64);
+            if (kk == 0 && i16 < T3X) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int gy = y0 + 2 * ty + a;
+                    if (gy >= H) continue;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int gx = x0 + 2 * i16 + b;
+                        if (gx < W) weight[(size_t)n * H * W + (size_t)gy * W + gx] = 1.0f / (1.0f + expf(-(part[a][b] + b3)));
+                    }
+                }
+            }
+        }
+        if (has_next) layer1(next);
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int mvs_vis_wino_prepare(const float* params, float* prepared, mvs_stream_t stream) {
+    MVS_REQUIRE(params && prepared, "mvs_vis_wino_prepare: null pointer");
+    hipLaunchKernelGGL(vis_wino_prepare_kernel, dim3(mvs::ceil_div(MVS_VIS_WINO_FLOATS, 256)), dim3(256), 0, MVS_STREAM(stream), params,
+                       prepared);
+    return mvs::finish_launch("mvs_vis_wino_prepare");
+}
+
+extern "C" int mvs_vis_wino_fwd(const float* entropy, const float* params, const float* prepared, int N, int H, int W, float* weight,
+                                mvs_stream_t stream) {
+    MVS_REQUIRE(entropy && params && prepared && weight, "mvs_vis_wino_fwd: null pointer");
+    MVS_REQUIRE(N >= 1 && H >= 1 && W >= 1, "mvs_vis_wino_fwd: bad shape N=%d H=%d W=%d", N, H, W);
+    const int ntx = mvs::ceil_div(W, TW), nty = mvs::ceil_div(H, TH);
+    MVS_REQUIRE((int64_t)N * ntx * nty < ((int64_t)1 << 31), "mvs_vis_wino_fwd: too many tiles");
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+            ncu = 256;
+    }
+    const int ntiles = N * ntx * nty;
+    const int blocks = ntiles < 2 * ncu ? ntiles : 2 * ncu;       // persistent: two resident blocks per CU
+    constexpr size_t lds = (size_t)(16 * (A1PL + A2PL) + INH * INW) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(vis_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+            mvs::set_error("mvs_vis_wino_fwd: cannot raise dynamic LDS to %zu bytes", lds);
+            return MVS_EINVAL;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(vis_wino_kernel, dim3(blocks), dim3(256), lds, MVS_STREAM(stream), entropy, params, prepared, N, H, W, ntx, nty,
+                       weight);
+    return mvs::finish_launch("mvs_vis_wino_fwd");
+}

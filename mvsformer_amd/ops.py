@@ -178,6 +178,32 @@ def vis(entropy: torch.Tensor, params: torch.Tensor) -> torch.Tensor:
     return out
 
 
+VIS_WINO_FLOATS = 8192
+
+
+def vis_wino_prepare(params: torch.Tensor) -> torch.Tensor:
+    """Transform-domain weights of the two 3x3 layers, laid out per MFMA lane, for :func:`vis_wino`."""
+    _chk(params, "vis params")
+    if params.numel() != VIS_PARAM_FLOATS:
+        raise _lib.MvsHipError("vis params must hold %d floats" % VIS_PARAM_FLOATS)
+    prepared = torch.empty(VIS_WINO_FLOATS, device=params.device, dtype=torch.float32)
+    _call("mvs_vis_wino_prepare", None, _ptr(params), _ptr(prepared), _stream())
+    return prepared
+
+
+def vis_wino(entropy: torch.Tensor, params: torch.Tensor, prepared: torch.Tensor) -> torch.Tensor:
+    """Same function as :func:`vis`; layers 2-3 as Winograd F(2x2,3x3) GEMMs on the matrix cores."""
+    _chk(entropy, "entropy"), _chk(params, "vis params"), _chk(prepared, "prepared vis weights")
+    if params.numel() != VIS_PARAM_FLOATS or prepared.numel() != VIS_WINO_FLOATS:
+        raise _lib.MvsHipError("vis params / prepared block have the wrong size")
+    H, W = entropy.shape[-2:]
+    N = entropy.numel() // (H * W)
+    out = torch.empty_like(entropy)
+    tag = ("vis_wino_kernel", "flops", 2.0 * 3608 * N * H * W)           # credited with the direct form's FLOPs
+    _call("mvs_vis_wino_fwd", tag, _ptr(entropy), _ptr(params), _ptr(prepared), N, H, W, _ptr(out), _stream())
+    return out
+
+
 def cv_aggregate(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, weight: torch.Tensor, G: int,
                  want_sim_depth: bool):
     _chk(feat, "features"), _chk(rt, "rt"), _chk(depth, "depth_values"), _chk(weight, "vis_weight")

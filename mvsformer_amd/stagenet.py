@@ -13,6 +13,8 @@ forward is 5 + 10 hand-written HIP launches per stage:
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -40,11 +42,14 @@ class StageNet(nn.Module):
             self.cost_reg = CostRegNet(in_channels, args["base_ch"])
         self._vis_cache = None
 
-    def _vis_params(self) -> torch.Tensor:
+    def _vis_params(self):
+        """-> (parameter block, transform-domain weights of the 3x3 layers or None when MVS_VIS_WINO=0)."""
         key = _versions(self.vis)
         if self._vis_cache is None or self._vis_cache[0] != key:
-            self._vis_cache = (key, pack_vis_params(self.vis))
-        return self._vis_cache[1]
+            params = pack_vis_params(self.vis)
+            prepared = ops.vis_wino_prepare(params) if os.environ.get("MVS_VIS_WINO", "1") != "0" else None
+            self._vis_cache = (key, params, prepared)
+        return self._vis_cache[1:]
 
     def forward(self, features, proj_matrices, depth_values, tmp=2.0):
         """``features [B,V,C,H,W]`` (view 0 = reference), ``proj_matrices [B,V,2,4,4]``, ``depth_values [B,D,H,W]``."""
@@ -66,7 +71,8 @@ class StageNet(nn.Module):
         rt = ops.proj_prepare(proj)
         feat = ops.to_channels_last(feat)                       # [B,V,H,W,C]: 16-byte-per-lane coalesced gathers
         entropy = ops.cv_entropy(feat, rt, hyp, G)
-        weight = ops.vis(entropy, self._vis_params())
+        vis_params, vis_prepared = self._vis_params()
+        weight = ops.vis_wino(entropy, vis_params, vis_prepared) if vis_prepared is not None else ops.vis(entropy, vis_params)
         volume, sim_depth = ops.cv_aggregate(feat, rt, hyp, weight, G, want_sim_depth=True)
 
         # step 3: regularization + head

@@ -100,11 +100,14 @@ def test_cost_volume_taps(dev, kind):
     rt = ops.proj_prepare(proj)
     ent = ops.cv_entropy(feat, rt, hyp, 8)
     robust_close(ent, g["tap_entropy"], atol=5e-5, frac=0, hard=5e-5)
-    w = ops.vis(ent, net._vis_params())
+    vis_params, vis_prepared = net._vis_params()
+    w = ops.vis(ent, vis_params)
     robust_close(w, g["tap_vis_weight"], atol=2e-5, frac=0)
-    # vis CNN alone on the reference's own entropy (decouples the two kernels)
-    w2 = ops.vis(g2d(g["tap_entropy"], dev), net._vis_params())
+    # vis CNN alone on the reference's own entropy (decouples the two kernels): VALU kernel and Winograd/MFMA kernel
+    w2 = ops.vis(g2d(g["tap_entropy"], dev), vis_params)
     robust_close(w2, g["tap_vis_weight"], atol=1e-5, frac=0)
+    w3 = ops.vis_wino(g2d(g["tap_entropy"], dev), vis_params, vis_prepared)
+    robust_close(w3, g["tap_vis_weight"], atol=1e-5, frac=0)
     vol, sim = ops.cv_aggregate(feat, rt, hyp, g2d(g["tap_vis_weight"], dev), 8, want_sim_depth=True)
     robust_close(vol, g["tap_volume_mean"], atol=5e-5, frac=0, hard=5e-5)
     assert (sim.cpu().numpy() != g["eval_sim_depth"]).mean() < 0.02
@@ -374,3 +377,19 @@ def test_wino_conv_matches_direct(dev, cin, cout, shape):
     assert (raw.double() - F.conv3d(x.double(), w.double(), padding=1)).abs().max().item() < tol
     assert not ops.conv3d_wino_supported(cin, cout, shape[0], shape[1], shape[2] + 2)          # W % 4 != 0 -> direct kernel
     assert not ops.conv3d_wino_supported(cin, 8, *shape)
+
+
+@pytest.mark.parametrize("shape", [(3, 37, 53), (2, 14, 30), (1, 144, 192), (5, 9, 7)])
+def test_vis_wino_matches_valu_kernel(dev, shape):
+    """Winograd/MFMA visibility CNN == the all-VALU kernel (itself pinned to the reference goldens) to fp32 rounding, on
+    sizes that are not multiples of the 30 x 14 block tile, smaller than one tile, and a real stage-1 map."""
+    from mvsformer_amd import ops
+    torch.manual_seed(sum(shape))
+    prm = torch.randn(ops.VIS_PARAM_FLOATS, device=dev) * 0.2
+    prm[144:160] = prm[144:160].abs() + 0.5            # BN scales
+    prm[2480:2496] = prm[2480:2496].abs() + 0.5
+    prm[3664:3672] = prm[3664:3672].abs() + 0.5
+    ent = torch.rand(*shape, device=dev) * 3.0
+    a = ops.vis(ent, prm)
+    b = ops.vis_wino(ent, prm, ops.vis_wino_prepare(prm))
+    assert (a - b).abs().max().item() < 5e-6, (a - b).abs().max().item()

@@ -29,7 +29,7 @@ net = m.StageNet(dict(base_ch=8, fusion_type="cnn", depth_type="ce"), D, 0).to(d
 rt = ops.proj_prepare(proj)
 fcl = ops.to_channels_last(feat)
 ent = ops.cv_entropy(fcl, rt, hyp, 8)
-w = ops.vis(ent, net._vis_params())
+w = ops.vis(ent, net._vis_params()[0])
 vol, _ = ops.cv_aggregate(fcl, rt, hyp, w, 8, True)
 
 
@@ -52,7 +52,8 @@ V = 5
 alg = 4.0 * H * W * (V * C + D + 8 * D)
 timeit("nchw_to_nhwc", lambda: ops.to_channels_last(feat), 8.0 * feat.numel(), "GB/s")
 timeit("cv_entropy", lambda: ops.cv_entropy(fcl, rt, hyp, 8), 4.0 * H * W * (V * C + D), "GB/s")
-timeit("vis", lambda: ops.vis(ent, net._vis_params()), 2.0 * 3608 * 4 * H * W, "TFLOP/s")
+timeit("vis", lambda: ops.vis(ent, net._vis_params()[0]), 2.0 * 3608 * 4 * H * W, "TFLOP/s")
+timeit("vis_wino", lambda: ops.vis_wino(ent, *net._vis_params()), 2.0 * 3608 * 4 * H * W, "TFLOP/s")
 timeit("cv_aggregate(sim)", lambda: ops.cv_aggregate(fcl, rt, hyp, w, 8, True), alg, "GB/s")
 timeit("cv_aggregate(nosim)", lambda: ops.cv_aggregate(fcl, rt, hyp, w, 8, False), alg, "GB/s")
 if D <= 8:

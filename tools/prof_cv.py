@@ -36,7 +36,11 @@ for _ in range(args.iters):
         ent = ops.cv_entropy(feat, rt, hyp, 8)
     else:
         ent = torch.rand(1, 4, H, W, device=dev)
-    w = ops.vis(ent, net._vis_params()) if "vis" in args.what else torch.rand(1, 4, H, W, device=dev)
+    if "vis" in args.what:
+        vp, vprep = net._vis_params()
+        w = ops.vis_wino(ent, vp, vprep) if vprep is not None else ops.vis(ent, vp)
+    else:
+        w = torch.rand(1, 4, H, W, device=dev)
     if "cv" in args.what:
         vol, sim = ops.cv_aggregate(feat, rt, hyp, w, 8, True)
     if "reg" in args.what:
