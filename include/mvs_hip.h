@@ -142,6 +142,14 @@ int mvs_head_fwd(const float* logits, const float* x8, const float* w1, const fl
                  const float* depth_values, float tmp, int training, int B, int D, int H, int W,
                  float* prob_volume_pre, float* prob_volume, float* depth, float* conf, mvs_stream_t stream);
 
+/* CostRegNet3D tail in one launch (module.py:573-575,582,591-592): logits = prob( residual + relu(bn(conv11(x))) ) with
+ * conv11 = ConvTranspose3d(Cin, 8, stride (1,2,2)) packed with mode 2 and prob = Conv3d(8, 1, 1): prob_w [8], prob_b [1] or
+ * NULL.  x [B,Cin,Di,Hi,Wi] (Wi % 4 == 0), residual [B,8,Di,2Hi,2Wi] or NULL, logits [B,1,Di,2Hi,2Wi].  The 8-channel
+ * feature volume is never written. */
+int mvs_deconv3d_prob1_fwd(const float* x, const float* wpacked, const float* scale, const float* shift, const float* residual,
+                           const float* prob_w, const float* prob_b, float* logits, int B, int Cin, int Di, int Hi, int Wi, int relu,
+                           mvs_stream_t stream);
+
 /* Stride-1 Conv3d (kernel 3, padding 1) with the (H, W) taps in Winograd F(2x2,3x3) form: same contract as
  * mvs_conv3d_fwd with stride (1,1,1) — y = [relu](conv(x)*scale + shift) [+ residual] — at 2.25x fewer MACs; used for
  * CostRegNet/CostRegNet3D conv2/conv4/conv6 (module.py:475-481,554-560).  Supported: Cin % 4 == 0, Cout in

@@ -68,6 +68,7 @@ SIGNATURES = {
     "mvs_conv3d_wino_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "mvs_vis_wino_prepare": (I, [P, P, P]),
     "mvs_vis_wino_fwd": (I, [P, P, P, I, I, I, P, P]),
+    "mvs_deconv3d_prob1_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "mvs_prob_filter": (I, [P, I, I, L, P, P, P, P]),
     "mvs_init_inverse_range": (I, [P, I, I, I, I, I, P, P]),
     "mvs_schedule_inverse_range": (I, [P, P, I, F, I, I, I, I, P, P]),

@@ -380,6 +380,16 @@ extern "C" int mvs_deconv3d_fwd(const float* x, const float* wpacked, const floa
 #undef MVS_DECONV
 }
 
+extern "C" int mvs_deconv3d_prob1_fwd(const float* x, const float* wpacked, const float* scale, const float* shift, const float* residual,
+                                      const float* prob_w, const float* prob_b, float* logits, int B, int Cin, int Di, int Hi, int Wi,
+                                      int relu, mvs_stream_t stream) {
+    MVS_REQUIRE(x && wpacked && prob_w && logits, "mvs_deconv3d_prob1_fwd: null pointer");
+    if (int rc = check_conv_args("mvs_deconv3d_prob1_fwd", B, Cin, 8, Di, Hi, Wi)) return rc;
+    MVS_REQUIRE(Wi % 4 == 0, "mvs_deconv3d_prob1_fwd: input width must be a multiple of 4 (got %d)", Wi);
+    MVS_REQUIRE((int64_t)B * Di <= 65535, "mvs_deconv3d_prob1_fwd: grid.z limit");
+    return deconv_s1_prob_launch(x, wpacked, scale, shift, residual, prob_w, prob_b, logits, B, Cin, Di, Hi, Wi, relu, MVS_STREAM(stream));
+}
+
 extern "C" int mvs_prob3_fwd(const float* x, const float* w, int B, int C, int D, int H, int W, float* logits, mvs_stream_t stream) {
     MVS_REQUIRE(x && w && logits, "mvs_prob3_fwd: null pointer");
     MVS_REQUIRE(B >= 1 && C >= 1 && D >= 1 && H >= 1 && W >= 1 && (int64_t)B * D <= 65535, "mvs_prob3_fwd: bad shape");

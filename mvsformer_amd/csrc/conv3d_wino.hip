@@ -76,11 +76,16 @@ __global__ __launch_bounds__(256) void wino_conv3d_kernel(const float* __restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kk = lane >> 4;
     const int ngroups = COUT / NB;
+    // Block order: the launch grid is (D * ngroups, tiles along W, tiles along H * B) so that, after the XCD remap (each
+    // XCD takes one contiguous slab of block ids), the blocks that share input — the D output planes over the same (x, y)
+    // tile read each other's depth planes, the channel groups read the same planes — run back to back on ONE XCD and find
+    // those planes in its L2 instead of fetching them once per XCD.
     unsigned bxi, byi, bzi;
     xcd_block_coords(bxi, byi, bzi);
-    const int ng = bzi % ngroups;
-    const int z = (bzi / ngroups) % D, b = bzi / (ngroups * D);
-    const int x0 = bxi * 32, y0 = byi * (2 * WTY);
+    const int hblocks = (H + 2 * WTY - 1) / (2 * WTY);
+    const int ng = bxi % ngroups, z = bxi / ngroups;
+    const int b = bzi / hblocks;
+    const int x0 = byi * 32, y0 = (bzi % hblocks) * (2 * WTY);
     const size_t plane = (size_t)H * W, vol = plane * D;
 
     // ---- chunk-invariant staging maps -------------------------------------------------------------------------
@@ -239,7 +244,7 @@ template <int NT>
 int launch_wino(const float* x, const float* U, const float* scale, const float* shift, const float* res, float* y, int B, int Cin,
                 int Cout, int D, int H, int W, int relu, hipStream_t s) {
     const int ngroups = Cout / (16 * NT);
-    dim3 grid(mvs::ceil_div(W, 32), mvs::ceil_div(H, 2 * WTY), B * D * ngroups);
+    dim3 grid(D * ngroups, mvs::ceil_div(W, 32), mvs::ceil_div(H, 2 * WTY) * B);
     hipLaunchKernelGGL(wino_conv3d_kernel<NT>, grid, dim3(256), 0, s, x, U, scale, shift, res, y, Cin, Cout, D, H, W, relu);
     return mvs::finish_launch("mvs_conv3d_wino_fwd");
 }
@@ -275,7 +280,7 @@ extern "C" int mvs_conv3d_wino_fwd(const float* x, const float* wpacked, const f
     // all output channels in one block up to 32 (128 accumulator registers); 48/64 channels split over blocks
     const char* env = getenv("MVS_WINO_NT");
     const int nt = (env && atoi(env) == 2 && Cout % 32 == 0) ? 2 : 1;
-    MVS_REQUIRE((int64_t)B * D * (Cout / (16 * nt)) <= 65535, "mvs_conv3d_wino_fwd: grid.z limit");
+    MVS_REQUIRE((int64_t)B * mvs::ceil_div(H, 8) <= 65535 && mvs::ceil_div(W, 32) <= 65535, "mvs_conv3d_wino_fwd: grid limit");
     if (nt == 2) return launch_wino<2>(x, wpacked, scale, shift, residual, y, B, Cin, Cout, D, H, W, relu, s);
     return launch_wino<1>(x, wpacked, scale, shift, residual, y, B, Cin, Cout, D, H, W, relu, s);
 }

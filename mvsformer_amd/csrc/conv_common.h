@@ -67,4 +67,8 @@ int deconv_s1_pack(const float* w, int Cin, int Cout, float* out, hipStream_t s)
 int deconv_s1_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y, int B,
                      int Cin, int Cout, int Di, int Hi, int Wi, int relu, hipStream_t s);
 
+int deconv_s1_prob_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
+                          const float* prob_w, const float* prob_b, float* logits, int B, int Cin, int Di, int Hi, int Wi, int relu,
+                          hipStream_t s);
+
 }  // namespace mvsconv

@@ -23,6 +23,19 @@
 namespace {
 using namespace mvsconv;
 
+// sum over the 8 lanes of an aligned group (every lane gets the total): quad_perm xor 1, xor 2, then row_half_mirror
+// (i <-> 7-i), which pairs the two quads once each quad holds its own sum
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+    return v + __builtin_bit_cast(float, o);
+}
+__device__ __forceinline__ float group8_sum(float v) {
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    return dpp_add<0x141>(v);
+}
+
 constexpr int npd_of(int NC) { return NC == 8 ? 80 : (NC == 16 ? 144 : 304); }       // 9*NC padded to == 16 (mod 32)
 constexpr int ntiles_of(int NC) { return NC == 8 ? 5 : 9 * NC / 16; }
 
@@ -53,11 +66,16 @@ __global__ void pack_deconv_s1_kernel(const float* __restrict__ w /*[Cin,Cout,3,
     }
 }
 
-template <int NC>
+// PROB (NC == 8 only): the layer is CostRegNet3D.conv11 and is followed by `prob` = Conv3d(8, 1, 1) (module.py:582,592): the
+// epilogue multiplies each finished channel by its 1x1x1 weight, adds the 8 channel lanes with three DPP steps and stores
+// ONE logit plane instead of eight feature planes (y = logits [B,1,D,2H,2W]; 8x less written here, 8x less read by the head).
+template <int NC, bool PROB>
 __global__ __launch_bounds__(256) void deconv3d_s1_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const float* __restrict__ res, float* __restrict__ y, int CIN, int Di, int Hi,
-                                                          int Wi, int relu) {
+                                                          int Wi, int relu, const float* __restrict__ prob_w,
+                                                          const float* __restrict__ prob_b) {
+    static_assert(!PROB || NC == 8, "the fused 1x1x1 head needs all channels of a voxel inside one 8-lane group");
     constexpr int MT = 4;                                    // 16-column M tiles per wavefront (64 input columns)
     constexpr int NPD = npd_of(NC), NTL = ntiles_of(NC);
     constexpr int K16 = (NC >= 16) ? NC / 16 : 1;            // 16-channel tiles per class
@@ -212,7 +230,33 @@ __global__ __launch_bounds__(256) void deconv3d_s1_kernel(const float* __restric
             // low lanes write output row 2hi (classes 00 even / 01 odd), high lanes row 2hi+1 (classes 10 / 11)
             const f32x4 e = low ? acc[m][0] : x1 + x3;
             const f32x4 o = low ? x0 + acc[m][2] : ((acc[m][1] + acc[m][2]) + acc[m][3]) + x4;
-            if (wi < Wi) store_row(i16 & 7, hi * 2 + (low ? 0 : 1), e, o, wi);
+            if (!PROB) {
+                if (wi < Wi) store_row(i16 & 7, hi * 2 + (low ? 0 : 1), e, o, wi);
+            } else {
+                // v = relu(bn(deconv)) + skip for this lane's channel, then sum_c w_c v_c over the 8 lanes of the group
+                const int co = i16 & 7, oh = hi * 2 + (low ? 0 : 1);
+                const float sc = scale ? scale[co] : 1.0f, sh = shift ? shift[co] : 0.0f, pw = prob_w[co];
+                f32x4 ee = bn_act(e, sc, sh, relu), oo = bn_act(o, sc, sh, relu);
+                const bool inb = wi < Wi;                         // Wi % 4 == 0 is required by the launcher
+                if (res && inb) {
+                    const size_t roff = (((size_t)(b * NC + co) * Do + od) * Ho + oh) * Wo + (size_t)wi * 2;
+                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(res + roff), r1 = *reinterpret_cast<const f32x4*>(res + roff + 4);
+                    ee += f32x4{r0[0], r0[2], r1[0], r1[2]};
+                    oo += f32x4{r0[1], r0[3], r1[1], r1[3]};
+                }
+                f32x4 v0 = {ee[0] * pw, oo[0] * pw, ee[1] * pw, oo[1] * pw}, v1 = {ee[2] * pw, oo[2] * pw, ee[3] * pw, oo[3] * pw};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v0[r] = group8_sum(v0[r]);
+                    v1[r] = group8_sum(v1[r]);
+                }
+                if (co == 0 && inb) {
+                    const float pb = prob_b ? prob_b[0] : 0.0f;
+                    const size_t off = (((size_t)b * Do + od) * Ho + oh) * Wo + (size_t)wi * 2;
+                    *reinterpret_cast<f32x4*>(y + off) = v0 + pb;
+                    *reinterpret_cast<f32x4*>(y + off + 4) = v1 + pb;
+                }
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < K16; ++k) {
@@ -226,14 +270,14 @@ __global__ __launch_bounds__(256) void deconv3d_s1_kernel(const float* __restric
     }
 }
 
-template <int NC>
+template <int NC, bool PROB = false>
 int launch_s1(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y, int B, int Cin,
-              int Di, int Hi, int Wi, int relu, hipStream_t s) {
+              int Di, int Hi, int Wi, int relu, hipStream_t s, const float* prob_w = nullptr, const float* prob_b = nullptr) {
     constexpr int CC = 8;
     constexpr size_t lds = (size_t)(CC * pad_cs(4 * 3 * 65, 1) + (CC / 4) * 3 * 4 * npd_of(NC)) * 4;
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(deconv3d_s1_kernel<NC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(deconv3d_s1_kernel<NC, PROB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
             mvs::set_error("mvs_deconv3d_fwd: cannot raise dynamic LDS to %zu bytes", lds);
             return -(1000 + (int)hipGetLastError());
@@ -241,7 +285,8 @@ int launch_s1(const float* x, const float* wp, const float* scale, const float* 
         attr_done = true;
     }
     dim3 grid(mvs::ceil_div(Wi, 64), mvs::ceil_div(Hi, 2), B * mvs::ceil_div(Di, 2));
-    hipLaunchKernelGGL(deconv3d_s1_kernel<NC>, grid, dim3(256), lds, s, x, wp, scale, shift, res, y, Cin, Di, Hi, Wi, relu);
+    hipLaunchKernelGGL((deconv3d_s1_kernel<NC, PROB>), grid, dim3(256), lds, s, x, wp, scale, shift, res, y, Cin, Di, Hi, Wi, relu, prob_w,
+                       prob_b);
     return mvs::finish_launch("mvs_deconv3d_fwd");
 }
 
@@ -269,6 +314,12 @@ int deconv_s1_launch(const float* x, const float* wp, const float* scale, const 
     if (Cout == 8) return launch_s1<8>(x, wp, scale, shift, res, y, B, Cin, Di, Hi, Wi, relu, s);
     if (Cout == 16) return launch_s1<16>(x, wp, scale, shift, res, y, B, Cin, Di, Hi, Wi, relu, s);
     return launch_s1<32>(x, wp, scale, shift, res, y, B, Cin, Di, Hi, Wi, relu, s);
+}
+
+int deconv_s1_prob_launch(const float* x, const float* wp, const float* scale, const float* shift, const float* res,
+                          const float* prob_w, const float* prob_b, float* logits, int B, int Cin, int Di, int Hi, int Wi, int relu,
+                          hipStream_t s) {
+    return launch_s1<8, true>(x, wp, scale, shift, res, logits, B, Cin, Di, Hi, Wi, relu, s, prob_w, prob_b);
 }
 
 }  // namespace mvsconv

@@ -281,6 +281,37 @@ class CostRegNet3D(nn.Module):
         return ops.deconv3d(x, packed, seq[0].in_channels, seq[0].out_channels, sd, scale, shift, residual, relu=True,
                             tag="deconv3d_%dto%d_s%d" % (seq[0].in_channels, seq[0].out_channels, sd))
 
+    def logits(self, x: torch.Tensor) -> torch.Tensor:
+        """Eval-mode ``forward`` without the channel axis, ``[B,D,H,W]``: conv11 and the 1x1x1 ``prob`` run as ONE launch
+        (the 8-channel volume between them is never written) when the shape allows, else as two."""
+        y, skip = self._trunk(x)
+        seq = self.conv11
+        w, b = self.prob_params()
+        if not self.training and seq[0].out_channels == 8 and tuple(seq[0].stride) == (1, 2, 2) and y.shape[4] % 4 == 0 \
+                and os.environ.get("MVS_FUSE_PROB", "1") != "0":
+            key = _versions(seq)
+            c = self._dcache.get("conv11")
+            if c is None or c[0] != key:
+                c = (key,) + _prepare_deconv(seq[0], seq[1])
+                self._dcache["conv11"] = c
+            _, packed, scale, shift, _sd = c
+            return ops.deconv3d_prob1(y, packed, seq[0].in_channels, scale, shift, skip, w, b, relu=True)
+        return ops.prob1(self._up("conv11", y, skip), w, b).squeeze(1)
+
+    def _trunk(self, x: torch.Tensor):
+        """Everything up to conv9: returns (conv9 output, skip tensor of conv11 = the input volume)."""
+        if not isinstance(self.inner, nn.Identity):
+            raise MvsHipError("CostRegNet3D: in_channels != base_channel (1x1x1 'inner' conv) is not built")
+        x = x.to(torch.float32)
+        x = x if x.is_contiguous() else x.contiguous()
+        if x.shape[3] % 8 or x.shape[4] % 8:
+            raise MvsHipError("CostRegNet3D needs H, W divisible by 8 (three stride-2 levels), got %s" % (tuple(x.shape[3:]),))
+        c2 = self.conv2(self.conv1(x))
+        c4 = self.conv4(self.conv3(c2))
+        y = self.conv6(self.conv5(c4))
+        y = self._up("conv7", y, c4)
+        return self._up("conv9", y, c2), x
+
     def features(self, x: torch.Tensor) -> torch.Tensor:
         if not isinstance(self.inner, nn.Identity):
             raise MvsHipError("CostRegNet3D: in_channels != base_channel (1x1x1 'inner' conv) is not built")

@@ -302,6 +302,22 @@ def deconv3d(x, wpacked, cin, cout, sd, scale=None, shift=None, residual=None, r
     return y
 
 
+def deconv3d_prob1(x, wpacked, cin, scale, shift, residual, prob_w, prob_b, relu=True):
+    """CostRegNet3D tail: ``prob(residual + relu(bn(conv11(x))))`` -> logits ``[B,D,2H,2W]`` without the 8-channel volume."""
+    _chk(x, "x"), _chk(wpacked, "packed weights"), _chk(prob_w, "prob.weight")
+    B, C, Di, Hi, Wi = x.shape
+    assert C == cin
+    if residual is not None:
+        _chk(residual, "residual")
+        if tuple(residual.shape) != (B, 8, Di, 2 * Hi, 2 * Wi):
+            raise _lib.MvsHipError("residual shape %s != %s" % (tuple(residual.shape), (B, 8, Di, 2 * Hi, 2 * Wi)))
+    logits = torch.empty(B, Di, 2 * Hi, 2 * Wi, device=x.device, dtype=torch.float32)
+    tag = ("deconv3d_s1_kernel<8,prob>", "flops", 2.0 * 27 * cin * 8 * B * Di * Hi * Wi)
+    _call("mvs_deconv3d_prob1_fwd", tag, _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(prob_w), _ptr(prob_b),
+          _ptr(logits), B, cin, Di, Hi, Wi, int(relu), _stream())
+    return logits
+
+
 def prob3(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     _chk(x, "x"), _chk(w, "prob weight")
     B, C, D, H, W = x.shape

@@ -78,13 +78,12 @@ class StageNet(nn.Module):
         # step 3: regularization + head
         if type(tmp) == list:
             tmp = tmp[self.stage_idx]
-        x = self.cost_reg.features(volume)
         if isinstance(self.cost_reg, CostRegNet3D):
-            w1, b1 = self.cost_reg.prob_params()
-            pre, prob, depth, conf = ops.head(hyp, float(tmp), False, x8=x, w1=w1, b1=b1)
+            logits = self.cost_reg.logits(volume)               # conv11 + 1x1x1 prob fused: the 8-channel volume is never written
         else:
+            x = self.cost_reg.features(volume)
             logits = ops.prob3(x, self.cost_reg.prob.weight.detach().to(torch.float32).contiguous())
-            pre, prob, depth, conf = ops.head(hyp, float(tmp), False, logits=logits)
+        pre, prob, depth, conf = ops.head(hyp, float(tmp), False, logits=logits)
         return {"depth": depth, "prob_volume": prob, "photometric_confidence": conf, "depth_values": depth_values,
                 "prob_volume_pre": pre, "sim_depth": sim_depth}
 

@@ -393,3 +393,23 @@ def test_vis_wino_matches_valu_kernel(dev, shape):
     a = ops.vis(ent, prm)
     b = ops.vis_wino(ent, prm, ops.vis_wino_prepare(prm))
     assert (a - b).abs().max().item() < 5e-6, (a - b).abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 2, 4, 12), (2, 16, 3, 5, 72), (1, 8, 1, 2, 4)])
+def test_fused_conv11_prob_matches_two_launches(dev, shape):
+    """mvs_deconv3d_prob1_fwd == mvs_deconv3d_fwd followed by the 1x1x1 conv, with and without skip tensor / bias."""
+    from mvsformer_amd import ops
+    B, Cin, D, H, W = shape
+    torch.manual_seed(sum(shape))
+    x = torch.randn(B, Cin, D, H, W, device=dev)
+    wt = torch.randn(Cin, 8, 3, 3, 3, device=dev) * 0.1
+    pk = ops.conv3d_pack(wt, True, 1)
+    scale, shift = torch.rand(8, device=dev) + 0.5, torch.randn(8, device=dev)
+    res = torch.randn(B, 8, D, 2 * H, 2 * W, device=dev)
+    pw, pb = torch.randn(8, device=dev), torch.randn(1, device=dev)
+    for r, b in ((res, pb), (None, None)):
+        y = ops.deconv3d(x, pk, Cin, 8, 1, scale, shift, r, relu=True)
+        want = (y.double() * pw.double().view(1, 8, 1, 1, 1)).sum(1) + (b.double() if b is not None else 0.0)
+        got = ops.deconv3d_prob1(x, pk, Cin, scale, shift, r, pw, b)
+        assert got.shape == (B, D, 2 * H, 2 * W)
+        assert (got.double() - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
