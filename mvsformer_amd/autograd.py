@@ -9,6 +9,8 @@ parameters; ``depth`` (arg-max gather) and ``photometric_confidence`` are not di
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -27,6 +29,12 @@ def _sync_sums(sums: torch.Tensor, count: float, bn) -> float:
     return count
 
 
+def _wino_ok(stride, cin, cout, x) -> bool:
+    """Stride-1 layers with 16/32/48/64 output channels take the Winograd F(2x2,3x3) kernel (MVS_CONV_WINO=0 disables)."""
+    return tuple(stride) == (1, 1) and os.environ.get("MVS_CONV_WINO", "1") != "0" and \
+        ops.conv3d_wino_supported(cin, cout, *x.shape[2:])
+
+
 class ConvFn(torch.autograd.Function):
     """Raw 3x3x3 convolution, padding 1, stride (sd, shw, shw); weight is the layer's ``nn.Conv3d.weight``."""
 
@@ -35,7 +43,10 @@ class ConvFn(torch.autograd.Function):
         x = x.contiguous()
         w = weight.detach().to(torch.float32).contiguous()
         cout, cin = w.shape[0], w.shape[1]
-        y = ops.conv3d(x, ops.conv3d_pack(w, False), cin, cout, stride, None, None, None, relu=False)
+        if _wino_ok(stride, cin, cout, x):
+            y = ops.conv3d_wino(x, ops.conv3d_wino_pack(w), cin, cout, None, None, None, relu=False)
+        else:
+            y = ops.conv3d(x, ops.conv3d_pack(w, False), cin, cout, stride, None, None, None, relu=False)
         ctx.save_for_backward(x, w)
         ctx.stride = stride
         return y
@@ -48,7 +59,11 @@ class ConvFn(torch.autograd.Function):
         sd, shw = ctx.stride
         dx = None
         if ctx.needs_input_grad[0]:
-            if shw == 1:
+            if shw == 1 and _wino_ok((1, 1), cout, cin, dy):
+                # data gradient of a stride-1 conv = stride-1 conv of dY with channels swapped and taps mirrored: Winograd too
+                wt = w.flip(2, 3, 4).transpose(0, 1).contiguous()
+                dx = ops.conv3d_wino(dy, ops.conv3d_wino_pack(wt), cout, cin, None, None, None, relu=False)
+            elif shw == 1:
                 dx = ops.conv3d(dy, ops.conv3d_pack(w, "dgrad"), cout, cin, (1, 1), None, None, None, relu=False)
             else:       # strided conv: the data gradient is the transposed conv with the same weight
                 dx = ops.deconv3d(dy, ops.conv3d_pack(w, True, sd), cout, cin, sd, None, None, None, relu=False)
