@@ -42,10 +42,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-div", type=int, default=4, help="CPU baseline runs on (H/div)x(W/div)")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="reference views per step (B of the [B,V,C,H,W] inputs)")
     ap.add_argument("--features-layout", choices=["nchw", "nhwc"], default="nchw",
                     help="nchw: what the reference's FPN decoder + torch.stack hand over (default, the BASELINE workload); nhwc: the "
                          "same [B,V,C,H,W] tensors channel-last in memory (decoder run in torch.channels_last), consumed zero-copy")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams per GPU; step i (one reference view) runs on stream i %% streams, so independent "
                          "reference views overlap (MFMA-bound regularizer of one with the VALU/TA-bound sweeps of another)")
     return ap.parse_args()
@@ -99,7 +100,7 @@ def main():
     net = net.to(dev)
 
     # each rank owns its reference view(s): different scene seed per rank, inputs resident in HBM before timing
-    feats, proj, dv, _ = synth.make_inputs(args.views, args.height, args.width, seed=rank, device=dev)
+    feats, proj, dv, _ = synth.make_inputs(args.views, args.height, args.width, seed=rank, batch=args.batch, device=dev)
     if args.features_layout == "nhwc":
         feats = {k: v.reshape(-1, *v.shape[2:]).contiguous(memory_format=torch.channels_last).view(v.shape) for k, v in feats.items()}
     tmp = [5.0, 5.0, 5.0, 1.0]
@@ -171,7 +172,7 @@ def main():
                 "algorithmic_per_launch": dom["algorithmic_per_launch"]}
 
     if rank == 0:
-        total = world * args.steps
+        total = world * args.steps * args.batch
         line = {
             "metric": "depth maps/sec @1536x1152 N=5 D=192", "value": round(total / dt, 3), "unit": "depth maps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -180,7 +181,8 @@ def main():
                                    "fp32, one reference view per step per GPU, precomputed features resident in HBM"
                                    % (args.width, args.height, args.views),
                        "parallelism": "inference sharding of reference views, no collective" if world > 1 else "single GPU",
-                       "streams_per_gpu": args.streams, "features_layout": args.features_layout},
+                       "streams_per_gpu": args.streams, "features_layout": args.features_layout,
+                       "reference_views_per_step": args.batch},
             "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_sum": round(sum(e["ms_per_step"] for e in kernels), 3),
             "kernels": kernels,
         }
