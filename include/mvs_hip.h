@@ -27,7 +27,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 1
+#define MVS_ABI_VERSION 2
 
 typedef void* mvs_stream_t;
 
