@@ -28,12 +28,14 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     __shared__ float red[8];
     const int c = blockIdx.y, b = blockIdx.z;
     const float* row = x + ((size_t)b * C + c) * N;
-    const size_t i0 = (size_t)blockIdx.x * CHUNK, i1 = min(i0 + CHUNK, N);
     float s = 0.0f, q = 0.0f;
-    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
-        const float v = row[i];
-        s += v;
-        q = fmaf(v, v, q);
+    for (size_t i0 = (size_t)blockIdx.x * CHUNK; i0 < N; i0 += (size_t)gridDim.x * CHUNK) {
+        const size_t i1 = min(i0 + CHUNK, N);
+        for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
+            const float v = row[i];
+            s += v;
+            q = fmaf(v, v, q);
+        }
     }
     s = block_sum(s, red);
     q = block_sum(q, red);
@@ -91,14 +93,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const int c = blockIdx.y, b = blockIdx.z;
     const size_t base = ((size_t)b * C + c) * N;
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
-    const size_t i0 = (size_t)blockIdx.x * CHUNK, i1 = min(i0 + CHUNK, N);
     float s1 = 0.0f, s2 = 0.0f;
-    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
-        const float xv = x[base + i];
-        float g = dy[base + i];
-        if (relu && !(fmaf(xv, sc, sh) > 0.0f)) g = 0.0f;
-        s1 += g;
-        s2 = fmaf(g, (xv - mu) * is, s2);
+    for (size_t i0 = (size_t)blockIdx.x * CHUNK; i0 < N; i0 += (size_t)gridDim.x * CHUNK) {
+        const size_t i1 = min(i0 + CHUNK, N);
+        for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
+            const float xv = x[base + i];
+            float g = dy[base + i];
+            if (relu && !(fmaf(xv, sc, sh) > 0.0f)) g = 0.0f;
+            s1 += g;
+            s2 = fmaf(g, (xv - mu) * is, s2);
+        }
     }
     s1 = block_sum(s1, red);
     s2 = block_sum(s2, red);
@@ -189,12 +193,21 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 }
 
 dim3 row_grid(int B, int C, size_t N) { return dim3((unsigned)((N + CHUNK - 1) / CHUNK), C, B); }
+// reductions end in one fp32 atomic per block on 2C addresses, and same-address atomics serialize in L2: cap the blocks per
+// (b, c) row (grid-stride over chunks) so that a channel sees at most ~RED_ADDERS atomics instead of N/4096
+constexpr int RED_ADDERS = 48;
+dim3 reduce_grid(int B, int C, size_t N) {
+    size_t nb = (N + CHUNK - 1) / CHUNK;
+    const size_t cap = (size_t)((RED_ADDERS + B - 1) / B);
+    if (nb > cap) nb = cap;
+    return dim3((unsigned)nb, C, B);
+}
 
 }  // namespace
 
 extern "C" int mvs_bn_stats(const float* x, int B, int C, int64_t N, float* sums, mvs_stream_t stream) {
     MVS_REQUIRE(x && sums && B >= 1 && C >= 1 && C <= 65535 && B <= 65535 && N >= 1, "mvs_bn_stats: bad arguments");
-    hipLaunchKernelGGL(bn_stats_kernel, row_grid(B, C, N), dim3(256), 0, MVS_STREAM(stream), x, C, (size_t)N, sums);
+    hipLaunchKernelGGL(bn_stats_kernel, reduce_grid(B, C, N), dim3(256), 0, MVS_STREAM(stream), x, C, (size_t)N, sums);
     return mvs::finish_launch("mvs_bn_stats");
 }
 
@@ -219,7 +232,7 @@ extern "C" int mvs_bn_bwd_reduce(const float* dy, const float* x, const float* s
                                  const float* invstd, int relu, int B, int C, int64_t N, float* sums, mvs_stream_t stream) {
     MVS_REQUIRE(dy && x && scale && shift && mean && invstd && sums && B >= 1 && C >= 1 && C <= 65535 && B <= 65535 && N >= 1,
                 "mvs_bn_bwd_reduce: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, row_grid(B, C, N), dim3(256), 0, MVS_STREAM(stream), dy, x, scale, shift, mean, invstd, relu,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, reduce_grid(B, C, N), dim3(256), 0, MVS_STREAM(stream), dy, x, scale, shift, mean, invstd, relu,
                        C, (size_t)N, sums);
     return mvs::finish_launch("mvs_bn_bwd_reduce");
 }
