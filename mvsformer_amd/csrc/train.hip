@@ -146,23 +146,31 @@ __global__ void softmax_bwd_kernel(const float* __restrict__ p, const float* __r
 // backward of logits[b,v] = sum_c w[c]*x[b,c,v] + bias:  dx[b,c,v] = w[c]*dl[b,v];  dwb[c] += sum dl*x[c], dwb[C] += sum dl
 __global__ __launch_bounds__(256) void prob1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dl,
                                                         int C, size_t N, float* __restrict__ dx, float* __restrict__ dwb) {
+    // grid-stride over chunks with the per-channel partial sums in registers: one block reduction + one atomic per
+    // channel per BLOCK (not per chunk) — dwb has C+1 addresses and same-address atomics serialize
+    constexpr int CMAX = 16;
     __shared__ float red[8];
     const int b = blockIdx.y;
-    const size_t i0 = (size_t)blockIdx.x * CHUNK, i1 = min(i0 + CHUNK, N);
-    float sb = 0.0f;
-    for (int c = 0; c < C; ++c) {
-        const float wc = w[c];
-        const size_t base = ((size_t)b * C + c) * N;
-        float s = 0.0f;
-        for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
-            const float g = dl[(size_t)b * N + i];
-            dx[base + i] = wc * g;
-            s = fmaf(g, x[base + i], s);
-            if (c == 0) sb += g;
-        }
-        s = block_sum(s, red);
-        if (threadIdx.x == 0) atomicAdd(&dwb[c], s);
+    float s[CMAX], sb = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) s[c] = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (size_t)gridDim.x * 256) {
+        const float g = dl[(size_t)b * N + i];
+        sb += g;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) {
+                const size_t o = ((size_t)b * C + c) * N + i;
+                dx[o] = w[c] * g;
+                s[c] = fmaf(g, x[o], s[c]);
+            }
     }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (c < C) {
+            const float t = block_sum(s[c], red);
+            if (threadIdx.x == 0) atomicAdd(&dwb[c], t);
+        }
     sb = block_sum(sb, red);
     if (threadIdx.x == 0) atomicAdd(&dwb[C], sb);
 }
@@ -256,8 +264,10 @@ extern "C" int mvs_softmax_bwd(const float* p, const float* dp, int B, int D, in
 
 extern "C" int mvs_prob1_bwd(const float* x, const float* w, const float* dlogits, int B, int C, int64_t N, float* dx, float* dwb,
                              mvs_stream_t stream) {
-    MVS_REQUIRE(x && w && dlogits && dx && dwb && B >= 1 && B <= 65535 && C >= 1 && N >= 1, "mvs_prob1_bwd: bad arguments");
-    hipLaunchKernelGGL(prob1_bwd_kernel, dim3((unsigned)((N + CHUNK - 1) / CHUNK), B), dim3(256), 0, MVS_STREAM(stream), x, w, dlogits, C,
+    MVS_REQUIRE(x && w && dlogits && dx && dwb && B >= 1 && B <= 65535 && C >= 1 && C <= 16 && N >= 1,
+                "mvs_prob1_bwd: bad arguments (C <= 16)");
+    const size_t nb_all = (size_t)((N + 255) / 256), nb_cap = (size_t)((512 + B - 1) / B);
+    hipLaunchKernelGGL(prob1_bwd_kernel, dim3((unsigned)(nb_all < nb_cap ? nb_all : nb_cap), B), dim3(256), 0, MVS_STREAM(stream), x, w, dlogits, C,
                        (size_t)N, dx, dwb);
     return mvs::finish_launch("mvs_prob1_bwd");
 }
