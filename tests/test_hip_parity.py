@@ -5,6 +5,8 @@ Tolerances (written here, per the north star): depth within 1e-3 relative per pi
 intermediate fp32 tensors within a few 1e-5 (only op ordering differs); arg-max style outputs may flip on
 exact-tie pixels, so they are compared as a mismatch fraction.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -413,3 +415,50 @@ def test_fused_conv11_prob_matches_two_launches(dev, shape):
         got = ops.deconv3d_prob1(x, pk, Cin, scale, shift, r, pw, b)
         assert got.shape == (B, D, 2 * H, 2 * W)
         assert (got.double() - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("C,ndepth,H,W,V,B", [(16, 8, 24, 40, 3, 2),      # CostRegNet3D: W/2 = 20 -> Winograd; conv11 input W = 20 -> fused tail
+                                                (16, 8, 16, 24, 2, 1),      # W/2 = 12, W/4 = 6 (not % 4): deeper layers fall back to the direct kernel
+                                                (8, 4, 40, 56, 4, 1),       # stage-4 geometry, W/2 = 28
+                                                (32, 16, 32, 48, 3, 1),     # CostRegNet (D-strided), prob3 blocked (W % 4 == 0)
+                                                (64, 32, 16, 32, 2, 2)])    # stage-1 geometry, batch 2
+def test_stage_vs_oracle_mixed_kernel_paths(dev, C, ndepth, H, W, V, B):
+    """Whole StageNet (eval) against the CPU oracle on shapes that send different layers down different kernels (Winograd /
+    direct convolution, fused / split conv11+prob, blocked / plain prob3, Winograd / VALU visibility CNN via the env
+    switches), fresh weights and randomized BatchNorm statistics."""
+    import mvsformer_amd as m
+    from mvsformer_amd import synth
+    from oracle import ref_torch
+    scale = {64: 8, 32: 4, 16: 2, 8: 1}[C]
+    torch.manual_seed(C + ndepth + W)
+    net = m.StageNet(dict(base_ch=8, fusion_type="cnn", depth_type="ce"), ndepth, 0).eval()
+    m.randomize_bn_(net, 7)
+    scene = synth.make_scene(V, H * scale, W * scale, seed=W)
+    feat = synth.render_features(scene, scale, C, batch=B)
+    proj = synth.proj_matrices(scene, (scale,), B)["stage1"]
+    hyp = ref_torch.init_inverse_range(synth.depth_range(B), ndepth, H, W)
+    with torch.no_grad():
+        want = ref_torch.stage_forward(feat, proj, hyp, net.state_dict(), ndepth=ndepth, tmp=5.0)
+    net = net.to(dev)
+    outs = []
+    for env in ({}, {"MVS_CONV_WINO": "0", "MVS_VIS_WINO": "0", "MVS_FUSE_PROB": "0"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            for mod in net.modules():                                   # the switches are read when the caches are built
+                if hasattr(mod, "_cache"):
+                    mod._cache = None
+            net._vis_cache = None
+            got = net(feat.to(dev), proj.to(dev), hyp.to(dev), tmp=5.0)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        assert rel_err(got["depth"].cpu(), want["depth"]) < DEPTH_RTOL
+        assert max_abs(got["prob_volume_pre"].cpu(), want["prob_volume_pre"]) < 5e-4
+        assert max_abs(got["photometric_confidence"].cpu(), want["photometric_confidence"]) < 1e-4
+        outs.append(got)
+    # the fast and the plain kernel paths agree with each other far below the tolerance against the oracle
+    assert max_abs(outs[0]["prob_volume_pre"].cpu(), outs[1]["prob_volume_pre"].cpu()) < 1e-4
