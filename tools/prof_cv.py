@@ -31,6 +31,7 @@ z = synth.plane_depth(scene, scale, device=dev)
 hyp = (1.0 / (1.0 / z[None, None] + torch.linspace(-1, 1, D, device=dev).view(1, D, 1, 1) * (4e-5 * scale))).contiguous()
 net = m.StageNet(dict(base_ch=8, fusion_type="cnn", depth_type="ce"), D, 0).to(dev).eval()
 rt = ops.proj_prepare(proj)
+feat = ops.to_channels_last(feat)                       # the sweeps read [B,V,H,W,C]
 for _ in range(args.iters):
     if "cv" in args.what:
         ent = ops.cv_entropy(feat, rt, hyp, 8)
