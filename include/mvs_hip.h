@@ -184,6 +184,11 @@ int mvs_bn_stats(const float* x, int B, int C, int64_t N, float* sums, mvs_strea
 int mvs_bn_finalize(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
                     float momentum, float eps, double count, int C, float* scale, float* shift, float* mean, float* invstd,
                     mvs_stream_t stream);
+/* `groups` BatchNorm calls of one module laid side by side as channels g*C + c (sums [2*groups*C], gamma/beta/running [C],
+ * scale/shift/mean/invstd [groups*C]); running statistics receive the groups' updates in order, as separate calls would. */
+int mvs_bn_finalize_grouped(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            float momentum, float eps, double count, int C, int groups, float* scale, float* shift, float* mean,
+                            float* invstd, mvs_stream_t stream);
 int mvs_affine_act(const float* x, const float* scale, const float* shift, const float* residual, int relu, int B, int C,
                    int64_t N, float* y, mvs_stream_t stream);
 int mvs_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,

@@ -42,6 +42,7 @@ SIGNATURES = {
     "mvs_head_fwd": (I, [P, P, P, P, I, P, F, I, I, I, I, I, P, P, P, P, P]),
     "mvs_bn_stats": (I, [P, I, I, L, P, P]),
     "mvs_bn_finalize": (I, [P, P, P, P, P, F, F, Dbl, I, P, P, P, P, P]),
+    "mvs_bn_finalize_grouped": (I, [P, P, P, P, P, F, F, Dbl, I, I, P, P, P, P, P]),
     "mvs_affine_act": (I, [P, P, P, P, I, I, I, L, P, P]),
     "mvs_bn_bwd_reduce": (I, [P, P, P, P, P, P, I, I, I, L, P, P]),
     "mvs_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, Dbl, I, I, I, L, P, P]),

@@ -101,11 +101,21 @@ class DeconvFn(torch.autograd.Function):
 
 
 class BnActFn(torch.autograd.Function):
-    """Training-mode BatchNorm (batch statistics, running-stat update) + optional ReLU + optional residual add."""
+    """Training-mode BatchNorm (batch statistics, running-stat update) + optional ReLU + optional residual add.
+
+    ``groups > 1``: the batch holds ``groups`` independent calls of the same module, batch index ``b*groups + g`` (the
+    visibility CNN is applied once per source view, mvsformer_model.py:91).  Statistics are taken per (group, channel) —
+    the tensor is simply viewed as ``[B, groups*C, ...]`` — the affine parameters are shared, running statistics receive the
+    groups' momentum updates in order, exactly as ``groups`` separate calls would leave them."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, bn, relu):
+    def forward(ctx, x, gamma, beta, residual, bn, relu, groups=1):
         x = x.contiguous()
+        shape = x.shape
+        if groups > 1:
+            if shape[0] % groups or residual is not None:
+                raise ops._lib.MvsHipError("grouped BatchNorm: batch %d is not a multiple of %d groups (or has a residual)" % (shape[0], groups))
+            x = x.view(shape[0] // groups, groups * shape[1], *shape[2:])
         B, C = x.shape[0], x.shape[1]
         count = float(x.numel() // C)
         sums = ops.bn_stats(x)
@@ -114,29 +124,38 @@ class BnActFn(torch.autograd.Function):
         b = beta.detach().to(torch.float32).contiguous() if beta is not None else None
         momentum = 0.1 if bn.momentum is None else bn.momentum
         track = bn.track_running_stats and bn.running_mean is not None
-        scale, shift, mean, invstd = ops.bn_finalize(sums, g, b, bn.running_mean if track else None,
-                                                     bn.running_var if track else None, momentum, bn.eps, count)
+        rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
+        if groups > 1:
+            scale, shift, mean, invstd = ops.bn_finalize_grouped(sums, g, b, rm, rv, momentum, bn.eps, count, groups)
+        else:
+            scale, shift, mean, invstd = ops.bn_finalize(sums, g, b, rm, rv, momentum, bn.eps, count)
         if track and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+            bn.num_batches_tracked.add_(groups)
         res = residual.contiguous() if residual is not None else None
         y = ops.affine_act(x, scale, shift, res, relu)
-        ctx.save_for_backward(x, scale, shift, mean, invstd, g if g is not None else scale.new_ones(C))
-        ctx.relu, ctx.count, ctx.bn, ctx.has_res = relu, count, bn, residual is not None
-        return y
+        gfull = (g if g is not None else scale.new_ones(C // groups))
+        if groups > 1:
+            gfull = gfull.repeat(groups)
+        ctx.save_for_backward(x, scale, shift, mean, invstd, gfull)
+        ctx.relu, ctx.count, ctx.bn, ctx.has_res, ctx.groups, ctx.shape = relu, count, bn, residual is not None, groups, shape
+        return y.view(shape)
 
     @staticmethod
     def backward(ctx, dy):
         x, scale, shift, mean, invstd, g = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy = dy.contiguous().view(x.shape)
         sums = ops.bn_bwd_reduce(dy, x, scale, shift, mean, invstd, ctx.relu)
         C = x.shape[1]
         local = sums.clone()                       # dgamma / dbeta stay per-rank (DDP averages parameter grads itself)
         _sync_sums(sums, 0.0, ctx.bn)
-        dx = ops.bn_bwd_apply(dy, x, scale, shift, mean, invstd, g, sums, ctx.count, ctx.relu)
+        dx = ops.bn_bwd_apply(dy, x, scale, shift, mean, invstd, g, sums, ctx.count, ctx.relu).view(ctx.shape)
         dgamma = local[C:].clone() if ctx.needs_input_grad[1] else None
         dbeta = local[:C].clone() if ctx.needs_input_grad[2] else None
+        if ctx.groups > 1:                         # shared parameters: sum the groups' gradients
+            dgamma = dgamma.view(ctx.groups, -1).sum(0) if dgamma is not None else None
+            dbeta = dbeta.view(ctx.groups, -1).sum(0) if dbeta is not None else None
         dres = dy if ctx.has_res else None
-        return dx, dgamma, dbeta, dres, None, None
+        return dx, dgamma, dbeta, dres, None, None, None
 
 
 class Prob1Fn(torch.autograd.Function):
@@ -235,3 +254,21 @@ def vis_train(entropy: torch.Tensor, vis: nn.Sequential) -> torch.Tensor:
         x = BnActFn.apply(x, blk.bn.weight, blk.bn.bias, None, blk.bn, True)
     y = Prob1Fn.apply(x, vis[3].weight, vis[3].bias)                    # [B,1,1,H,W]
     return SigmoidFn.apply(y).reshape(B, 1, H, W)
+
+
+def vis_train_views(entropy: torch.Tensor, vis: nn.Sequential) -> torch.Tensor:
+    """All source views of ``entropy [B,Vs,H,W]`` through ``self.vis`` in training mode in ONE batched pass, with the
+    statistics, running-stat updates and gradients of ``Vs`` separate per-view calls (reference mvsformer_model.py:91 calls
+    the CNN once per view): the convolutions see a batch of ``B*Vs`` maps, BatchNorm works per (view, channel) group."""
+    B, Vs, H, W = entropy.shape
+    if os.environ.get("MVS_VIS_PER_VIEW", "0") == "1" or Vs == 1:
+        return torch.cat([vis_train(entropy[:, v:v + 1], vis) for v in range(Vs)], dim=1)
+    x = torch.zeros(B * Vs, 4, 1, H, W, device=entropy.device, dtype=torch.float32)
+    x[:, 0, 0] = entropy.reshape(B * Vs, H, W)                          # batch index b*Vs + v
+    for i in range(3):
+        blk = vis[i]
+        cin_pad = 4 if i == 0 else blk.conv.in_channels
+        x = ConvFn.apply(x, embed_conv2d_weight(blk.conv.weight, cin_pad), (1, 1))
+        x = BnActFn.apply(x, blk.bn.weight, blk.bn.bias, None, blk.bn, True, Vs)
+    y = Prob1Fn.apply(x, vis[3].weight, vis[3].bias)                    # [B*Vs,1,1,H,W]
+    return SigmoidFn.apply(y).reshape(B, Vs, H, W)

@@ -68,6 +68,38 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* 
     }
 }
 
+// Grouped form: the tensor holds `groups` independent BatchNorm calls of the SAME module side by side as channels
+// g*C + c (the visibility CNN is applied once per source view in the reference, mvsformer_model.py:91: statistics per view,
+// one set of affine parameters, running statistics updated once per call IN ORDER).  One thread per base channel walks the groups.
+__global__ void bn_finalize_grouped_kernel(const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                           float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+                                           double count, int C, int groups, float* __restrict__ scale, float* __restrict__ shift,
+                                           float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int CT = C * groups;
+    const float g = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
+    float rm = running_mean ? running_mean[c] : 0.0f, rv = running_var ? running_var[c] : 0.0f;
+    for (int q = 0; q < groups; ++q) {
+        const int cc = q * C + c;
+        const double mean = (double)sums[cc] / count;
+        double var = (double)sums[CT + cc] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        scale[cc] = g * invstd;
+        shift[cc] = bt - (float)mean * g * invstd;
+        mean_out[cc] = (float)mean;
+        invstd_out[cc] = invstd;
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        rm = (1.0f - momentum) * rm + momentum * (float)mean;
+        rv = (1.0f - momentum) * rv + momentum * (float)unbiased;
+    }
+    if (running_mean) {
+        running_mean[c] = rm;
+        running_var[c] = rv;
+    }
+}
+
 // y = [relu](x*scale[c] + shift[c]) [+ residual]
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const float* __restrict__ res, int relu,
@@ -226,6 +258,15 @@ extern "C" int mvs_bn_finalize(const float* sums, const float* gamma, const floa
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, MVS_STREAM(stream), sums, gamma, beta, running_mean,
                        running_var, momentum, eps, count, C, scale, shift, mean, invstd);
     return mvs::finish_launch("mvs_bn_finalize");
+}
+
+extern "C" int mvs_bn_finalize_grouped(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                       float momentum, float eps, double count, int C, int groups, float* scale, float* shift,
+                                       float* mean, float* invstd, mvs_stream_t stream) {
+    MVS_REQUIRE(sums && scale && shift && mean && invstd && C >= 1 && groups >= 1 && count >= 1.0, "mvs_bn_finalize_grouped: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_grouped_kernel, dim3((C + 63) / 64), dim3(64), 0, MVS_STREAM(stream), sums, gamma, beta, running_mean,
+                       running_var, momentum, eps, count, C, groups, scale, shift, mean, invstd);
+    return mvs::finish_launch("mvs_bn_finalize_grouped");
 }
 
 extern "C" int mvs_affine_act(const float* x, const float* scale, const float* shift, const float* residual, int relu, int B, int C,

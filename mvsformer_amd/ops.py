@@ -424,6 +424,17 @@ def bn_finalize(sums, gamma, beta, running_mean, running_var, momentum, eps, cou
     return scale, shift, mean, invstd
 
 
+def bn_finalize_grouped(sums, gamma, beta, running_mean, running_var, momentum, eps, count, groups: int):
+    """``groups`` BatchNorm calls of one module side by side as channels ``g*C + c``: ``sums [2*groups*C]``, parameters ``[C]``."""
+    CT = sums.numel() // 2
+    C = CT // groups
+    dev = sums.device
+    scale, shift, mean, invstd = (torch.empty(CT, device=dev, dtype=torch.float32) for _ in range(4))
+    _call("mvs_bn_finalize_grouped", None, _ptr(sums), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), float(momentum),
+          float(eps), float(count), C, int(groups), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _stream())
+    return scale, shift, mean, invstd
+
+
 def affine_act(x, scale, shift, residual, relu):
     _chk(x, "x")
     B, C = x.shape[0], x.shape[1]

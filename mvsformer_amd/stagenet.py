@@ -98,7 +98,7 @@ class StageNet(nn.Module):
         feat_cl = ops.to_channels_last(features.detach().to(torch.float32))
         entropy = ops.cv_entropy(feat_cl, rt, hyp, G)                       # sim_vol.detach() in the reference
         V = features.shape[1]
-        weight = torch.cat([ag.vis_train(entropy[:, v:v + 1], self.vis) for v in range(V - 1)], dim=1)
+        weight = ag.vis_train_views(entropy, self.vis)                     # per-view statistics, one batched pass
         volume = ag.AggregateFn.apply(features, weight, rt, hyp, G)
         if type(tmp) == list:
             tmp = tmp[self.stage_idx]
