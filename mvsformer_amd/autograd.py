@@ -19,14 +19,32 @@ import torch.nn.functional as F
 from . import ops
 
 
+_equal_counts: dict = {}        # (process group id, world size, local count) -> True once verified
+
+
 def _sync_sums(sums: torch.Tensor, count: float, bn) -> float:
-    """SyncBatchNorm: all-reduce [sum, sumsq] (and the element count) over the process group."""
-    if isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        packed = torch.cat([sums, sums.new_tensor([count])])
-        dist.all_reduce(packed, group=bn.process_group)
-        sums.copy_(packed[:-1])
-        return float(packed[-1].item())
-    return count
+    """SyncBatchNorm: all-reduce [sum, sumsq] over the process group and return the global element count.
+
+    The count is all-reduced WITH the sums only the first time a (group, local count) pair is seen — reading it back is a
+    host synchronization — and when every rank turns out to hold the same number of elements (the normal data-parallel
+    case) later calls use ``count * world_size`` and reduce only the sums, keeping the step asynchronous.  ``count == 0``
+    (backward: only the sums matter) never synchronizes."""
+    if not (isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized()):
+        return count
+    world = dist.get_world_size(bn.process_group)
+    if world <= 1:
+        return count
+    key = (id(bn.process_group), world, count)
+    if count == 0.0 or _equal_counts.get(key):
+        dist.all_reduce(sums, group=bn.process_group)
+        return count * world
+    packed = torch.cat([sums, sums.new_tensor([count])])
+    dist.all_reduce(packed, group=bn.process_group)
+    sums.copy_(packed[:-1])
+    total = float(packed[-1].item())
+    if total == count * world:
+        _equal_counts[key] = True
+    return total
 
 
 def _wino_ok(stride, cin, cout, x) -> bool:
