@@ -6,8 +6,8 @@ step.  With N > 1 (torchrun) the cascade is wrapped in DistributedDataParallel: 
 SyncBatchNorm statistics exchanged by the BatchNorm autograd function.  fp32 (the reference trains under fp16 autocast
 with the cost volume forced to fp32; a bf16 MFMA path for the regularizer is future work).
 
-    python bench_train.py --steps 10
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 bench_train.py --steps 10
+    python bench_train.py --steps 10 [--gpus N]          (N > 1 without a launcher: spawns one rank per GPU itself)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 bench_train.py --gpus 8 --steps 10
 """
 import argparse
 import json
@@ -20,7 +20,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -29,7 +29,10 @@ def main():
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP + SyncBatchNorm even with one rank (smoke test)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def main(args):
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     import torch.distributed as dist
     dev = torch.device("cuda", local)
@@ -87,4 +90,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    _args = parse()
+    from mvsformer_amd import sharding
+    if not sharding.launch_ranks(main, _args, _args.gpus):      # --gpus N without a launcher: spawn N ranks (train.py:179-191)
+        main(_args)

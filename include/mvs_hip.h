@@ -27,7 +27,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 2
+#define MVS_ABI_VERSION 3
 
 typedef void* mvs_stream_t;
 
@@ -169,7 +169,10 @@ int mvs_conv3d_wino_fwd(const float* x, const float* wpacked, const float* scale
  * the same MFMA conv kernels with re-packed weights -> mvs_conv3d_wgrad.  Tensors are [B,C,N], N = D*H*W or H*W.
  *   mvs_bn_stats:      sums[c] += sum x, sums[C+c] += sum x^2   (sums zeroed by the caller)
  *   mvs_bn_finalize:   mean/var from sums and count -> scale = gamma*invstd, shift = beta - mean*scale, mean, invstd;
- *                      running stats updated with momentum (unbiased variance), as nn.BatchNorm does; NULL to skip
+ *                      running stats updated with momentum (unbiased variance), as nn.BatchNorm does; NULL to skip.
+ *                      `count` is the per-channel element count as a host value; SyncBatchNorm (train.py:138-139) passes
+ *                      `count_dev` instead: two DEVICE floats {n / 4096, n % 4096} that were summed over the ranks by the same
+ *                      all-reduce as `sums` (exact up to 2^36 elements; the host never reads the global count back)
  *   mvs_affine_act:    y = [relu](x*scale[c] + shift[c]) [+ residual]
  *   mvs_bn_bwd_reduce: g = dy*[x*scale+shift > 0 or !relu]; sums[c] += sum g, sums[C+c] += sum g*xhat
  *   mvs_bn_bwd_apply:  dx = gamma*invstd*(g - sums[c]/count - xhat*sums[C+c]/count);  dgamma = sums[C+c], dbeta = sums[c]
@@ -182,20 +185,20 @@ int mvs_conv3d_wino_fwd(const float* x, const float* wpacked, const float* scale
  * ------------------------------------------------------------------------------------------------------- */
 int mvs_bn_stats(const float* x, int B, int C, int64_t N, float* sums, mvs_stream_t stream);
 int mvs_bn_finalize(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                    float momentum, float eps, double count, int C, float* scale, float* shift, float* mean, float* invstd,
-                    mvs_stream_t stream);
+                    float momentum, float eps, double count, const float* count_dev, int C, float* scale, float* shift, float* mean,
+                    float* invstd, mvs_stream_t stream);
 /* `groups` BatchNorm calls of one module laid side by side as channels g*C + c (sums [2*groups*C], gamma/beta/running [C],
  * scale/shift/mean/invstd [groups*C]); running statistics receive the groups' updates in order, as separate calls would. */
 int mvs_bn_finalize_grouped(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                            float momentum, float eps, double count, int C, int groups, float* scale, float* shift, float* mean,
-                            float* invstd, mvs_stream_t stream);
+                            float momentum, float eps, double count, const float* count_dev, int C, int groups, float* scale,
+                            float* shift, float* mean, float* invstd, mvs_stream_t stream);
 int mvs_affine_act(const float* x, const float* scale, const float* shift, const float* residual, int relu, int B, int C,
                    int64_t N, float* y, mvs_stream_t stream);
 int mvs_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
                       const float* invstd, int relu, int B, int C, int64_t N, float* sums, mvs_stream_t stream);
 int mvs_bn_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
-                     const float* invstd, const float* gamma, const float* sums, double count, int relu, int B, int C,
-                     int64_t N, float* dx, mvs_stream_t stream);
+                     const float* invstd, const float* gamma, const float* sums, double count, const float* count_dev, int relu,
+                     int B, int C, int64_t N, float* dx, mvs_stream_t stream);
 int mvs_conv3d_wgrad(const float* A, const float* Bt, float* dW, int nbatch, int CA, int CB, int Dp, int Hp, int Wp, int Db,
                      int Hb, int Wb, int sd, int shw, mvs_stream_t stream);
 int mvs_cv_aggregate_bwd(const float* feat, const float* rt, const float* depth, const float* weight, const float* volume,

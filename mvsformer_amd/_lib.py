@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 from ctypes import c_double  # noqa: E402
 
@@ -41,11 +41,11 @@ SIGNATURES = {
     "mvs_prob3_fwd": (I, [P, P, I, I, I, I, I, P, P]),
     "mvs_head_fwd": (I, [P, P, P, P, I, P, F, I, I, I, I, I, P, P, P, P, P]),
     "mvs_bn_stats": (I, [P, I, I, L, P, P]),
-    "mvs_bn_finalize": (I, [P, P, P, P, P, F, F, Dbl, I, P, P, P, P, P]),
-    "mvs_bn_finalize_grouped": (I, [P, P, P, P, P, F, F, Dbl, I, I, P, P, P, P, P]),
+    "mvs_bn_finalize": (I, [P, P, P, P, P, F, F, Dbl, P, I, P, P, P, P, P]),
+    "mvs_bn_finalize_grouped": (I, [P, P, P, P, P, F, F, Dbl, P, I, I, P, P, P, P, P]),
     "mvs_affine_act": (I, [P, P, P, P, I, I, I, L, P, P]),
     "mvs_bn_bwd_reduce": (I, [P, P, P, P, P, P, I, I, I, L, P, P]),
-    "mvs_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, Dbl, I, I, I, L, P, P]),
+    "mvs_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, Dbl, P, I, I, I, L, P, P]),
     "mvs_conv3d_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "mvs_cv_aggregate_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P]),
     "mvs_softmax_bwd": (I, [P, P, I, I, L, P, P]),

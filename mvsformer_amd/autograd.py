@@ -19,32 +19,35 @@ import torch.nn.functional as F
 from . import ops
 
 
-_equal_counts: dict = {}        # (process group id, world size, local count) -> True once verified
+def _sync_sums(sums: torch.Tensor, count: float, bn):
+    """SyncBatchNorm (reference train.py:138-139): all-reduce ``[sum, sumsq]`` and the element count over the process group.
 
-
-def _sync_sums(sums: torch.Tensor, count: float, bn) -> float:
-    """SyncBatchNorm: all-reduce [sum, sumsq] over the process group and return the global element count.
-
-    The count is all-reduced WITH the sums only the first time a (group, local count) pair is seen — reading it back is a
-    host synchronization — and when every rank turns out to hold the same number of elements (the normal data-parallel
-    case) later calls use ``count * world_size`` and reduce only the sums, keeping the step asynchronous.  ``count == 0``
-    (backward: only the sums matter) never synchronizes."""
+    Returns ``(sums, count_dev)``.  ``count_dev`` is None when nothing was reduced (plain BatchNorm, or world size 1: the
+    caller keeps its host count); otherwise it is a 2-element DEVICE tensor ``[n / 4096, n % 4096]`` summed over the ranks in
+    the SAME collective as the sums (one all-reduce of 2C+2 floats per layer, identical on every rank whatever the local
+    batch shapes are; each half stays exact in fp32 up to 2^36 elements) - the BatchNorm kernels read the global count from
+    device memory, so the step never synchronizes with the host and no rank has to guess whether counts are equal.
+    ``count == 0`` (backward: the caller already holds the forward's ``count_dev``) reduces only the sums."""
     if not (isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized()):
-        return count
+        return sums, None
     world = dist.get_world_size(bn.process_group)
     if world <= 1:
-        return count
-    key = (id(bn.process_group), world, count)
-    if count == 0.0 or _equal_counts.get(key):
+        return sums, None
+    if count == 0.0:
         dist.all_reduce(sums, group=bn.process_group)
-        return count * world
-    packed = torch.cat([sums, sums.new_tensor([count])])
+        return sums, None
+    n = int(count)
+    packed = torch.cat([sums, sums.new_tensor([float(n // 4096), float(n % 4096)])])
     dist.all_reduce(packed, group=bn.process_group)
-    sums.copy_(packed[:-1])
-    total = float(packed[-1].item())
-    if total == count * world:
-        _equal_counts[key] = True
-    return total
+    return packed[:-2], packed[-2:]
+
+
+def _momentum(bn) -> float:
+    """``momentum=None`` is torch's cumulative moving average: factor 1/(num_batches_tracked + 1) for this update."""
+    if bn.momentum is not None:
+        return float(bn.momentum)
+    seen = int(bn.num_batches_tracked.item()) if bn.num_batches_tracked is not None else 0
+    return 1.0 / float(seen + 1)
 
 
 def _wino_ok(stride, cin, cout, x) -> bool:
@@ -137,16 +140,17 @@ class BnActFn(torch.autograd.Function):
         B, C = x.shape[0], x.shape[1]
         count = float(x.numel() // C)
         sums = ops.bn_stats(x)
-        count = _sync_sums(sums, count, bn)
+        sums, count_dev = _sync_sums(sums, count, bn)
         g = gamma.detach().to(torch.float32).contiguous() if gamma is not None else None
         b = beta.detach().to(torch.float32).contiguous() if beta is not None else None
-        momentum = 0.1 if bn.momentum is None else bn.momentum
         track = bn.track_running_stats and bn.running_mean is not None
         rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
         if groups > 1:
-            scale, shift, mean, invstd = ops.bn_finalize_grouped(sums, g, b, rm, rv, momentum, bn.eps, count, groups)
+            if bn.momentum is None:
+                raise ops._lib.MvsHipError("grouped BatchNorm needs a fixed momentum (cumulative averaging changes per group)")
+            scale, shift, mean, invstd = ops.bn_finalize_grouped(sums, g, b, rm, rv, bn.momentum, bn.eps, count, groups, count_dev)
         else:
-            scale, shift, mean, invstd = ops.bn_finalize(sums, g, b, rm, rv, momentum, bn.eps, count)
+            scale, shift, mean, invstd = ops.bn_finalize(sums, g, b, rm, rv, _momentum(bn) if track else 0.0, bn.eps, count, count_dev)
         if track and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(groups)
         res = residual.contiguous() if residual is not None else None
@@ -154,19 +158,19 @@ class BnActFn(torch.autograd.Function):
         gfull = (g if g is not None else scale.new_ones(C // groups))
         if groups > 1:
             gfull = gfull.repeat(groups)
-        ctx.save_for_backward(x, scale, shift, mean, invstd, gfull)
+        ctx.save_for_backward(x, scale, shift, mean, invstd, gfull, count_dev)
         ctx.relu, ctx.count, ctx.bn, ctx.has_res, ctx.groups, ctx.shape = relu, count, bn, residual is not None, groups, shape
         return y.view(shape)
 
     @staticmethod
     def backward(ctx, dy):
-        x, scale, shift, mean, invstd, g = ctx.saved_tensors
+        x, scale, shift, mean, invstd, g, count_dev = ctx.saved_tensors
         dy = dy.contiguous().view(x.shape)
         sums = ops.bn_bwd_reduce(dy, x, scale, shift, mean, invstd, ctx.relu)
         C = x.shape[1]
         local = sums.clone()                       # dgamma / dbeta stay per-rank (DDP averages parameter grads itself)
-        _sync_sums(sums, 0.0, ctx.bn)
-        dx = ops.bn_bwd_apply(dy, x, scale, shift, mean, invstd, g, sums, ctx.count, ctx.relu).view(ctx.shape)
+        sums, _ = _sync_sums(sums, 0.0, ctx.bn)
+        dx = ops.bn_bwd_apply(dy, x, scale, shift, mean, invstd, g, sums, ctx.count, ctx.relu, count_dev).view(ctx.shape)
         dgamma = local[C:].clone() if ctx.needs_input_grad[1] else None
         dbeta = local[:C].clone() if ctx.needs_input_grad[2] else None
         if ctx.groups > 1:                         # shared parameters: sum the groups' gradients

@@ -45,13 +45,21 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
+// Element count per channel: a host value, or (SyncBatchNorm) two floats {n / 4096, n % 4096} that rode through the same
+// all-reduce as the sums - each stays exactly representable in fp32 up to 2^36 elements, so the total is exact and the
+// host never has to read it back.
+__device__ __forceinline__ double resolve_count(double count_host, const float* __restrict__ count_dev) {
+    return count_dev ? (double)count_dev[0] * 4096.0 + (double)count_dev[1] : count_host;
+}
+
 // mean/var from the (possibly all-reduced) sums; eval-style scale/shift for the apply kernel; running-stat update
 __global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
-                                   double count, int C, float* __restrict__ scale, float* __restrict__ shift,
-                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+                                   double count_host, const float* __restrict__ count_dev, int C, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    const double count = resolve_count(count_host, count_dev);
     const double mean = (double)sums[c] / count;
     double var = (double)sums[C + c] / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -73,10 +81,12 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* 
 // one set of affine parameters, running statistics updated once per call IN ORDER).  One thread per base channel walks the groups.
 __global__ void bn_finalize_grouped_kernel(const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
                                            float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
-                                           double count, int C, int groups, float* __restrict__ scale, float* __restrict__ shift,
+                                           double count_host, const float* __restrict__ count_dev, int C, int groups,
+                                           float* __restrict__ scale, float* __restrict__ shift,
                                            float* __restrict__ mean_out, float* __restrict__ invstd_out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    const double count = resolve_count(count_host, count_dev);
     const int CT = C * groups;
     const float g = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
     float rm = running_mean ? running_mean[c] : 0.0f, rv = running_var ? running_var[c] : 0.0f;
@@ -149,7 +159,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ sums,
-                                                           double count, int relu, int C, size_t N, float* __restrict__ dx) {
+                                                           double count_host, const float* __restrict__ count_dev, int relu, int C,
+                                                           size_t N, float* __restrict__ dx) {
+    const double count = resolve_count(count_host, count_dev);
     const int c = blockIdx.y, b = blockIdx.z;
     const size_t base = ((size_t)b * C + c) * N;
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
@@ -252,20 +264,21 @@ extern "C" int mvs_bn_stats(const float* x, int B, int C, int64_t N, float* sums
 }
 
 extern "C" int mvs_bn_finalize(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                               float momentum, float eps, double count, int C, float* scale, float* shift, float* mean, float* invstd,
-                               mvs_stream_t stream) {
-    MVS_REQUIRE(sums && scale && shift && mean && invstd && C >= 1 && count >= 1.0, "mvs_bn_finalize: bad arguments");
+                               float momentum, float eps, double count, const float* count_dev, int C, float* scale, float* shift,
+                               float* mean, float* invstd, mvs_stream_t stream) {
+    MVS_REQUIRE(sums && scale && shift && mean && invstd && C >= 1 && (count_dev || count >= 1.0), "mvs_bn_finalize: bad arguments");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, MVS_STREAM(stream), sums, gamma, beta, running_mean,
-                       running_var, momentum, eps, count, C, scale, shift, mean, invstd);
+                       running_var, momentum, eps, count, count_dev, C, scale, shift, mean, invstd);
     return mvs::finish_launch("mvs_bn_finalize");
 }
 
 extern "C" int mvs_bn_finalize_grouped(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                       float momentum, float eps, double count, int C, int groups, float* scale, float* shift,
-                                       float* mean, float* invstd, mvs_stream_t stream) {
-    MVS_REQUIRE(sums && scale && shift && mean && invstd && C >= 1 && groups >= 1 && count >= 1.0, "mvs_bn_finalize_grouped: bad arguments");
+                                       float momentum, float eps, double count, const float* count_dev, int C, int groups, float* scale,
+                                       float* shift, float* mean, float* invstd, mvs_stream_t stream) {
+    MVS_REQUIRE(sums && scale && shift && mean && invstd && C >= 1 && groups >= 1 && (count_dev || count >= 1.0),
+                "mvs_bn_finalize_grouped: bad arguments");
     hipLaunchKernelGGL(bn_finalize_grouped_kernel, dim3((C + 63) / 64), dim3(64), 0, MVS_STREAM(stream), sums, gamma, beta, running_mean,
-                       running_var, momentum, eps, count, C, groups, scale, shift, mean, invstd);
+                       running_var, momentum, eps, count, count_dev, C, groups, scale, shift, mean, invstd);
     return mvs::finish_launch("mvs_bn_finalize_grouped");
 }
 
@@ -287,12 +300,12 @@ extern "C" int mvs_bn_bwd_reduce(const float* dy, const float* x, const float* s
 }
 
 extern "C" int mvs_bn_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
-                                const float* invstd, const float* gamma, const float* sums, double count, int relu, int B, int C,
-                                int64_t N, float* dx, mvs_stream_t stream) {
+                                const float* invstd, const float* gamma, const float* sums, double count, const float* count_dev,
+                                int relu, int B, int C, int64_t N, float* dx, mvs_stream_t stream) {
     MVS_REQUIRE(dy && x && scale && shift && mean && invstd && sums && dx && B >= 1 && C >= 1 && C <= 65535 && B <= 65535 && N >= 1,
                 "mvs_bn_bwd_apply: bad arguments");
     hipLaunchKernelGGL(bn_bwd_apply_kernel, row_grid(B, C, N), dim3(256), 0, MVS_STREAM(stream), dy, x, scale, shift, mean, invstd, gamma,
-                       sums, count, relu, C, (size_t)N, dx);
+                       sums, count, count_dev, relu, C, (size_t)N, dx);
     return mvs::finish_launch("mvs_bn_bwd_apply");
 }
 

@@ -18,18 +18,21 @@ class CeLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, depth_values, depth_gt, mask, inverse_depth, weight):
-        need_grad = logits.requires_grad
+        need_grad = bool(ctx.needs_input_grad[0])
         loss, acc, grad = ops.ce_loss(logits.contiguous(), depth_values.contiguous(), depth_gt.contiguous(), mask.contiguous(),
                                       bool(inverse_depth), float(weight), want_grad=need_grad)
-        ctx.weight = float(weight)
+        ctx.weight, ctx.has_grad = float(weight), need_grad
         ctx.save_for_backward(acc, grad if need_grad else acc)
         return loss
 
     @staticmethod
     def backward(ctx, gout):
         acc, grad = ctx.saved_tensors
-        ops.ce_loss_bwd_scale(grad, acc, gout.contiguous().reshape(1), ctx.weight)      # in place: the buffer is ours
-        return grad, None, None, None, None, None
+        if not ctx.has_grad:
+            return None, None, None, None, None, None
+        g = grad.clone()            # the saved buffer stays unscaled: a second backward (retain_graph) scales a fresh copy
+        ops.ce_loss_bwd_scale(g, acc, gout.contiguous().reshape(1), ctx.weight)
+        return g, None, None, None, None, None
 
 
 def ce_loss_stage4(inputs, depth_gt_ms, mask_ms, dlossw, focal=False, gamma=0.0, inverse_depth=True):

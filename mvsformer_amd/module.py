@@ -43,6 +43,14 @@ def _versions(mod: nn.Module) -> tuple:
     return tuple((t.data_ptr(), t._version) for t in list(mod.parameters()) + list(mod.buffers()))
 
 
+def _publish_cache() -> None:
+    """Packed weights / folded BatchNorm are produced by kernels on the CURRENT stream and then reused by every later
+    forward, possibly on other streams (bench.py walks reference views over several).  The cache is rebuilt only when a
+    parameter changes, so one stream synchronization per rebuild makes the cached tensors safe to read from any stream."""
+    if torch.cuda.is_available():
+        torch.cuda.current_stream().synchronize()
+
+
 def _train_conv_bn_act(x, conv, bn, relu, residual, transposed_sd=None):
     """Training-mode layer: raw (transposed) conv -> batch-stat BN -> ReLU (+ residual), all autograd-tracked HIP ops."""
     from . import autograd as ag
@@ -95,6 +103,7 @@ class Conv3d(nn.Module):
             else:
                 scale = None
                 shift = _f32c(conv.bias) if conv.bias is not None else None
+            _publish_cache()
             self._cache = (key, packed, scale, shift, (s[0], s[1]), wino)
         return self._cache[1:]
 
@@ -126,7 +135,9 @@ class Deconv3d(nn.Module):
             return _train_conv_bn_act(x, self.conv, self.bn, self.relu, residual, transposed_sd=self.conv.stride[0])
         key = _versions(self)
         if self._cache is None or self._cache[0] != key:
-            self._cache = (key,) + _prepare_deconv(self.conv, self.bn)
+            prepared = _prepare_deconv(self.conv, self.bn)
+            _publish_cache()
+            self._cache = (key,) + prepared
         _, packed, scale, shift, sd = self._cache
         return ops.deconv3d(x, packed, self.conv.in_channels, self.conv.out_channels, sd, scale, shift, residual,
                             relu=self.relu, tag="deconv3d_%dto%d_s%d" % (self.conv.in_channels, self.conv.out_channels, sd))
@@ -276,6 +287,7 @@ class CostRegNet3D(nn.Module):
         c = self._dcache.get(name)
         if c is None or c[0] != key:
             c = (key,) + _prepare_deconv(seq[0], seq[1])
+            _publish_cache()
             self._dcache[name] = c
         _, packed, scale, shift, sd = c
         return ops.deconv3d(x, packed, seq[0].in_channels, seq[0].out_channels, sd, scale, shift, residual, relu=True,
@@ -293,6 +305,7 @@ class CostRegNet3D(nn.Module):
             c = self._dcache.get("conv11")
             if c is None or c[0] != key:
                 c = (key,) + _prepare_deconv(seq[0], seq[1])
+                _publish_cache()
                 self._dcache["conv11"] = c
             _, packed, scale, shift, _sd = c
             return ops.deconv3d_prob1(y, packed, seq[0].in_channels, scale, shift, skip, w, b, relu=True)

@@ -29,7 +29,16 @@ def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
         raise _lib.MvsHipError("%s must be %s, got %s" % (name, dtype, t.dtype))
     if not t.is_contiguous():
         raise _lib.MvsHipError("%s must be contiguous" % name)
+    if t.device.index != torch.cuda.current_device():
+        # kernels are launched on the CURRENT device's current stream; a tensor of another GPU would be dereferenced there
+        raise _lib.MvsHipError("%s lives on %s but the current device is cuda:%d - wrap the call in torch.cuda.device(...)"
+                               % (name, t.device, torch.cuda.current_device()))
     return t
+
+
+def _opt(t: Optional[torch.Tensor], name: str) -> Optional[torch.Tensor]:
+    """Optional tensor argument: same device / dtype / contiguity rules as the mandatory ones."""
+    return None if t is None else _chk(t, name)
 
 
 def _stream() -> int:
@@ -237,7 +246,7 @@ def conv3d_pack(weight: torch.Tensor, transposed: bool, sd: int = 2) -> torch.Te
 
 
 def conv3d(x, wpacked, cin, cout, stride, scale=None, shift=None, residual=None, relu=True, tag=None):
-    _chk(x, "x"), _chk(wpacked, "packed weights")
+    _chk(x, "x"), _chk(wpacked, "packed weights"), _opt(scale, "scale"), _opt(shift, "shift")
     B, C, Di, Hi, Wi = x.shape
     assert C == cin
     sd, shw = stride
@@ -270,7 +279,7 @@ def conv3d_wino_pack(weight: torch.Tensor) -> torch.Tensor:
 
 
 def conv3d_wino(x, wpacked, cin, cout, scale=None, shift=None, residual=None, relu=True):
-    _chk(x, "x"), _chk(wpacked, "packed weights")
+    _chk(x, "x"), _chk(wpacked, "packed weights"), _opt(scale, "scale"), _opt(shift, "shift")
     B, C, D, H, W = x.shape
     assert C == cin
     y = torch.empty(B, cout, D, H, W, device=x.device, dtype=torch.float32)
@@ -286,7 +295,7 @@ def conv3d_wino(x, wpacked, cin, cout, scale=None, shift=None, residual=None, re
 
 
 def deconv3d(x, wpacked, cin, cout, sd, scale=None, shift=None, residual=None, relu=True, tag=None):
-    _chk(x, "x"), _chk(wpacked, "packed weights")
+    _chk(x, "x"), _chk(wpacked, "packed weights"), _opt(scale, "scale"), _opt(shift, "shift")
     B, C, Di, Hi, Wi = x.shape
     assert C == cin
     y = torch.empty(B, cout, Di * sd, Hi * 2, Wi * 2, device=x.device, dtype=torch.float32)
@@ -304,7 +313,8 @@ def deconv3d(x, wpacked, cin, cout, sd, scale=None, shift=None, residual=None, r
 
 def deconv3d_prob1(x, wpacked, cin, scale, shift, residual, prob_w, prob_b, relu=True):
     """CostRegNet3D tail: ``prob(residual + relu(bn(conv11(x))))`` -> logits ``[B,D,2H,2W]`` without the 8-channel volume."""
-    _chk(x, "x"), _chk(wpacked, "packed weights"), _chk(prob_w, "prob.weight")
+    _chk(x, "x"), _chk(wpacked, "packed weights"), _chk(prob_w, "prob.weight"), _opt(prob_b, "prob.bias")
+    _opt(scale, "scale"), _opt(shift, "shift")
     B, C, Di, Hi, Wi = x.shape
     assert C == cin
     if residual is not None:
@@ -415,28 +425,37 @@ def bn_stats(x: torch.Tensor) -> torch.Tensor:
     return sums
 
 
-def bn_finalize(sums, gamma, beta, running_mean, running_var, momentum, eps, count):
+def _bn_args(sums, gamma, beta, running_mean, running_var, count_dev):
+    _chk(sums, "sums"), _opt(gamma, "bn.weight"), _opt(beta, "bn.bias"), _opt(running_mean, "bn.running_mean")
+    _opt(running_var, "bn.running_var"), _opt(count_dev, "count_dev")
+
+
+def bn_finalize(sums, gamma, beta, running_mean, running_var, momentum, eps, count, count_dev=None):
+    """``count``: per-channel element count (host float); ``count_dev`` (SyncBatchNorm): device floats ``[n/4096, n%4096]``
+    summed over the ranks with the sums - then ``count`` is ignored and nothing is read back to the host."""
+    _bn_args(sums, gamma, beta, running_mean, running_var, count_dev)
     C = sums.numel() // 2
     dev = sums.device
     scale, shift, mean, invstd = (torch.empty(C, device=dev, dtype=torch.float32) for _ in range(4))
     _call("mvs_bn_finalize", None, _ptr(sums), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), float(momentum),
-          float(eps), float(count), C, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _stream())
+          float(eps), float(count), _ptr(count_dev), C, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _stream())
     return scale, shift, mean, invstd
 
 
-def bn_finalize_grouped(sums, gamma, beta, running_mean, running_var, momentum, eps, count, groups: int):
+def bn_finalize_grouped(sums, gamma, beta, running_mean, running_var, momentum, eps, count, groups: int, count_dev=None):
     """``groups`` BatchNorm calls of one module side by side as channels ``g*C + c``: ``sums [2*groups*C]``, parameters ``[C]``."""
+    _bn_args(sums, gamma, beta, running_mean, running_var, count_dev)
     CT = sums.numel() // 2
     C = CT // groups
     dev = sums.device
     scale, shift, mean, invstd = (torch.empty(CT, device=dev, dtype=torch.float32) for _ in range(4))
     _call("mvs_bn_finalize_grouped", None, _ptr(sums), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), float(momentum),
-          float(eps), float(count), C, int(groups), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _stream())
+          float(eps), float(count), _ptr(count_dev), C, int(groups), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _stream())
     return scale, shift, mean, invstd
 
 
 def affine_act(x, scale, shift, residual, relu):
-    _chk(x, "x")
+    _chk(x, "x"), _chk(scale, "scale"), _chk(shift, "shift"), _opt(residual, "residual")
     B, C = x.shape[0], x.shape[1]
     y = torch.empty_like(x)
     _call("mvs_affine_act", None, _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), int(relu), B, C, x.numel() // (B * C), _ptr(y), _stream())
@@ -452,11 +471,12 @@ def bn_bwd_reduce(dy, x, scale, shift, mean, invstd, relu):
     return sums
 
 
-def bn_bwd_apply(dy, x, scale, shift, mean, invstd, gamma, sums, count, relu):
+def bn_bwd_apply(dy, x, scale, shift, mean, invstd, gamma, sums, count, relu, count_dev=None):
+    _chk(dy, "dy"), _chk(x, "x"), _chk(sums, "sums"), _opt(gamma, "gamma"), _opt(count_dev, "count_dev")
     B, C = x.shape[0], x.shape[1]
     dx = torch.empty_like(x)
     _call("mvs_bn_bwd_apply", None, _ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(sums),
-          float(count), int(relu), B, C, x.numel() // (B * C), _ptr(dx), _stream())
+          float(count), _ptr(count_dev), int(relu), B, C, x.numel() // (B * C), _ptr(dx), _stream())
     return dx
 
 

@@ -48,3 +48,41 @@ def aggregate_throughput(local_units: int, seconds: float, device=None) -> Tuple
     dist.all_reduce(n, op=dist.ReduceOp.SUM)
     tmax = timed_region_max(seconds, device)
     return int(n.item()), int(n.item()) / tmax
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _spawn_entry(local_rank: int, world: int, port: int, fn, args) -> None:
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(local_rank),
+                      LOCAL_RANK=str(local_rank), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    fn(args)
+
+
+def launch_ranks(fn, args, gpus: int) -> bool:
+    """One process per GPU, as the reference's ``train.py:179-191`` does with ``mp.spawn`` + NCCL ``env://``.
+
+    * launched by ``torch.distributed.run`` (``WORLD_SIZE`` in the environment): nothing to do here, returns False and the
+      caller runs ``fn(args)`` as the rank it already is;
+    * ``gpus == 1``: returns False (single process);
+    * ``gpus > 1`` and no launcher: spawns ``gpus`` local ranks (127.0.0.1 rendezvous on a free port), each calling
+      ``fn(args)`` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, waits for them, returns True.
+
+    Asking for more ranks than the node has GPUs is an error (never a silent single-rank run)."""
+    import os
+    if "WORLD_SIZE" in os.environ or gpus <= 1:
+        return False
+    have = torch.cuda.device_count()
+    if have < gpus:
+        raise RuntimeError("--gpus %d requested but this node exposes %d GPU(s); one process per GPU is the only mode" % (gpus, have))
+    import torch.multiprocessing as mp
+    mp.spawn(_spawn_entry, args=(gpus, _free_port(), fn, args), nprocs=gpus, join=True)
+    return True

@@ -48,6 +48,8 @@ class StageNet(nn.Module):
         if self._vis_cache is None or self._vis_cache[0] != key:
             params = pack_vis_params(self.vis)
             prepared = ops.vis_wino_prepare(params) if os.environ.get("MVS_VIS_WINO", "1") != "0" else None
+            from .module import _publish_cache
+            _publish_cache()                                    # cached tensors are read from any stream afterwards
             self._vis_cache = (key, params, prepared)
         return self._vis_cache[1:]
 
