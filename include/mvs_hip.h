@@ -99,6 +99,29 @@ int mvs_cv_aggregate_fwd(const float* feat, const float* rt, const float* depth,
                          float* volume, float* sim_depth, mvs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * LDS-tiled form of the same two sweeps (cost_volume_tiled.hip) - the default eval path of StageNet.  Same math as
+ * mvs_cv_entropy_fwd / mvs_cv_aggregate_fwd (models/mvsformer_model.py:73-105,151-158 + models/warping.py:84-106), but
+ *   feat [B,V,C,H,W]  the FPN decoder's NCHW maps as they are (no transpose launch): a block stages the source texels
+ *                     its tile of reference pixels touches into LDS once per (view, plane chunk) and serves every
+ *                     bilinear tap from LDS;
+ *   flags bit 0       0 = sampling coordinates from one reciprocal + Newton step (deviates from the reference's
+ *                     grid_sample coordinates by ~1e-4 px, far inside the 1e-3 depth tolerance), 1 = the reference's
+ *                     op order with IEEE divisions (warping.py:90-96), as the direct sweeps compute them;
+ *   workspace         sweep B with sim_depth at C >= 32 splits the planes over blocks and merges the per-block
+ *                     similarity maxima through mvs_cv_tiled_workspace_bytes(...) bytes (0 for C <= 16); may be NULL
+ *                     when that is 0 or sim_depth is NULL;
+ *   stats             optional device uint32[2]: [0] += rounds (block x plane pass x view), [1] += rounds whose tap
+ *                     bounding box did not fit the LDS tile and took the direct-gather path; NULL to skip.
+ * Constraints: G == 8, C in {8,16,32,64}; a view's feature block, a sample's volume and weight block < 2 GiB.
+ * ------------------------------------------------------------------------------------------------------- */
+int64_t mvs_cv_tiled_workspace_bytes(int B, int V, int C, int D, int H, int W);
+int mvs_cv_tiled_entropy_fwd(const float* feat, const float* rt, const float* depth, int B, int V, int C, int G, int D,
+                             int H, int W, float* entropy, int flags, uint32_t* stats, mvs_stream_t stream);
+int mvs_cv_tiled_aggregate_fwd(const float* feat, const float* rt, const float* depth, const float* weight, int B, int V,
+                               int C, int G, int D, int H, int W, float* volume, float* sim_depth, void* workspace,
+                               int flags, uint32_t* stats, mvs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * 3-D regularizer layers on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), implicit GEMM with the input
  * tile + weights staged through LDS and a fused epilogue  y = [relu](acc*scale + shift) [+ residual].
  * Replaces Conv3d / Deconv3d (conv -> BatchNorm3d -> ReLU, models/module.py:83-165) and the residual adds

@@ -34,6 +34,9 @@ SIGNATURES = {
     "mvs_cv_entropy_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P]),
     "mvs_vis_fwd": (I, [P, P, I, I, I, P, P]),
     "mvs_cv_aggregate_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, P]),
+    "mvs_cv_tiled_workspace_bytes": (L, [I, I, I, I, I, I]),
+    "mvs_cv_tiled_entropy_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, I, P, P]),
+    "mvs_cv_tiled_aggregate_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, P, I, P, P]),
     "mvs_conv3d_packed_floats": (L, [I, I, I]),
     "mvs_conv3d_pack_weights": (I, [P, I, I, I, P, P]),
     "mvs_conv3d_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),

@@ -227,6 +227,57 @@ def cv_aggregate(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, weig
     return vol, sim
 
 
+def cv_tiled_supported(feat: torch.Tensor) -> bool:
+    """The LDS-tiled sweeps take the FPN decoder's NCHW ``[B,V,C,H,W]`` maps directly (C in 8/16/32/64, contiguous fp32)."""
+    return (isinstance(feat, torch.Tensor) and feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 5 and feat.is_contiguous()
+            and feat.shape[2] in (8, 16, 32, 64))
+
+
+def _cv_flags(exact: Optional[bool]) -> int:
+    import os
+    if exact is None:
+        exact = os.environ.get("MVS_CV_EXACT", "0") == "1"
+    return 1 if exact else 0
+
+
+def cv_tiled_entropy(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, G: int, exact: Optional[bool] = None,
+                     stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Sweep A, LDS-tiled: ``feat`` is NCHW ``[B,V,C,H,W]`` -> entropy ``[B,V-1,H,W]`` (reference mvsformer_model.py:73-79,88-90)."""
+    _chk(feat, "features"), _chk(rt, "rt"), _chk(depth, "depth_values")
+    B, V, C, H, W = feat.shape
+    D = depth.shape[1]
+    if depth.shape != (B, D, H, W):
+        raise _lib.MvsHipError("depth_values must be [B,D,H,W]=%s, got %s" % ((B, D, H, W), tuple(depth.shape)))
+    ent = torch.empty(B, V - 1, H, W, device=feat.device, dtype=torch.float32)
+    tag = ("cv_tiled_entropy<%d>" % C, "bytes", 4.0 * B * H * W * (V * C + D))
+    _call("mvs_cv_tiled_entropy_fwd", tag, _ptr(feat), _ptr(rt), _ptr(depth), B, V, C, G, D, H, W, _ptr(ent), _cv_flags(exact),
+          _ptr(stats), _stream())
+    return ent
+
+
+def cv_tiled_aggregate(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, weight: torch.Tensor, G: int, want_sim_depth: bool,
+                       exact: Optional[bool] = None, stats: Optional[torch.Tensor] = None):
+    """Sweep B, LDS-tiled: -> ``volume_mean [B,G,D,H,W]``, ``sim_depth [B,H,W]`` or None (mvsformer_model.py:81-85,101-105,151-158)."""
+    _chk(feat, "features"), _chk(rt, "rt"), _chk(depth, "depth_values"), _chk(weight, "vis_weight")
+    B, V, C, H, W = feat.shape
+    D = depth.shape[1]
+    if weight.shape != (B, V - 1, H, W):
+        raise _lib.MvsHipError("vis_weight must be %s, got %s" % ((B, V - 1, H, W), tuple(weight.shape)))
+    vol = torch.empty(B, G, D, H, W, device=feat.device, dtype=torch.float32)
+    sim = torch.empty(B, H, W, device=feat.device, dtype=torch.float32) if want_sim_depth else None
+    ws = None
+    if want_sim_depth:
+        nbytes = _lib.load().mvs_cv_tiled_workspace_bytes(B, V, C, D, H, W)
+        if nbytes < 0:
+            raise _lib.MvsHipError("mvs_cv_tiled_workspace_bytes: unsupported shape")
+        if nbytes > 0:
+            ws = torch.empty(nbytes, device=feat.device, dtype=torch.uint8)
+    tag = ("cv_tiled_aggregate<%d,%s>" % (C, "sim" if want_sim_depth else "nosim"), "bytes", 4.0 * B * H * W * (V * C + D + G * D))
+    _call("mvs_cv_tiled_aggregate_fwd", tag, _ptr(feat), _ptr(rt), _ptr(depth), _ptr(weight), B, V, C, G, D, H, W, _ptr(vol), _ptr(sim),
+          _ptr(ws), _cv_flags(exact), _ptr(stats), _stream())
+    return vol, sim
+
+
 # ----------------------------------------------------------------------------------------------- 3-D convs
 def conv3d_pack(weight: torch.Tensor, transposed: bool, sd: int = 2) -> torch.Tensor:
     """Re-lay a Conv3d (``[Cout,Cin,3,3,3]``) or ConvTranspose3d (``[Cin,Cout,3,3,3]``, ``sd`` = its depth stride) weight."""

@@ -6,7 +6,8 @@
 Where the reference runs ~40 ATen launches per source view over materialized [B,C,D,H,W] temporaries, this
 forward is 5 + 10 hand-written HIP launches per stage:
 
-    mvs_proj_prepare -> mvs_nchw_to_nhwc -> mvs_cv_entropy_fwd -> mvs_vis_fwd -> mvs_cv_aggregate_fwd
+    mvs_proj_prepare -> mvs_cv_tiled_entropy_fwd -> mvs_vis_wino_fwd -> mvs_cv_tiled_aggregate_fwd
+    (MVS_CV_TILED=0 or channel-last inputs: mvs_nchw_to_nhwc -> mvs_cv_entropy_fwd -> ... -> mvs_cv_aggregate_fwd)
     -> 9 fused conv/deconv MFMA layers -> (mvs_prob3_fwd) -> mvs_head_fwd
 
 ``DepthNet`` is the name BASELINE.json uses for the same thing.
@@ -71,11 +72,18 @@ class StageNet(nn.Module):
 
         # step 2 of the reference forward: fused warp + group correlation + visibility-weighted aggregation
         rt = ops.proj_prepare(proj)
-        feat = ops.to_channels_last(feat)                       # [B,V,H,W,C]: 16-byte-per-lane coalesced gathers
-        entropy = ops.cv_entropy(feat, rt, hyp, G)
         vis_params, vis_prepared = self._vis_params()
+        tiled = os.environ.get("MVS_CV_TILED", "1") != "0" and ops.cv_tiled_supported(feat)
+        if tiled:                                               # LDS-tiled sweeps straight from the decoder's NCHW maps
+            entropy = ops.cv_tiled_entropy(feat, rt, hyp, G)
+        else:                                                   # direct gather sweeps over channel-last maps (zero-copy if NHWC already)
+            feat = ops.to_channels_last(feat)
+            entropy = ops.cv_entropy(feat, rt, hyp, G)
         weight = ops.vis_wino(entropy, vis_params, vis_prepared) if vis_prepared is not None else ops.vis(entropy, vis_params)
-        volume, sim_depth = ops.cv_aggregate(feat, rt, hyp, weight, G, want_sim_depth=True)
+        if tiled:
+            volume, sim_depth = ops.cv_tiled_aggregate(feat, rt, hyp, weight, G, want_sim_depth=True)
+        else:
+            volume, sim_depth = ops.cv_aggregate(feat, rt, hyp, weight, G, want_sim_depth=True)
 
         # step 3: regularization + head
         if type(tmp) == list:
