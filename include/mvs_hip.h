@@ -79,12 +79,16 @@ int mvs_warp_fwd(const float* src, const float* rt, const float* depth, int dept
  *          sum_v w_v*corr_v / (sum_v w_v + 1e-6)  (mvsformer_model.py:101-105) and, if sim_depth != NULL, the
  *          eval-only similarity arg-max depth (mvsformer_model.py:81-85,151-158)
  *   weight  [B,V-1,H,W]   volume [B,G,D,H,W]   sim_depth [B,H,W] or NULL
+ * flags bit 0 (both sweeps): 0 = sampling coordinates from one reciprocal + Newton step and hardware exp2/log2 in the
+ * entropy (the default: ~1e-4 px / ~1e-6 entropy away from the reference's arithmetic, measured <= 1e-5 relative on the
+ * cascade's depth), 1 = the reference's op order with IEEE divisions (warping.py:90-96) and libm exp/log - what the
+ * training forward uses so that it matches mvs_cv_aggregate_bwd's recomputed geometry bit for bit.
  * Constraints: G == 8, C in {8,16,32,64} (C/G channels per group); sweep A needs (1024/C)*D*4 + 8192 bytes of
  * LDS per block (<= 64 KiB).
  * ------------------------------------------------------------------------------------------------------- */
 int mvs_nchw_to_nhwc(const float* in, float* out, int N, int C, int64_t HW, mvs_stream_t stream);
 int mvs_cv_entropy_fwd(const float* feat, const float* rt, const float* depth,
-                       int B, int V, int C, int G, int D, int H, int W, float* entropy, mvs_stream_t stream);
+                       int B, int V, int C, int G, int D, int H, int W, float* entropy, int flags, mvs_stream_t stream);
 #define MVS_VIS_PARAM_FLOATS 3689
 /* Winograd/MFMA form of the same CNN (vis_net_wino.hip): `prepared` = MVS_VIS_WINO_FLOATS floats written once per
  * parameter set by mvs_vis_wino_prepare(params, prepared) (the two 3x3 layers' weights in F(2x2,3x3) transform domain,
@@ -96,7 +100,7 @@ int mvs_vis_wino_fwd(const float* entropy, const float* params, const float* pre
 int mvs_vis_fwd(const float* entropy, const float* params, int N, int H, int W, float* weight, mvs_stream_t stream);
 int mvs_cv_aggregate_fwd(const float* feat, const float* rt, const float* depth, const float* weight,
                          int B, int V, int C, int G, int D, int H, int W,
-                         float* volume, float* sim_depth, mvs_stream_t stream);
+                         float* volume, float* sim_depth, int flags, mvs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * LDS-tiled form of the same two sweeps (cost_volume_tiled.hip) - the default eval path of StageNet.  Same math as

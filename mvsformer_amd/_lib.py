@@ -31,9 +31,9 @@ SIGNATURES = {
     "mvs_proj_relative": (I, [P, P, I, P, P]),
     "mvs_warp_fwd": (I, [P, P, P, I, I, I, I, I, I, P, P, P]),
     "mvs_nchw_to_nhwc": (I, [P, P, I, I, L, P]),
-    "mvs_cv_entropy_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P]),
+    "mvs_cv_entropy_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, I, P]),
     "mvs_vis_fwd": (I, [P, P, I, I, I, P, P]),
-    "mvs_cv_aggregate_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, P]),
+    "mvs_cv_aggregate_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, I, P]),
     "mvs_cv_tiled_workspace_bytes": (L, [I, I, I, I, I, I]),
     "mvs_cv_tiled_entropy_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, I, P, P]),
     "mvs_cv_tiled_aggregate_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, P, I, P, P]),

@@ -223,7 +223,7 @@ class AggregateFn(torch.autograd.Function):
     def forward(ctx, feat, weight, rt, hyp, G):
         feat_cl = ops.to_channels_last(feat.detach().to(torch.float32).contiguous())
         weight = weight.contiguous()
-        vol, _ = ops.cv_aggregate(feat_cl, rt, hyp, weight, G, want_sim_depth=False)
+        vol, _ = ops.cv_aggregate(feat_cl, rt, hyp, weight, G, want_sim_depth=False, exact=True)   # same geometry as the backward kernel
         ctx.save_for_backward(feat_cl, rt, hyp, weight, vol)
         ctx.G, ctx.dtype = G, feat.dtype
         return vol

@@ -67,11 +67,27 @@ __device__ __forceinline__ float parity_sum16(float v) {
     return dpp_add<DPP_ROR8>(v);
 }
 
+// XCD-aware block order.  Blocks are dispatched round-robin over the 8 XCDs (block i -> XCD i % 8) and every XCD has its own
+// L2, so the natural (x fastest) order makes each XCD pull EVERY feature map through its own L2 (measured 7.6x the
+// algorithmic bytes at stage 1).  The grid is launched 1-D; XCD k takes the k-th contiguous eighth of the logical
+// (z, y, x) order - a band of rows of one (batch, view) - so what neighbouring blocks share stays in one L2.
+struct BlockId { int x, y, z; bool valid; };
+__device__ __forceinline__ BlockId xcd_block(int gx, int gy, int total) {
+    const int per = (total + 7) >> 3;
+    const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    BlockId b;
+    b.valid = logical < total;
+    b.x = logical % gx;
+    b.y = (logical / gx) % gy;
+    b.z = logical / (gx * gy);
+    return b;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // geometry pass: lane l = (p = l % PPW, dd = l / PPW) evaluates sample (pixel x0+p, depth c0+dd) and leaves
 // {tap pixel indices, tap weights} in the wavefront's LDS slab at slot l = dd*PPW + p.
 // ---------------------------------------------------------------------------------------------------------
-template <int PPW>
+template <int PPW, bool FAST>
 __device__ __forceinline__ void geometry_pass(const float* __restrict__ rt, const float* __restrict__ depth_row /* + d*HW */,
                                               size_t HW, int c0, int D, int x0, int y, int H, int W, float half_w, float half_h,
                                               int lane, u32x4* taps_o, f32x4* taps_w) {
@@ -79,9 +95,18 @@ __device__ __forceinline__ void geometry_pass(const float* __restrict__ rt, cons
     const int d = min(c0 + dd, D - 1);                    // clamped duplicates are never consumed
     const int x = min(x0 + p, W - 1);
     const float dv = depth_row[(size_t)d * HW + x];
-    float un, vn, z;
-    mvs::sweep_project(rt, (float)x, (float)y, dv, half_w, half_h, &un, &vn, &z);
-    const mvs::Taps t = mvs::sweep_taps(un, vn, H, W, half_w, half_h);
+    mvs::Taps t;
+    if constexpr (FAST) {
+        const float xf = (float)x, yf = (float)y;
+        const float rx = fmaf(rt[2], 1.0f, fmaf(rt[1], yf, rt[0] * xf));
+        const float ry = fmaf(rt[5], 1.0f, fmaf(rt[4], yf, rt[3] * xf));
+        const float rz = fmaf(rt[8], 1.0f, fmaf(rt[7], yf, rt[6] * xf));
+        t = mvs::sweep_taps_fast(rt, rx, ry, rz, dv, H, W);
+    } else {
+        float un, vn, z;
+        mvs::sweep_project(rt, (float)x, (float)y, dv, half_w, half_h, &un, &vn, &z);
+        t = mvs::sweep_taps(un, vn, H, W, half_w, half_h);
+    }
     taps_o[lane] = u32x4{(unsigned)t.o00, (unsigned)t.o01, (unsigned)t.o10, (unsigned)t.o11};
     taps_w[lane] = f32x4{t.w00, t.w01, t.w10, t.w11};
 }
@@ -130,10 +155,10 @@ constexpr bool pipelined(int LPP) { return LPP <= 4; }
 // ---------------------------------------------------------------------------------------------------------
 // sweep A
 // ---------------------------------------------------------------------------------------------------------
-template <int LPP>
+template <int LPP, bool FAST>
 __global__ __launch_bounds__(64 * NW) void cv_entropy_kernel(const float* __restrict__ feat /*[B,V,H,W,C]*/,
                                                              const float* __restrict__ rt_all, const float* __restrict__ depth,
-                                                             int V, int D, int H, int W, float* __restrict__ entropy) {
+                                                             int V, int D, int H, int W, float* __restrict__ entropy, int gx, int total) {
     constexpr int C = 4 * LPP, CPG = C / G, PPW = 64 / LPP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -143,8 +168,10 @@ __global__ __launch_bounds__(64 * NW) void cv_entropy_kernel(const float* __rest
     f32x4* taps_w = reinterpret_cast<f32x4*>(smem + NW * 128 * 16) + wave * 128;
     float* sims = reinterpret_cast<float*>(smem + NW * 128 * 32) + (size_t)wave * PPW * D;     // [D][PPW]
 
-    const int x0 = (blockIdx.x * NW + wave) * PPW, y = blockIdx.y;
-    const int b = blockIdx.z / (V - 1), sv = blockIdx.z % (V - 1);
+    const BlockId bid = xcd_block(gx, H, total);
+    if (!bid.valid) return;
+    const int x0 = (bid.x * NW + wave) * PPW, y = bid.y;
+    const int b = bid.z / (V - 1), sv = bid.z % (V - 1);
     if (x0 >= W) return;                                   // wave-uniform; no block-wide barrier is used below
     const size_t HW = (size_t)H * W;
     const unsigned pix_bytes = C * 4u;
@@ -170,7 +197,7 @@ __global__ __launch_bounds__(64 * NW) void cv_entropy_kernel(const float* __rest
         if (valid && cq == 0) sims[(c0 + dd) * PPW + pg] = s;
     };
     if constexpr (pipelined(LPP)) {
-        geometry_pass<PPW>(rt, depth_row, HW, 0, D, x0, y, H, W, half_w, half_h, lane, taps_o, taps_w);
+        geometry_pass<PPW, FAST>(rt, depth_row, HW, 0, D, x0, y, H, W, half_w, half_h, lane, taps_o, taps_w);
         int buf = 0;
         for (int c0 = 0; c0 < D; c0 += LPP, buf ^= 1) {
             __builtin_amdgcn_wave_barrier();
@@ -181,7 +208,7 @@ __global__ __launch_bounds__(64 * NW) void cv_entropy_kernel(const float* __rest
                 load_taps4(src, pix_bytes, cq * 16u, taps_o[buf * 64 + dd * PPW + pg], t[dd]);
             }
             if (c0 + LPP < D)
-                geometry_pass<PPW>(rt, depth_row, HW, c0 + LPP, D, x0, y, H, W, half_w, half_h, lane, taps_o + (buf ^ 1) * 64,
+                geometry_pass<PPW, FAST>(rt, depth_row, HW, c0 + LPP, D, x0, y, H, W, half_w, half_h, lane, taps_o + (buf ^ 1) * 64,
                                    taps_w + (buf ^ 1) * 64);
 #pragma unroll
             for (int dd = 0; dd < LPP; ++dd) {
@@ -197,7 +224,7 @@ __global__ __launch_bounds__(64 * NW) void cv_entropy_kernel(const float* __rest
         __builtin_amdgcn_wave_barrier();
     } else
     for (int c0 = 0; c0 < D; c0 += LPP) {
-        geometry_pass<PPW>(rt, depth_row, HW, c0, D, x0, y, H, W, half_w, half_h, lane, taps_o, taps_w);
+        geometry_pass<PPW, FAST>(rt, depth_row, HW, c0, D, x0, y, H, W, half_w, half_h, lane, taps_o, taps_w);
         __builtin_amdgcn_wave_barrier();
         if (c0 + LPP <= D) {
 #pragma unroll
@@ -216,14 +243,16 @@ __global__ __launch_bounds__(64 * NW) void cv_entropy_kernel(const float* __rest
         for (int d = k; d < D; d += LPP) m = fmaxf(m, sims[d * PPW + p]);
 #pragma unroll
         for (int s = PPW; s < 64; s <<= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+        // FAST: hardware exp2 / log2 / reciprocal (1 ulp each) instead of the library sequences - the entropy moves by ~1e-6
         float sum = 0.0f;
-        for (int d = k; d < D; d += LPP) sum += expf(sims[d * PPW + p] - m);
+        for (int d = k; d < D; d += LPP) sum += FAST ? __expf(sims[d * PPW + p] - m) : expf(sims[d * PPW + p] - m);
 #pragma unroll
         for (int s = PPW; s < 64; s <<= 1) sum += __shfl_xor(sum, s, 64);
+        const float inv_sum = __builtin_amdgcn_rcpf(sum);
         float ent = 0.0f;
         for (int d = k; d < D; d += LPP) {
-            const float pr = expf(sims[d * PPW + p] - m) / sum;
-            ent = ent + (-pr) * logf(pr + 1e-7f);
+            const float pr = FAST ? __expf(sims[d * PPW + p] - m) * inv_sum : expf(sims[d * PPW + p] - m) / sum;
+            ent = ent + (-pr) * (FAST ? __logf(pr + 1e-7f) : logf(pr + 1e-7f));
         }
 #pragma unroll
         for (int s = PPW; s < 64; s <<= 1) ent += __shfl_xor(ent, s, 64);
@@ -234,11 +263,11 @@ __global__ __launch_bounds__(64 * NW) void cv_entropy_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------------------
 // sweep B
 // ---------------------------------------------------------------------------------------------------------
-template <int LPP, bool SIM>
+template <int LPP, bool SIM, bool FAST>
 __global__ __launch_bounds__(64 * NW) void cv_aggregate_kernel(const float* __restrict__ feat, const float* __restrict__ rt_all,
                                                                const float* __restrict__ depth, const float* __restrict__ weight,
                                                                int V, int D, int H, int W, float* __restrict__ volume,
-                                                               float* __restrict__ sim_depth) {
+                                                               float* __restrict__ sim_depth, int gx, int total) {
     constexpr int C = 4 * LPP, CPG = C / G, PPW = 64 / LPP;
     constexpr int NG = (CPG >= 4) ? 1 : 4 / CPG;          // correlation groups whose sums live in this lane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -247,7 +276,9 @@ __global__ __launch_bounds__(64 * NW) void cv_aggregate_kernel(const float* __re
     u32x4* taps_o = reinterpret_cast<u32x4*>(smem) + wave * 128;
     f32x4* taps_w = reinterpret_cast<f32x4*>(smem + NW * 128 * 16) + wave * 128;
 
-    const int x0 = (blockIdx.x * NW + wave) * PPW, y = blockIdx.y, b = blockIdx.z;
+    const BlockId bid = xcd_block(gx, H, total);
+    if (!bid.valid) return;
+    const int x0 = (bid.x * NW + wave) * PPW, y = bid.y, b = bid.z;
     if (x0 >= W) return;
     const size_t HW = (size_t)H * W;
     const unsigned pix_bytes = C * 4u;
@@ -290,7 +321,7 @@ __global__ __launch_bounds__(64 * NW) void cv_aggregate_kernel(const float* __re
         const int nviews = V - 1, npass = ((D + LPP - 1) / LPP) * nviews;
         float acc[LPP][NG];
         float simtot[LPP];
-        geometry_pass<PPW>(rt_all + (size_t)(b * nviews) * 12, depth_row, HW, 0, D, x0, y, H, W, half_w, half_h, lane, taps_o, taps_w);
+        geometry_pass<PPW, FAST>(rt_all + (size_t)(b * nviews) * 12, depth_row, HW, 0, D, x0, y, H, W, half_w, half_h, lane, taps_o, taps_w);
         int c0 = 0, sv = 0, buf = 0;
         for (int i = 0; i < npass; ++i, buf ^= 1) {
             if (sv == 0) {
@@ -312,7 +343,7 @@ __global__ __launch_bounds__(64 * NW) void cv_aggregate_kernel(const float* __re
             }
             const int nsv = (sv + 1 == nviews) ? 0 : sv + 1, nc0 = (sv + 1 == nviews) ? c0 + LPP : c0;
             if (i + 1 < npass)
-                geometry_pass<PPW>(rt_all + (size_t)(b * nviews + nsv) * 12, depth_row, HW, nc0, D, x0, y, H, W, half_w, half_h, lane,
+                geometry_pass<PPW, FAST>(rt_all + (size_t)(b * nviews + nsv) * 12, depth_row, HW, nc0, D, x0, y, H, W, half_w, half_h, lane,
                                    taps_o + (buf ^ 1) * 64, taps_w + (buf ^ 1) * 64);
 #pragma unroll
             for (int dd = 0; dd < LPP; ++dd) {
@@ -376,7 +407,7 @@ __global__ __launch_bounds__(64 * NW) void cv_aggregate_kernel(const float* __re
             const mvs::rsrc_t src = mvs::make_rsrc(feat + (size_t)(b * V + sv + 1) * HW * C, (unsigned)(HW * pix_bytes));
             const float wv = wp[(size_t)sv * HW];
             __builtin_amdgcn_wave_barrier();
-            geometry_pass<PPW>(rt, depth_row, HW, c0, D, x0, y, H, W, half_w, half_h, lane, taps_o, taps_w);
+            geometry_pass<PPW, FAST>(rt, depth_row, HW, c0, D, x0, y, H, W, half_w, half_h, lane, taps_o, taps_w);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int dd = 0; dd < LPP; ++dd) {
@@ -497,39 +528,55 @@ extern "C" int mvs_nchw_to_nhwc(const float* in, float* out, int N, int C, int64
 }
 
 extern "C" int mvs_cv_entropy_fwd(const float* feat, const float* rt, const float* depth, int B, int V, int C, int Gin, int D,
-                                  int H, int W, float* entropy, mvs_stream_t stream) {
+                                  int H, int W, float* entropy, int flags, mvs_stream_t stream) {
     MVS_REQUIRE(feat && rt && depth && entropy, "mvs_cv_entropy_fwd: null pointer");
     if (int rc = check_shapes("mvs_cv_entropy_fwd", B, V, C, Gin, D, H, W)) return rc;
     const int LPP = C / 4, PPW = 64 / LPP;
     const size_t lds = (size_t)NW * 128 * 32 + (size_t)NW * PPW * D * sizeof(float);
     MVS_REQUIRE(lds <= 64 * 1024, "mvs_cv_entropy_fwd: D=%d with C=%d needs %zu bytes of LDS (> 64 KiB)", D, C, lds);
-    dim3 grid(mvs::ceil_div(W, NW * PPW), H, B * (V - 1)), block(64 * NW);
+    const int gx = mvs::ceil_div(W, NW * PPW);
+    const int64_t total64 = (int64_t)gx * H * B * (V - 1);
+    MVS_REQUIRE(total64 < ((int64_t)1 << 30), "mvs_cv_entropy_fwd: too many blocks");
+    const int total = (int)total64;
+    dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(64 * NW);
     hipStream_t s = MVS_STREAM(stream);
+    const bool fast = !(flags & 1);
+#define MVS_LAUNCH_ENT(L)                                                                                                       \
+    if (fast) hipLaunchKernelGGL((cv_entropy_kernel<L, true>), grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy, gx, total); \
+    else hipLaunchKernelGGL((cv_entropy_kernel<L, false>), grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy, gx, total)
     switch (LPP) {
-        case 2: hipLaunchKernelGGL(cv_entropy_kernel<2>, grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy); break;
-        case 4: hipLaunchKernelGGL(cv_entropy_kernel<4>, grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy); break;
-        case 8: hipLaunchKernelGGL(cv_entropy_kernel<8>, grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy); break;
-        default: hipLaunchKernelGGL(cv_entropy_kernel<16>, grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy); break;
+        case 2: MVS_LAUNCH_ENT(2); break;
+        case 4: MVS_LAUNCH_ENT(4); break;
+        case 8: MVS_LAUNCH_ENT(8); break;
+        default: MVS_LAUNCH_ENT(16); break;
     }
+#undef MVS_LAUNCH_ENT
     return mvs::finish_launch("mvs_cv_entropy_fwd");
 }
 
 extern "C" int mvs_cv_aggregate_fwd(const float* feat, const float* rt, const float* depth, const float* weight, int B, int V,
-                                    int C, int Gin, int D, int H, int W, float* volume, float* sim_depth,
+                                    int C, int Gin, int D, int H, int W, float* volume, float* sim_depth, int flags,
                                     mvs_stream_t stream) {
     MVS_REQUIRE(feat && rt && depth && weight && volume, "mvs_cv_aggregate_fwd: null pointer");
     if (int rc = check_shapes("mvs_cv_aggregate_fwd", B, V, C, Gin, D, H, W)) return rc;
     const int LPP = C / 4, PPW = 64 / LPP;
-    dim3 grid(mvs::ceil_div(W, NW * PPW), H, B), block(64 * NW);
+    const int gx = mvs::ceil_div(W, NW * PPW);
+    const int64_t total64 = (int64_t)gx * H * B;
+    MVS_REQUIRE(total64 < ((int64_t)1 << 30), "mvs_cv_aggregate_fwd: too many blocks");
+    const int total = (int)total64;
+    dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(64 * NW);
     hipStream_t s = MVS_STREAM(stream);
     const size_t lds = (size_t)NW * 128 * 32;
-#define MVS_LAUNCH_AGG(L)                                                                                               \
-    if (sim_depth)                                                                                                      \
-        hipLaunchKernelGGL((cv_aggregate_kernel<L, true>), grid, block, lds, s, feat, rt, depth, weight, V, D, H, W,    \
-                           volume, sim_depth);                                                                          \
-    else                                                                                                                \
-        hipLaunchKernelGGL((cv_aggregate_kernel<L, false>), grid, block, lds, s, feat, rt, depth, weight, V, D, H, W,   \
-                           volume, sim_depth)
+    const bool fast = !(flags & 1);
+#define MVS_LAUNCH_AGG2(L, SIMV, FASTV)                                                                                  \
+    hipLaunchKernelGGL((cv_aggregate_kernel<L, SIMV, FASTV>), grid, block, lds, s, feat, rt, depth, weight, V, D, H, W, volume, \
+                       sim_depth, gx, total)
+#define MVS_LAUNCH_AGG(L)                                                              \
+    if (sim_depth) {                                                                   \
+        if (fast) MVS_LAUNCH_AGG2(L, true, true); else MVS_LAUNCH_AGG2(L, true, false);   \
+    } else {                                                                           \
+        if (fast) MVS_LAUNCH_AGG2(L, false, true); else MVS_LAUNCH_AGG2(L, false, false); \
+    }
     switch (LPP) {
         case 2: MVS_LAUNCH_AGG(2); break;
         case 4: MVS_LAUNCH_AGG(4); break;
@@ -537,5 +584,6 @@ extern "C" int mvs_cv_aggregate_fwd(const float* feat, const float* rt, const fl
         default: MVS_LAUNCH_AGG(16); break;
     }
 #undef MVS_LAUNCH_AGG
+#undef MVS_LAUNCH_AGG2
     return mvs::finish_launch("mvs_cv_aggregate_fwd");
 }

@@ -53,10 +53,22 @@ struct TileCfg {
     static_assert(TILE_BYTES <= 65536 - 32, "tap offsets must fit the DS instruction's 16-bit immediate");
 };
 // stage 1 / 2 (many planes, few pixels): 4x16 pixels x 4 plane slots; stage 3 / 4 (few planes, many pixels): 16x16 pixels, 4 planes each
-using Cfg64 = TileCfg<64, 16, 4, 4, 1, 16, 768, 3>;
-using Cfg32 = TileCfg<32, 16, 4, 4, 1, 16, 768, 3>;
-using Cfg16 = TileCfg<16, 16, 16, 1, 4, 16, 768, 3>;
-using Cfg8 = TileCfg<8, 16, 16, 1, 4, 8, 1536, 3>;
+#ifndef MVS_T8
+#define MVS_T8 16, 16, 1, 4, 8, 1536, 3
+#endif
+#ifndef MVS_T16
+#define MVS_T16 16, 16, 1, 4, 16, 768, 3
+#endif
+#ifndef MVS_T32
+#define MVS_T32 16, 4, 4, 1, 16, 768, 3
+#endif
+#ifndef MVS_T64
+#define MVS_T64 16, 4, 4, 1, 16, 768, 3
+#endif
+using Cfg64 = TileCfg<64, MVS_T64>;
+using Cfg32 = TileCfg<32, MVS_T32>;
+using Cfg16 = TileCfg<16, MVS_T16>;
+using Cfg8 = TileCfg<8, MVS_T8>;
 
 struct Args {
     const float* feat;     // [B,V,C,H,W]
@@ -71,6 +83,7 @@ struct Args {
     int B, V, D, H, W;
     int ntx, ntiles, nz, total;
     int passes_per_block;  // sweep B
+    int allviews;          // sweep A: one block walks all source views of its tile (nz = 1)
 };
 
 __device__ __forceinline__ float buf_load1(mvs::rsrc_t r, unsigned voff) {
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(NT, T::OCC) void cv_tiled_kernel(const Args a) {
 
     if constexpr (!SWEEP_B) {
         // =========================================== sweep A: z = source view ===========================================
-        const int sv = z;
+        for (int sv = a.allviews ? 0 : z; sv < (a.allviews ? V - 1 : z + 1); ++sv) {
         for (int d0 = 0; d0 < D; d0 += T::PPP) {
             float sim[DCL];
 #pragma unroll
@@ -395,6 +408,8 @@ __global__ __launch_bounds__(NT, T::OCC) void cv_tiled_kernel(const Args a) {
                 ent = ent + (-pr) * logf(pr + 1e-7f);
             }
             a.entropy[(size_t)(b * (V - 1) + sv) * HW + pix] = ent;
+        }
+        if (a.allviews) __syncthreads();                 // sims is rewritten by the next view
         }
     } else {
         // ================================= sweep B: z = group of plane passes, all views =================================
@@ -552,7 +567,8 @@ int launch(const char* who, Args a, bool sim, int flags, hipStream_t s) {
         const int npass = (a.D + T::PPP - 1) / T::PPP;
         a.nz = (npass + a.passes_per_block - 1) / a.passes_per_block;
     } else {
-        a.nz = a.V - 1;
+        a.allviews = (flags >> 2) & 1;
+        a.nz = a.allviews ? 1 : a.V - 1;
     }
     const int64_t total = (int64_t)a.B * a.ntiles * a.nz;
     MVS_REQUIRE(total < ((int64_t)1 << 30), "%s: too many blocks", who);

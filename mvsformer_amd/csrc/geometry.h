@@ -63,6 +63,39 @@ __device__ __forceinline__ Taps sweep_taps(float un, float vn, int H, int W, flo
     return t;
 }
 
+// Fast form of sweep_project + sweep_taps for the fused sweeps (one reciprocal + Newton step instead of four IEEE divisions, no
+// normalize / un-normalize round trip, tap validity as four unsigned compares): the sampling position differs from the
+// reference's by ~1e-4 px (the reference's own coordinates carry that much rounding from the round trip through [-1, 1]), which
+// moves a bilinear sample by ~1e-4 of the local feature gradient - far inside the 1e-3 depth tolerance.  Taps outside the image
+// keep offset 0 and weight 0 exactly as in sweep_taps.  rx, ry, rz = rot @ (x, y, 1) are passed in (computed once per pixel).
+__device__ __forceinline__ Taps sweep_taps_fast(const float* __restrict__ rt, float rx, float ry, float rz, float d, int H, int W) {
+    const float X0 = fmaf(rx, d, rt[9]), X1 = fmaf(ry, d, rt[10]), X2 = fmaf(rz, d, rt[11]);
+    const float zz = X2 + 1e-6f;
+    float rc = __builtin_amdgcn_rcpf(zz);
+    rc = fmaf(rc, fmaf(-zz, rc, 1.0f), rc);
+    // clamp to one texel outside the image: beyond that every tap is invalid anyway; fmaxf/fminf also drop NaN
+    const float ix = fminf(fmaxf(X0 * rc, -2.0f), (float)W + 1.0f);
+    const float iy = fminf(fmaxf(X1 * rc, -2.0f), (float)H + 1.0f);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float wx = ix - x0f, wy = iy - y0f;
+    const float ex = 1.0f - wx, ey = 1.0f - wy;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+    const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+    const int r0 = vy0 ? y0 * W : 0, r1 = vy1 ? (y0 + 1) * W : 0;
+    const int c0 = vx0 ? x0 : 0, c1 = vx1 ? x0 + 1 : 0;
+    Taps t;
+    t.o00 = r0 + c0;
+    t.o01 = r0 + c1;
+    t.o10 = r1 + c0;
+    t.o11 = r1 + c1;
+    t.w00 = (vx0 && vy0) ? ey * ex : 0.0f;
+    t.w01 = (vx1 && vy0) ? ey * wx : 0.0f;
+    t.w10 = (vx0 && vy1) ? wy * ex : 0.0f;
+    t.w11 = (vx1 && vy1) ? wy * wx : 0.0f;
+    return t;
+}
+
 // ---- buffer-descriptor gathers -----------------------------------------------------------------------------
 // A source view's [C,H,W] block is addressed through one wave-uniform buffer descriptor: the per-lane tap
 // offset goes in the 32-bit voffset, the channel plane (c*H*W*4 bytes) in the scalar soffset, so a gather

@@ -145,6 +145,15 @@ def warp(src: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, with_mask: bo
 
 
 # ----------------------------------------------------------------------------------------------- cost volume
+def _cv_flags(exact: Optional[bool]) -> int:
+    """bit 0 of the sweeps' ``flags``: reference op order + IEEE divisions (``exact``) vs reciprocal + hardware exp2/log2 (default;
+    MVS_CV_EXACT=1 flips the default)."""
+    import os
+    if exact is None:
+        exact = os.environ.get("MVS_CV_EXACT", "0") == "1"
+    return 1 if exact else 0
+
+
 def to_channels_last(feat: torch.Tensor) -> torch.Tensor:
     """``[B,V,C,H,W]`` (FPN decoder layout) -> ``[B,V,H,W,C]`` for the gather sweeps.  A tensor that already IS
     channel-last in memory (an FPN decoder run in ``torch.channels_last`` and viewed as ``[B,V,C,H,W]``) is
@@ -160,7 +169,7 @@ def to_channels_last(feat: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def cv_entropy(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, G: int) -> torch.Tensor:
+def cv_entropy(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, G: int, exact: Optional[bool] = None) -> torch.Tensor:
     """``feat`` is channel-last ``[B,V,H,W,C]`` (see :func:`to_channels_last`)."""
     _chk(feat, "features"), _chk(rt, "rt"), _chk(depth, "depth_values")
     B, V, H, W, C = feat.shape
@@ -171,7 +180,7 @@ def cv_entropy(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, G: int
     # algorithmic bytes of a sweep over ALL source views: features once + hypotheses once; the entropy
     # maps themselves are <1 %
     tag = ("cv_entropy_kernel<%d>" % (C // 4), "bytes", 4.0 * B * H * W * (V * C + D))
-    _call("mvs_cv_entropy_fwd", tag, _ptr(feat), _ptr(rt), _ptr(depth), B, V, C, G, D, H, W, _ptr(ent), _stream())
+    _call("mvs_cv_entropy_fwd", tag, _ptr(feat), _ptr(rt), _ptr(depth), B, V, C, G, D, H, W, _ptr(ent), _cv_flags(exact), _stream())
     return ent
 
 
@@ -214,7 +223,7 @@ def vis_wino(entropy: torch.Tensor, params: torch.Tensor, prepared: torch.Tensor
 
 
 def cv_aggregate(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, weight: torch.Tensor, G: int,
-                 want_sim_depth: bool):
+                 want_sim_depth: bool, exact: Optional[bool] = None):
     _chk(feat, "features"), _chk(rt, "rt"), _chk(depth, "depth_values"), _chk(weight, "vis_weight")
     B, V, H, W, C = feat.shape
     D = depth.shape[1]
@@ -223,7 +232,7 @@ def cv_aggregate(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, weig
     tag = ("cv_aggregate_kernel<%d,%s>" % (C // 4, "true" if want_sim_depth else "false"), "bytes",
            4.0 * B * H * W * (V * C + D + G * D))          # 4*H*W*(V*C + D + G*D)
     _call("mvs_cv_aggregate_fwd", tag, _ptr(feat), _ptr(rt), _ptr(depth), _ptr(weight), B, V, C, G, D, H, W,
-          _ptr(vol), _ptr(sim), _stream())
+          _ptr(vol), _ptr(sim), _cv_flags(exact), _stream())
     return vol, sim
 
 
@@ -231,13 +240,6 @@ def cv_tiled_supported(feat: torch.Tensor) -> bool:
     """The LDS-tiled sweeps take the FPN decoder's NCHW ``[B,V,C,H,W]`` maps directly (C in 8/16/32/64, contiguous fp32)."""
     return (isinstance(feat, torch.Tensor) and feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 5 and feat.is_contiguous()
             and feat.shape[2] in (8, 16, 32, 64))
-
-
-def _cv_flags(exact: Optional[bool]) -> int:
-    import os
-    if exact is None:
-        exact = os.environ.get("MVS_CV_EXACT", "0") == "1"
-    return 1 if exact else 0
 
 
 def cv_tiled_entropy(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, G: int, exact: Optional[bool] = None,

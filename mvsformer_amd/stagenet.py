@@ -73,7 +73,9 @@ class StageNet(nn.Module):
         # step 2 of the reference forward: fused warp + group correlation + visibility-weighted aggregation
         rt = ops.proj_prepare(proj)
         vis_params, vis_prepared = self._vis_params()
-        tiled = os.environ.get("MVS_CV_TILED", "1") != "0" and ops.cv_tiled_supported(feat)
+        # MVS_CV_TILED=1: the LDS-tiled sweeps (cost_volume_tiled.hip).  Measured: they win on spatially coherent
+        # hypotheses, lose on the noisy ones a random-weight cascade predicts, so the direct sweeps stay the default.
+        tiled = os.environ.get("MVS_CV_TILED", "0") == "1" and ops.cv_tiled_supported(feat)
         if tiled:                                               # LDS-tiled sweeps straight from the decoder's NCHW maps
             entropy = ops.cv_tiled_entropy(feat, rt, hyp, G)
         else:                                                   # direct gather sweeps over channel-last maps (zero-copy if NHWC already)
@@ -106,7 +108,7 @@ class StageNet(nn.Module):
         hyp = depth_values.detach().to(torch.float32).contiguous()
         rt = ops.proj_prepare(proj)
         feat_cl = ops.to_channels_last(features.detach().to(torch.float32))
-        entropy = ops.cv_entropy(feat_cl, rt, hyp, G)                       # sim_vol.detach() in the reference
+        entropy = ops.cv_entropy(feat_cl, rt, hyp, G, exact=True)           # sim_vol.detach() in the reference
         V = features.shape[1]
         weight = ag.vis_train_views(entropy, self.vis)                     # per-view statistics, one batched pass
         volume = ag.AggregateFn.apply(features, weight, rt, hyp, G)

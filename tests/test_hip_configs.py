@@ -80,13 +80,17 @@ def run_stage_vs_oracle(dev, C, ndepth, H, W, V, full_hw, seed, B=1, tmp=5.0):
     with torch.no_grad():
         got = net(feat.to(dev), proj.to(dev), hyp.to(dev), tmp=tmp)
         rt = ops.proj_prepare(proj.to(dev))
-        fcl = ops.to_channels_last(feat.to(dev))
-        ent = ops.cv_entropy(fcl, rt, hyp.to(dev), 8)
-        vol, _ = ops.cv_aggregate(fcl, rt, hyp.to(dev), torch.cat(taps["vis_weight"], 1).to(dev).contiguous(), 8, False)
-    # entropy spans [0, ln D]: 1e-4 absolute with a 1e-3 hard ceiling; volume_mean is O(1)
-    close_frac(ent, torch.cat(taps["entropy"], 1), 1e-4, frac=2e-3, hard=1e-3, what="entropy")
-    close_frac(vol, taps["volume_mean"], 1e-4 * max(1.0, taps["volume_mean"].abs().max().item()), frac=1e-3,
-               hard=1e-3 * max(1.0, taps["volume_mean"].abs().max().item()), what="volume_mean")
+        fg, hg = feat.to(dev).contiguous(), hyp.to(dev)
+        wg = torch.cat(taps["vis_weight"], 1).to(dev).contiguous()
+        fcl = ops.to_channels_last(fg)
+        sweeps = {"direct": (ops.cv_entropy(fcl, rt, hg, 8), ops.cv_aggregate(fcl, rt, hg, wg, 8, False)[0]),
+                  "tiled": (ops.cv_tiled_entropy(fg, rt, hg, 8), ops.cv_tiled_aggregate(fg, rt, hg, wg, 8, False)[0])}
+    # both implementations in their default (fast) arithmetic.  entropy spans [0, ln D]: 2e-4 absolute with a 2e-3 hard ceiling;
+    # volume_mean is O(1)
+    vscale = max(1.0, taps["volume_mean"].abs().max().item())
+    for impl, (ent, vol) in sweeps.items():
+        close_frac(ent, torch.cat(taps["entropy"], 1), 2e-4, frac=2e-3, hard=2e-3, what=impl + " entropy")
+        close_frac(vol, taps["volume_mean"], 2e-4 * vscale, frac=1e-3, hard=2e-3 * vscale, what=impl + " volume_mean")
     assert rel_err(got["depth"].cpu(), want["depth"]) < DEPTH_RTOL
     assert max_abs(got["prob_volume_pre"].cpu(), want["prob_volume_pre"]) < 5e-4
     assert max_abs(got["photometric_confidence"].cpu(), want["photometric_confidence"]) < 1e-4

@@ -88,8 +88,25 @@ def test_warp_general(dev, which):
 
 
 # ------------------------------------------------------------------------------------------------ a3/a4
+def _sweeps(impl, exact):
+    """(entropy fn, aggregate fn) of one implementation: ``direct`` gathers channel-last maps, ``tiled`` stages NCHW maps through
+    LDS; ``exact`` = reference op order with IEEE divisions, else reciprocal + hardware exp2/log2 (the default)."""
+    from mvsformer_amd import ops
+    if impl == "direct":
+        return (lambda f, rt, hyp: ops.cv_entropy(ops.to_channels_last(f), rt, hyp, 8, exact=exact),
+                lambda f, rt, hyp, w, sim: ops.cv_aggregate(ops.to_channels_last(f), rt, hyp, w, 8, sim, exact=exact))
+    return (lambda f, rt, hyp: ops.cv_tiled_entropy(f.contiguous(), rt, hyp, 8, exact=exact),
+            lambda f, rt, hyp, w, sim: ops.cv_tiled_aggregate(f.contiguous(), rt, hyp, w, 8, sim, exact=exact))
+
+
+# exact arithmetic reproduces the reference's intermediates to summation order (5e-5); the default fast arithmetic samples ~1e-4 px
+# away (one reciprocal instead of four IEEE divisions), which moves O(1) correlations by up to ~2e-4
+SWEEP_VARIANTS = [("direct", True, 5e-5), ("direct", False, 3e-4), ("tiled", True, 5e-5), ("tiled", False, 3e-4)]
+
+
+@pytest.mark.parametrize("impl,exact,tol", SWEEP_VARIANTS)
 @pytest.mark.parametrize("kind", ["costregnet", "costregnet3d"])
-def test_cost_volume_taps(dev, kind):
+def test_cost_volume_taps(dev, kind, impl, exact, tol):
     """Sweep A entropy, fused vis CNN, sweep B volume and similarity depth against the reference's intermediates."""
     import mvsformer_amd as m
     from mvsformer_amd import ops
@@ -97,29 +114,33 @@ def test_cost_volume_taps(dev, kind):
     net = m.StageNet(dict(base_ch=8, fusion_type="cnn", depth_type="ce"), int(g["ndepth"]), 1)
     net.load_state_dict(make_sd("stage_" + kind, g["weight_seed"]), strict=True)
     net = net.to(dev).eval()
-    feat, proj, hyp = ops.to_channels_last(g2d(g["features"], dev)), g2d(g["proj"], dev), g2d(g["depth_values"], dev)
-    assert torch.equal(feat.cpu(), t(g["features"]).permute(0, 1, 3, 4, 2).contiguous())
+    feat, proj, hyp = g2d(g["features"], dev), g2d(g["proj"], dev), g2d(g["depth_values"], dev)
+    assert torch.equal(ops.to_channels_last(feat).cpu(), t(g["features"]).permute(0, 1, 3, 4, 2).contiguous())
+    sweep_a, sweep_b = _sweeps(impl, exact)
     rt = ops.proj_prepare(proj)
-    ent = ops.cv_entropy(feat, rt, hyp, 8)
-    robust_close(ent, g["tap_entropy"], atol=5e-5, frac=0, hard=5e-5)
+    ent = sweep_a(feat, rt, hyp)
+    robust_close(ent, g["tap_entropy"], atol=tol, frac=0, hard=tol)
     vis_params, vis_prepared = net._vis_params()
     w = ops.vis(ent, vis_params)
-    robust_close(w, g["tap_vis_weight"], atol=2e-5, frac=0)
+    robust_close(w, g["tap_vis_weight"], atol=max(2e-5, tol), frac=0)
     # vis CNN alone on the reference's own entropy (decouples the two kernels): VALU kernel and Winograd/MFMA kernel
     w2 = ops.vis(g2d(g["tap_entropy"], dev), vis_params)
     robust_close(w2, g["tap_vis_weight"], atol=1e-5, frac=0)
     w3 = ops.vis_wino(g2d(g["tap_entropy"], dev), vis_params, vis_prepared)
     robust_close(w3, g["tap_vis_weight"], atol=1e-5, frac=0)
-    vol, sim = ops.cv_aggregate(feat, rt, hyp, g2d(g["tap_vis_weight"], dev), 8, want_sim_depth=True)
-    robust_close(vol, g["tap_volume_mean"], atol=5e-5, frac=0, hard=5e-5)
+    vol, sim = sweep_b(feat, rt, hyp, g2d(g["tap_vis_weight"], dev), True)
+    robust_close(vol, g["tap_volume_mean"], atol=tol, frac=0, hard=tol)
     assert (sim.cpu().numpy() != g["eval_sim_depth"]).mean() < 0.02
-    vol2, none = ops.cv_aggregate(feat, rt, hyp, g2d(g["tap_vis_weight"], dev), 8, want_sim_depth=False)
+    vol2, none = sweep_b(feat, rt, hyp, g2d(g["tap_vis_weight"], dev), False)
     assert none is None and torch.equal(vol, vol2)
 
 
-@pytest.mark.parametrize("C,D,H,W,V", [(64, 6, 9, 70, 3), (32, 5, 17, 33, 2), (16, 3, 8, 130, 4), (8, 2, 5, 64, 2), (64, 48, 8, 16, 2)])
-def test_cost_volume_vs_oracle_odd_sizes(dev, C, D, H, W, V):
-    """Ragged sizes (W not a multiple of 64, odd D, D not divisible by the depth-slice count) against the CPU oracle."""
+@pytest.mark.parametrize("impl,exact,tol", SWEEP_VARIANTS)
+@pytest.mark.parametrize("C,D,H,W,V", [(64, 6, 9, 70, 3), (32, 5, 17, 33, 2), (16, 3, 8, 130, 4), (8, 2, 5, 64, 2), (64, 48, 8, 16, 2),
+                                       (8, 9, 21, 37, 3), (16, 8, 40, 52, 6), (32, 16, 12, 44, 8)])
+def test_cost_volume_vs_oracle_odd_sizes(dev, C, D, H, W, V, impl, exact, tol):
+    """Ragged sizes (W not a multiple of 64 or of 4, odd D, D not divisible by the planes per pass, up to 7 source views) against
+    the CPU oracle."""
     from mvsformer_amd import ops, synth
     from oracle import ref_torch
     gen = torch.Generator().manual_seed(C * 131 + D)
@@ -138,14 +159,44 @@ def test_cost_volume_vs_oracle_odd_sizes(dev, C, D, H, W, V):
         sims = sims + ref_torch.group_similarity(feat[:, 0], warped, 8)
         vol_sum = vol_sum + ip * weight[:, v - 1:v].unsqueeze(1)
     want_vol = vol_sum / (weight.sum(1, keepdim=True).unsqueeze(1) + 1e-6)
+    sweep_a, sweep_b = _sweeps(impl, exact)
     rt = ops.proj_prepare(proj.to(dev))
-    feat_cl = ops.to_channels_last(feat.to(dev))
-    ent = ops.cv_entropy(feat_cl, rt, hyp.to(dev), 8)
-    robust_close(ent, torch.cat(ents, 1), atol=1e-4, frac=2e-3)
-    vol, sim = ops.cv_aggregate(feat_cl, rt, hyp.to(dev), weight.to(dev), 8, True)
-    robust_close(vol, want_vol, atol=1e-4, frac=2e-3)
+    ent = sweep_a(feat.to(dev), rt, hyp.to(dev))
+    robust_close(ent, torch.cat(ents, 1), atol=2 * tol, frac=2e-3)
+    vol, sim = sweep_b(feat.to(dev), rt, hyp.to(dev), weight.to(dev), True)
+    robust_close(vol, want_vol, atol=2 * tol, frac=2e-3)
     want_sim = torch.gather(hyp, 1, sims.argmax(1, keepdim=True)).squeeze(1)
     assert (sim.cpu() != want_sim).double().mean() < 0.03
+
+
+def test_tiled_sweeps_equal_direct_sweeps_exactly(dev):
+    """Same arithmetic, different data movement: in exact mode the LDS-tiled sweeps reproduce the direct sweeps' volume BIT FOR
+    BIT (same blend and summation order) and the entropy to the softmax's rounding, including the rounds whose tap box does
+    not fit the LDS tile (wild hypotheses: behind the camera, far outside the frustum) and a batch of 2."""
+    from mvsformer_amd import ops, synth
+    for C, D, H, W, V, wild in ((8, 4, 40, 64, 3, False), (16, 8, 40, 56, 5, True), (32, 16, 24, 32, 3, False), (64, 32, 16, 24, 5, True)):
+        scale = {64: 8, 32: 4, 16: 2, 8: 1}[C]
+        scene = synth.make_scene(V, H * scale, W * scale, seed=C)
+        feat = synth.render_features(scene, scale, C, batch=2, device=dev).contiguous()
+        proj = synth.proj_matrices(scene, (scale,), 2, device=dev)["stage1"]
+        g = torch.Generator().manual_seed(C)
+        if wild:
+            hyp = (torch.rand(2, D, H, W, generator=g) * 1500.0 - 200.0).to(dev)
+        else:
+            z = synth.plane_depth(scene, scale, device=dev)
+            hyp = (1.0 / (1.0 / z[None, None] + torch.linspace(1, -1, D, device=dev).view(1, D, 1, 1) * (1e-5 * D))).repeat(2, 1, 1, 1).contiguous()
+        w = torch.rand(2, V - 1, H, W, generator=g).to(dev)
+        rt = ops.proj_prepare(proj)
+        fcl = ops.to_channels_last(feat)
+        stats = torch.zeros(2, dtype=torch.int32, device=dev)
+        e0, (v0, s0) = ops.cv_entropy(fcl, rt, hyp, 8, exact=True), ops.cv_aggregate(fcl, rt, hyp, w, 8, True, exact=True)
+        e1 = ops.cv_tiled_entropy(feat, rt, hyp, 8, exact=True, stats=stats)
+        v1, s1 = ops.cv_tiled_aggregate(feat, rt, hyp, w, 8, True, exact=True)
+        assert torch.equal(v0, v1), (C, (v0 - v1).abs().max().item())
+        assert (e0 - e1).abs().max().item() < 5e-6
+        assert (s0 != s1).double().mean().item() < 0.01
+        nofit = stats[1].item() / max(1, stats[0].item())
+        assert (nofit > 0.5) == wild, (C, nofit)         # the wild cases exercise the direct-gather rounds, the others the LDS rounds
 
 
 # ------------------------------------------------------------------------------------------------ a5/a6
