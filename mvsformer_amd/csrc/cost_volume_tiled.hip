@@ -252,10 +252,13 @@ __global__ __launch_bounds__(NT, T::OCC) void cv_tiled_kernel(const Args a) {
         lymax = row_reduce<true>(lymax);
         __syncthreads();                                 // [A] previous round's LDS reads done; box[cur] was reset after its last use
         if ((tid & 15) == 0 && lxmin <= lxmax) {
-            atomicMin(&box[cur * 4 + 0], lxmin);
-            atomicMin(&box[cur * 4 + 1], lymin);
-            atomicMax(&box[cur * 4 + 2], lxmax);
-            atomicMax(&box[cur * 4 + 3], lymax);
+            // one DS atomic per value from the row leaders, written out: hipcc's atomic optimizer otherwise wraps each atomicMin/Max
+            // in a scalar loop over the active lanes (~100 instructions per round).  The dynamic LDS block starts at LDS address 0
+            // (this kernel has no static __shared__), and the wait is inside the asm because the compiler cannot see these DS ops
+            // when it decides whether the barrier below needs one
+            const unsigned baddr = (unsigned)(T::TILE_BYTES + cur * 16);
+            asm volatile("ds_min_i32 %0, %1\n\tds_min_i32 %0, %2 offset:4\n\tds_max_i32 %0, %3 offset:8\n\tds_max_i32 %0, %4 offset:12\n\ts_waitcnt lgkmcnt(0)"
+                         :: "v"(baddr), "v"(lxmin), "v"(lymin), "v"(lxmax), "v"(lymax) : "memory");
         }
         __syncthreads();                                 // [B]
         const int xmin = box[cur * 4 + 0], ymin = box[cur * 4 + 1], xmax = box[cur * 4 + 2], ymax = box[cur * 4 + 3];
@@ -400,12 +403,13 @@ __global__ __launch_bounds__(NT, T::OCC) void cv_tiled_kernel(const Args a) {
         if (slot == 0 && inimg) {                        // softmax_d entropy (mvsformer_model.py:88-90), one thread per pixel
             float m = -INFINITY;
             for (int d = 0; d < D; ++d) m = fmaxf(m, sims[d * TP + pi]);
-            float sum = 0.0f;
-            for (int d = 0; d < D; ++d) sum += expf(sims[d * TP + pi] - m);
+            float sum = 0.0f;                            // FAST: hardware exp2 / log2 / reciprocal, as the direct sweep
+            for (int d = 0; d < D; ++d) sum += FAST ? __expf(sims[d * TP + pi] - m) : expf(sims[d * TP + pi] - m);
+            const float inv_sum = __builtin_amdgcn_rcpf(sum);
             float ent = 0.0f;
             for (int d = 0; d < D; ++d) {
-                const float pr = expf(sims[d * TP + pi] - m) / sum;
-                ent = ent + (-pr) * logf(pr + 1e-7f);
+                const float pr = FAST ? __expf(sims[d * TP + pi] - m) * inv_sum : expf(sims[d * TP + pi] - m) / sum;
+                ent = ent + (-pr) * (FAST ? __logf(pr + 1e-7f) : logf(pr + 1e-7f));
             }
             a.entropy[(size_t)(b * (V - 1) + sv) * HW + pix] = ent;
         }
