@@ -2,9 +2,10 @@
 """bench_train.py — training-step throughput of the plane-sweep path at BASELINE config 3 geometry (not the judged
 metric; bench.py is).  One step = forward + backward of the 4-stage cascade (ndepths 32/16/8/8 as BASELINE states) on
 one 640x512, 5-view sample per GPU with the reference's ``ce_loss_stage4`` (fused HIP kernel) on every stage's ``prob_volume_pre``, plus an AdamW
-step.  With N > 1 (torchrun) the cascade is wrapped in DistributedDataParallel: RCCL gradient all-reduce over xGMI,
-SyncBatchNorm statistics exchanged by the BatchNorm autograd function.  fp32 (the reference trains under fp16 autocast
-with the cost volume forced to fp32; a bf16 MFMA path for the regularizer is future work).
+step.  With N > 1 the cascade is wrapped in DistributedDataParallel: RCCL gradient all-reduce over xGMI,
+SyncBatchNorm statistics exchanged by the BatchNorm autograd function.  ``--dtype bf16`` (default) is the config-3 line: forward
+under ``torch.autocast(bfloat16)`` as the reference trainer does (trainer/mvsformer_trainer.py:104-106) - bf16 regularizer on the
+bf16 matrix cores, fp32 cost volume / statistics / head / loss / master weights; ``--dtype f32`` keeps everything fp32.
 
     python bench_train.py --steps 10 [--gpus N]          (N > 1 without a launcher: spawns one rank per GPU itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 bench_train.py --gpus 8 --steps 10
@@ -29,6 +30,10 @@ def parse():
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP + SyncBatchNorm even with one rank (smoke test)")
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
+                    help="bf16 (BASELINE configs[2]): forward under torch.autocast(bfloat16) - the regularizer runs on bf16 channel-last "
+                         "activations and v_mfma_f32_16x16x32_bf16, the cost volume, BatchNorm statistics, head and loss stay fp32, "
+                         "master weights fp32 (what the reference's autocast training does); f32: everything fp32")
     return ap.parse_args()
 
 
@@ -57,9 +62,13 @@ def main(args):
     gts = {"stage%d" % (i + 1): synth.plane_depth(scene, s, device=dev)[None] for i, s in enumerate(synth.STAGE_SCALES)}
     masks = {k: torch.ones_like(v) for k, v in gts.items()}
 
+    import contextlib
+    amp = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if args.dtype == "bf16" else contextlib.nullcontext
+
     def step():
         opt.zero_grad(set_to_none=True)
-        out = model(feats, proj, dv, tmp=[5.0, 5.0, 5.0, 1.0])
+        with amp():
+            out = model(feats, proj, dv, tmp=[5.0, 5.0, 5.0, 1.0])
         # the reference's loss for depth_type='ce' (trainer/mvsformer_trainer.py:119-120), fused HIP kernel per stage
         loss = sum(ce_loss_stage4(out, gts, masks, dlossw=[1, 1, 1, 1], inverse_depth=True).values())
         loss.backward()
@@ -83,7 +92,7 @@ def main(args):
     if rank == 0:
         print(json.dumps({"metric": "training samples/s (fwd+bwd+AdamW), 640x512, 5 views, cascade 32/16/8/8", "value": round(world * args.steps / dt.item(), 3),
                           "unit": "samples/s", "n_gpus": world, "steps": args.steps, "ms_per_step": round(dt.item() / args.steps * 1e3, 2),
-                          "dtype": "f32", "data": "synthetic", "scaling": "weak", "final_loss": round(float(loss.detach()), 4),
+                          "dtype": args.dtype, "data": "synthetic", "scaling": "weak", "final_loss": round(float(loss.detach()), 4),
                           "parallelism": "DDP + SyncBatchNorm over RCCL" if ddp else "single GPU"}))
     if ddp:
         dist.destroy_process_group()

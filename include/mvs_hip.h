@@ -228,6 +228,41 @@ int mvs_bn_bwd_apply(const float* dy, const float* x, const float* scale, const 
                      int B, int C, int64_t N, float* dx, mvs_stream_t stream);
 int mvs_conv3d_wgrad(const float* A, const float* Bt, float* dW, int nbatch, int CA, int CB, int Dp, int Hp, int Wp, int Db,
                      int Hb, int Wb, int sd, int shw, mvs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * bf16 regularizer for training under autocast (BASELINE configs[2]; the reference wraps the model in torch.cuda.amp.autocast,
+ * trainer/mvsformer_trainer.py:43-45,104-106, so Conv3d / ConvTranspose3d of models/module.py:83-165,469-594 run in half
+ * precision with fp32 accumulation while the cost volume stays fp32, models/mvsformer_model.py:65,68,78).  Activations are bf16
+ * CHANNEL-LAST [B,D,H,W,C] (void* = device bf16), parameters stay fp32 and are packed to bf16 per call; every kernel
+ * accumulates in fp32 on v_mfma_f32_16x16x32_bf16.  Channels: 8, 16, 32 or 64.
+ *   mvs_bf16_packed_elems / mvs_bf16_pack_weights: w = [d0][d1][27] fp32 -> per-lane MFMA A fragments of a Cin -> Cout map;
+ *       src 0: w[cout][cin][tap] (Conv3d forward, ConvTranspose3d data gradient), 1: w[cin][cout][tap] (ConvTranspose3d forward,
+ *       strided Conv3d data gradient), 2: w[cin][cout][26 - tap] (stride-1 Conv3d data gradient)
+ *   mvs_bf16_conv3d: gather 0 = Conv3d k3 p1 stride (sd,shw,shw); gather 1 = ConvTranspose3d k3 p1 output_padding stride-1;
+ *       optional fused epilogue y = [relu](acc*scale + shift) [+ residual] (NULL scale/shift: raw output for batch-stat BatchNorm)
+ *   mvs_bf16_conv3d_wgrad: dW[a][b][tap] += sum A[p][a] * Bt[p*s - 1 + k][b] (dW fp32, zeroed by the caller; same operand roles as
+ *       mvs_conv3d_wgrad)
+ *   mvs_bf16_from_f32_ncdhw / mvs_bf16_to_f32_ncdhw: fp32 [B,C,N] <-> bf16 [B,N,C]
+ *   mvs_bf16_bn_stats / mvs_bf16_affine_act / mvs_bf16_bn_bwd_reduce / mvs_bf16_bn_bwd_apply: channel-last bf16 twins of
+ *       mvs_bn_stats / mvs_affine_act / mvs_bn_bwd_reduce / mvs_bn_bwd_apply over R = B*D*H*W rows (fp32 statistics;
+ *       mvs_bn_finalize is shared)
+ * ------------------------------------------------------------------------------------------------------- */
+int64_t mvs_bf16_packed_elems(int Cin, int Cout);
+int mvs_bf16_pack_weights(const float* w, int d0, int d1, int src, int Cout, int Cin, void* wpacked, mvs_stream_t stream);
+int mvs_bf16_conv3d(const void* x, const void* wpacked, const float* scale, const float* shift, const void* residual, void* y,
+                    int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd, int shw, int relu, mvs_stream_t stream);
+int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, int nbatch, int CA, int CB, int Dp, int Hp, int Wp, int Db, int Hb,
+                          int Wb, int sd, int shw, mvs_stream_t stream);
+int mvs_bf16_from_f32_ncdhw(const float* in, void* out, int B, int C, int64_t N, mvs_stream_t stream);
+int mvs_bf16_to_f32_ncdhw(const void* in, float* out, int B, int C, int64_t N, mvs_stream_t stream);
+int mvs_bf16_bn_stats(const void* x, int C, int64_t R, float* sums, mvs_stream_t stream);
+int mvs_bf16_affine_act(const void* x, const float* scale, const float* shift, const void* residual, int relu, int C, int64_t R,
+                        void* y, mvs_stream_t stream);
+int mvs_bf16_bn_bwd_reduce(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
+                           const float* invstd, int relu, int C, int64_t R, float* sums, mvs_stream_t stream);
+int mvs_bf16_bn_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
+                          const float* invstd, const float* gamma, const float* sums, double count, const float* count_dev,
+                          int relu, int C, int64_t R, void* dx, mvs_stream_t stream);
 int mvs_cv_aggregate_bwd(const float* feat, const float* rt, const float* depth, const float* weight, const float* volume,
                          const float* gvolume, int B, int V, int C, int G, int D, int H, int W, float* dfeat, float* dweight,
                          mvs_stream_t stream);

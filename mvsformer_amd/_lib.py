@@ -50,6 +50,16 @@ SIGNATURES = {
     "mvs_bn_bwd_reduce": (I, [P, P, P, P, P, P, I, I, I, L, P, P]),
     "mvs_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, Dbl, P, I, I, I, L, P, P]),
     "mvs_conv3d_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "mvs_bf16_packed_elems": (L, [I, I]),
+    "mvs_bf16_pack_weights": (I, [P, I, I, I, I, I, P, P]),
+    "mvs_bf16_conv3d": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "mvs_bf16_conv3d_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "mvs_bf16_from_f32_ncdhw": (I, [P, P, I, I, L, P]),
+    "mvs_bf16_to_f32_ncdhw": (I, [P, P, I, I, L, P]),
+    "mvs_bf16_bn_stats": (I, [P, I, L, P, P]),
+    "mvs_bf16_affine_act": (I, [P, P, P, P, I, I, L, P, P]),
+    "mvs_bf16_bn_bwd_reduce": (I, [P, P, P, P, P, P, I, I, L, P, P]),
+    "mvs_bf16_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, Dbl, P, I, I, L, P, P]),
     "mvs_cv_aggregate_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P]),
     "mvs_softmax_bwd": (I, [P, P, I, I, L, P, P]),
     "mvs_prob1_bwd": (I, [P, P, P, I, I, L, P, P, P]),

@@ -294,3 +294,124 @@ def vis_train_views(entropy: torch.Tensor, vis: nn.Sequential) -> torch.Tensor:
         x = BnActFn.apply(x, blk.bn.weight, blk.bn.bias, None, blk.bn, True, Vs)
     y = Prob1Fn.apply(x, vis[3].weight, vis[3].bias)                    # [B*Vs,1,1,H,W]
     return SigmoidFn.apply(y).reshape(B, Vs, H, W)
+
+
+# =========================================================================================================
+# bf16 channel-last regularizer (training under torch autocast; reference trainer/mvsformer_trainer.py:104-106)
+# =========================================================================================================
+class ToBf16Fn(torch.autograd.Function):
+    """fp32 ``[B,C,D,H,W]`` -> bf16 channel-last ``[B,D,H,W,C]`` (the cost volume enters the half-precision regularizer)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.bf16_from_f32(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.bf16_to_f32(dy.contiguous())
+
+
+class FromBf16Fn(torch.autograd.Function):
+    """bf16 channel-last -> fp32 ``[B,C,D,H,W]`` (the logits leave it)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.bf16_to_f32(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.bf16_from_f32(dy.contiguous())
+
+
+class ConvBf16Fn(torch.autograd.Function):
+    """Raw 3x3x3 convolution on bf16 channel-last activations, fp32 master weight ``[Cout,Cin,3,3,3]`` cast per call."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride):
+        x = x.contiguous()
+        w = weight.detach().to(torch.float32).contiguous()
+        cout, cin = w.shape[0], w.shape[1]
+        y = ops.bf16_conv3d(x, ops.bf16_pack(w, 0, cin, cout), cin, cout, 0, stride)
+        ctx.save_for_backward(x, w)
+        ctx.stride = stride
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        cout, cin = w.shape[0], w.shape[1]
+        sd, shw = ctx.stride
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if shw == 1:        # stride-1 conv: the data gradient is the same conv with channels swapped and taps mirrored
+                dx = ops.bf16_conv3d(dy, ops.bf16_pack(w, 2, cout, cin), cout, cin, 0, (1, 1))
+            else:               # strided conv: the transposed conv of the same weight
+                dx = ops.bf16_conv3d(dy, ops.bf16_pack(w, 1, cout, cin), cout, cin, 1, (sd, shw))
+            if dx.shape != x.shape:
+                raise ops._lib.MvsHipError("conv backward: input %s is not 2x the output grid %s" % (tuple(x.shape), tuple(dy.shape)))
+        dw = ops.bf16_conv3d_wgrad(dy, x, (sd, shw)) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
+class DeconvBf16Fn(torch.autograd.Function):
+    """Raw ConvTranspose3d k3, stride (sd,2,2), padding 1, output_padding (sd-1,1,1) on bf16 channel-last activations."""
+
+    @staticmethod
+    def forward(ctx, x, weight, sd):
+        x = x.contiguous()
+        w = weight.detach().to(torch.float32).contiguous()          # [Cin,Cout,3,3,3]
+        cin, cout = w.shape[0], w.shape[1]
+        y = ops.bf16_conv3d(x, ops.bf16_pack(w, 1, cin, cout), cin, cout, 1, (sd, 2))
+        ctx.save_for_backward(x, w)
+        ctx.sd = sd
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        cin, cout = w.shape[0], w.shape[1]
+        dx = None
+        if ctx.needs_input_grad[0]:   # strided conv of dY with W read as [out = cin, in = cout]
+            dx = ops.bf16_conv3d(dy, ops.bf16_pack(w, 0, cout, cin), cout, cin, 0, (ctx.sd, 2))
+        dw = ops.bf16_conv3d_wgrad(x, dy, (ctx.sd, 2)) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
+class BnActBf16Fn(torch.autograd.Function):
+    """Training-mode BatchNorm (fp32 batch statistics of the bf16 conv output, running-stat update) + ReLU + optional skip,
+    channel-last bf16 in and out; SyncBatchNorm statistics ride the same all-reduce as in :class:`BnActFn`."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, bn, relu):
+        x = x.contiguous()
+        C = x.shape[-1]
+        count = float(x.numel() // C)
+        sums = ops.bf16_bn_stats(x)
+        sums, count_dev = _sync_sums(sums, count, bn)
+        g = gamma.detach().to(torch.float32).contiguous() if gamma is not None else None
+        b = beta.detach().to(torch.float32).contiguous() if beta is not None else None
+        track = bn.track_running_stats and bn.running_mean is not None
+        rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
+        scale, shift, mean, invstd = ops.bn_finalize(sums, g, b, rm, rv, _momentum(bn) if track else 0.0, bn.eps, count, count_dev)
+        if track and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        res = residual.contiguous() if residual is not None else None
+        y = ops.bf16_affine_act(x, scale, shift, res, relu)
+        ctx.save_for_backward(x, scale, shift, mean, invstd, g if g is not None else scale.new_ones(C), count_dev)
+        ctx.relu, ctx.count, ctx.bn, ctx.has_res = relu, count, bn, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, shift, mean, invstd, g, count_dev = ctx.saved_tensors
+        dy = dy.contiguous()
+        sums = ops.bf16_bn_bwd_reduce(dy, x, scale, shift, mean, invstd, ctx.relu)
+        C = x.shape[-1]
+        local = sums.clone()
+        sums, _ = _sync_sums(sums, 0.0, ctx.bn)
+        dx = ops.bf16_bn_bwd_apply(dy, x, scale, shift, mean, invstd, g, sums, ctx.count, ctx.relu, count_dev)
+        dgamma = local[C:].clone() if ctx.needs_input_grad[1] else None
+        dbeta = local[:C].clone() if ctx.needs_input_grad[2] else None
+        return dx, dgamma, dbeta, (dy if ctx.has_res else None), None, None

@@ -1,0 +1,547 @@
+// bf16 regularizer for training under autocast (BASELINE configs[2]; reference trainer/mvsformer_trainer.py:43-45,104-106 wraps the
+// model in torch.cuda.amp.autocast: Conv3d / ConvTranspose3d of models/module.py:83-165,469-594 then run in half precision with
+// fp32 accumulation and half-precision activations, BatchNorm statistics in fp32; the cost volume itself stays fp32,
+// models/mvsformer_model.py:65,68,78).
+//
+// MI355X form: activations are bf16 CHANNEL-LAST [B,D,H,W,C] (NDHWC) in HBM - half the bytes of the fp32 path, and the 8 input
+// channels a v_mfma_f32_16x16x32_bf16 k-block needs are 16 contiguous bytes of one voxel, so both MFMA operands are plain 16-byte
+// loads (weights: pre-packed per lane; inputs: straight from L1/L2, every voxel is re-read by its 27 taps) - no LDS staging, no
+// barriers in the convolution.  D[co, voxel] = sum_k W[co, k] * X[k, voxel]: M = 16 output channels, N = 16 consecutive output
+// voxels of a row, K = (tap, cin) flattened in blocks of 8 channels, 4 blocks per MFMA.  One kernel covers Conv3d stride
+// (1,1,1)/(2,2,2)/(1,2,2) and, as a gather over output parities, ConvTranspose3d stride (2,2,2)/(1,2,2) - which is also every
+// data gradient (stride-1 conv <-> flipped stride-1 conv, strided conv <-> transposed conv).  Weight gradients contract over voxels
+// on the same MFMA with fragments gathered from LDS tiles.  BatchNorm / ReLU / skip kernels are the channel-last bf16 twins of
+// train.hip (statistics, and all arithmetic, in fp32).
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ bf16x8 ld8(rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ void xcd_item(int total, int& logical, bool& valid) {
+    const int per = (total + 7) >> 3;
+    logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    valid = logical < total;
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// out[((step * NT + nt) * 64 + lane) * 8 + e] = A[m = nt*16 + (lane & 15)][k-block t = 4*step + (lane >> 4)][e]  as bf16, where k-block
+// t = (tap, channel octet cq) = (t / (KC/8), t % (KC/8)), channel c = cq*8 + e; zero beyond M rows / 27*KC/8 blocks.
+// src: 0 = w[m][c][tap], 1 = w[c][m][tap], 2 = w[c][m][26 - tap]   (w = [d0][d1][27] fp32)
+__global__ void bf16_pack_kernel(const float* __restrict__ w, int d1, int src, int M, int KC, int NT, int steps, __bf16* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= steps * NT * 64) return;
+    const int lane = idx & 63, nt = (idx >> 6) % NT, step = idx / (64 * NT);
+    const int m = nt * 16 + (lane & 15), t = 4 * step + (lane >> 4), KQ = KC / 8;
+    const int tap = t / KQ, cq = t % KQ;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = cq * 8 + e;
+        float f = 0.0f;
+        if (m < M && t < 27 * KQ) f = src == 0 ? w[((size_t)m * d1 + c) * 27 + tap] : w[((size_t)c * d1 + m) * 27 + (src == 2 ? 26 - tap : tap)];
+        v[e] = (__bf16)f;
+    }
+    reinterpret_cast<bf16x8*>(out)[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ convolution (forward and data gradients)
+struct ConvArgs {
+    const __bf16* x;          // [B,Di,Hi,Wi,CIN]
+    const __bf16* wp;         // packed, see bf16_pack_kernel
+    __bf16* y;                // [B,Do,Ho,Wo,Cout]
+    const float* scale;       // optional epilogue: y = [relu](acc*scale[co] + shift[co]) [+ residual]
+    const float* shift;
+    const __bf16* residual;
+    int relu;
+    int B, Di, Hi, Wi, Do, Ho, Wo, Cout;
+    int nwchunks, items;
+};
+
+// GATHER = 0: Conv3d, input voxel = out*stride - 1 + k.  GATHER = 1: ConvTranspose3d (k=3, padding 1, output_padding stride-1) as a
+// gather: input voxel = (out + 1 - k) / stride where divisible.
+template <int CIN, int NT, int GATHER, int SD, int SHW>
+__global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
+    constexpr int KQ = CIN / 8, NKB = 27 * KQ, STEPS = (NKB + 3) / 4, VT = 4;
+    int logical;
+    bool ok;
+    xcd_item((a.items + 3) / 4, logical, ok);
+    if (!ok) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = logical * 4 + wave;
+    if (item >= a.items) return;                           // no block-wide barrier below
+    const int wchunk = item % a.nwchunks;
+    const int oh = (item / a.nwchunks) % a.Ho;
+    const int od = (item / (a.nwchunks * a.Ho)) % a.Do;
+    const int b = item / (a.nwchunks * a.Ho * a.Do);
+    const int j = lane & 15, kb = lane >> 4;
+    const int ow0 = wchunk * 64;
+    const rsrc_t xr = make_rsrc(a.x + (size_t)b * a.Di * a.Hi * a.Wi * CIN, (unsigned)((size_t)a.Di * a.Hi * a.Wi * CIN * 2));
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wp) + lane;
+
+    f32x4 acc[NT][VT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt) acc[nt][vt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 2
+    for (int step = 0; step < STEPS; ++step) {
+        const int t = 4 * step + kb;
+        const int tap = t / KQ, cq = t % KQ;
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        bool rowok = t < NKB;
+        int id, ih;
+        if (GATHER == 0) {
+            id = od * SD - 1 + kd;
+            ih = oh * SHW - 1 + kh;
+        } else {
+            const int nd = od + 1 - kd, nh = oh + 1 - kh;
+            rowok = rowok && nd >= 0 && nh >= 0 && (nd % SD) == 0 && (nh % SHW) == 0;
+            id = nd / SD;
+            ih = nh / SHW;
+        }
+        rowok = rowok && (unsigned)id < (unsigned)a.Di && (unsigned)ih < (unsigned)a.Hi;
+        const unsigned rowbase = (unsigned)((id * a.Hi + ih) * a.Wi) * (unsigned)(CIN * 2) + (unsigned)(cq * 16);
+        bf16x8 xb[VT];
+#pragma unroll
+        for (int vt = 0; vt < VT; ++vt) {
+            const int ow = ow0 + vt * 16 + j;
+            int iw;
+            bool v = rowok;
+            if (GATHER == 0) {
+                iw = ow * SHW - 1 + kw;
+            } else {
+                const int nw = ow + 1 - kw;
+                v = v && nw >= 0 && (nw % SHW) == 0;
+                iw = nw / SHW;
+            }
+            v = v && (unsigned)iw < (unsigned)a.Wi;
+            xb[vt] = ld8(xr, v ? rowbase + (unsigned)iw * (unsigned)(CIN * 2) : OOB);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const bf16x8 wa = wp[(size_t)(step * NT + nt) * 64];
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) acc[nt][vt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[vt], acc[nt][vt], 0, 0, 0);
+        }
+    }
+    // D[i = co (4*kb + r inside the tile)][j = voxel]: a lane owns 4 consecutive output channels of one voxel -> one 8-byte store
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+        const int ow = ow0 + vt * 16 + j;
+        if (ow >= a.Wo) continue;
+        const size_t vox = (((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co0 = nt * 16 + kb * 4;
+            if (co0 >= a.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[nt][vt][r];
+                if (a.scale) v[r] = fmaf(v[r], a.scale[co0 + r], a.shift[co0 + r]);
+                if (a.relu) v[r] = fmaxf(v[r], 0.0f);
+            }
+            if (a.residual) {
+                const bf16x4 rs = *reinterpret_cast<const bf16x4*>(a.residual + vox * a.Cout + co0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rs[r];
+            }
+            *reinterpret_cast<bf16x4*>(a.y + vox * a.Cout + co0) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[a][b][tap] += sum_{batch, p} A[p][a] * Bt[p*s - 1 + k][b]   (A on the grid the stride divides; both channel-last bf16, dW fp32).
+// Block = (16 a-channels, 16 b-channels, a chunk of A rows); per 32 voxels of a row both tiles are copied to LDS as they are and
+// every lane gathers its MFMA fragment (8 voxels of one channel) from there with 2-byte reads: any stride, shift or alignment,
+// zero padding from zero-filled halo cells.  The 27 taps are spread over the 4 wavefronts (7 accumulators each).
+struct WgradArgs {
+    const __bf16* A;
+    const __bf16* Bt;
+    float* dW;
+    int nb, CA, CB, Dp, Hp, Wp, Db, Hb, Wb, sd, shw, rows_per_block, nrows;
+};
+
+__global__ __launch_bounds__(256) void bf16_wgrad_kernel(const WgradArgs a) {
+    constexpr int KV = 32;                                  // voxels per MFMA (K)
+    constexpr int BW_MAX = KV * 2 + 2;
+    __shared__ __attribute__((aligned(16))) unsigned short sA[KV * 16];
+    __shared__ __attribute__((aligned(16))) unsigned short sB[9 * BW_MAX * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntb = (a.CB + 15) / 16;
+    const int ta = blockIdx.y / ntb, tb = blockIdx.y % ntb;
+    const int i16 = lane & 15, kb = lane >> 4;
+    const int bw = KV * a.shw + 2;                          // Bt columns needed per K step
+    f32x4 acc[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int row0 = blockIdx.x * a.rows_per_block;
+    for (int row = row0; row < min(row0 + a.rows_per_block, a.nrows); ++row) {
+        const int hp = row % a.Hp, dp = (row / a.Hp) % a.Dp, n = row / (a.Hp * a.Dp);
+        for (int w0 = 0; w0 < a.Wp; w0 += KV) {
+            __syncthreads();                                // previous step's fragments consumed
+            // ---- A tile: [KV voxels][16 channels] ----
+            if (tid < KV * 2) {
+                const int v = tid >> 1, h = tid & 1;
+                const int c0 = ta * 16 + h * 8;
+                u32x4 val = {0u, 0u, 0u, 0u};
+                if (w0 + v < a.Wp && c0 < a.CA)
+                    val = *reinterpret_cast<const u32x4*>(a.A + ((((size_t)n * a.Dp + dp) * a.Hp + hp) * a.Wp + w0 + v) * a.CA + c0);
+                *reinterpret_cast<u32x4*>(sA + v * 16 + h * 8) = val;
+            }
+            // ---- Bt tile: 9 (kd, kh) rows x bw voxels x 16 channels, voxel 0 of the tile = column w0*shw - 1 ----
+            for (int i = tid; i < 9 * bw * 2; i += 256) {
+                const int h = i & 1, col = (i >> 1) % bw, r = (i >> 1) / bw;
+                const int kd = r / 3, kh = r % 3;
+                const int db = dp * a.sd - 1 + kd, hb = hp * a.shw - 1 + kh, wb = w0 * a.shw - 1 + col;
+                const int c0 = tb * 16 + h * 8;
+                u32x4 val = {0u, 0u, 0u, 0u};
+                if ((unsigned)db < (unsigned)a.Db && (unsigned)hb < (unsigned)a.Hb && (unsigned)wb < (unsigned)a.Wb && c0 < a.CB)
+                    val = *reinterpret_cast<const u32x4*>(a.Bt + ((((size_t)n * a.Db + db) * a.Hb + hb) * a.Wb + wb) * a.CB + c0);
+                *reinterpret_cast<u32x4*>(sB + (r * BW_MAX + col) * 16 + h * 8) = val;
+            }
+            __syncthreads();
+            // ---- fragments + MFMAs: A[i = a-channel][k = voxel], B[k = voxel][j = b-channel] ----
+            unsigned short fa[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fa[e] = sA[(kb * 8 + e) * 16 + i16];       // voxels beyond Wp were zero-filled
+            bf16x8 fragA;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fragA[e] = __builtin_bit_cast(__bf16, fa[e]);
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const int tap = wave + 4 * q;
+                if (tap >= 27) break;                       // wave-uniform
+                const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                const unsigned short* rowp = sB + ((kd * 3 + kh) * BW_MAX) * 16 + i16;
+                bf16x8 fragB;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fragB[e] = __builtin_bit_cast(__bf16, rowp[((kb * 8 + e) * a.shw + kw) * 16]);
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fragA, fragB, acc[q], 0, 0, 0);
+            }
+        }
+    }
+    // D[i = a (4*kb + r)][j = b]
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        const int tap = wave + 4 * q;
+        if (tap >= 27) break;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ca = ta * 16 + kb * 4 + r, cb = tb * 16 + i16;
+            if (ca < a.CA && cb < a.CB && acc[q][r] != 0.0f) atomicAdd(a.dW + ((size_t)ca * a.CB + cb) * 27 + tap, acc[q][r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ layout / precision converters
+// fp32 [B,C,N] (NCDHW) -> bf16 [B,N,C] (NDHWC) and back; C a multiple of 8
+template <int C>
+__global__ void f32_ncdhw_to_bf16_ndhwc_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t N) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t b = blockIdx.y;
+    if (i >= N) return;
+#pragma unroll
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)in[(b * C + c0 + e) * N + i];
+        *reinterpret_cast<bf16x8*>(out + (b * N + i) * C + c0) = v;
+    }
+}
+template <int C>
+__global__ void bf16_ndhwc_to_f32_ncdhw_kernel(const __bf16* __restrict__ in, float* __restrict__ out, size_t N) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t b = blockIdx.y;
+    if (i >= N) return;
+#pragma unroll
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(in + (b * N + i) * C + c0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[(b * C + c0 + e) * N + i] = (float)v[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm / ReLU / skip, channel-last bf16
+// x is [R rows (voxels), C]; a thread owns one channel octet of a strided set of rows.
+constexpr int ROWS_PER_BLOCK = 2048;
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bf16_bn_reduce_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                             int C, size_t R, float* __restrict__ sums) {
+    __shared__ float red[2 * 64];
+    const int CQ = C / 8;
+    const int cq = threadIdx.x % CQ, rsub = threadIdx.x / CQ, rstep = 256 / CQ;
+    if (threadIdx.x < 2 * C) red[threadIdx.x] = 0.0f;
+    __syncthreads();
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.0f;
+    float sc[8], sh[8], mu[8], is[8];
+    if (BWD) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = scale[cq * 8 + e];
+            sh[e] = shift[cq * 8 + e];
+            mu[e] = mean[cq * 8 + e];
+            is[e] = invstd[cq * 8 + e];
+        }
+    }
+    const size_t r0 = (size_t)blockIdx.x * ROWS_PER_BLOCK, r1 = min(r0 + ROWS_PER_BLOCK, R);
+    for (size_t r = r0 + rsub; r < r1; r += rstep) {
+        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + r * C + cq * 8);
+        if (!BWD) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)xv[e];
+                s[e] += f;
+                q[e] = fmaf(f, f, q[e]);
+            }
+        } else {
+            const bf16x8 gv = *reinterpret_cast<const bf16x8*>(dy + r * C + cq * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)xv[e];
+                float g = (float)gv[e];
+                if (relu && !(fmaf(f, sc[e], sh[e]) > 0.0f)) g = 0.0f;
+                s[e] += g;
+                q[e] = fmaf(g, (f - mu[e]) * is[e], q[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        atomicAdd(&red[cq * 8 + e], s[e]);
+        atomicAdd(&red[C + cq * 8 + e], q[e]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * C) atomicAdd(&sums[threadIdx.x], red[threadIdx.x]);
+}
+
+// y = [relu](x*scale[c] + shift[c]) [+ residual]
+__global__ __launch_bounds__(256) void bf16_affine_act_kernel(const __bf16* __restrict__ x, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const __bf16* __restrict__ res, int relu, int C,
+                                                              size_t total8, __bf16* __restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one channel octet
+    if (i >= total8) return;
+    const int c0 = (int)(i % (C / 8)) * 8;
+    const bf16x8 xv = reinterpret_cast<const bf16x8*>(x)[i];
+    bf16x8 rv;
+    if (res) rv = reinterpret_cast<const bf16x8*>(res)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = fmaf((float)xv[e], scale[c0 + e], shift[c0 + e]);
+        if (relu) v = fmaxf(v, 0.0f);
+        if (res) v += (float)rv[e];
+        o[e] = (__bf16)v;
+    }
+    reinterpret_cast<bf16x8*>(y)[i] = o;
+}
+
+// dx = gamma*invstd*(g - s1/n - xhat*s2/n), g = dy*[x*scale+shift > 0 or !relu]
+__device__ __forceinline__ double resolve_count(double count_host, const float* __restrict__ count_dev) {
+    return count_dev ? (double)count_dev[0] * 4096.0 + (double)count_dev[1] : count_host;
+}
+__global__ __launch_bounds__(256) void bf16_bn_bwd_apply_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ x,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                                double count_host, const float* __restrict__ count_dev, int relu, int C,
+                                                                size_t total8, __bf16* __restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const double count = resolve_count(count_host, count_dev);
+    const int c0 = (int)(i % (C / 8)) * 8;
+    const bf16x8 xv = reinterpret_cast<const bf16x8*>(x)[i], gv = reinterpret_cast<const bf16x8*>(dy)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        const float f = (float)xv[e];
+        float g = (float)gv[e];
+        if (relu && !(fmaf(f, scale[c], shift[c]) > 0.0f)) g = 0.0f;
+        const float m1 = (float)((double)sums[c] / count), m2 = (float)((double)sums[C + c] / count);
+        const float gi = (gamma ? gamma[c] : 1.0f) * invstd[c];
+        o[e] = (__bf16)(gi * (g - m1 - (f - mean[c]) * invstd[c] * m2));
+    }
+    reinterpret_cast<bf16x8*>(dx)[i] = o;
+}
+
+bool chan_ok(int c) { return c == 8 || c == 16 || c == 32 || c == 64; }
+
+template <int GATHER, int SD, int SHW>
+int launch_conv(const ConvArgs& a, int cin, int nt, hipStream_t s) {
+    const unsigned grid = (unsigned)((((a.items + 3) / 4 + 7) / 8) * 8);
+#define MVS_BF16_GO(CINV, NTV) hipLaunchKernelGGL((bf16_conv_kernel<CINV, NTV, GATHER, SD, SHW>), dim3(grid), dim3(256), 0, s, a)
+#define MVS_BF16_NT(CINV)                      \
+    switch (nt) {                              \
+        case 1: MVS_BF16_GO(CINV, 1); break;   \
+        case 2: MVS_BF16_GO(CINV, 2); break;   \
+        default: MVS_BF16_GO(CINV, 4); break;  \
+    }
+    switch (cin) {
+        case 8: MVS_BF16_NT(8); break;
+        case 16: MVS_BF16_NT(16); break;
+        case 32: MVS_BF16_NT(32); break;
+        default: MVS_BF16_NT(64); break;
+    }
+#undef MVS_BF16_NT
+#undef MVS_BF16_GO
+    return mvs::finish_launch("mvs_bf16_conv3d");
+}
+
+int nt_of(int cout) { return cout <= 16 ? 1 : (cout <= 32 ? 2 : 4); }
+
+}  // namespace
+
+extern "C" int64_t mvs_bf16_packed_elems(int Cin, int Cout) {
+    if (!chan_ok(Cin) || !chan_ok(Cout)) return -1;
+    const int steps = (27 * Cin / 8 + 3) / 4;
+    return (int64_t)steps * nt_of(Cout) * 64 * 8;
+}
+
+extern "C" int mvs_bf16_pack_weights(const float* w, int d0, int d1, int src, int Cout, int Cin, void* wpacked, mvs_stream_t stream) {
+    MVS_REQUIRE(w && wpacked, "mvs_bf16_pack_weights: null pointer");
+    MVS_REQUIRE(chan_ok(Cin) && chan_ok(Cout) && src >= 0 && src <= 2, "mvs_bf16_pack_weights: Cin=%d Cout=%d src=%d", Cin, Cout, src);
+    MVS_REQUIRE((src == 0 && d0 == Cout && d1 == Cin) || (src != 0 && d0 == Cin && d1 == Cout), "mvs_bf16_pack_weights: weight is [%d][%d][27], "
+                "expected %s", d0, d1, src == 0 ? "[Cout][Cin]" : "[Cin][Cout]");
+    const int steps = (27 * Cin / 8 + 3) / 4, nt = nt_of(Cout), n = steps * nt * 64;
+    hipLaunchKernelGGL(bf16_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, MVS_STREAM(stream), w, d1, src, Cout, Cin, nt, steps,
+                       reinterpret_cast<__bf16*>(wpacked));
+    return mvs::finish_launch("mvs_bf16_pack_weights");
+}
+
+// gather: 0 = Conv3d (out = (in - 1)/stride + 1), 1 = ConvTranspose3d k3 p1 op(stride-1) (out = in*stride)
+extern "C" int mvs_bf16_conv3d(const void* x, const void* wpacked, const float* scale, const float* shift, const void* residual, void* y,
+                               int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd, int shw, int relu,
+                               mvs_stream_t stream) {
+    MVS_REQUIRE(x && wpacked && y, "mvs_bf16_conv3d: null pointer");
+    MVS_REQUIRE(chan_ok(Cin) && chan_ok(Cout), "mvs_bf16_conv3d: channels must be 8/16/32/64 (Cin=%d Cout=%d)", Cin, Cout);
+    MVS_REQUIRE(B >= 1 && Di >= 1 && Hi >= 1 && Wi >= 1 && (gather == 0 || gather == 1), "mvs_bf16_conv3d: bad shape");
+    MVS_REQUIRE((sd == 1 || sd == 2) && (shw == 1 || shw == 2) && !(sd == 2 && shw == 1), "mvs_bf16_conv3d: stride (%d,%d,%d) is not built", sd, shw, shw);
+    MVS_REQUIRE((!scale) == (!shift), "mvs_bf16_conv3d: scale and shift come together");
+    MVS_REQUIRE((int64_t)Di * Hi * Wi * Cin * 2 < ((int64_t)1 << 31), "mvs_bf16_conv3d: one sample's input exceeds the 2 GiB buffer range");
+    ConvArgs a{};
+    a.x = reinterpret_cast<const __bf16*>(x), a.wp = reinterpret_cast<const __bf16*>(wpacked), a.y = reinterpret_cast<__bf16*>(y);
+    a.scale = scale, a.shift = shift, a.residual = reinterpret_cast<const __bf16*>(residual), a.relu = relu;
+    a.B = B, a.Di = Di, a.Hi = Hi, a.Wi = Wi, a.Cout = Cout;
+    if (gather == 0) a.Do = (Di - 1) / sd + 1, a.Ho = (Hi - 1) / shw + 1, a.Wo = (Wi - 1) / shw + 1;
+    else a.Do = Di * sd, a.Ho = Hi * shw, a.Wo = Wi * shw;
+    a.nwchunks = (a.Wo + 63) / 64;
+    const int64_t items = (int64_t)B * a.Do * a.Ho * a.nwchunks;
+    MVS_REQUIRE(items < ((int64_t)1 << 30), "mvs_bf16_conv3d: too many rows");
+    a.items = (int)items;
+    hipStream_t s = MVS_STREAM(stream);
+    const int nt = nt_of(Cout);
+    if (gather == 0) {
+        if (sd == 1 && shw == 1) return launch_conv<0, 1, 1>(a, Cin, nt, s);
+        if (sd == 2) return launch_conv<0, 2, 2>(a, Cin, nt, s);
+        return launch_conv<0, 1, 2>(a, Cin, nt, s);
+    }
+    if (sd == 1 && shw == 1) return launch_conv<1, 1, 1>(a, Cin, nt, s);
+    if (sd == 2) return launch_conv<1, 2, 2>(a, Cin, nt, s);
+    return launch_conv<1, 1, 2>(a, Cin, nt, s);
+}
+
+extern "C" int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, int nbatch, int CA, int CB, int Dp, int Hp, int Wp, int Db, int Hb,
+                                     int Wb, int sd, int shw, mvs_stream_t stream) {
+    MVS_REQUIRE(A && Bt && dW, "mvs_bf16_conv3d_wgrad: null pointer");
+    MVS_REQUIRE(chan_ok(CA) && chan_ok(CB) && nbatch >= 1, "mvs_bf16_conv3d_wgrad: channels must be 8/16/32/64 (CA=%d CB=%d)", CA, CB);
+    MVS_REQUIRE((sd == 1 || sd == 2) && (shw == 1 || shw == 2), "mvs_bf16_conv3d_wgrad: bad stride");
+    WgradArgs a{};
+    a.A = reinterpret_cast<const __bf16*>(A), a.Bt = reinterpret_cast<const __bf16*>(Bt), a.dW = dW;
+    a.nb = nbatch, a.CA = CA, a.CB = CB, a.Dp = Dp, a.Hp = Hp, a.Wp = Wp, a.Db = Db, a.Hb = Hb, a.Wb = Wb, a.sd = sd, a.shw = shw;
+    a.nrows = nbatch * Dp * Hp;
+    // enough blocks to fill the chip a few times over, few enough that the closing atomics stay cheap
+    const int tiles = ((CA + 15) / 16) * ((CB + 15) / 16);
+    int chunks = (2048 + tiles - 1) / tiles;
+    if (chunks > a.nrows) chunks = a.nrows;
+    a.rows_per_block = (a.nrows + chunks - 1) / chunks;
+    chunks = (a.nrows + a.rows_per_block - 1) / a.rows_per_block;
+    hipLaunchKernelGGL(bf16_wgrad_kernel, dim3(chunks, tiles), dim3(256), 0, MVS_STREAM(stream), a);
+    return mvs::finish_launch("mvs_bf16_conv3d_wgrad");
+}
+
+extern "C" int mvs_bf16_from_f32_ncdhw(const float* in, void* out, int B, int C, int64_t N, mvs_stream_t stream) {
+    MVS_REQUIRE(in && out && B >= 1 && B <= 65535 && N >= 1 && chan_ok(C), "mvs_bf16_from_f32_ncdhw: bad arguments (C=%d)", C);
+    dim3 grid((unsigned)((N + 255) / 256), B);
+    hipStream_t s = MVS_STREAM(stream);
+    __bf16* o = reinterpret_cast<__bf16*>(out);
+    switch (C) {
+        case 8: hipLaunchKernelGGL(f32_ncdhw_to_bf16_ndhwc_kernel<8>, grid, dim3(256), 0, s, in, o, (size_t)N); break;
+        case 16: hipLaunchKernelGGL(f32_ncdhw_to_bf16_ndhwc_kernel<16>, grid, dim3(256), 0, s, in, o, (size_t)N); break;
+        case 32: hipLaunchKernelGGL(f32_ncdhw_to_bf16_ndhwc_kernel<32>, grid, dim3(256), 0, s, in, o, (size_t)N); break;
+        default: hipLaunchKernelGGL(f32_ncdhw_to_bf16_ndhwc_kernel<64>, grid, dim3(256), 0, s, in, o, (size_t)N); break;
+    }
+    return mvs::finish_launch("mvs_bf16_from_f32_ncdhw");
+}
+
+extern "C" int mvs_bf16_to_f32_ncdhw(const void* in, float* out, int B, int C, int64_t N, mvs_stream_t stream) {
+    MVS_REQUIRE(in && out && B >= 1 && B <= 65535 && N >= 1 && chan_ok(C), "mvs_bf16_to_f32_ncdhw: bad arguments (C=%d)", C);
+    dim3 grid((unsigned)((N + 255) / 256), B);
+    hipStream_t s = MVS_STREAM(stream);
+    const __bf16* i = reinterpret_cast<const __bf16*>(in);
+    switch (C) {
+        case 8: hipLaunchKernelGGL(bf16_ndhwc_to_f32_ncdhw_kernel<8>, grid, dim3(256), 0, s, i, out, (size_t)N); break;
+        case 16: hipLaunchKernelGGL(bf16_ndhwc_to_f32_ncdhw_kernel<16>, grid, dim3(256), 0, s, i, out, (size_t)N); break;
+        case 32: hipLaunchKernelGGL(bf16_ndhwc_to_f32_ncdhw_kernel<32>, grid, dim3(256), 0, s, i, out, (size_t)N); break;
+        default: hipLaunchKernelGGL(bf16_ndhwc_to_f32_ncdhw_kernel<64>, grid, dim3(256), 0, s, i, out, (size_t)N); break;
+    }
+    return mvs::finish_launch("mvs_bf16_to_f32_ncdhw");
+}
+
+extern "C" int mvs_bf16_bn_stats(const void* x, int C, int64_t R, float* sums, mvs_stream_t stream) {
+    MVS_REQUIRE(x && sums && chan_ok(C) && R >= 1, "mvs_bf16_bn_stats: bad arguments");
+    hipLaunchKernelGGL(bf16_bn_reduce_kernel<false>, dim3((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, MVS_STREAM(stream),
+                       reinterpret_cast<const __bf16*>(x), (const __bf16*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, 0, C, (size_t)R, sums);
+    return mvs::finish_launch("mvs_bf16_bn_stats");
+}
+
+extern "C" int mvs_bf16_affine_act(const void* x, const float* scale, const float* shift, const void* residual, int relu, int C, int64_t R,
+                                   void* y, mvs_stream_t stream) {
+    MVS_REQUIRE(x && scale && shift && y && chan_ok(C) && R >= 1, "mvs_bf16_affine_act: bad arguments");
+    const size_t total8 = (size_t)R * (C / 8);
+    hipLaunchKernelGGL(bf16_affine_act_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, MVS_STREAM(stream),
+                       reinterpret_cast<const __bf16*>(x), scale, shift, reinterpret_cast<const __bf16*>(residual), relu, C, total8,
+                       reinterpret_cast<__bf16*>(y));
+    return mvs::finish_launch("mvs_bf16_affine_act");
+}
+
+extern "C" int mvs_bf16_bn_bwd_reduce(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
+                                      const float* invstd, int relu, int C, int64_t R, float* sums, mvs_stream_t stream) {
+    MVS_REQUIRE(dy && x && scale && shift && mean && invstd && sums && chan_ok(C) && R >= 1, "mvs_bf16_bn_bwd_reduce: bad arguments");
+    hipLaunchKernelGGL(bf16_bn_reduce_kernel<true>, dim3((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, MVS_STREAM(stream),
+                       reinterpret_cast<const __bf16*>(x), reinterpret_cast<const __bf16*>(dy), scale, shift, mean, invstd, relu, C, (size_t)R,
+                       sums);
+    return mvs::finish_launch("mvs_bf16_bn_bwd_reduce");
+}
+
+extern "C" int mvs_bf16_bn_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
+                                     const float* invstd, const float* gamma, const float* sums, double count, const float* count_dev,
+                                     int relu, int C, int64_t R, void* dx, mvs_stream_t stream) {
+    MVS_REQUIRE(dy && x && scale && shift && mean && invstd && sums && dx && chan_ok(C) && R >= 1, "mvs_bf16_bn_bwd_apply: bad arguments");
+    const size_t total8 = (size_t)R * (C / 8);
+    hipLaunchKernelGGL(bf16_bn_bwd_apply_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, MVS_STREAM(stream),
+                       reinterpret_cast<const __bf16*>(dy), reinterpret_cast<const __bf16*>(x), scale, shift, mean, invstd, gamma, sums, count,
+                       count_dev, relu, C, total8, reinterpret_cast<__bf16*>(dx));
+    return mvs::finish_launch("mvs_bf16_bn_bwd_apply");
+}

@@ -51,9 +51,33 @@ def _publish_cache() -> None:
         torch.cuda.current_stream().synchronize()
 
 
+def autocast_bf16() -> bool:
+    """True inside ``torch.autocast('cuda', dtype=torch.bfloat16)`` (how BASELINE configs[2] trains; the reference trainer wraps
+    the model in ``torch.cuda.amp.autocast``, trainer/mvsformer_trainer.py:104-106) or with MVS_TRAIN_BF16=1: the regularizer
+    then runs on bf16 channel-last activations and the bf16 matrix cores."""
+    if os.environ.get("MVS_TRAIN_BF16", "") == "1":
+        return True
+    try:
+        if hasattr(torch, "get_autocast_dtype"):
+            return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+        return torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+    except Exception:                                                    # noqa: BLE001 - torch builds without these queries
+        return False
+
+
 def _train_conv_bn_act(x, conv, bn, relu, residual, transposed_sd=None):
-    """Training-mode layer: raw (transposed) conv -> batch-stat BN -> ReLU (+ residual), all autograd-tracked HIP ops."""
+    """Training-mode layer: raw (transposed) conv -> batch-stat BN -> ReLU (+ residual), all autograd-tracked HIP ops.
+    bf16 channel-last input (``[B,D,H,W,C]``) selects the bf16 kernels, fp32 ``[B,C,D,H,W]`` the fp32 ones."""
     from . import autograd as ag
+    if x.dtype == torch.bfloat16:
+        if conv.bias is not None or bn is None:
+            raise MvsHipError("bf16 training layer without BatchNorm / with bias is not built")
+        if transposed_sd is None:
+            s = tuple(conv.stride)
+            y = ag.ConvBf16Fn.apply(x, conv.weight, (s[0], s[1]))
+        else:
+            y = ag.DeconvBf16Fn.apply(x, conv.weight, transposed_sd)
+        return ag.BnActBf16Fn.apply(y, bn.weight, bn.bias, residual, bn, bool(relu))
     if transposed_sd is None:
         s = tuple(conv.stride)
         y = ag.ConvFn.apply(x, conv.weight, (s[0], s[1]))
@@ -229,6 +253,9 @@ class CostRegNet(nn.Module):
         x = x if x.is_contiguous() else x.contiguous()
         if x.shape[2] % 8 or x.shape[3] % 8 or x.shape[4] % 8:
             raise MvsHipError("CostRegNet needs D, H, W divisible by 8 (three stride-2 levels), got %s" % (tuple(x.shape[2:]),))
+        if self.training and autocast_bf16():
+            from . import autograd as ag
+            x = ag.ToBf16Fn.apply(x)                     # fp32 cost volume -> bf16 channel-last; every layer below follows the dtype
         c2 = self.conv2(self.conv1(x))
         c4 = self.conv4(self.conv3(c2))
         y = self.conv6(self.conv5(c4))
@@ -243,7 +270,10 @@ class CostRegNet(nn.Module):
                 from . import autograd as ag
                 # N = 1 conv embedded in an 8-channel MFMA conv (zero rows) so forward, dgrad and wgrad reuse the conv kernels
                 w8 = torch.nn.functional.pad(self.prob.weight, (0, 0, 0, 0, 0, 0, 0, 0, 0, 7))
-                y = ag.ConvFn.apply(y, w8, (1, 1))[:, :1]
+                if y.dtype == torch.bfloat16:            # autocast: the logits come out of a half-precision conv, then fp32
+                    y = ag.FromBf16Fn.apply(ag.ConvBf16Fn.apply(y, w8, (1, 1)))[:, :1]
+                else:
+                    y = ag.ConvFn.apply(y, w8, (1, 1))[:, :1]
             else:
                 y = ops.prob3(y, _f32c(self.prob.weight)).unsqueeze(1)
         return y
@@ -332,6 +362,9 @@ class CostRegNet3D(nn.Module):
         x = x if x.is_contiguous() else x.contiguous()
         if x.shape[3] % 8 or x.shape[4] % 8:
             raise MvsHipError("CostRegNet3D needs H, W divisible by 8 (three stride-2 levels), got %s" % (tuple(x.shape[3:]),))
+        if self.training and autocast_bf16():
+            from . import autograd as ag
+            x = ag.ToBf16Fn.apply(x)                     # fp32 cost volume -> bf16 channel-last; every layer below follows the dtype
         c2 = self.conv2(self.conv1(x))
         c4 = self.conv4(self.conv3(c2))
         y = self.conv6(self.conv5(c4))
@@ -346,6 +379,8 @@ class CostRegNet3D(nn.Module):
         y = self.features(x)
         if self.training:
             from . import autograd as ag
+            if y.dtype == torch.bfloat16:                # the 1x1x1 head and everything after it are fp32 again
+                y = ag.FromBf16Fn.apply(y)
             return ag.Prob1Fn.apply(y, self.prob.weight, self.prob.bias)
         w, b = self.prob_params()
         return ops.prob1(y, w, b)

@@ -716,3 +716,109 @@ def ce_loss(logits, depth_values, depth_gt, mask, inverse_depth: bool, weight: f
 def ce_loss_bwd_scale(grad, acc, gout, weight: float) -> None:
     _chk(grad, "grad"), _chk(acc, "acc"), _chk(gout, "grad_out")
     _call("mvs_ce_loss_bwd_scale", "ce_loss_bwd_scale", _ptr(grad), grad.numel(), _ptr(acc), _ptr(gout), float(weight), _stream())
+
+
+# ------------------------------------------------------------------ bf16 channel-last regularizer (training under autocast)
+def _chk16(t: torch.Tensor, name: str) -> torch.Tensor:
+    return _chk(t, name, dtype=torch.bfloat16)
+
+
+def bf16_from_f32(x: torch.Tensor) -> torch.Tensor:
+    """fp32 ``[B,C,D,H,W]`` -> bf16 channel-last ``[B,D,H,W,C]``."""
+    _chk(x, "x")
+    B, C = x.shape[0], x.shape[1]
+    y = torch.empty((B,) + tuple(x.shape[2:]) + (C,), device=x.device, dtype=torch.bfloat16)
+    _call("mvs_bf16_from_f32_ncdhw", "bf16_from_f32", _ptr(x), _ptr(y), B, C, x.numel() // (B * C), _stream())
+    return y
+
+
+def bf16_to_f32(x: torch.Tensor) -> torch.Tensor:
+    """bf16 channel-last ``[B,D,H,W,C]`` -> fp32 ``[B,C,D,H,W]``."""
+    _chk16(x, "x")
+    B, C = x.shape[0], x.shape[-1]
+    y = torch.empty((B, C) + tuple(x.shape[1:-1]), device=x.device, dtype=torch.float32)
+    _call("mvs_bf16_to_f32_ncdhw", "bf16_to_f32", _ptr(x), _ptr(y), B, C, x.numel() // (B * C), _stream())
+    return y
+
+
+def bf16_pack(weight: torch.Tensor, src: int, cin: int, cout: int) -> torch.Tensor:
+    """fp32 ``[d0,d1,3,3,3]`` parameter -> bf16 MFMA fragments of a ``cin -> cout`` map (``src``: see include/mvs_hip.h)."""
+    _chk(weight, "conv weight")
+    if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3):
+        raise _lib.MvsHipError("conv weight must be [*,*,3,3,3], got %s" % (tuple(weight.shape),))
+    n = _lib.load().mvs_bf16_packed_elems(cin, cout)
+    if n <= 0:
+        raise _lib.MvsHipError("bf16 conv: channels must be 8/16/32/64 (Cin=%d Cout=%d)" % (cin, cout))
+    packed = torch.empty(n, device=weight.device, dtype=torch.bfloat16)
+    _call("mvs_bf16_pack_weights", None, _ptr(weight), weight.shape[0], weight.shape[1], int(src), cout, cin, _ptr(packed), _stream())
+    return packed
+
+
+def bf16_conv3d(x, wpacked, cin, cout, gather: int, stride, scale=None, shift=None, residual=None, relu=False):
+    """``x [B,D,H,W,cin]`` bf16 -> ``[B,Do,Ho,Wo,cout]`` bf16; ``gather`` 0 = Conv3d, 1 = ConvTranspose3d (k3, p1, op = stride-1)."""
+    _chk16(x, "x"), _chk16(wpacked, "packed weights"), _opt(scale, "scale"), _opt(shift, "shift")
+    B, Di, Hi, Wi, C = x.shape
+    assert C == cin
+    sd, shw = stride
+    if gather == 0:
+        Do, Ho, Wo = (Di - 1) // sd + 1, (Hi - 1) // shw + 1, (Wi - 1) // shw + 1
+    else:
+        Do, Ho, Wo = Di * sd, Hi * shw, Wi * shw
+    y = torch.empty(B, Do, Ho, Wo, cout, device=x.device, dtype=torch.bfloat16)
+    if residual is not None:
+        _chk16(residual, "residual")
+        if residual.shape != y.shape:
+            raise _lib.MvsHipError("residual shape %s != output %s" % (tuple(residual.shape), tuple(y.shape)))
+    # credited with the kernel's useful FLOPs: every output voxel of a Conv3d has 27 taps, of a ConvTranspose3d 27 per INPUT voxel
+    flops = 2.0 * 27 * cin * cout * B * (Do * Ho * Wo if gather == 0 else Di * Hi * Wi)
+    tag = ("bf16_conv_kernel<%d,%d,g%d,s%d%d>" % (cin, cout, gather, sd, shw), "flops", flops)
+    _call("mvs_bf16_conv3d", tag, _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), B, cin, cout, Di, Hi, Wi,
+          int(gather), sd, shw, int(relu), _stream())
+    return y
+
+
+def bf16_conv3d_wgrad(A: torch.Tensor, Bt: torch.Tensor, stride) -> torch.Tensor:
+    """``dW[a][b][27] = sum A[p][a] * Bt[p*s-1+k][b]`` (fp32); ``A [N,Dp,Hp,Wp,CA]`` lives on the grid the stride divides."""
+    _chk16(A, "A"), _chk16(Bt, "Bt")
+    N, Dp, Hp, Wp, CA = A.shape
+    _, Db, Hb, Wb, CB = Bt.shape
+    dW = torch.zeros(CA, CB, 3, 3, 3, device=A.device, dtype=torch.float32)
+    tag = ("bf16_wgrad_kernel", "flops", 2.0 * 27 * CA * CB * N * Dp * Hp * Wp)
+    _call("mvs_bf16_conv3d_wgrad", tag, _ptr(A), _ptr(Bt), _ptr(dW), N, CA, CB, Dp, Hp, Wp, Db, Hb, Wb, stride[0], stride[1], _stream())
+    return dW
+
+
+def bf16_bn_stats(x: torch.Tensor) -> torch.Tensor:
+    _chk16(x, "x")
+    C = x.shape[-1]
+    sums = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
+    _call("mvs_bf16_bn_stats", "bf16_bn_stats", _ptr(x), C, x.numel() // C, _ptr(sums), _stream())
+    return sums
+
+
+def bf16_affine_act(x, scale, shift, residual, relu):
+    _chk16(x, "x"), _chk(scale, "scale"), _chk(shift, "shift")
+    if residual is not None:
+        _chk16(residual, "residual")
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    _call("mvs_bf16_affine_act", "bf16_affine_act", _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), int(relu), C, x.numel() // C, _ptr(y), _stream())
+    return y
+
+
+def bf16_bn_bwd_reduce(dy, x, scale, shift, mean, invstd, relu):
+    _chk16(dy, "dy"), _chk16(x, "x")
+    C = x.shape[-1]
+    sums = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
+    _call("mvs_bf16_bn_bwd_reduce", "bf16_bn_bwd_reduce", _ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), int(relu), C,
+          x.numel() // C, _ptr(sums), _stream())
+    return sums
+
+
+def bf16_bn_bwd_apply(dy, x, scale, shift, mean, invstd, gamma, sums, count, relu, count_dev=None):
+    _chk16(dy, "dy"), _chk16(x, "x"), _chk(sums, "sums"), _opt(gamma, "gamma"), _opt(count_dev, "count_dev")
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    _call("mvs_bf16_bn_bwd_apply", "bf16_bn_bwd_apply", _ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _ptr(gamma),
+          _ptr(sums), float(count), _ptr(count_dev), int(relu), C, x.numel() // C, _ptr(dx), _stream())
+    return dx
