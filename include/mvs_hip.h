@@ -240,8 +240,9 @@ int mvs_conv3d_wgrad(const float* A, const float* Bt, float* dW, int nbatch, int
  *       strided Conv3d data gradient), 2: w[cin][cout][26 - tap] (stride-1 Conv3d data gradient)
  *   mvs_bf16_conv3d: gather 0 = Conv3d k3 p1 stride (sd,shw,shw); gather 1 = ConvTranspose3d k3 p1 output_padding stride-1;
  *       optional fused epilogue y = [relu](acc*scale + shift) [+ residual] (NULL scale/shift: raw output for batch-stat BatchNorm)
- *   mvs_bf16_conv3d_wgrad: dW[a][b][tap] += sum A[p][a] * Bt[p*s - 1 + k][b] (dW fp32, zeroed by the caller; same operand roles as
- *       mvs_conv3d_wgrad)
+ *   mvs_bf16_conv3d_wgrad: dW[a][b][tap] = sum A[p][a] * Bt[p*s - 1 + k][b] (dW fp32, overwritten; same operand roles as
+ *       mvs_conv3d_wgrad); row chunks write partial slabs into `workspace` (mvs_bf16_conv3d_wgrad_workspace_bytes) that a second
+ *       launch sums - no atomics, deterministic
  *   mvs_bf16_from_f32_ncdhw / mvs_bf16_to_f32_ncdhw: fp32 [B,C,N] <-> bf16 [B,N,C]
  *   mvs_bf16_bn_stats / mvs_bf16_affine_act / mvs_bf16_bn_bwd_reduce / mvs_bf16_bn_bwd_apply: channel-last bf16 twins of
  *       mvs_bn_stats / mvs_affine_act / mvs_bn_bwd_reduce / mvs_bn_bwd_apply over R = B*D*H*W rows (fp32 statistics;
@@ -251,8 +252,9 @@ int64_t mvs_bf16_packed_elems(int Cin, int Cout);
 int mvs_bf16_pack_weights(const float* w, int d0, int d1, int src, int Cout, int Cin, void* wpacked, mvs_stream_t stream);
 int mvs_bf16_conv3d(const void* x, const void* wpacked, const float* scale, const float* shift, const void* residual, void* y,
                     int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd, int shw, int relu, mvs_stream_t stream);
-int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, int nbatch, int CA, int CB, int Dp, int Hp, int Wp, int Db, int Hb,
-                          int Wb, int sd, int shw, mvs_stream_t stream);
+int64_t mvs_bf16_conv3d_wgrad_workspace_bytes(int nbatch, int CA, int CB, int Dp, int Hp);
+int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, void* workspace, int nbatch, int CA, int CB, int Dp, int Hp, int Wp,
+                          int Db, int Hb, int Wb, int sd, int shw, mvs_stream_t stream);
 int mvs_bf16_from_f32_ncdhw(const float* in, void* out, int B, int C, int64_t N, mvs_stream_t stream);
 int mvs_bf16_to_f32_ncdhw(const void* in, float* out, int B, int C, int64_t N, mvs_stream_t stream);
 int mvs_bf16_bn_stats(const void* x, int C, int64_t R, float* sums, mvs_stream_t stream);

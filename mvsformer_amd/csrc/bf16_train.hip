@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
 struct WgradArgs {
     const __bf16* A;
     const __bf16* Bt;
-    float* dW;
+    float* part;              // [chunks][CA][CB][27] partial sums, one slab per row chunk (plain stores; summed by bf16_wgrad_reduce_kernel:
+                              // fp32 atomics from a thousand blocks onto the same few thousand dW addresses cost more than the GEMM)
     int nb, CA, CB, Dp, Hp, Wp, Db, Hb, Wb, sd, shw, rows_per_block, nrows;
 };
 
@@ -204,16 +205,20 @@ __global__ __launch_bounds__(256) void bf16_wgrad_kernel(const WgradArgs a) {
                     val = *reinterpret_cast<const u32x4*>(a.A + ((((size_t)n * a.Dp + dp) * a.Hp + hp) * a.Wp + w0 + v) * a.CA + c0);
                 *reinterpret_cast<u32x4*>(sA + v * 16 + h * 8) = val;
             }
-            // ---- Bt tile: 9 (kd, kh) rows x bw voxels x 16 channels, voxel 0 of the tile = column w0*shw - 1 ----
-            for (int i = tid; i < 9 * bw * 2; i += 256) {
-                const int h = i & 1, col = (i >> 1) % bw, r = (i >> 1) / bw;
-                const int kd = r / 3, kh = r % 3;
-                const int db = dp * a.sd - 1 + kd, hb = hp * a.shw - 1 + kh, wb = w0 * a.shw - 1 + col;
-                const int c0 = tb * 16 + h * 8;
-                u32x4 val = {0u, 0u, 0u, 0u};
-                if ((unsigned)db < (unsigned)a.Db && (unsigned)hb < (unsigned)a.Hb && (unsigned)wb < (unsigned)a.Wb && c0 < a.CB)
-                    val = *reinterpret_cast<const u32x4*>(a.Bt + ((((size_t)n * a.Db + db) * a.Hb + hb) * a.Wb + wb) * a.CB + c0);
-                *reinterpret_cast<u32x4*>(sB + (r * BW_MAX + col) * 16 + h * 8) = val;
+            // ---- Bt tile: 9 (kd, kh) rows x bw voxels x 16 channels, voxel 0 of the tile = column w0*shw - 1;
+            //      thread -> (column tid >> 1, channel half tid & 1), one (kd, kh) row per iteration ----
+            {
+                const int h = tid & 1, col = tid >> 1;
+                const int c0 = tb * 16 + h * 8, wb = w0 * a.shw - 1 + col;
+                const bool colok = col < bw && (unsigned)wb < (unsigned)a.Wb && c0 < a.CB;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    const int db = dp * a.sd - 1 + r / 3, hb = hp * a.shw - 1 + r % 3;
+                    u32x4 val = {0u, 0u, 0u, 0u};
+                    if (colok && (unsigned)db < (unsigned)a.Db && (unsigned)hb < (unsigned)a.Hb)
+                        val = *reinterpret_cast<const u32x4*>(a.Bt + ((((size_t)n * a.Db + db) * a.Hb + hb) * a.Wb + wb) * a.CB + c0);
+                    if (col < bw) *reinterpret_cast<u32x4*>(sB + (r * BW_MAX + col) * 16 + h * 8) = val;
+                }
             }
             __syncthreads();
             // ---- fragments + MFMAs: A[i = a-channel][k = voxel], B[k = voxel][j = b-channel] ----
@@ -236,7 +241,8 @@ __global__ __launch_bounds__(256) void bf16_wgrad_kernel(const WgradArgs a) {
             }
         }
     }
-    // D[i = a (4*kb + r)][j = b]
+    // D[i = a (4*kb + r)][j = b] -> this chunk's slab
+    float* slab = a.part + (size_t)blockIdx.x * a.CA * a.CB * 27;
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
         const int tap = wave + 4 * q;
@@ -244,9 +250,17 @@ __global__ __launch_bounds__(256) void bf16_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ca = ta * 16 + kb * 4 + r, cb = tb * 16 + i16;
-            if (ca < a.CA && cb < a.CB && acc[q][r] != 0.0f) atomicAdd(a.dW + ((size_t)ca * a.CB + cb) * 27 + tap, acc[q][r]);
+            if (ca < a.CA && cb < a.CB) slab[((size_t)ca * a.CB + cb) * 27 + tap] = acc[q][r];
         }
     }
+}
+
+__global__ void bf16_wgrad_reduce_kernel(const float* __restrict__ part, int chunks, int n, float* __restrict__ dW) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * n + i];
+    dW[i] = s;
 }
 
 // ------------------------------------------------------------------------------------------------ layout / precision converters
@@ -461,22 +475,38 @@ extern "C" int mvs_bf16_conv3d(const void* x, const void* wpacked, const float* 
     return launch_conv<1, 1, 2>(a, Cin, nt, s);
 }
 
-extern "C" int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, int nbatch, int CA, int CB, int Dp, int Hp, int Wp, int Db, int Hb,
-                                     int Wb, int sd, int shw, mvs_stream_t stream) {
-    MVS_REQUIRE(A && Bt && dW, "mvs_bf16_conv3d_wgrad: null pointer");
+namespace {
+int wgrad_chunks(int nrows, int CA, int CB) {
+    const int tiles = ((CA + 15) / 16) * ((CB + 15) / 16);
+    int chunks = (1024 + tiles - 1) / tiles;                // ~4 blocks per CU over all tile pairs
+    if (chunks > nrows) chunks = nrows;
+    const int rows_per_block = (nrows + chunks - 1) / chunks;
+    return (nrows + rows_per_block - 1) / rows_per_block;
+}
+}  // namespace
+
+extern "C" int64_t mvs_bf16_conv3d_wgrad_workspace_bytes(int nbatch, int CA, int CB, int Dp, int Hp) {
+    if (!chan_ok(CA) || !chan_ok(CB) || nbatch < 1 || Dp < 1 || Hp < 1) return -1;
+    return (int64_t)wgrad_chunks(nbatch * Dp * Hp, CA, CB) * CA * CB * 27 * (int64_t)sizeof(float);
+}
+
+extern "C" int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, void* workspace, int nbatch, int CA, int CB, int Dp, int Hp,
+                                     int Wp, int Db, int Hb, int Wb, int sd, int shw, mvs_stream_t stream) {
+    MVS_REQUIRE(A && Bt && dW && workspace, "mvs_bf16_conv3d_wgrad: null pointer");
     MVS_REQUIRE(chan_ok(CA) && chan_ok(CB) && nbatch >= 1, "mvs_bf16_conv3d_wgrad: channels must be 8/16/32/64 (CA=%d CB=%d)", CA, CB);
     MVS_REQUIRE((sd == 1 || sd == 2) && (shw == 1 || shw == 2), "mvs_bf16_conv3d_wgrad: bad stride");
     WgradArgs a{};
-    a.A = reinterpret_cast<const __bf16*>(A), a.Bt = reinterpret_cast<const __bf16*>(Bt), a.dW = dW;
+    a.A = reinterpret_cast<const __bf16*>(A), a.Bt = reinterpret_cast<const __bf16*>(Bt), a.part = reinterpret_cast<float*>(workspace);
     a.nb = nbatch, a.CA = CA, a.CB = CB, a.Dp = Dp, a.Hp = Hp, a.Wp = Wp, a.Db = Db, a.Hb = Hb, a.Wb = Wb, a.sd = sd, a.shw = shw;
     a.nrows = nbatch * Dp * Hp;
-    // enough blocks to fill the chip a few times over, few enough that the closing atomics stay cheap
     const int tiles = ((CA + 15) / 16) * ((CB + 15) / 16);
-    int chunks = (2048 + tiles - 1) / tiles;
-    if (chunks > a.nrows) chunks = a.nrows;
+    const int chunks = wgrad_chunks(a.nrows, CA, CB);
     a.rows_per_block = (a.nrows + chunks - 1) / chunks;
-    chunks = (a.nrows + a.rows_per_block - 1) / a.rows_per_block;
-    hipLaunchKernelGGL(bf16_wgrad_kernel, dim3(chunks, tiles), dim3(256), 0, MVS_STREAM(stream), a);
+    hipStream_t s = MVS_STREAM(stream);
+    hipLaunchKernelGGL(bf16_wgrad_kernel, dim3(chunks, tiles), dim3(256), 0, s, a);
+    if (int rc = mvs::finish_launch("mvs_bf16_conv3d_wgrad")) return rc;
+    const int n = CA * CB * 27;
+    hipLaunchKernelGGL(bf16_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.part, chunks, n, dW);
     return mvs::finish_launch("mvs_bf16_conv3d_wgrad");
 }
 

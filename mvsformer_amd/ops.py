@@ -782,9 +782,13 @@ def bf16_conv3d_wgrad(A: torch.Tensor, Bt: torch.Tensor, stride) -> torch.Tensor
     _chk16(A, "A"), _chk16(Bt, "Bt")
     N, Dp, Hp, Wp, CA = A.shape
     _, Db, Hb, Wb, CB = Bt.shape
-    dW = torch.zeros(CA, CB, 3, 3, 3, device=A.device, dtype=torch.float32)
+    dW = torch.empty(CA, CB, 3, 3, 3, device=A.device, dtype=torch.float32)
+    nws = _lib.load().mvs_bf16_conv3d_wgrad_workspace_bytes(N, CA, CB, Dp, Hp)
+    if nws <= 0:
+        raise _lib.MvsHipError("bf16 wgrad: channels must be 8/16/32/64 (CA=%d CB=%d)" % (CA, CB))
+    ws = torch.empty(nws, device=A.device, dtype=torch.uint8)
     tag = ("bf16_wgrad_kernel", "flops", 2.0 * 27 * CA * CB * N * Dp * Hp * Wp)
-    _call("mvs_bf16_conv3d_wgrad", tag, _ptr(A), _ptr(Bt), _ptr(dW), N, CA, CB, Dp, Hp, Wp, Db, Hb, Wb, stride[0], stride[1], _stream())
+    _call("mvs_bf16_conv3d_wgrad", tag, _ptr(A), _ptr(Bt), _ptr(dW), _ptr(ws), N, CA, CB, Dp, Hp, Wp, Db, Hb, Wb, stride[0], stride[1], _stream())
     return dW
 
 

@@ -12,8 +12,12 @@ feats, proj, dv, scene = synth.make_inputs(5, 512, 640, seed=0, device=dev)
 feats = {k: v.requires_grad_(True) for k, v in feats.items()}
 gts = {"stage%d" % (i + 1): synth.plane_depth(scene, s, device=dev)[None] for i, s in enumerate(synth.STAGE_SCALES)}
 masks = {k: torch.ones_like(v) for k, v in gts.items()}
+import contextlib
+bf16 = "--bf16" in sys.argv
+amp = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if bf16 else contextlib.nullcontext
 def step():
-    out = net(feats, proj, dv, tmp=[5.0, 5.0, 5.0, 1.0])
+    with amp():
+        out = net(feats, proj, dv, tmp=[5.0, 5.0, 5.0, 1.0])
     loss = sum(ce_loss_stage4(out, gts, masks, dlossw=[1, 1, 1, 1]).values())
     loss.backward()
 for _ in range(2): step()
@@ -22,6 +26,6 @@ with ops.kernel_timer() as kt:
     step()
 tot = 0.0
 rows = sorted(kt.summary().items(), key=lambda kv: -kv[1]["total_ms"])
-for k, v in rows[:28]:
+for k, v in rows[:40]:
     print("%-36s calls %3d  total %7.3f ms" % (k, v["calls"], v["total_ms"]))
 print("SUM %.3f ms over %d launches" % (sum(v["total_ms"] for _, v in rows), sum(v["calls"] for _, v in rows)))
