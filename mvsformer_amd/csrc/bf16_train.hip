@@ -177,7 +177,7 @@ struct WgradArgs {
     int nb, CA, CB, Dp, Hp, Wp, Db, Hb, Wb, sd, shw, rows_per_block, nrows;
 };
 
-__global__ __launch_bounds__(256) void bf16_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 4) void bf16_wgrad_kernel(const WgradArgs a) {
     constexpr int KV = 32;                                  // voxels per MFMA (K)
     constexpr int BW_MAX = KV * 2 + 2;
     __shared__ __attribute__((aligned(16))) unsigned short sA[KV * 16];
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void bf16_wgrad_kernel(const WgradArgs a) {
                 const int h = tid & 1, col = tid >> 1;
                 const int c0 = tb * 16 + h * 8, wb = w0 * a.shw - 1 + col;
                 const bool colok = col < bw && (unsigned)wb < (unsigned)a.Wb && c0 < a.CB;
-#pragma unroll
+#pragma unroll 3
                 for (int r = 0; r < 9; ++r) {
                     const int db = dp * a.sd - 1 + r / 3, hb = hp * a.shw - 1 + r % 3;
                     u32x4 val = {0u, 0u, 0u, 0u};

@@ -165,7 +165,7 @@ def test_config3_train_cascade_stages(dev):
         gs = dfeat.abs().max().item()
         err = (fg.grad.cpu().double() - dfeat.double()).abs()
         assert (err > 3e-3 * gs).double().mean().item() < 5e-3, (i, err.max().item() / gs)     # 32x40 .. 256x320 maps: many border pixels
-        assert err.mean().item() < 1e-4 * gs, (i, err.mean().item() / gs)
+        assert err.mean().item() < 5e-4 * gs, (i, err.mean().item() / gs)
         for name, p in stage.named_parameters():
             w = dparams[name]
             assert max_abs(p.grad.cpu(), w) < 3e-3 * max(w.abs().max().item(), 1e-6), (i, name)
