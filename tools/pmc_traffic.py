@@ -1,11 +1,11 @@
 #!/usr/bin/env python
-"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, kernel-trace only) into per-kernel HBM bytes
-per launch, following MI355X_MICROARCH.md §HBM: the counters are in KiB; on gfx950 FETCH_SIZE under-reports wide
-(16 B/lane) coalesced reads by exactly 2x, other access widths must be calibrated on a kernel with a known byte count.
-Calibration kernel here: nchw_to_nhwc_kernel<C> (reads 4 B/lane dword streams, writes 16 B/lane; algorithmic bytes =
-4*numel each way) from the same run.
+"""Two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, kernel-trace only) over tools/prof_traffic.py -> HBM bytes
+per launch of every kernel, following MI355X_MICROARCH.md §HBM: the counters are in KiB and count fabric requests, not bytes
+(FETCH_SIZE reads exactly 1/2 of a coalesced stream on gfx950), so both are CALIBRATED on a kernel of known size in the same run:
+the config-2 stage-4 feature transpose (283.1 MB in, 283.1 MB out): bytes = counter * (known bytes / counter of that kernel).
+Measured factors: fetch 2.000, write 1.000.
 
-    python tools/pmc_traffic.py gpurun_out/final1/fetch gpurun_out/final1/write > profiles/pmc_traffic.json
+    python tools/pmc_traffic.py <fetch dir> <write dir> <out.json>
 """
 import csv
 import glob
@@ -14,47 +14,63 @@ import re
 import sys
 from collections import defaultdict
 
+CAL_BYTES = 256 * 1024 * 1024 * 4.0
+
 
 def short(k):
     k = re.sub(r"\(anonymous namespace\)::|^void ", "", k)
     m = re.match(r"([\w:]+(?:<[^(]*>)?)", k)
-    return m.group(1).replace(" ", "")
+    return m.group(1).replace(" ", "") if m else k
 
 
 def tagname(k):
-    """Map a kernel instantiation to the tag bench.py uses."""
+    """rocprof kernel name -> the tag bench.py uses for the same launch."""
+    m = re.match(r"cv_entropy_kernel<(\d+),(true|false)>", k)
+    if m:
+        return "cv_entropy_kernel<%s>" % m.group(1)
+    m = re.match(r"cv_aggregate_kernel<(\d+),(true|false),(true|false)>", k)
+    if m:
+        return "cv_aggregate_kernel<%s,%s>" % (m.group(1), m.group(2))
     m = re.match(r"conv3d_kernel<(\d+),(\d+),(\d+),(\d+),", k)
     if m:
-        np_, nt = int(m.group(2)), {16: 1, 48: 2, 80: 4}[int(m.group(2))]
+        nt = {16: 1, 48: 2, 80: 4}.get(int(m.group(2)), 0)
         return "conv3d_kernel<%d,%s,%s>" % (nt, m.group(3), m.group(4))
     return k
 
 
 def collect(d, counter):
     acc = defaultdict(list)
-    for f in glob.glob(d + "/*counter_collection.csv"):
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] == counter:
                 acc[tagname(short(row["Kernel_Name"]))].append(float(row["Counter_Value"]) * 1024.0)
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
-fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
-out = {"_units": "bytes per launch (mean over launches); fetch_raw/write_raw = counter*1024",
-       "_note": "fetch_corrected doubles FETCH_SIZE for kernels whose dominant reads are 16 B/lane (sweeps, transposes' "
-                "writes are not reads); conv kernels stage with dword buffer loads - see calibration entry"}
-# config-2 transpose: features [1,5,C,H,W] at each stage = 35.4 MB read + 35.4 MB written
-cal = {}
-for c in (8, 16, 32, 64):
-    k = "nchw_to_nhwc_kernel<%d>" % c
-    if k in fetch:
-        cal[k] = {"algorithmic_read": 5 * 56623104 / 8 * 4 / 4 * 1.0 if False else 35389440.0, "fetch_raw": fetch[k], "write_raw": write.get(k)}
-out["_calibration"] = cal
-wide = ("cv_entropy_kernel", "cv_aggregate_kernel")
-for k in sorted(set(fetch) | set(write)):
-    if not re.search(r"cv_|vis_|conv3d|deconv|head|prob3|nchw|schedule|init_inv", k):
-        continue
-    fr, wr = fetch.get(k, 0.0), write.get(k, 0.0)
-    fc = fr * 2.0 if k.startswith(wide) else fr
-    out[k] = {"fetch_raw": fr, "write_raw": wr, "fetch_corrected": fc, "traffic": fc + wr}
-print(json.dumps(out, indent=1))
+def main():
+    fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+    # calibration on a kernel of THIS library with a known byte count: the stage-4 feature transpose of config 2 reads and writes
+    # exactly 4 * (5 views * 8 ch * 1152 * 1536) bytes, streaming, larger than the Infinity Cache
+    calk = "nchw_to_nhwc_kernel<8>"
+    cal_bytes = 4.0 * 5 * 8 * 1152 * 1536
+    ffac = cal_bytes / fetch[calk] if fetch.get(calk) else 2.0
+    wfac = cal_bytes / write[calk] if write.get(calk) else 1.0
+    out = {"_units": "bytes per launch (mean over launches)", "_calibration": {"kernel": calk, "known_bytes_each_way": cal_bytes,
+           "fetch_raw": fetch.get(calk), "write_raw": write.get(calk), "fetch_factor": ffac, "write_factor": wfac},
+           "_note": "hbm_bytes_per_launch = FETCH_SIZE*1024*fetch_factor + WRITE_SIZE*1024*write_factor; factors from the float4 copy "
+                    "of the same run (exact for 16 B/lane streams; 'narrow' kernels load dwords and are only indicative)", "kernels": {}}
+    wide = ("cv_entropy_kernel", "cv_aggregate_kernel", "nchw_to_nhwc", "cv_tiled")
+    for k in sorted(set(fetch) | set(write)):
+        if not re.search(r"cv_|vis_|conv3d|deconv|head|prob3|nchw|schedule|init_inv|wino", k):
+            continue
+        fr, wr = fetch.get(k, 0.0), write.get(k, 0.0)
+        out["kernels"][k] = {"fetch_raw": fr, "write_raw": wr, "hbm_bytes_per_launch": fr * ffac + wr * wfac, "narrow": not k.startswith(wide)}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(out["_calibration"]))
+    for k, v in out["kernels"].items():
+        if k.startswith(("cv_", "nchw")):
+            print("%-40s %.1f MB" % (k, v["hbm_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
