@@ -172,16 +172,20 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
 struct WgradArgs {
     const __bf16* A;
     const __bf16* Bt;
-    float* part;              // [chunks][CA][CB][27] partial sums, one slab per row chunk (plain stores; summed by bf16_wgrad_reduce_kernel:
+    float* part;              // [chunks][CA][CB][27] partial sums, one slab per work item (plain stores; summed by bf16_wgrad_reduce_kernel:
                               // fp32 atomics from a thousand blocks onto the same few thousand dW addresses cost more than the GEMM)
-    int nb, CA, CB, Dp, Hp, Wp, Db, Hb, Wb, sd, shw, rows_per_block, nrows;
+    int nb, CA, CB, Dp, Hp, Wp, Db, Hb, Wb, sd, shw;
+    int nwc, seg, nseg;       // 32-voxel chunks along W, A rows per work item, row segments per (n, d) plane
 };
 
+// Work item = (batch n, A depth d, 32-voxel chunk of W, segment of `seg` consecutive A rows); the block walks the rows of its segment
+// and keeps the Bt rows it needs in an LDS ring (slot = row & 3 per kd): a new A row brings 1 (stride 1) or 2 (stride 2) new Bt rows
+// per kd instead of all 9.
 __global__ __launch_bounds__(256, 4) void bf16_wgrad_kernel(const WgradArgs a) {
     constexpr int KV = 32;                                  // voxels per MFMA (K)
     constexpr int BW_MAX = KV * 2 + 2;
     __shared__ __attribute__((aligned(16))) unsigned short sA[KV * 16];
-    __shared__ __attribute__((aligned(16))) unsigned short sB[9 * BW_MAX * 16];
+    __shared__ __attribute__((aligned(16))) unsigned short sB[3 * 4 * BW_MAX * 16];     // [kd][ring slot][column][16 channels]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntb = (a.CB + 15) / 16;
     const int ta = blockIdx.y / ntb, tb = blockIdx.y % ntb;
@@ -191,57 +195,71 @@ __global__ __launch_bounds__(256, 4) void bf16_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int q = 0; q < 7; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int row0 = blockIdx.x * a.rows_per_block;
-    for (int row = row0; row < min(row0 + a.rows_per_block, a.nrows); ++row) {
-        const int hp = row % a.Hp, dp = (row / a.Hp) % a.Dp, n = row / (a.Hp * a.Dp);
-        for (int w0 = 0; w0 < a.Wp; w0 += KV) {
-            __syncthreads();                                // previous step's fragments consumed
-            // ---- A tile: [KV voxels][16 channels] ----
-            if (tid < KV * 2) {
-                const int v = tid >> 1, h = tid & 1;
-                const int c0 = ta * 16 + h * 8;
-                u32x4 val = {0u, 0u, 0u, 0u};
-                if (w0 + v < a.Wp && c0 < a.CA)
-                    val = *reinterpret_cast<const u32x4*>(a.A + ((((size_t)n * a.Dp + dp) * a.Hp + hp) * a.Wp + w0 + v) * a.CA + c0);
-                *reinterpret_cast<u32x4*>(sA + v * 16 + h * 8) = val;
-            }
-            // ---- Bt tile: 9 (kd, kh) rows x bw voxels x 16 channels, voxel 0 of the tile = column w0*shw - 1;
-            //      thread -> (column tid >> 1, channel half tid & 1), one (kd, kh) row per iteration ----
-            {
-                const int h = tid & 1, col = tid >> 1;
-                const int c0 = tb * 16 + h * 8, wb = w0 * a.shw - 1 + col;
-                const bool colok = col < bw && (unsigned)wb < (unsigned)a.Wb && c0 < a.CB;
-#pragma unroll 3
-                for (int r = 0; r < 9; ++r) {
-                    const int db = dp * a.sd - 1 + r / 3, hb = hp * a.shw - 1 + r % 3;
-                    u32x4 val = {0u, 0u, 0u, 0u};
-                    if (colok && (unsigned)db < (unsigned)a.Db && (unsigned)hb < (unsigned)a.Hb)
-                        val = *reinterpret_cast<const u32x4*>(a.Bt + ((((size_t)n * a.Db + db) * a.Hb + hb) * a.Wb + wb) * a.CB + c0);
-                    if (col < bw) *reinterpret_cast<u32x4*>(sB + (r * BW_MAX + col) * 16 + h * 8) = val;
-                }
-            }
-            __syncthreads();
-            // ---- fragments + MFMAs: A[i = a-channel][k = voxel], B[k = voxel][j = b-channel] ----
-            unsigned short fa[8];
+    int item = blockIdx.x;
+    const int sg = item % a.nseg;
+    item /= a.nseg;
+    const int wc = item % a.nwc;
+    item /= a.nwc;
+    const int dp = item % a.Dp, n = item / a.Dp;
+    const int w0 = wc * KV, hp0 = sg * a.seg, hp1 = min(hp0 + a.seg, a.Hp);
+    const rsrc_t ra = make_rsrc(a.A + (size_t)n * a.Dp * a.Hp * a.Wp * a.CA, (unsigned)((size_t)a.Dp * a.Hp * a.Wp * a.CA * 2));
+    const rsrc_t rb = make_rsrc(a.Bt + (size_t)n * a.Db * a.Hb * a.Wb * a.CB, (unsigned)((size_t)a.Db * a.Hb * a.Wb * a.CB * 2));
+    // staging roles: A tile thread -> (voxel tid >> 1, channel half tid & 1); Bt thread -> (column tid >> 1, half tid & 1)
+    const int half = tid & 1, col = tid >> 1;
+    const int ca0 = ta * 16 + half * 8, cb0 = tb * 16 + half * 8;
+    const bool a_ok = tid < KV * 2 && w0 + col < a.Wp && ca0 < a.CA;
+    const int wb = w0 * a.shw - 1 + col;                    // Bt column of this thread
+    const bool b_ok = col < bw && (unsigned)wb < (unsigned)a.Wb && cb0 < a.CB;
+    const unsigned b_coloff = (unsigned)(wb * a.CB + cb0) * 2u;
+
+    auto stage_b_row = [&](int hb) {                        // one Bt image row (all three kd planes) into ring slot hb & 3
+        const int slot = (hb + 4) & 3;
+        const bool rowok = b_ok && (unsigned)hb < (unsigned)a.Hb;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) fa[e] = sA[(kb * 8 + e) * 16 + i16];       // voxels beyond Wp were zero-filled
-            bf16x8 fragA;
+        for (int kd = 0; kd < 3; ++kd) {
+            const int db = dp * a.sd - 1 + kd;
+            const bool ok = rowok && (unsigned)db < (unsigned)a.Db;
+            const unsigned off = (unsigned)((db * a.Hb + hb) * a.Wb) * (unsigned)(a.CB * 2) + b_coloff;
+            const u32x4 val = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, ok ? off : OOB, 0, 0));
+            if (col < bw) *reinterpret_cast<u32x4*>(sB + ((kd * 4 + slot) * BW_MAX + col) * 16 + half * 8) = val;
+        }
+    };
+
+    for (int hp = hp0; hp < hp1; ++hp) {
+        __syncthreads();                                    // previous row's fragments consumed
+        if (tid < KV * 2) {
+            const unsigned off = (unsigned)(((dp * a.Hp + hp) * a.Wp + w0 + col) * a.CA + ca0) * 2u;
+            const u32x4 val = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, a_ok ? off : OOB, 0, 0));
+            *reinterpret_cast<u32x4*>(sA + col * 16 + half * 8) = val;
+        }
+        const int hb_lo = hp * a.shw - 1;                   // Bt rows hb_lo .. hb_lo + 2 are needed
+        if (hp == hp0) {
+            stage_b_row(hb_lo);
+            stage_b_row(hb_lo + 1);
+            stage_b_row(hb_lo + 2);
+        } else {                                            // rows below hb_lo + 3 - shw are still in the ring
+            stage_b_row(hb_lo + 2);
+            if (a.shw == 2) stage_b_row(hb_lo + 1);
+        }
+        __syncthreads();
+        // ---- fragments + MFMAs: A[i = a-channel][k = voxel], B[k = voxel][j = b-channel] ----
+        bf16x8 fragA;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) fragA[e] = __builtin_bit_cast(__bf16, fa[e]);
+        for (int e = 0; e < 8; ++e) fragA[e] = __builtin_bit_cast(__bf16, sA[(kb * 8 + e) * 16 + i16]);      // voxels beyond Wp are zero
 #pragma unroll
-            for (int q = 0; q < 7; ++q) {
-                const int tap = wave + 4 * q;
-                if (tap >= 27) break;                       // wave-uniform
-                const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-                const unsigned short* rowp = sB + ((kd * 3 + kh) * BW_MAX) * 16 + i16;
-                bf16x8 fragB;
+        for (int q = 0; q < 7; ++q) {
+            const int tap = wave + 4 * q;
+            if (tap >= 27) break;                           // wave-uniform
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            const int slot = (hb_lo + kh + 4) & 3;
+            const unsigned short* rowp = sB + ((kd * 4 + slot) * BW_MAX) * 16 + i16;
+            bf16x8 fragB;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) fragB[e] = __builtin_bit_cast(__bf16, rowp[((kb * 8 + e) * a.shw + kw) * 16]);
-                acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fragA, fragB, acc[q], 0, 0, 0);
-            }
+            for (int e = 0; e < 8; ++e) fragB[e] = __builtin_bit_cast(__bf16, rowp[((kb * 8 + e) * a.shw + kw) * 16]);
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fragA, fragB, acc[q], 0, 0, 0);
         }
     }
-    // D[i = a (4*kb + r)][j = b] -> this chunk's slab
+    // D[i = a (4*kb + r)][j = b] -> this work item's slab
     float* slab = a.part + (size_t)blockIdx.x * a.CA * a.CB * 27;
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
@@ -476,18 +494,27 @@ extern "C" int mvs_bf16_conv3d(const void* x, const void* wpacked, const float* 
 }
 
 namespace {
-int wgrad_chunks(int nrows, int CA, int CB) {
+struct WgradPlan { int nwc, seg, nseg, chunks; };
+WgradPlan wgrad_plan(int nbatch, int CA, int CB, int Dp, int Hp, int Wp) {
     const int tiles = ((CA + 15) / 16) * ((CB + 15) / 16);
-    int chunks = (1024 + tiles - 1) / tiles;                // ~4 blocks per CU over all tile pairs
-    if (chunks > nrows) chunks = nrows;
-    const int rows_per_block = (nrows + chunks - 1) / chunks;
-    return (nrows + rows_per_block - 1) / rows_per_block;
+    WgradPlan p;
+    p.nwc = (Wp + 31) / 32;
+    // rows per work item: long segments amortize the 3-row prologue of the ring, short ones give the chip enough blocks (~1024)
+    const int64_t planes = (int64_t)nbatch * Dp * p.nwc * tiles;
+    int nseg = (int)((1024 + planes - 1) / planes);
+    if (nseg < 1) nseg = 1;
+    if (nseg > (Hp + 3) / 4) nseg = (Hp + 3) / 4;
+    if (nseg < 1) nseg = 1;
+    p.seg = (Hp + nseg - 1) / nseg;
+    p.nseg = (Hp + p.seg - 1) / p.seg;
+    p.chunks = nbatch * Dp * p.nwc * p.nseg;
+    return p;
 }
 }  // namespace
 
-extern "C" int64_t mvs_bf16_conv3d_wgrad_workspace_bytes(int nbatch, int CA, int CB, int Dp, int Hp) {
-    if (!chan_ok(CA) || !chan_ok(CB) || nbatch < 1 || Dp < 1 || Hp < 1) return -1;
-    return (int64_t)wgrad_chunks(nbatch * Dp * Hp, CA, CB) * CA * CB * 27 * (int64_t)sizeof(float);
+extern "C" int64_t mvs_bf16_conv3d_wgrad_workspace_bytes(int nbatch, int CA, int CB, int Dp, int Hp, int Wp) {
+    if (!chan_ok(CA) || !chan_ok(CB) || nbatch < 1 || Dp < 1 || Hp < 1 || Wp < 1) return -1;
+    return (int64_t)wgrad_plan(nbatch, CA, CB, Dp, Hp, Wp).chunks * CA * CB * 27 * (int64_t)sizeof(float);
 }
 
 extern "C" int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, void* workspace, int nbatch, int CA, int CB, int Dp, int Hp,
@@ -495,18 +522,19 @@ extern "C" int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, v
     MVS_REQUIRE(A && Bt && dW && workspace, "mvs_bf16_conv3d_wgrad: null pointer");
     MVS_REQUIRE(chan_ok(CA) && chan_ok(CB) && nbatch >= 1, "mvs_bf16_conv3d_wgrad: channels must be 8/16/32/64 (CA=%d CB=%d)", CA, CB);
     MVS_REQUIRE((sd == 1 || sd == 2) && (shw == 1 || shw == 2), "mvs_bf16_conv3d_wgrad: bad stride");
+    MVS_REQUIRE((int64_t)Dp * Hp * Wp * CA * 2 < ((int64_t)1 << 31) && (int64_t)Db * Hb * Wb * CB * 2 < ((int64_t)1 << 31),
+                "mvs_bf16_conv3d_wgrad: one sample exceeds the 2 GiB buffer range");
+    const WgradPlan p = wgrad_plan(nbatch, CA, CB, Dp, Hp, Wp);
     WgradArgs a{};
     a.A = reinterpret_cast<const __bf16*>(A), a.Bt = reinterpret_cast<const __bf16*>(Bt), a.part = reinterpret_cast<float*>(workspace);
     a.nb = nbatch, a.CA = CA, a.CB = CB, a.Dp = Dp, a.Hp = Hp, a.Wp = Wp, a.Db = Db, a.Hb = Hb, a.Wb = Wb, a.sd = sd, a.shw = shw;
-    a.nrows = nbatch * Dp * Hp;
+    a.nwc = p.nwc, a.seg = p.seg, a.nseg = p.nseg;
     const int tiles = ((CA + 15) / 16) * ((CB + 15) / 16);
-    const int chunks = wgrad_chunks(a.nrows, CA, CB);
-    a.rows_per_block = (a.nrows + chunks - 1) / chunks;
     hipStream_t s = MVS_STREAM(stream);
-    hipLaunchKernelGGL(bf16_wgrad_kernel, dim3(chunks, tiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bf16_wgrad_kernel, dim3(p.chunks, tiles), dim3(256), 0, s, a);
     if (int rc = mvs::finish_launch("mvs_bf16_conv3d_wgrad")) return rc;
     const int n = CA * CB * 27;
-    hipLaunchKernelGGL(bf16_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.part, chunks, n, dW);
+    hipLaunchKernelGGL(bf16_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.part, p.chunks, n, dW);
     return mvs::finish_launch("mvs_bf16_conv3d_wgrad");
 }
 

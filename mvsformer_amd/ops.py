@@ -783,7 +783,7 @@ def bf16_conv3d_wgrad(A: torch.Tensor, Bt: torch.Tensor, stride) -> torch.Tensor
     N, Dp, Hp, Wp, CA = A.shape
     _, Db, Hb, Wb, CB = Bt.shape
     dW = torch.empty(CA, CB, 3, 3, 3, device=A.device, dtype=torch.float32)
-    nws = _lib.load().mvs_bf16_conv3d_wgrad_workspace_bytes(N, CA, CB, Dp, Hp)
+    nws = _lib.load().mvs_bf16_conv3d_wgrad_workspace_bytes(N, CA, CB, Dp, Hp, Wp)
     if nws <= 0:
         raise _lib.MvsHipError("bf16 wgrad: channels must be 8/16/32/64 (CA=%d CB=%d)" % (CA, CB))
     ws = torch.empty(nws, device=A.device, dtype=torch.uint8)

@@ -125,5 +125,50 @@ def main():
         json.dump(report, f, indent=1)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--windows" not in sys.argv:
     main()
+
+
+def window_outliers(u, v, TH, TW, WX, WY, H, W):
+    """Fraction of samples whose 2x2 taps do NOT fall inside a fixed WX x WY texel window centred on the projection of the tile's
+    centre pixel at its middle plane (the 'software cache' form of the tiled sweep: no bounding-box reduction, per-sample fallback)."""
+    Vs, D = u.shape[:2]
+    Hc, Wc = (H // TH) * TH, (W // TW) * TW
+    uu = u[:, :, :Hc, :Wc].clamp(-1, W).reshape(Vs, D, Hc // TH, TH, Wc // TW, TW)
+    vv = v[:, :, :Hc, :Wc].clamp(-1, H).reshape(Vs, D, Hc // TH, TH, Wc // TW, TW)
+    cu = uu[:, D // 2, :, TH // 2, :, TW // 2].floor()[:, None, :, None, :, None]     # centre pixel, middle plane
+    cv = vv[:, D // 2, :, TH // 2, :, TW // 2].floor()[:, None, :, None, :, None]
+    x0, y0 = uu.floor() - (cu - WX // 2), vv.floor() - (cv - WY // 2)
+    inside = (x0 >= 0) & (x0 + 1 < WX) & (y0 >= 0) & (y0 + 1 < WY)
+    out = (~inside)
+    frac = out.float().mean().item()
+    # fraction of (wavefront = 64 consecutive pixels of the tile, plane) steps that contain at least one outlier
+    per_wave = out.permute(0, 1, 2, 4, 3, 5).reshape(Vs, D, Hc // TH, Wc // TW, (TH * TW) // 64, 64).any(-1).float().mean().item()
+    return frac, per_wave
+
+
+def window_report():
+    import mvsformer_amd as m
+    from mvsformer_amd import synth
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = m.CascadeMVS().eval()
+    m.randomize_bn_(net, seed=1)
+    net = net.to(dev)
+    feats, proj, dv, scene = synth.make_inputs(5, 1152, 1536, seed=0, device=dev)
+    out = net(feats, proj, dv, tmp=[5.0, 5.0, 5.0, 1.0])
+    torch.cuda.synchronize()
+    for i in (2, 3, 4):
+        hyp = out["stage%d" % i]["depth_values"][0]
+        D, H, W = hyp.shape
+        u, v = sweep_uv(proj["stage%d" % i][0], hyp)
+        for dchunk in ([slice(0, D)] if D <= 4 else [slice(0, 4), slice(0, D)]):
+            for (TH, TW) in ((16, 16), (8, 32)):
+                for (WX, WY) in ((32, 32), (40, 32), (48, 24), (48, 32), (64, 24), (64, 32), (48, 48)):
+                    f, pw = window_outliers(u[:, dchunk], v[:, dchunk], TH, TW, WX, WY, H, W)
+                    print("stage%d planes %d tile %2dx%-2d window %2dx%-2d (%4d texels): outlier samples %.4f, (wave,plane) steps with an outlier %.3f" % (
+                        i, dchunk.stop - dchunk.start, TH, TW, WX, WY, WX * WY, f, pw))
+
+
+if __name__ == "__main__" and "--windows" in sys.argv:
+    window_report()
