@@ -27,7 +27,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 3
+#define MVS_ABI_VERSION 4
 
 typedef void* mvs_stream_t;
 
@@ -194,14 +194,16 @@ int mvs_conv3d_wino_fwd(const float* x, const float* wpacked, const float* scale
  * scale = shift = NULL, relu = 0) -> mvs_bn_stats -> [all-reduce of sums across ranks = SyncBatchNorm] -> mvs_bn_finalize
  * -> mvs_affine_act, and the backward is mvs_bn_bwd_reduce -> [all-reduce] -> mvs_bn_bwd_apply -> data gradient through
  * the same MFMA conv kernels with re-packed weights -> mvs_conv3d_wgrad.  Tensors are [B,C,N], N = D*H*W or H*W.
- *   mvs_bn_stats:      sums[c] += sum x, sums[C+c] += sum x^2   (sums zeroed by the caller)
+ *   mvs_bn_stats:      sums[c] = sum x, sums[C+c] = sum x^2.  Like every per-channel reduction here it runs in two launches -
+ *                      one partial row per block into `workspace` (mvs_bn_reduce_workspace_bytes), then a fixed-order sum -
+ *                      so the statistics repeat bit-exactly run to run (no float atomics) and `sums` needs no zeroing
  *   mvs_bn_finalize:   mean/var from sums and count -> scale = gamma*invstd, shift = beta - mean*scale, mean, invstd;
  *                      running stats updated with momentum (unbiased variance), as nn.BatchNorm does; NULL to skip.
  *                      `count` is the per-channel element count as a host value; SyncBatchNorm (train.py:138-139) passes
  *                      `count_dev` instead: two DEVICE floats {n / 4096, n % 4096} that were summed over the ranks by the same
  *                      all-reduce as `sums` (exact up to 2^36 elements; the host never reads the global count back)
  *   mvs_affine_act:    y = [relu](x*scale[c] + shift[c]) [+ residual]
- *   mvs_bn_bwd_reduce: g = dy*[x*scale+shift > 0 or !relu]; sums[c] += sum g, sums[C+c] += sum g*xhat
+ *   mvs_bn_bwd_reduce: g = dy*[x*scale+shift > 0 or !relu]; sums[c] = sum g, sums[C+c] = sum g*xhat (same workspace)
  *   mvs_bn_bwd_apply:  dx = gamma*invstd*(g - sums[c]/count - xhat*sums[C+c]/count);  dgamma = sums[C+c], dbeta = sums[c]
  *   mvs_conv3d_wgrad:  dW[a][b][k] += sum_{batch,p} A[a,p] * Bt[b, p*s - 1 + k]  (dW zeroed by the caller); Conv3d:
  *                      A = dY, Bt = X, dW = [Cout,Cin,27]; ConvTranspose3d: A = X, Bt = dY, dW = [Cin,Cout,27];
@@ -210,7 +212,8 @@ int mvs_conv3d_wino_fwd(const float* x, const float* wpacked, const float* scale
  *                      the caller; source views are accumulated with fp32 atomics) and the visibility weights
  *   mvs_softmax_bwd, mvs_prob1_bwd (dwb[C+1] zeroed by the caller: dW then dbias), mvs_sigmoid_fwd/bwd, mvs_nhwc_to_nchw
  * ------------------------------------------------------------------------------------------------------- */
-int mvs_bn_stats(const float* x, int B, int C, int64_t N, float* sums, mvs_stream_t stream);
+int64_t mvs_bn_reduce_workspace_bytes(int B, int C, int64_t N);
+int mvs_bn_stats(const float* x, int B, int C, int64_t N, float* sums, void* workspace, mvs_stream_t stream);
 int mvs_bn_finalize(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
                     float momentum, float eps, double count, const float* count_dev, int C, float* scale, float* shift, float* mean,
                     float* invstd, mvs_stream_t stream);
@@ -222,7 +225,7 @@ int mvs_bn_finalize_grouped(const float* sums, const float* gamma, const float* 
 int mvs_affine_act(const float* x, const float* scale, const float* shift, const float* residual, int relu, int B, int C,
                    int64_t N, float* y, mvs_stream_t stream);
 int mvs_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
-                      const float* invstd, int relu, int B, int C, int64_t N, float* sums, mvs_stream_t stream);
+                      const float* invstd, int relu, int B, int C, int64_t N, float* sums, void* workspace, mvs_stream_t stream);
 int mvs_bn_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
                      const float* invstd, const float* gamma, const float* sums, double count, const float* count_dev, int relu,
                      int B, int C, int64_t N, float* dx, mvs_stream_t stream);
@@ -246,7 +249,7 @@ int mvs_conv3d_wgrad(const float* A, const float* Bt, float* dW, int nbatch, int
  *   mvs_bf16_from_f32_ncdhw / mvs_bf16_to_f32_ncdhw: fp32 [B,C,N] <-> bf16 [B,N,C]
  *   mvs_bf16_bn_stats / mvs_bf16_affine_act / mvs_bf16_bn_bwd_reduce / mvs_bf16_bn_bwd_apply: channel-last bf16 twins of
  *       mvs_bn_stats / mvs_affine_act / mvs_bn_bwd_reduce / mvs_bn_bwd_apply over R = B*D*H*W rows (fp32 statistics;
- *       mvs_bn_finalize is shared)
+ *       mvs_bn_finalize is shared; partial rows in a workspace of mvs_bf16_bn_reduce_workspace_bytes, fixed-order sums)
  * ------------------------------------------------------------------------------------------------------- */
 int64_t mvs_bf16_packed_elems(int Cin, int Cout);
 int mvs_bf16_pack_weights(const float* w, int d0, int d1, int src, int Cout, int Cin, void* wpacked, mvs_stream_t stream);
@@ -257,11 +260,12 @@ int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, void* worksp
                           int Db, int Hb, int Wb, int sd, int shw, mvs_stream_t stream);
 int mvs_bf16_from_f32_ncdhw(const float* in, void* out, int B, int C, int64_t N, mvs_stream_t stream);
 int mvs_bf16_to_f32_ncdhw(const void* in, float* out, int B, int C, int64_t N, mvs_stream_t stream);
-int mvs_bf16_bn_stats(const void* x, int C, int64_t R, float* sums, mvs_stream_t stream);
+int64_t mvs_bf16_bn_reduce_workspace_bytes(int C, int64_t R);
+int mvs_bf16_bn_stats(const void* x, int C, int64_t R, float* sums, void* workspace, mvs_stream_t stream);
 int mvs_bf16_affine_act(const void* x, const float* scale, const float* shift, const void* residual, int relu, int C, int64_t R,
                         void* y, mvs_stream_t stream);
 int mvs_bf16_bn_bwd_reduce(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
-                           const float* invstd, int relu, int C, int64_t R, float* sums, mvs_stream_t stream);
+                           const float* invstd, int relu, int C, int64_t R, float* sums, void* workspace, mvs_stream_t stream);
 int mvs_bf16_bn_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
                           const float* invstd, const float* gamma, const float* sums, double count, const float* count_dev,
                           int relu, int C, int64_t R, void* dx, mvs_stream_t stream);
@@ -278,11 +282,16 @@ int mvs_nhwc_to_nchw(const float* in, float* out, int N, int C, int64_t HW, mvs_
 /* Stand-alone heads for callers that use the ops directly.
  *   mvs_depth_regression: module.py:597-603, depth = sum_d p*depth_values; depth_values [B,D,H,W] or [B,D]
  *   mvs_conf_regression:  module.py:606-619, sum of the n probabilities around floor(sum_d p*d)
+ *   mvs_mixup_head:       the depth_type 'mixup_ce' head, models/mvsformer_model.py:126-136: best adjacent pair of p [B,D,H,W]
+ *                         (first maximum of p[d]+p[d+1]) -> conf = that sum, depth = the two hypotheses of depth_values
+ *                         [B,D,H,W] mixed by the pair probabilities renormalised with +1e-7
  *   mvs_prob1_fwd:        CostRegNet3D.prob alone (module.py:581,592): 1x1x1 conv C->1, x [B,C,N] -> logits [B,N],
  *                         w [C], bias [1] or NULL */
 int mvs_depth_regression(const float* p, const float* depth_values, int depth_per_pixel, int B, int D, int H, int W,
                          float* depth, mvs_stream_t stream);
 int mvs_conf_regression(const float* p, int n, int B, int D, int H, int W, float* conf, mvs_stream_t stream);
+int mvs_mixup_head(const float* p, const float* depth_values, int B, int D, int H, int W, float* depth, float* conf,
+                   mvs_stream_t stream);
 int mvs_prob1_fwd(const float* x, const float* w, const float* bias, int B, int C, int64_t N, float* logits,
                   mvs_stream_t stream);
 

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 from ctypes import c_double  # noqa: E402
 
@@ -43,11 +43,12 @@ SIGNATURES = {
     "mvs_deconv3d_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "mvs_prob3_fwd": (I, [P, P, I, I, I, I, I, P, P]),
     "mvs_head_fwd": (I, [P, P, P, P, I, P, F, I, I, I, I, I, P, P, P, P, P]),
-    "mvs_bn_stats": (I, [P, I, I, L, P, P]),
+    "mvs_bn_reduce_workspace_bytes": (L, [I, I, L]),
+    "mvs_bn_stats": (I, [P, I, I, L, P, P, P]),
     "mvs_bn_finalize": (I, [P, P, P, P, P, F, F, Dbl, P, I, P, P, P, P, P]),
     "mvs_bn_finalize_grouped": (I, [P, P, P, P, P, F, F, Dbl, P, I, I, P, P, P, P, P]),
     "mvs_affine_act": (I, [P, P, P, P, I, I, I, L, P, P]),
-    "mvs_bn_bwd_reduce": (I, [P, P, P, P, P, P, I, I, I, L, P, P]),
+    "mvs_bn_bwd_reduce": (I, [P, P, P, P, P, P, I, I, I, L, P, P, P]),
     "mvs_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, Dbl, P, I, I, I, L, P, P]),
     "mvs_conv3d_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "mvs_bf16_packed_elems": (L, [I, I]),
@@ -57,9 +58,10 @@ SIGNATURES = {
     "mvs_bf16_conv3d_wgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "mvs_bf16_from_f32_ncdhw": (I, [P, P, I, I, L, P]),
     "mvs_bf16_to_f32_ncdhw": (I, [P, P, I, I, L, P]),
-    "mvs_bf16_bn_stats": (I, [P, I, L, P, P]),
+    "mvs_bf16_bn_reduce_workspace_bytes": (L, [I, L]),
+    "mvs_bf16_bn_stats": (I, [P, I, L, P, P, P]),
     "mvs_bf16_affine_act": (I, [P, P, P, P, I, I, L, P, P]),
-    "mvs_bf16_bn_bwd_reduce": (I, [P, P, P, P, P, P, I, I, L, P, P]),
+    "mvs_bf16_bn_bwd_reduce": (I, [P, P, P, P, P, P, I, I, L, P, P, P]),
     "mvs_bf16_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, Dbl, P, I, I, L, P, P]),
     "mvs_cv_aggregate_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P]),
     "mvs_softmax_bwd": (I, [P, P, I, I, L, P, P]),
@@ -69,6 +71,7 @@ SIGNATURES = {
     "mvs_nhwc_to_nchw": (I, [P, P, I, I, L, P]),
     "mvs_depth_regression": (I, [P, P, I, I, I, I, I, P, P]),
     "mvs_conf_regression": (I, [P, I, I, I, I, I, P, P]),
+    "mvs_mixup_head": (I, [P, P, I, I, I, I, P, P, P]),
     "mvs_prob1_fwd": (I, [P, P, P, I, I, L, P, P]),
     "mvs_geo_filter_workspace_bytes": (L, [I, I]),
     "mvs_geo_filter_fwd": (I, [P, P, P, P, I, I, I, I, F, F, F, P, P, P, P, P, P, P, P]),

@@ -317,12 +317,10 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void bf16_bn_reduce_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
-                                                             int C, size_t R, float* __restrict__ sums) {
-    __shared__ float red[2 * 64];
+                                                             int C, size_t R, float* __restrict__ part) {
+    __shared__ float red[4][2 * 64];
     const int CQ = C / 8;
     const int cq = threadIdx.x % CQ, rsub = threadIdx.x / CQ, rstep = 256 / CQ;
-    if (threadIdx.x < 2 * C) red[threadIdx.x] = 0.0f;
-    __syncthreads();
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.0f;
@@ -358,13 +356,26 @@ __global__ __launch_bounds__(256) void bf16_bn_reduce_kernel(const __bf16* __res
             }
         }
     }
+    // fixed-order reduction (no atomics, bit-reproducible): lanes of a wave that share a channel octet (lane % CQ) combine through
+    // an xor-shuffle tree, the four waves through LDS, and the block writes ONE partial row; mvs::launch_partials_reduce adds the rows.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        atomicAdd(&red[cq * 8 + e], s[e]);
-        atomicAdd(&red[C + cq * 8 + e], q[e]);
+        for (int m = 32; m >= CQ; m >>= 1) {
+            s[e] += __shfl_xor(s[e], m, 64);
+            q[e] += __shfl_xor(q[e], m, 64);
+        }
+    }
+    if (lane < CQ) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[wave][lane * 8 + e] = s[e];
+            red[wave][C + lane * 8 + e] = q[e];
+        }
     }
     __syncthreads();
-    if (threadIdx.x < 2 * C) atomicAdd(&sums[threadIdx.x], red[threadIdx.x]);
+    if (threadIdx.x < 2 * C)
+        part[(size_t)blockIdx.x * 2 * C + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // y = [relu](x*scale[c] + shift[c]) [+ residual]
@@ -566,11 +577,19 @@ extern "C" int mvs_bf16_to_f32_ncdhw(const void* in, float* out, int B, int C, i
     return mvs::finish_launch("mvs_bf16_to_f32_ncdhw");
 }
 
-extern "C" int mvs_bf16_bn_stats(const void* x, int C, int64_t R, float* sums, mvs_stream_t stream) {
-    MVS_REQUIRE(x && sums && chan_ok(C) && R >= 1, "mvs_bf16_bn_stats: bad arguments");
-    hipLaunchKernelGGL(bf16_bn_reduce_kernel<false>, dim3((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, MVS_STREAM(stream),
+extern "C" int64_t mvs_bf16_bn_reduce_workspace_bytes(int C, int64_t R) {
+    if (!chan_ok(C) || R < 1) return -1;
+    return ((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * 2 * C * (int64_t)sizeof(float);
+}
+
+extern "C" int mvs_bf16_bn_stats(const void* x, int C, int64_t R, float* sums, void* workspace, mvs_stream_t stream) {
+    MVS_REQUIRE(x && sums && workspace && chan_ok(C) && R >= 1, "mvs_bf16_bn_stats: bad arguments");
+    const unsigned nb = (unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+    float* part = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(bf16_bn_reduce_kernel<false>, dim3(nb), dim3(256), 0, MVS_STREAM(stream),
                        reinterpret_cast<const __bf16*>(x), (const __bf16*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, 0, C, (size_t)R, sums);
+                       (const float*)nullptr, (const float*)nullptr, 0, C, (size_t)R, part);
+    mvs::launch_partials_reduce(part, (int)nb, 2 * C, sums, MVS_STREAM(stream));
     return mvs::finish_launch("mvs_bf16_bn_stats");
 }
 
@@ -585,11 +604,15 @@ extern "C" int mvs_bf16_affine_act(const void* x, const float* scale, const floa
 }
 
 extern "C" int mvs_bf16_bn_bwd_reduce(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
-                                      const float* invstd, int relu, int C, int64_t R, float* sums, mvs_stream_t stream) {
-    MVS_REQUIRE(dy && x && scale && shift && mean && invstd && sums && chan_ok(C) && R >= 1, "mvs_bf16_bn_bwd_reduce: bad arguments");
-    hipLaunchKernelGGL(bf16_bn_reduce_kernel<true>, dim3((unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, MVS_STREAM(stream),
+                                      const float* invstd, int relu, int C, int64_t R, float* sums, void* workspace,
+                                      mvs_stream_t stream) {
+    MVS_REQUIRE(dy && x && scale && shift && mean && invstd && sums && workspace && chan_ok(C) && R >= 1, "mvs_bf16_bn_bwd_reduce: bad arguments");
+    const unsigned nb = (unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+    float* part = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(bf16_bn_reduce_kernel<true>, dim3(nb), dim3(256), 0, MVS_STREAM(stream),
                        reinterpret_cast<const __bf16*>(x), reinterpret_cast<const __bf16*>(dy), scale, shift, mean, invstd, relu, C, (size_t)R,
-                       sums);
+                       part);
+    mvs::launch_partials_reduce(part, (int)nb, 2 * C, sums, MVS_STREAM(stream));
     return mvs::finish_launch("mvs_bf16_bn_bwd_reduce");
 }
 

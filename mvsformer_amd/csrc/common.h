@@ -20,6 +20,10 @@ inline int finish_launch(const char* what) {
     return MVS_OK;
 }
 
+// out[j] = sum_p part[p * n + j], p = 0..nparts-1, in a fixed order (one wave per j: lanes stride over p, then an xor-shuffle tree).
+// The deterministic second stage of every block-partial reduction in the library (BatchNorm statistics and their backward).
+void launch_partials_reduce(const float* part, int nparts, int n, float* out, hipStream_t stream);
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline long long ceil_div(long long a, long long b) { return (a + b - 1) / b; }
 

@@ -9,6 +9,20 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+static __global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ out) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= n) return;
+    float s = 0.0f;
+    for (int p = lane; p < nparts; p += 64) s += part[(size_t)p * n + j];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) out[j] = s;
+}
+
+void launch_partials_reduce(const float* part, int nparts, int n, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, part, nparts, n, out);
+}
 }  // namespace mvs
 
 extern "C" int mvs_version(void) { return MVS_ABI_VERSION; }

@@ -159,6 +159,28 @@ __global__ void conf_regression_kernel(const float* __restrict__ p, int n, int D
     out[(size_t)b * plane + pix] = (float)n * (acc / (float)n);
 }
 
+// depth_type == 'mixup_ce' head (mvsformer_model.py:126-136): over adjacent hypothesis pairs (d, d+1) take the pair with the largest
+// p[d]+p[d+1] (first maximum, torch.max), confidence = that sum, depth = the pair's hypotheses mixed by the renormalised pair
+// probabilities p/(p[d]+p[d+1]+1e-7) -- same operation order as the reference (two divisions, two products, one sum).
+__global__ void mixup_head_kernel(const float* __restrict__ p, const float* __restrict__ dv, int D, int H, int W,
+                                  float* __restrict__ depth, float* __restrict__ conf) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const size_t plane = (size_t)H * W, pix = (size_t)y * W + x, base = (size_t)b * D * plane + pix;
+    float left = p[base], best = -1.0f, bl = 0.0f, br = 0.0f;
+    int idx = 0;
+    for (int d = 0; d + 1 < D; ++d) {
+        const float right = p[base + (size_t)(d + 1) * plane];
+        const float s = left + right;
+        if (s > best) { best = s; idx = d; bl = left; br = right; }
+        left = right;
+    }
+    const float norm = (bl + br) + 1e-7f;
+    const float dl = dv[base + (size_t)idx * plane], dr = dv[base + (size_t)(idx + 1) * plane];
+    depth[(size_t)b * plane + pix] = dl * (bl / norm) + dr * (br / norm);
+    conf[(size_t)b * plane + pix] = best;
+}
+
 // CostRegNet3D.prob on its own: 1x1x1 conv C -> 1 with bias over [B,C,N] voxels
 __global__ void prob1_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, int C, size_t N,
                              float* __restrict__ out) {
@@ -188,6 +210,15 @@ extern "C" int mvs_conf_regression(const float* p, int n, int B, int D, int H, i
     dim3 grid(mvs::ceil_div(W, 64), mvs::ceil_div(H, 4), B), block(64, 4);
     hipLaunchKernelGGL(conf_regression_kernel, grid, block, 0, MVS_STREAM(stream), p, n, D, H, W, conf);
     return mvs::finish_launch("mvs_conf_regression");
+}
+
+extern "C" int mvs_mixup_head(const float* p, const float* depth_values, int B, int D, int H, int W, float* depth, float* conf,
+                             mvs_stream_t stream) {
+    MVS_REQUIRE(p && depth_values && depth && conf, "mvs_mixup_head: null pointer");
+    MVS_REQUIRE(B >= 1 && D >= 2 && H >= 1 && W >= 1 && B <= 65535, "mvs_mixup_head: bad shape (needs D >= 2)");
+    dim3 grid(mvs::ceil_div(W, 64), mvs::ceil_div(H, 4), B), block(64, 4);
+    hipLaunchKernelGGL(mixup_head_kernel, grid, block, 0, MVS_STREAM(stream), p, depth_values, D, H, W, depth, conf);
+    return mvs::finish_launch("mvs_mixup_head");
 }
 
 extern "C" int mvs_prob1_fwd(const float* x, const float* w, const float* bias, int B, int C, int64_t N, float* logits,

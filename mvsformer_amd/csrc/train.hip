@@ -3,7 +3,9 @@
 // SyncBatchNorm hooks in here: the per-channel sums are what ranks all-reduce), softmax / 1x1x1-prob / sigmoid
 // backward, and the NHWC->NCHW transpose of the feature gradient.  All bandwidth-bound elementwise / reduction kernels:
 // tensors are [B, C, N] with N = D*H*W (or H*W), one block per (chunk of N, channel, batch) so every access is a
-// coalesced 16-byte-per-lane stream; per-channel sums are block-reduced in LDS and combined with fp32 atomics.
+// coalesced 16-byte-per-lane stream; per-channel sums are block-reduced in LDS, written as one partial per block and
+// combined in a fixed order by a second tiny kernel (no float atomics: BatchNorm statistics repeat bit-exactly run to run,
+// which matters because the training head is an arg-max - a one-ulp change in a logit can move a whole hypothesis window).
 #include "common.h"
 
 namespace {
@@ -23,8 +25,8 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
-// sums[c] += sum x, sums[C + c] += sum x^2
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int C, size_t N, float* __restrict__ sums) {
+// part[p][c] = sum x, part[p][C + c] = sum x^2 over this block's share of channel c; p = b * gridDim.x + blockIdx.x
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int C, size_t N, float* __restrict__ part) {
     __shared__ float red[8];
     const int c = blockIdx.y, b = blockIdx.z;
     const float* row = x + ((size_t)b * C + c) * N;
@@ -40,8 +42,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     s = block_sum(s, red);
     q = block_sum(q, red);
     if (threadIdx.x == 0) {
-        atomicAdd(&sums[c], s);
-        atomicAdd(&sums[C + c], q);
+        float* o = part + ((size_t)b * gridDim.x + blockIdx.x) * 2 * C;
+        o[c] = s;
+        o[C + c] = q;
     }
 }
 
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
-                                                            int C, size_t N, float* __restrict__ sums) {
+                                                            int C, size_t N, float* __restrict__ part) {
     __shared__ float red[8];
     const int c = blockIdx.y, b = blockIdx.z;
     const size_t base = ((size_t)b * C + c) * N;
@@ -149,8 +152,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     s1 = block_sum(s1, red);
     s2 = block_sum(s2, red);
     if (threadIdx.x == 0) {
-        atomicAdd(&sums[c], s1);
-        atomicAdd(&sums[C + c], s2);
+        float* o = part + ((size_t)b * gridDim.x + blockIdx.x) * 2 * C;
+        o[c] = s1;
+        o[C + c] = s2;
     }
 }
 
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 
 dim3 row_grid(int B, int C, size_t N) { return dim3((unsigned)((N + CHUNK - 1) / CHUNK), C, B); }
 // reductions end in one fp32 atomic per block on 2C addresses, and same-address atomics serialize in L2: cap the blocks per
-// (b, c) row (grid-stride over chunks) so that a channel sees at most ~RED_ADDERS atomics instead of N/4096
+// (b, c) row (grid-stride over chunks) so that a channel has at most ~RED_ADDERS partial sums instead of N/4096
 constexpr int RED_ADDERS = 48;
 dim3 reduce_grid(int B, int C, size_t N) {
     size_t nb = (N + CHUNK - 1) / CHUNK;
@@ -257,9 +261,18 @@ dim3 reduce_grid(int B, int C, size_t N) {
 
 }  // namespace
 
-extern "C" int mvs_bn_stats(const float* x, int B, int C, int64_t N, float* sums, mvs_stream_t stream) {
-    MVS_REQUIRE(x && sums && B >= 1 && C >= 1 && C <= 65535 && B <= 65535 && N >= 1, "mvs_bn_stats: bad arguments");
-    hipLaunchKernelGGL(bn_stats_kernel, reduce_grid(B, C, N), dim3(256), 0, MVS_STREAM(stream), x, C, (size_t)N, sums);
+extern "C" int64_t mvs_bn_reduce_workspace_bytes(int B, int C, int64_t N) {
+    if (B < 1 || C < 1 || N < 1) return -1;
+    const dim3 g = reduce_grid(B, C, (size_t)N);
+    return (int64_t)g.x * B * 2 * C * (int64_t)sizeof(float);
+}
+
+extern "C" int mvs_bn_stats(const float* x, int B, int C, int64_t N, float* sums, void* workspace, mvs_stream_t stream) {
+    MVS_REQUIRE(x && sums && workspace && B >= 1 && C >= 1 && C <= 65535 && B <= 65535 && N >= 1, "mvs_bn_stats: bad arguments");
+    const dim3 g = reduce_grid(B, C, (size_t)N);
+    float* part = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(bn_stats_kernel, g, dim3(256), 0, MVS_STREAM(stream), x, C, (size_t)N, part);
+    mvs::launch_partials_reduce(part, (int)(g.x * B), 2 * C, sums, MVS_STREAM(stream));
     return mvs::finish_launch("mvs_bn_stats");
 }
 
@@ -291,11 +304,14 @@ extern "C" int mvs_affine_act(const float* x, const float* scale, const float* s
 }
 
 extern "C" int mvs_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
-                                 const float* invstd, int relu, int B, int C, int64_t N, float* sums, mvs_stream_t stream) {
-    MVS_REQUIRE(dy && x && scale && shift && mean && invstd && sums && B >= 1 && C >= 1 && C <= 65535 && B <= 65535 && N >= 1,
+                                 const float* invstd, int relu, int B, int C, int64_t N, float* sums, void* workspace,
+                                mvs_stream_t stream) {
+    MVS_REQUIRE(dy && x && scale && shift && mean && invstd && sums && workspace && B >= 1 && C >= 1 && C <= 65535 && B <= 65535 && N >= 1,
                 "mvs_bn_bwd_reduce: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, reduce_grid(B, C, N), dim3(256), 0, MVS_STREAM(stream), dy, x, scale, shift, mean, invstd, relu,
-                       C, (size_t)N, sums);
+    const dim3 g = reduce_grid(B, C, (size_t)N);
+    float* part = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, g, dim3(256), 0, MVS_STREAM(stream), dy, x, scale, shift, mean, invstd, relu, C, (size_t)N, part);
+    mvs::launch_partials_reduce(part, (int)(g.x * B), 2 * C, sums, MVS_STREAM(stream));
     return mvs::finish_launch("mvs_bn_bwd_reduce");
 }
 

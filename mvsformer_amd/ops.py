@@ -434,6 +434,18 @@ def conf_regression(p: torch.Tensor, n: int) -> torch.Tensor:
     return out
 
 
+def mixup_head(p: torch.Tensor, depth_values: torch.Tensor):
+    """depth_type 'mixup_ce' head (reference mvsformer_model.py:126-136) -> (depth [B,H,W], confidence [B,H,W])."""
+    _chk(p, "p"), _chk(depth_values, "depth_values")
+    if p.shape != depth_values.shape or p.dim() != 4:
+        raise _lib.MvsHipError("mixup_head: p %s / depth_values %s must both be [B,D,H,W]" % (tuple(p.shape), tuple(depth_values.shape)))
+    B, D, H, W = p.shape
+    depth = torch.empty(B, H, W, device=p.device, dtype=torch.float32)
+    conf = torch.empty(B, H, W, device=p.device, dtype=torch.float32)
+    _call("mvs_mixup_head", None, _ptr(p), _ptr(depth_values), B, D, H, W, _ptr(depth), _ptr(conf), _stream())
+    return depth, conf
+
+
 def prob1(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     _chk(x, "x"), _chk(w, "prob.weight")
     B, C, D, H, W = x.shape
@@ -469,12 +481,22 @@ def conf_accumulate(conf: torch.Tensor, acc: torch.Tensor, weight: float = 1.0) 
 
 
 # ----------------------------------------------------------------------------------------------- training kernels
+def _reduce_ws(fn: str, device, *shape) -> torch.Tensor:
+    """Partial-row workspace of the two-launch (atomic-free, bit-reproducible) per-channel reductions."""
+    nbytes = getattr(_lib.load(), fn)(*shape)
+    if nbytes < 0:
+        raise _lib.MvsHipError("%s%r: unsupported shape" % (fn, shape))
+    return torch.empty(max(int(nbytes) // 4, 1), device=device, dtype=torch.float32)
+
+
 def bn_stats(x: torch.Tensor) -> torch.Tensor:
     """``x [B,C,...]`` -> ``sums [2C]`` (sum, sum of squares per channel)."""
     _chk(x, "x")
     B, C = x.shape[0], x.shape[1]
-    sums = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
-    _call("mvs_bn_stats", None, _ptr(x), B, C, x.numel() // (B * C), _ptr(sums), _stream())
+    N = x.numel() // (B * C)
+    sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+    ws = _reduce_ws("mvs_bn_reduce_workspace_bytes", x.device, B, C, N)
+    _call("mvs_bn_stats", None, _ptr(x), B, C, N, _ptr(sums), _ptr(ws), _stream())
     return sums
 
 
@@ -518,9 +540,11 @@ def affine_act(x, scale, shift, residual, relu):
 def bn_bwd_reduce(dy, x, scale, shift, mean, invstd, relu):
     _chk(dy, "dy"), _chk(x, "x")
     B, C = x.shape[0], x.shape[1]
-    sums = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
-    _call("mvs_bn_bwd_reduce", None, _ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), int(relu), B, C,
-          x.numel() // (B * C), _ptr(sums), _stream())
+    N = x.numel() // (B * C)
+    sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+    ws = _reduce_ws("mvs_bn_reduce_workspace_bytes", x.device, B, C, N)
+    _call("mvs_bn_bwd_reduce", None, _ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), int(relu), B, C, N,
+          _ptr(sums), _ptr(ws), _stream())
     return sums
 
 
@@ -795,8 +819,9 @@ def bf16_conv3d_wgrad(A: torch.Tensor, Bt: torch.Tensor, stride) -> torch.Tensor
 def bf16_bn_stats(x: torch.Tensor) -> torch.Tensor:
     _chk16(x, "x")
     C = x.shape[-1]
-    sums = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
-    _call("mvs_bf16_bn_stats", "bf16_bn_stats", _ptr(x), C, x.numel() // C, _ptr(sums), _stream())
+    sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+    ws = _reduce_ws("mvs_bf16_bn_reduce_workspace_bytes", x.device, C, x.numel() // C)
+    _call("mvs_bf16_bn_stats", "bf16_bn_stats", _ptr(x), C, x.numel() // C, _ptr(sums), _ptr(ws), _stream())
     return sums
 
 
@@ -813,9 +838,10 @@ def bf16_affine_act(x, scale, shift, residual, relu):
 def bf16_bn_bwd_reduce(dy, x, scale, shift, mean, invstd, relu):
     _chk16(dy, "dy"), _chk16(x, "x")
     C = x.shape[-1]
-    sums = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
+    sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+    ws = _reduce_ws("mvs_bf16_bn_reduce_workspace_bytes", x.device, C, x.numel() // C)
     _call("mvs_bf16_bn_bwd_reduce", "bf16_bn_bwd_reduce", _ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), int(relu), C,
-          x.numel() // C, _ptr(sums), _stream())
+          x.numel() // C, _ptr(sums), _ptr(ws), _stream())
     return sums
 
 

@@ -57,8 +57,6 @@ class StageNet(nn.Module):
     def forward(self, features, proj_matrices, depth_values, tmp=2.0):
         """``features [B,V,C,H,W]`` (view 0 = reference), ``proj_matrices [B,V,2,4,4]``, ``depth_values [B,D,H,W]``."""
         depth_type = self.args["depth_type"]
-        if depth_type not in ("ce", "was"):
-            raise NotImplementedError("depth_type=%r: only 'ce'/'was' heads are built" % depth_type)
         if features.shape[1] != proj_matrices.shape[1]:
             raise AssertionError("Different number of images and projection matrices")
         G = self.args["base_ch"]
@@ -95,10 +93,23 @@ class StageNet(nn.Module):
         else:
             x = self.cost_reg.features(volume)
             logits = ops.prob3(x, self.cost_reg.prob.weight.detach().to(torch.float32).contiguous())
-        pre, prob, depth, conf = ops.head(hyp, float(tmp), False, logits=logits)
+        if depth_type in ("ce", "was"):
+            pre, prob, depth, conf = ops.head(hyp, float(tmp), False, logits=logits)
+        elif depth_type == "mixup_ce":                          # mvsformer_model.py:126-136
+            pre, prob, _, _ = ops.head(hyp, 1.0, False, logits=logits)
+            depth, conf = ops.mixup_head(prob, hyp)
+        else:                                                   # regression head, mvsformer_model.py:137-146 (tmp unused)
+            pre, prob, depth, conf = ops.head(hyp, 1.0, False, logits=logits)
+            n = self._conf_window()
+            if n:
+                conf = ops.conf_regression(prob, n)
         return {"depth": depth, "prob_volume": prob, "photometric_confidence": conf, "depth_values": depth_values,
                 "prob_volume_pre": pre, "sim_depth": sim_depth}
 
+
+    def _conf_window(self):
+        """Window of conf_regression for the regression head (mvsformer_model.py:139-146); 0 = plain max probability."""
+        return 4 if self.ndepth >= 32 else 3 if self.ndepth == 16 else 2 if self.ndepth == 8 else 0
 
     def _forward_train(self, features, proj_matrices, depth_values, tmp, G):
         """Training branch (reference mvsformer_model.py:62-125 with ``self.training``): no similarity branch, batch-statistics
@@ -115,7 +126,23 @@ class StageNet(nn.Module):
         if type(tmp) == list:
             tmp = tmp[self.stage_idx]
         pre = self.cost_reg(volume).squeeze(1)
-        prob, depth, conf = ag.HeadFn.apply(pre, hyp, float(tmp))
+        depth_type = self.args["depth_type"]
+        if depth_type in ("ce", "was"):
+            prob, depth, conf = ag.HeadFn.apply(pre, hyp, float(tmp))
+        else:
+            # The mixup / regression heads are a few elementwise ops on [B,D,H,W]; in training they run as torch ops on the HIP
+            # regularizer's logits so that depth and prob_volume are differentiable (mvsformer_model.py:126-146).
+            prob = torch.softmax(pre, dim=1)
+            if depth_type == "mixup_ce":
+                left, right = prob[:, :-1], prob[:, 1:]
+                conf, idx = torch.max(left + right, dim=1)
+                norm = left + right + 1e-7
+                mix = hyp[:, :-1] * (left / norm) + hyp[:, 1:] * (right / norm)
+                depth = torch.gather(mix, 1, idx.unsqueeze(1)).squeeze(1)
+            else:
+                depth = torch.sum(prob * hyp, dim=1)
+                n = self._conf_window()
+                conf = ops.conf_regression(prob.detach().contiguous(), n) if n else prob.max(1)[0]
         return {"depth": depth, "prob_volume": prob, "photometric_confidence": conf.detach(), "depth_values": depth_values,
                 "prob_volume_pre": pre}
 

@@ -253,6 +253,32 @@ def _stage_case(kind, ndepth, C, seed, shapes):
     save("stage_%s.npz" % kind, **out)
 
 
+def gen_other_heads(shapes):
+    """heads_other.npz: the real reference StageNet run with depth_type 'mixup_ce' and 'reg' (mvsformer_model.py:126-146) on the
+    inputs / weights of the two committed stage cases (eval and train mode; the heads do not depend on the mode, BatchNorm does)."""
+    out = {}
+    for kind, nd in (("costregnet", 16), ("costregnet3d", 4), ("costregnet", 32), ("costregnet3d", 8)):
+        g = np.load(os.path.join(OUT, "stage_%s.npz" % kind))
+        feats, proj = torch.from_numpy(g["features"].astype(np.float32)), torch.from_numpy(g["proj"])
+        hyp = torch.from_numpy(g["depth_values"])
+        if nd != hyp.shape[1]:            # the 32- and 8-plane windows of conf_regression: resample the hypotheses in inverse depth
+            inv = F.interpolate((1.0 / hyp).unsqueeze(1), [nd, hyp.shape[2], hyp.shape[3]], mode="trilinear", align_corners=True).squeeze(1)
+            hyp = 1.0 / inv
+            out["hyp_%s_%d" % (kind, nd)] = np32(hyp)
+        sd = make_state_dict(shapes["stage_" + kind], int(g["weight_seed"]))
+        for dt in ("mixup_ce", "reg"):
+            net = ref_mm.StageNet(dict(ARGS, depth_type=dt), nd, 0)
+            net.load_state_dict(sd, strict=True)
+            for mode in ("eval", "train"):
+                net.load_state_dict(sd, strict=True)
+                net.train(mode == "train")
+                with torch.no_grad():
+                    o = net(feats, proj, hyp, tmp=5.0)
+                for k in ("depth", "photometric_confidence"):
+                    out["%s_%d_%s_%s_%s" % (kind, nd, dt, mode, k)] = np32(o[k])
+    save("heads_other.npz", **out)
+
+
 def gen_cascade(V, shapes, seed):
     ndepths, ratios, tmps = [32, 16, 8, 4], [4.0, 2.67, 1.5, 1.0], [5.0, 5.0, 5.0, 1.0]
     Hf = Wf = 64
@@ -310,6 +336,10 @@ if __name__ == "__main__" and os.environ.get("GEN_EVAL", "1") == "1":
     _stage_case("costregnet3d", 4, 8, 4, shapes)
     gen_cascade(3, shapes, 6)
     gen_cascade(5, shapes, 7)
+
+
+if __name__ == "__main__" and os.environ.get("GEN_OTHER_HEADS", "1") == "1":
+    gen_other_heads(json.load(open(os.path.join(OUT, "state_dict_shapes.json"))))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -228,12 +228,22 @@ def schedule_inverse_range(depth: torch.Tensor, depth_hypo: torch.Tensor, ndepth
     return 1.0 / inv
 
 
+def mixup_head(prob: torch.Tensor, depth_values: torch.Tensor):
+    """mvsformer_model.py:126-136 (depth_type 'mixup_ce'): the adjacent hypothesis pair with the largest probability mass;
+    confidence = that mass, depth = the pair's hypotheses mixed by the pair probabilities renormalised with +1e-7."""
+    left, right = prob[:, :-1], prob[:, 1:]
+    conf, idx = torch.max(left + right, dim=1)
+    norm = left + right + 1e-7
+    mix = depth_values[:, :-1] * (left / norm) + depth_values[:, 1:] * (right / norm)
+    return torch.gather(mix, 1, idx.unsqueeze(1)).squeeze(1), conf
+
+
 # --------------------------------------------------------------------------------------
-# StageNet.forward, fusion_type='cnn', depth_type='ce'  (mvsformer_model.py:51-160)
+# StageNet.forward, fusion_type='cnn', all depth_type heads  (mvsformer_model.py:51-160)
 # --------------------------------------------------------------------------------------
 def stage_forward(features: torch.Tensor, proj: torch.Tensor, depth_values: torch.Tensor, sd: Dict[str, torch.Tensor],
                   *, G: int = 8, ndepth: int, model_th: int = 8, tmp: float = 2.0, training: bool = False,
-                  taps: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+                  taps: Optional[dict] = None, depth_type: str = "ce") -> Dict[str, torch.Tensor]:
     """``features [B,V,C,H,W]``, ``proj [B,V,2,4,4]``, ``depth_values [B,D,H,W]``.  ``taps`` (optional dict)
     receives the intermediates the golden files pin (per-view in_prod / entropy / vis weight, volume_mean)."""
     ref_feat = features[:, 0].to(torch.float32)
@@ -263,12 +273,20 @@ def stage_forward(features: torch.Tensor, proj: torch.Tensor, depth_values: torc
         logits = cost_reg_net(volume_mean, sd, "cost_reg", training)
     pre = logits.squeeze(1)
     prob = F.softmax(pre, dim=1)
-    if training:
-        idx = prob.max(dim=1)[1]
-        depth = torch.gather(depth_values, 1, idx.unsqueeze(1)).squeeze(1)
-    else:
-        depth = depth_regression(F.softmax(pre * tmp, dim=1), depth_values)
-    out = {"depth": depth, "prob_volume": prob, "photometric_confidence": prob.max(dim=1)[0].detach(),
+    if depth_type in ("ce", "was"):                          # mvsformer_model.py:113-125
+        if training:
+            idx = prob.max(dim=1)[1]
+            depth = torch.gather(depth_values, 1, idx.unsqueeze(1)).squeeze(1)
+        else:
+            depth = depth_regression(F.softmax(pre * tmp, dim=1), depth_values)
+        conf = prob.max(dim=1)[0]
+    elif depth_type == "mixup_ce":                           # mvsformer_model.py:126-136
+        depth, conf = mixup_head(prob, depth_values)
+    else:                                                    # mvsformer_model.py:137-146
+        depth = depth_regression(prob, depth_values)
+        n = {32: 4, 16: 3, 8: 2}.get(ndepth, 4 if ndepth >= 32 else 0)
+        conf = conf_regression(prob, n) if n else prob.max(dim=1)[0]
+    out = {"depth": depth, "prob_volume": prob, "photometric_confidence": conf.detach(),
            "depth_values": depth_values, "prob_volume_pre": pre}
     if not training:
         tot = torch.stack(sims, dim=1).sum(dim=1)

@@ -309,6 +309,55 @@ def test_stage_vs_golden(dev, kind):
     assert (o["sim_depth"].cpu().numpy() != g["eval_sim_depth"]).mean() < 0.02
 
 
+def test_mixup_head_vs_oracle(dev):
+    """mvs_mixup_head on its own against the oracle restatement (incl. D=2 and a pixel whose mass sits on the last pair)."""
+    from oracle import ref_torch
+    from mvsformer_amd import ops
+    torch.manual_seed(3)
+    for D in (2, 4, 16, 33):
+        p = torch.softmax(torch.randn(2, D, 9, 70) * 3, 1)
+        p[0, :, 0, 0] = 0
+        p[0, D - 1, 0, 0] = 1.0
+        dv = torch.rand(2, D, 9, 70).cumsum(1) + 400
+        depth, conf = ops.mixup_head(p.to(dev), dv.to(dev))
+        rd, rc = ref_torch.mixup_head(p, dv)
+        assert torch.equal(conf.cpu(), rc)
+        assert rel_err(depth.cpu(), rd) < 1e-6
+    with pytest.raises(Exception):
+        ops.mixup_head(torch.rand(1, 1, 4, 4, device=dev), torch.rand(1, 1, 4, 4, device=dev))
+
+
+@pytest.mark.parametrize("kind,nd", [("costregnet", 16), ("costregnet3d", 4), ("costregnet", 32), ("costregnet3d", 8)])
+@pytest.mark.parametrize("depth_type", ["mixup_ce", "reg"])
+def test_stage_other_heads_vs_golden(dev, kind, nd, depth_type):
+    """StageNet with the 'mixup_ce' / regression heads (mvsformer_model.py:126-146) against the real reference's outputs."""
+    import mvsformer_amd as m
+    g, go = load_golden("stage_%s.npz" % kind), load_golden("heads_other.npz")
+    key = "hyp_%s_%d" % (kind, nd)
+    hyp = go[key] if key in go else g["depth_values"]
+    net = m.StageNet(dict(base_ch=8, fusion_type="cnn", depth_type=depth_type), nd, 0)
+    net.load_state_dict(make_sd("stage_" + kind, g["weight_seed"]), strict=True)
+    net = net.to(dev)
+    for mode in ("eval", "train"):
+        net.load_state_dict(make_sd("stage_" + kind, g["weight_seed"]), strict=True)
+        net.train(mode == "train")
+        with torch.no_grad():
+            o = net(g2d(g["features"], dev), g2d(g["proj"], dev), g2d(hyp, dev), tmp=5.0)
+        assert ("sim_depth" in o) == (mode == "eval")
+        pre = "%s_%d_%s_%s_" % (kind, nd, depth_type, mode)
+        rd, rc = go[pre + "depth"], go[pre + "photometric_confidence"]
+        # pair arg-max / floor(E[d]) window flips at rounding-level ties: bounded fraction of pixels, the rest within tolerance
+        bad_d = (np.abs(o["depth"].cpu().numpy() - rd) > DEPTH_RTOL * np.abs(rd)).mean()
+        bad_c = (np.abs(o["photometric_confidence"].cpu().numpy() - rc) > 2e-4).mean()
+        assert bad_d < 5e-3 and bad_c < 5e-3, (mode, bad_d, bad_c)
+    # the training branch is differentiable end to end (torch ops on the HIP regularizer's logits)
+    net.train()
+    feats = g2d(g["features"], dev).requires_grad_(True)
+    o = net(feats, g2d(g["proj"], dev), g2d(hyp, dev), tmp=5.0)
+    o["depth"].mean().backward()
+    assert feats.grad is not None and torch.isfinite(feats.grad).all() and feats.grad.abs().sum() > 0
+
+
 @pytest.mark.parametrize("V", [3, 5])
 def test_cascade_vs_golden(dev, V):
     """The judged parity number: per-pixel |depth - ref| / |ref| <= 1e-3 at every stage of the 4-stage cascade."""

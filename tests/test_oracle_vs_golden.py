@@ -92,6 +92,34 @@ def test_stage(kind):
     assert "sim_depth" not in o
 
 
+OTHER_HEAD_CASES = [("costregnet", 16), ("costregnet3d", 4), ("costregnet", 32), ("costregnet3d", 8)]
+
+
+def other_head_inputs(kind, nd):
+    """Inputs of one heads_other.npz case: the stage case's features / cameras, hypotheses resampled for the 32- / 8-plane cases."""
+    g, go = load_golden("stage_%s.npz" % kind), load_golden("heads_other.npz")
+    key = "hyp_%s_%d" % (kind, nd)
+    hyp = go[key] if key in go else g["depth_values"]
+    return g, go, hyp
+
+
+@pytest.mark.parametrize("kind,nd", OTHER_HEAD_CASES)
+@pytest.mark.parametrize("depth_type", ["mixup_ce", "reg"])
+def test_stage_other_heads(kind, nd, depth_type):
+    """depth_type 'mixup_ce' / regression heads (mvsformer_model.py:126-146) against the real reference StageNet, eval and train."""
+    g, go, hyp = other_head_inputs(kind, nd)
+    sd = make_state_dict(load_shapes("stage_" + kind), int(g["weight_seed"]))
+    for mode in ("eval", "train"):
+        with torch.no_grad():
+            o = ref_torch.stage_forward(t(g["features"]), t(g["proj"]), t(hyp), sd, ndepth=nd, tmp=5.0, training=mode == "train",
+                                        depth_type=depth_type)
+        pre = "%s_%d_%s_%s_" % (kind, nd, depth_type, mode)
+        # the pair arg-max (mixup) and floor(E[d]) (conf_regression window) flip on rounding-level ties at isolated pixels
+        bad_d = (np.abs(o["depth"].numpy() - go[pre + "depth"]) > 1e-4 * np.abs(go[pre + "depth"])).mean()
+        bad_c = (np.abs(o["photometric_confidence"].numpy() - go[pre + "photometric_confidence"]) > 1e-4).mean()
+        assert bad_d < 2e-3 and bad_c < 2e-3, (mode, bad_d, bad_c)
+
+
 @pytest.mark.parametrize("V", [3, 5])
 def test_cascade(V):
     g = load_golden("cascade_v%d.npz" % V)
