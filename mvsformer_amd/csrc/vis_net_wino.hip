@@ -51,21 +51,34 @@ __global__ void vis_wino_prepare_kernel(const float* __restrict__ prm, float* __
     out[idx] = v;
 }
 
-__device__ __forceinline__ void xform(const float (&d)[4][4], float (&X)[16]) {      // X = B^T d B
-    float t[4][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        t[0][c] = d[0][c] - d[2][c];
-        t[1][c] = d[1][c] + d[2][c];
-        t[2][c] = d[2][c] - d[1][c];
-        t[3][c] = d[1][c] - d[3][c];
-    }
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
+// a - b in one packed instruction.  The backend has no packed fsub (a <2 x float> fsub is split into two v_sub_f32), so the
+// subtraction is spelled b * -1 + a: exact product, one rounding - bit-identical to a - b.
+// (The -1 comes out of an opaque asm so that the optimizer cannot fold the fma back into the fsub it would then split.)
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    float m1;
+    asm("s_mov_b32 %0, -1.0" : "=s"(m1));
+    return pk_fma(b, f32x2{m1, m1}, a);
+}
+
+// X = B^T d B with the packed fp32 adds of gfx950 (v_pk_add_f32: two lanes' worth of adds per issue slot - this kernel is bound by
+// vector-instruction issue, not by the matrix cores).  The patch arrives as E[q] = (d[q][0], d[q][2]) and O[q] = (d[q][1], d[q][3]),
+// exactly the register pairs the ds_read2_b32 of the even / odd column halves deliver, so the row transform is 8 packed ops with no
+// shuffles; the column transform packs (X1, X2) of each row (op_sel/neg modifiers) and leaves X0, X3 scalar: 20 instead of 32 ops.
+__device__ __forceinline__ void xform(const f32x2 (&E)[4], const f32x2 (&O)[4], float (&X)[16]) {
+    f32x2 T[4], U[4];                                       // T[a] = (t[a][0], t[a][2]), U[a] = (t[a][1], t[a][3])
+    T[0] = pk_sub(E[0], E[2]);  U[0] = pk_sub(O[0], O[2]);
+    T[1] = E[1] + E[2];         U[1] = O[1] + O[2];
+    T[2] = pk_sub(E[2], E[1]);  U[2] = pk_sub(O[2], O[1]);
+    T[3] = pk_sub(E[1], E[3]);  U[3] = pk_sub(O[1], O[3]);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        X[a * 4 + 0] = t[a][0] - t[a][2];
-        X[a * 4 + 1] = t[a][1] + t[a][2];
-        X[a * 4 + 2] = t[a][2] - t[a][1];
-        X[a * 4 + 3] = t[a][1] - t[a][3];
+        const f32x2 m = pk_fma(f32x2{U[a].x, U[a].x}, f32x2{1.0f, -1.0f}, f32x2{T[a].y, T[a].y});     // (t1 + t2, t2 - t1)
+        X[a * 4 + 0] = T[a].x - T[a].y;
+        X[a * 4 + 1] = m.x;
+        X[a * 4 + 2] = m.y;
+        X[a * 4 + 3] = U[a].x - U[a].y;
     }
 }
 
@@ -78,32 +91,33 @@ __device__ __forceinline__ void tile_row_gemm(const float* __restrict__ act, int
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float* p = act + (4 * j + kk) * PL + (2 * ty) * RS + i16;
-        float d[4][4], X[16];
+        f32x2 E[4], O[4];
+        float X[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            d[q][0] = p[q * RS];
-            d[q][1] = p[q * RS + OO];
-            d[q][2] = p[q * RS + 1];
-            d[q][3] = p[q * RS + OO + 1];
+            E[q] = f32x2{p[q * RS], p[q * RS + 1]};
+            O[q] = f32x2{p[q * RS + OO], p[q * RS + OO + 1]};
         }
-        xform(d, X);
+        xform(E, O, X);
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) Z[xi] = mfma4(U[xi][j], X[xi], Z[xi]);
     }
 }
 
-// A^T Z A for accumulator row r: o[a][b], a = output row, b = output column inside the 2x2 tile
-__device__ __forceinline__ void out_xform(const f32x4 (&Z)[16], int r, float (&o)[2][2]) {
-    float s[2][4];
+// A^T Z A for the accumulator row pair (2h, 2h+1): o[a][b] = (row 2h, row 2h+1) of output (a, b) inside the 2x2 tile; packed adds
+// over the two rows (they sit in adjacent registers of every Z[xi])
+__device__ __forceinline__ void out_xform(const f32x4 (&Z)[16], int h, f32x2 (&o)[2][2]) {
+    auto z = [&](int xi) { return h ? f32x2{Z[xi][2], Z[xi][3]} : f32x2{Z[xi][0], Z[xi][1]}; };
+    f32x2 s[2][4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        s[0][b] = Z[b][r] + Z[4 + b][r] + Z[8 + b][r];
-        s[1][b] = Z[4 + b][r] - Z[8 + b][r] - Z[12 + b][r];
+        s[0][b] = z(b) + z(4 + b) + z(8 + b);
+        s[1][b] = pk_sub(pk_sub(z(4 + b), z(8 + b)), z(12 + b));
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         o[a][0] = s[a][0] + s[a][1] + s[a][2];
-        o[a][1] = s[a][1] - s[a][2] - s[a][3];
+        o[a][1] = pk_sub(pk_sub(s[a][1], s[a][2]), s[a][3]);
     }
 }
 
@@ -137,6 +151,22 @@ __global__ __launch_bounds__(256, 2) void vis_wino_kernel(const float* __restric
         w3[r] = co < 8 ? prm[OFF_W3 + co] : 0.0f;
     }
     const float b3 = prm[OFF_B3];
+    // layer 1 as an MFMA A operand: lane (kk, co = i16) holds w0[tap = 4t + kk][co]; the matching B operand is the entropy at the
+    // tap's offset inside the halo tile
+    float W1A[3], sc0[4], sh0[4];
+    int tap_off[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int tap = 4 * t + kk;
+        W1A[t] = tap < 9 ? prm[OFF_W0 + tap * 16 + i16] : 0.0f;
+        const int tc = tap < 9 ? tap : 8;
+        tap_off[t] = (tc / 3) * INW + tc % 3;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sc0[r] = prm[OFF_S0 + 4 * kk + r];
+        sh0[r] = prm[OFF_B0 + 4 * kk + r];
+    }
 
     // Software pipeline over this block's tiles, two barriers per tile:
     //   phase A: layer 2 of tile t (s_a1 -> s_a2); the entropy of tile t+1, fetched into registers before, lands in s_in
@@ -165,29 +195,28 @@ __global__ __launch_bounds__(256, 2) void vis_wino_kernel(const float* __restric
         for (int e = 0; e < EPT; ++e)
             if (tid + e * 256 < INH * INW) s_in[tid + e * 256] = pre[e];
     };
-    auto layer1 = [&](int tile) {                          // 1 -> 16 on the 34 x 18 region (VALU, weights via the scalar cache)
+    // Layer 1 (1 -> 16 channels, 3x3) on the matrix cores as well: M = 16 output channels, N = 16 consecutive pixels of the
+    // flattened 34 x 18 region, K = the 9 taps padded to 12 (three K = 4 steps; lane kk supplies tap 4t + kk, taps 9-11 carry zero
+    // weights).  In the VALU form its 144 multiply-adds per pixel, with the weights in (spilled) scalar registers, cost as many
+    // vector instructions as both Winograd layers' transforms together.
+    auto layer1 = [&](int tile) {
         int n, x0, y0;
         tile_origin(tile, n, x0, y0);
-        for (int i = tid; i < A1W * A1H; i += 256) {
-            const int py = i / A1W, px = i % A1W;
+        constexpr int NPIX = A1W * A1H, NT1 = (NPIX + 15) / 16;
+#pragma unroll 1
+        for (int nt = wave; nt < NT1; nt += 4) {
+            const int pidx = min(nt * 16 + i16, NPIX - 1);
+            const int py = pidx / A1W, px = pidx % A1W;
+            const float* src = s_in + py * INW + px;
+            f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < 3; ++t) z = mfma4(W1A[t], src[tap_off[t]], z);
             const int gy = y0 - 2 + py, gx = x0 - 2 + px;
-            float acc[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float v = s_in[(py + ky) * INW + px + kx];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) acc[c] = fmaf(prm[OFF_W0 + (ky * 3 + kx) * 16 + c], v, acc[c]);
-                }
             const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            float* dst = s_a1 + py * A1W + (px & 1) * A1O + (px >> 1);
+            if (nt * 16 + i16 < NPIX) {
+                float* dst = s_a1 + (4 * kk) * A1PL + py * A1W + (px & 1) * A1O + (px >> 1);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const float o = fmaxf(fmaf(acc[c], prm[OFF_S0 + c], prm[OFF_B0 + c]), 0.0f);
-                dst[c * A1PL] = inside ? o : 0.0f;
+                for (int r = 0; r < 4; ++r) dst[r * A1PL] = inside ? fmaxf(fmaf(z[r], sc0[r], sh0[r]), 0.0f) : 0.0f;
             }
         }
     };
@@ -220,15 +249,19 @@ __global__ __launch_bounds__(256, 2) void vis_wino_kernel(const float* __restric
                     in_img[a][b] = gy >= 0 && gy < H && gx >= 0 && gx < W;
                 }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float o[2][2];
-                out_xform(Z, r, o);
-                float* dst = s_a2 + (4 * kk + r) * A2PL + (2 * ty) * A2W + i16;
+            for (int h = 0; h < 2; ++h) {
+                f32x2 o[2][2];
+                out_xform(Z, h, o);
+                const f32x2 sc = {sc1[2 * h], sc1[2 * h + 1]}, sh = {sh1[2 * h], sh1[2 * h + 1]};
+                float* dst = s_a2 + (4 * kk + 2 * h) * A2PL + (2 * ty) * A2W + i16;
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        dst[a * A2W + b * A2O] = in_img[a][b] ? fmaxf(fmaf(o[a][b], sc1[r], sh1[r]), 0.0f) : 0.0f;
+                    for (int b = 0; b < 2; ++b) {
+                        const f32x2 v = pk_fma(o[a][b], sc, sh);
+                        dst[a * A2W + b * A2O] = in_img[a][b] ? fmaxf(v.x, 0.0f) : 0.0f;
+                        dst[A2PL + a * A2W + b * A2O] = in_img[a][b] ? fmaxf(v.y, 0.0f) : 0.0f;
+                    }
             }
         }
         if (has_next) commit_entropy();
@@ -241,13 +274,18 @@ __global__ __launch_bounds__(256, 2) void vis_wino_kernel(const float* __restric
             tile_row_gemm<A2PL, A2W, A2O>(s_a2, ty, i16, kk, U3, Z);
             float part[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float o[2][2];
-                out_xform(Z, r, o);
+            for (int h = 0; h < 2; ++h) {
+                f32x2 o[2][2];
+                out_xform(Z, h, o);
+                const f32x2 sc = {sc2[2 * h], sc2[2 * h + 1]}, sh = {sh2[2 * h], sh2[2 * h + 1]};
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) part[a][b] = fmaf(w3[r], fmaxf(fmaf(o[a][b], sc2[r], sh2[r]), 0.0f), part[a][b]);
+                    for (int b = 0; b < 2; ++b) {
+                        const f32x2 v = pk_fma(o[a][b], sc, sh);
+                        part[a][b] = fmaf(w3[2 * h], fmaxf(v.x, 0.0f), part[a][b]);
+                        part[a][b] = fmaf(w3[2 * h + 1], fmaxf(v.y, 0.0f), part[a][b]);
+                    }
             }
             // channels 0-3 live in lanes kk = 0, channels 4-7 in kk = 1 (kk = 2, 3 hold the zero padding rows)
 #pragma unroll
