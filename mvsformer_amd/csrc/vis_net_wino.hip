@@ -88,19 +88,28 @@ __device__ __forceinline__ void tile_row_gemm(const float* __restrict__ act, int
                                               f32x4 (&Z)[16]) {
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) Z[xi] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float* p = act + (4 * j + kk) * PL + (2 * ty) * RS + i16;
-        f32x2 E[4], O[4];
-        float X[16];
+    const float* p = act + kk * PL + (2 * ty) * RS + i16;
+    f32x2 E[4], O[4];
+    auto load_patch = [&](int j) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            E[q] = f32x2{p[q * RS], p[q * RS + 1]};
-            O[q] = f32x2{p[q * RS + OO], p[q * RS + OO + 1]};
+            E[q] = f32x2{p[4 * j * PL + q * RS], p[4 * j * PL + q * RS + 1]};
+            O[q] = f32x2{p[4 * j * PL + q * RS + OO], p[4 * j * PL + q * RS + OO + 1]};
         }
+    };
+    load_patch(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float X[16];
         xform(E, O, X);
+        // software pipeline: the next channel group's patch is requested BEFORE this group's 16 MFMAs are issued, so the LDS latency
+        // runs under ~500 cycles of matrix work instead of in front of it (the sched_barriers keep the compiler from sinking it back)
+        __builtin_amdgcn_sched_barrier(0);
+        if (j < 3) load_patch(j + 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) Z[xi] = mfma4(U[xi][j], X[xi], Z[xi]);
+        __builtin_amdgcn_sched_barrier(0);                  // the next transform (and its wait on the LDS) stays behind these MFMAs
     }
 }
 
@@ -132,14 +141,17 @@ __global__ __launch_bounds__(256, 2) void vis_wino_kernel(const float* __restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kk = lane >> 4;
 
-    float U2[16][4], U3[16][4];
+    // Transform-domain weights of ONE layer at a time in registers (64 per lane), re-read from the 32 KB `prep` block (L1/L2 resident)
+    // at the start of each phase: holding both layers' (128 registers) left the GEMM loops no room to keep LDS loads in flight.
+    float U[16][4];
+    auto load_weights = [&](int layer) {
+        const float* src = prep + layer * 4096 + lane;
+        asm volatile("" : "+v"(src));                      // opaque per call: keeps LICM from hoisting both layers' loads out of the tile loop
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi)
+        for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            U2[xi][j] = prep[(xi * 4 + j) * 64 + lane];
-            U3[xi][j] = prep[4096 + (xi * 4 + j) * 64 + lane];
-        }
+            for (int j = 0; j < 4; ++j) U[xi][j] = src[(xi * 4 + j) * 64];
+    };
     float sc1[4], sh1[4], sc2[4], sh2[4], w3[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -236,10 +248,11 @@ __global__ __launch_bounds__(256, 2) void vis_wino_kernel(const float* __restric
         if (has_next) fetch_entropy(next);
 
         // ---- phase A: layer 2, 16 -> 16 on 16 x 8 tiles, two tile rows per wavefront ----
+        load_weights(0);
 #pragma unroll 1
         for (int ty = wave; ty < T2Y; ty += 4) {
             f32x4 Z[16];
-            tile_row_gemm<A1PL, A1W, A1O>(s_a1, ty, i16, kk, U2, Z);
+            tile_row_gemm<A1PL, A1W, A1O>(s_a1, ty, i16, kk, U, Z);
             bool in_img[2][2];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -268,10 +281,11 @@ __global__ __launch_bounds__(256, 2) void vis_wino_kernel(const float* __restric
         __syncthreads();
 
         // ---- phase B: layer 3, 16 -> 8 on 15 x 7 tiles (+ 1x1 conv + sigmoid), then layer 1 of the next tile ----
+        load_weights(1);
 #pragma unroll 1
         for (int ty = wave; ty < T3Y; ty += 4) {
             f32x4 Z[16];
-            tile_row_gemm<A2PL, A2W, A2O>(s_a2, ty, i16, kk, U3, Z);
+            tile_row_gemm<A2PL, A2W, A2O>(s_a2, ty, i16, kk, U, Z);
             float part[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
