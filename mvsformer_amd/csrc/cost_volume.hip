@@ -478,25 +478,34 @@ __global__ __launch_bounds__(64 * NW) void cv_aggregate_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// NCHW -> NHWC feature transpose ([N,C,HW] -> [N,HW,C]) through an LDS tile: reads are 256-B row segments per
-// channel, writes are one contiguous 64*C-float run per block (dwordx4 per lane).
+// NCHW -> NHWC feature transpose ([N,C,HW] -> [N,HW,C]) through an LDS tile of TP pixels: reads are 16 bytes per lane along a
+// channel row (a wavefront reads 1 KB contiguous), writes are one contiguous TP*C-float run per block (dwordx4 per lane).  VEC = false
+// (HW not a multiple of 4, or a ragged last block) falls back to dword reads.
 // ---------------------------------------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, size_t HW) {
-    __shared__ float tile[C][65];
+template <int C, int TP>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, size_t HW, int vec_ok) {
+    constexpr int LD = TP + 4;                               // row stride: 16-byte aligned rows, rows 4 banks apart
+    __shared__ __attribute__((aligned(16))) float tile[C * LD];
     const int tid = threadIdx.x;
-    const size_t p0 = (size_t)blockIdx.x * 64;
+    const size_t p0 = (size_t)blockIdx.x * TP;
     const size_t n = blockIdx.y;
-    const int npix = (int)min((size_t)64, HW - p0);
-    for (int i = tid; i < C * 64; i += 256) {
-        const int c = i >> 6, p = i & 63;
-        tile[c][p] = (p < npix) ? in[(n * C + c) * HW + p0 + p] : 0.0f;
+    const int npix = (int)min((size_t)TP, HW - p0);
+    if (vec_ok && npix == TP) {
+        for (int i = tid; i < C * (TP / 4); i += 256) {
+            const int c = i / (TP / 4), q = i % (TP / 4);
+            *reinterpret_cast<f32x4*>(tile + c * LD + 4 * q) = *reinterpret_cast<const f32x4*>(in + (n * C + c) * HW + p0 + 4 * q);
+        }
+    } else {
+        for (int i = tid; i < C * TP; i += 256) {
+            const int c = i / TP, p = i % TP;
+            tile[c * LD + p] = (p < npix) ? in[(n * C + c) * HW + p0 + p] : 0.0f;
+        }
     }
     __syncthreads();
     float* o = out + (n * HW + p0) * C;
     for (int i = tid; i < npix * C / 4; i += 256) {
         const int p = (i * 4) / C, c = (i * 4) % C;
-        const f32x4 v = {tile[c][p], tile[c + 1][p], tile[c + 2][p], tile[c + 3][p]};
+        const f32x4 v = {tile[c * LD + p], tile[(c + 1) * LD + p], tile[(c + 2) * LD + p], tile[(c + 3) * LD + p]};
         *reinterpret_cast<f32x4*>(o + (size_t)i * 4) = v;
     }
 }
@@ -516,14 +525,17 @@ extern "C" int mvs_nchw_to_nhwc(const float* in, float* out, int N, int C, int64
     MVS_REQUIRE(in && out, "mvs_nchw_to_nhwc: null pointer");
     MVS_REQUIRE(N >= 1 && N <= 65535 && HW >= 1, "mvs_nchw_to_nhwc: bad shape N=%d HW=%lld", N, (long long)HW);
     MVS_REQUIRE(C == 8 || C == 16 || C == 32 || C == 64, "mvs_nchw_to_nhwc: C must be 8, 16, 32 or 64 (got %d)", C);
-    dim3 grid((unsigned)((HW + 63) / 64), N);
     hipStream_t s = MVS_STREAM(stream);
-    switch (C) {
-        case 8: hipLaunchKernelGGL(nchw_to_nhwc_kernel<8>, grid, dim3(256), 0, s, in, out, (size_t)HW); break;
-        case 16: hipLaunchKernelGGL(nchw_to_nhwc_kernel<16>, grid, dim3(256), 0, s, in, out, (size_t)HW); break;
-        case 32: hipLaunchKernelGGL(nchw_to_nhwc_kernel<32>, grid, dim3(256), 0, s, in, out, (size_t)HW); break;
-        default: hipLaunchKernelGGL(nchw_to_nhwc_kernel<64>, grid, dim3(256), 0, s, in, out, (size_t)HW); break;
+    const int vec_ok = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+#define MVS_LAUNCH_T(CC, TP) \
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<CC, TP>), dim3((unsigned)((HW + TP - 1) / TP), N), dim3(256), 0, s, in, out, (size_t)HW, vec_ok)
+    switch (C) {                                             // 8-16 KB of LDS per block whatever C
+        case 8: MVS_LAUNCH_T(8, 256); break;
+        case 16: MVS_LAUNCH_T(16, 256); break;
+        case 32: MVS_LAUNCH_T(32, 128); break;
+        default: MVS_LAUNCH_T(64, 64); break;
     }
+#undef MVS_LAUNCH_T
     return mvs::finish_launch("mvs_nchw_to_nhwc");
 }
 

@@ -31,6 +31,9 @@ def tagname(k):
     m = re.match(r"cv_aggregate_kernel<(\d+),(true|false),(true|false)>", k)
     if m:
         return "cv_aggregate_kernel<%s,%s>" % (m.group(1), m.group(2))
+    m = re.match(r"nchw_to_nhwc_kernel<(\d+),", k)
+    if m:
+        return "nchw_to_nhwc_kernel<%s>" % m.group(1)
     m = re.match(r"conv3d_kernel<(\d+),(\d+),(\d+),(\d+),", k)
     if m:
         nt = {16: 1, 48: 2, 80: 4}.get(int(m.group(2)), 0)
