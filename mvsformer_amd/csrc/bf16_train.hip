@@ -165,120 +165,194 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
-// dW[a][b][tap] += sum_{batch, p} A[p][a] * Bt[p*s - 1 + k][b]   (A on the grid the stride divides; both channel-last bf16, dW fp32).
-// Block = (16 a-channels, 16 b-channels, a chunk of A rows); per 32 voxels of a row both tiles are copied to LDS as they are and
-// every lane gathers its MFMA fragment (8 voxels of one channel) from there with 2-byte reads: any stride, shift or alignment,
-// zero padding from zero-filled halo cells.  The 27 taps are spread over the 4 wavefronts (7 accumulators each).
+// dW[a][b][tap] = sum_{batch, p} A[p][a] * Bt[p*s - 1 + k][b]   (A on the grid the stride divides; both channel-last bf16, dW fp32).
+// The contraction runs over VOXELS while memory is channel-contiguous, so both MFMA operands are "columns" of the stored tiles.
+// gfx950's LDS transpose read does that turn for free: ds_read_b64_tr_b16 hands lane l the 4 keys (voxels) x channel (l & 15) of a
+// [4 voxels][16 channels] block whose 16 lanes each supplied the address of 4 contiguous channels of one voxel (any row stride;
+// tools/probe/tr16.hip pins the mapping) - two such reads are one v_mfma_f32_16x16x32_bf16 operand (K = 32 voxels, 8 per lane).
+//
+// Block = a patch of PH x 16 voxels of one (n, d) plane of A (PH = 2, 4 or 8 rows: what keeps the Bt halo tile under ~40 KB of LDS)
+// and TA x TB channel tiles (16 x 16 each; TA*TB <= 4).  Per patch the block stages the A tile [PH*16 voxels][CA block] and the Bt
+// halo tile [3 kd][PH*s + 2][16*s + 2][CB] as they are (16-byte global loads -> registers -> LDS, the next patch's loads in flight
+// under this patch's MFMAs; out-of-image cells arrive as zeros from out-of-range buffer loads), then every K step (2 rows x 16
+// columns of A) wave w runs taps w, w+4, ... for all its tiles: the A fragments are read once per K step, a Bt fragment once per
+// (tap, tb).  A block walks patches blockIdx.x, blockIdx.x + gridDim.x, ... with its partial sums in registers and writes ONE slab
+// at the end; bf16_wgrad_reduce_kernel adds the slabs in a fixed order (no float atomics: the weight gradient is bit-reproducible).
 struct WgradArgs {
     const __bf16* A;
     const __bf16* Bt;
-    float* part;              // [chunks][CA][CB][27] partial sums, one slab per work item (plain stores; summed by bf16_wgrad_reduce_kernel:
-                              // fp32 atomics from a thousand blocks onto the same few thousand dW addresses cost more than the GEMM)
+    float* part;              // [gridDim.x][CA][CB][27]
     int nb, CA, CB, Dp, Hp, Wp, Db, Hb, Wb, sd, shw;
-    int nwc, seg, nseg;       // 32-voxel chunks along W, A rows per work item, row segments per (n, d) plane
+    int PH, npr, npc, npatch; // patch rows, patches per column / row of a plane, patches in total
 };
 
-// Work item = (batch n, A depth d, 32-voxel chunk of W, segment of `seg` consecutive A rows); the block walks the rows of its segment
-// and keeps the Bt rows it needs in an LDS ring (slot = row & 3 per kd): a new A row brings 1 (stride 1) or 2 (stride 2) new Bt rows
-// per kd instead of all 9.
-__global__ __launch_bounds__(256, 4) void bf16_wgrad_kernel(const WgradArgs a) {
-    constexpr int KV = 32;                                  // voxels per MFMA (K)
-    constexpr int BW_MAX = KV * 2 + 2;
-    __shared__ __attribute__((aligned(16))) unsigned short sA[KV * 16];
-    __shared__ __attribute__((aligned(16))) unsigned short sB[3 * 4 * BW_MAX * 16];     // [kd][ring slot][column][16 channels]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntb = (a.CB + 15) / 16;
-    const int ta = blockIdx.y / ntb, tb = blockIdx.y % ntb;
-    const int i16 = lane & 15, kb = lane >> 4;
-    const int bw = KV * a.shw + 2;                          // Bt columns needed per K step
-    f32x4 acc[7];
-#pragma unroll
-    for (int q = 0; q < 7; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 lds_tr16(const unsigned short* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned short* p0, const unsigned short* p1) {
+    const s16x4 lo = lds_tr16(p0), hi = lds_tr16(p1);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(bf16x8, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+}
 
-    int item = blockIdx.x;
-    const int sg = item % a.nseg;
-    item /= a.nseg;
-    const int wc = item % a.nwc;
-    item /= a.nwc;
-    const int dp = item % a.Dp, n = item / a.Dp;
-    const int w0 = wc * KV, hp0 = sg * a.seg, hp1 = min(hp0 + a.seg, a.Hp);
-    const rsrc_t ra = make_rsrc(a.A + (size_t)n * a.Dp * a.Hp * a.Wp * a.CA, (unsigned)((size_t)a.Dp * a.Hp * a.Wp * a.CA * 2));
-    const rsrc_t rb = make_rsrc(a.Bt + (size_t)n * a.Db * a.Hb * a.Wb * a.CB, (unsigned)((size_t)a.Db * a.Hb * a.Wb * a.CB * 2));
-    // staging roles: A tile thread -> (voxel tid >> 1, channel half tid & 1); Bt thread -> (column tid >> 1, half tid & 1)
-    const int half = tid & 1, col = tid >> 1;
-    const int ca0 = ta * 16 + half * 8, cb0 = tb * 16 + half * 8;
-    const bool a_ok = tid < KV * 2 && w0 + col < a.Wp && ca0 < a.CA;
-    const int wb = w0 * a.shw - 1 + col;                    // Bt column of this thread
-    const bool b_ok = col < bw && (unsigned)wb < (unsigned)a.Wb && cb0 < a.CB;
-    const unsigned b_coloff = (unsigned)(wb * a.CB + cb0) * 2u;
+constexpr int WG_PW = 16;                                   // patch columns
+constexpr int WG_MAXI = 12;                                 // 16-byte Bt pieces per thread and patch, at most
+constexpr int WG_LDS_B = 42 * 1024;                         // Bt halo tile budget (bytes)
 
-    auto stage_b_row = [&](int hb) {                        // one Bt image row (all three kd planes) into ring slot hb & 3
-        const int slot = (hb + 4) & 3;
-        const bool rowok = b_ok && (unsigned)hb < (unsigned)a.Hb;
+template <int TA, int TB>                                   // channel tiles per block
+__global__ __launch_bounds__(256, 2) void bf16_wgrad_kernel(const WgradArgs a) {
+    constexpr int TT = TA * TB;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t16 = lane & 15, kb = lane >> 4;
+    const int s = a.shw;
+    const int BH = a.PH * s + 2, BW = WG_PW * s + 2;
+    constexpr int CAB = TA * 16, CBB = TB * 16;             // channels of the staged tiles (a CA / CB of 8 stages 8, see *_row)
+    const int a_row = min(CAB, a.CA), b_row = min(CBB, a.CB);            // stored channels per voxel
+    const int ca0 = blockIdx.y * CAB;                       // TB covers all of CB
+    unsigned short* sA = smem;                              // [PH*16][a_row]
+    unsigned short* sB = smem + a.PH * WG_PW * a_row + 64;  // [3][BH][BW][b_row] (+ slack: an 8-channel tile is read as 16 wide)
+    const int nvoxB = 3 * BH * BW, pcsB = b_row / 8, itemsB = nvoxB * pcsB;
+    const int nvoxA = a.PH * WG_PW, pcsA = a_row / 8, itemsA = nvoxA * pcsA;
+
+    // patch-invariant staging maps: item -> (kd, row, col, piece) relative to the patch origin
+    int relB[WG_MAXI];
 #pragma unroll
-        for (int kd = 0; kd < 3; ++kd) {
-            const int db = dp * a.sd - 1 + kd;
-            const bool ok = rowok && (unsigned)db < (unsigned)a.Db;
-            const unsigned off = (unsigned)((db * a.Hb + hb) * a.Wb) * (unsigned)(a.CB * 2) + b_coloff;
-            const u32x4 val = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, ok ? off : OOB, 0, 0));
-            if (col < bw) *reinterpret_cast<u32x4*>(sB + ((kd * 4 + slot) * BW_MAX + col) * 16 + half * 8) = val;
+    for (int i = 0; i < WG_MAXI; ++i) {
+        const int it = tid + i * 256;
+        const int pc = it % pcsB, v = it / pcsB;
+        const int bc = v % BW, br = (v / BW) % BH, kd = v / (BW * BH);
+        relB[i] = it < itemsB ? (kd << 24) | (br << 16) | (bc << 8) | pc : -1;
+    }
+    int relA[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int it = tid + i * 256;
+        const int pc = it % pcsA, v = it / pcsA;
+        relA[i] = it < itemsA ? ((v / WG_PW) << 16) | ((v % WG_PW) << 8) | pc : -1;
+    }
+    u32x4 pfB[WG_MAXI], pfA[2];
+    auto fetch = [&](int patch) {
+        int r = patch;
+        const int pcx = r % a.npc;
+        r /= a.npc;
+        const int pry = r % a.npr;
+        r /= a.npr;
+        const int dp = r % a.Dp, n = r / a.Dp;
+        const int h0 = pry * a.PH, w0 = pcx * WG_PW;
+        const rsrc_t ra = make_rsrc(a.A + (size_t)n * a.Dp * a.Hp * a.Wp * a.CA, (unsigned)((size_t)a.Dp * a.Hp * a.Wp * a.CA * 2));
+        const rsrc_t rb = make_rsrc(a.Bt + (size_t)n * a.Db * a.Hb * a.Wb * a.CB, (unsigned)((size_t)a.Db * a.Hb * a.Wb * a.CB * 2));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rel = relA[i];
+            const int hh = h0 + ((rel >> 16) & 0xFF), ww = w0 + ((rel >> 8) & 0xFF), pc = rel & 0xFF;
+            const bool ok = rel >= 0 && hh < a.Hp && ww < a.Wp;
+            const unsigned off = (unsigned)((((dp * a.Hp + hh) * a.Wp + ww) * a.CA + ca0 + pc * 8) * 2);
+            pfA[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? off : OOB, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < WG_MAXI; ++i) {
+            const int rel = relB[i];
+            const int db = dp * a.sd - 1 + (rel >> 24), hb = h0 * s - 1 + ((rel >> 16) & 0xFF), wb = w0 * s - 1 + ((rel >> 8) & 0xFF);
+            const bool ok = rel >= 0 && (unsigned)db < (unsigned)a.Db && (unsigned)hb < (unsigned)a.Hb && (unsigned)wb < (unsigned)a.Wb;
+            const unsigned off = (unsigned)((((db * a.Hb + hb) * a.Wb + wb) * a.CB + (rel & 0xFF) * 8) * 2);
+            if (i * 256 < itemsB) pfB[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, ok ? off : OOB, 0, 0));
         }
     };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (relA[i] >= 0) *reinterpret_cast<u32x4*>(sA + (tid + i * 256) * 8) = pfA[i];
+#pragma unroll
+        for (int i = 0; i < WG_MAXI; ++i)
+            if (relB[i] >= 0) *reinterpret_cast<u32x4*>(sB + (tid + i * 256) * 8) = pfB[i];
+    };
 
-    for (int hp = hp0; hp < hp1; ++hp) {
-        __syncthreads();                                    // previous row's fragments consumed
-        if (tid < KV * 2) {
-            const unsigned off = (unsigned)(((dp * a.Hp + hp) * a.Wp + w0 + col) * a.CA + ca0) * 2u;
-            const u32x4 val = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, a_ok ? off : OOB, 0, 0));
-            *reinterpret_cast<u32x4*>(sA + col * 16 + half * 8) = val;
-        }
-        const int hb_lo = hp * a.shw - 1;                   // Bt rows hb_lo .. hb_lo + 2 are needed
-        if (hp == hp0) {
-            stage_b_row(hb_lo);
-            stage_b_row(hb_lo + 1);
-            stage_b_row(hb_lo + 2);
-        } else {                                            // rows below hb_lo + 3 - shw are still in the ring
-            stage_b_row(hb_lo + 2);
-            if (a.shw == 2) stage_b_row(hb_lo + 1);
-        }
+    constexpr int NTAP = 7;
+    f32x4 acc[NTAP][TT];
+#pragma unroll
+    for (int q = 0; q < NTAP; ++q)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // lane-invariant parts of the transpose-read addresses: lane t16 of group kb supplies voxel (8*kb + 4*r + t16/4), channels 4*(t16%4)..+3
+    const int vsub = t16 >> 2, csub = (t16 & 3) * 4;
+    int patch = blockIdx.x;
+    if (patch < a.npatch) fetch(patch);
+    for (; patch < a.npatch; patch += gridDim.x) {
+        __syncthreads();                                    // previous patch's fragments consumed
+        commit();
         __syncthreads();
-        // ---- fragments + MFMAs: A[i = a-channel][k = voxel], B[k = voxel][j = b-channel] ----
-        bf16x8 fragA;
+        if (patch + (int)gridDim.x < a.npatch) fetch(patch + gridDim.x);
+        for (int ks = 0; ks < a.PH / 2; ++ks) {
+            // the lane's two voxel quartets of this K step: v = ks*32 + 8*kb + 4*r + vsub -> (row, col) inside the patch
+            int arow[2], acol[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) fragA[e] = __builtin_bit_cast(__bf16, sA[(kb * 8 + e) * 16 + i16]);      // voxels beyond Wp are zero
+            for (int r = 0; r < 2; ++r) {
+                const int v = 8 * kb + 4 * r + vsub;
+                arow[r] = 2 * ks + (v >> 4);
+                acol[r] = v & 15;
+            }
+            bf16x8 fa[TA];
 #pragma unroll
-        for (int q = 0; q < 7; ++q) {
-            const int tap = wave + 4 * q;
-            if (tap >= 27) break;                           // wave-uniform
-            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-            const int slot = (hb_lo + kh + 4) & 3;
-            const unsigned short* rowp = sB + ((kd * 4 + slot) * BW_MAX) * 16 + i16;
-            bf16x8 fragB;
+            for (int t = 0; t < TA; ++t)
+                    fa[t] = frag_tr(sA + (arow[0] * WG_PW + acol[0]) * a_row + t * 16 + csub, sA + (arow[1] * WG_PW + acol[1]) * a_row + t * 16 + csub);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) fragB[e] = __builtin_bit_cast(__bf16, rowp[((kb * 8 + e) * a.shw + kw) * 16]);
-            acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fragA, fragB, acc[q], 0, 0, 0);
+            for (int q = 0; q < NTAP; ++q) {
+                const int tap = wave + 4 * q;
+                if (tap >= 27) break;                       // wave-uniform
+                const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                const unsigned short* b0 = sB + (((kd * BH + arow[0] * s + kh) * BW + acol[0] * s + kw) * b_row) + csub;
+                const unsigned short* b1 = sB + (((kd * BH + arow[1] * s + kh) * BW + acol[1] * s + kw) * b_row) + csub;
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb) {
+                    const bf16x8 fb = frag_tr(b0 + tb * 16, b1 + tb * 16);
+#pragma unroll
+                    for (int ta = 0; ta < TA; ++ta)
+                        acc[q][ta * TB + tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ta], fb, acc[q][ta * TB + tb], 0, 0, 0);
+                }
+            }
         }
     }
-    // D[i = a (4*kb + r)][j = b] -> this work item's slab
+    // D[i = a (4*kb + r)][j = b] -> this block's slab
     float* slab = a.part + (size_t)blockIdx.x * a.CA * a.CB * 27;
 #pragma unroll
-    for (int q = 0; q < 7; ++q) {
+    for (int q = 0; q < NTAP; ++q) {
         const int tap = wave + 4 * q;
         if (tap >= 27) break;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ca = ta * 16 + kb * 4 + r, cb = tb * 16 + i16;
-            if (ca < a.CA && cb < a.CB) slab[((size_t)ca * a.CB + cb) * 27 + tap] = acc[q][r];
+        for (int t = 0; t < TT; ++t) {
+            const int ta = t / TB, tb = t % TB;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ca = ca0 + ta * 16 + kb * 4 + r, cb = tb * 16 + t16;
+                if (ca < a.CA && cb < a.CB) slab[((size_t)ca * a.CB + cb) * 27 + tap] = acc[q][t][r];
+            }
         }
     }
 }
 
-__global__ void bf16_wgrad_reduce_kernel(const float* __restrict__ part, int chunks, int n, float* __restrict__ dW) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.0f;
-    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * n + i];
-    dW[i] = s;
+// dW[i] = sum over slabs, in a fixed order: 64 outputs per block (coalesced), the four waves take every fourth slab each
+__global__ __launch_bounds__(256) void bf16_wgrad_reduce_kernel(const float* __restrict__ part, int chunks, int n, float* __restrict__ dW) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (i < n) {
+        int c = wave;
+        for (; c + 12 < chunks; c += 16) {
+            s0 += part[(size_t)c * n + i];
+            s1 += part[(size_t)(c + 4) * n + i];
+            s2 += part[(size_t)(c + 8) * n + i];
+            s3 += part[(size_t)(c + 12) * n + i];
+        }
+        for (; c < chunks; c += 4) s0 += part[(size_t)c * n + i];
+    }
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && i < n) dW[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // ------------------------------------------------------------------------------------------------ layout / precision converters
@@ -505,27 +579,33 @@ extern "C" int mvs_bf16_conv3d(const void* x, const void* wpacked, const float* 
 }
 
 namespace {
-struct WgradPlan { int nwc, seg, nseg, chunks; };
-WgradPlan wgrad_plan(int nbatch, int CA, int CB, int Dp, int Hp, int Wp) {
-    const int tiles = ((CA + 15) / 16) * ((CB + 15) / 16);
+struct WgradPlan { int PH, npr, npc, npatch, TA, TB, gy, blocks; size_t lds; };
+WgradPlan wgrad_plan(int nbatch, int CA, int CB, int Dp, int Hp, int Wp, int shw) {
     WgradPlan p;
-    p.nwc = (Wp + 31) / 32;
-    // rows per work item: long segments amortize the 3-row prologue of the ring, short ones give the chip enough blocks (~1024)
-    const int64_t planes = (int64_t)nbatch * Dp * p.nwc * tiles;
-    int nseg = (int)((1024 + planes - 1) / planes);
-    if (nseg < 1) nseg = 1;
-    if (nseg > (Hp + 3) / 4) nseg = (Hp + 3) / 4;
-    if (nseg < 1) nseg = 1;
-    p.seg = (Hp + nseg - 1) / nseg;
-    p.nseg = (Hp + p.seg - 1) / p.seg;
-    p.chunks = nbatch * Dp * p.nwc * p.nseg;
+    const int nA = (CA + 15) / 16, nB = (CB + 15) / 16;
+    p.TB = nB;                                               // one block sees all of CB (nB <= 4)
+    p.TA = nA < 4 / nB ? nA : 4 / nB;
+    if (p.TA < 1) p.TA = 1;
+    p.gy = (nA + p.TA - 1) / p.TA;
+    const int b_row = CB < p.TB * 16 ? CB : p.TB * 16, a_row = CA < p.TA * 16 ? CA : p.TA * 16;
+    p.PH = 8;
+    while (p.PH > 2 && (size_t)3 * (p.PH * shw + 2) * (WG_PW * shw + 2) * b_row * 2 > (size_t)WG_LDS_B) p.PH >>= 1;
+    p.npr = (Hp + p.PH - 1) / p.PH;
+    p.npc = (Wp + WG_PW - 1) / WG_PW;
+    p.npatch = nbatch * Dp * p.npr * p.npc;
+    p.blocks = 512 / p.gy;                                   // two resident blocks per CU over all channel groups; never more than the
+    const int least = nbatch * Dp * ((Hp + 7) / 8) * p.npc;  // patch count at PH = 8, so the slab count does not depend on the stride
+    if (p.blocks > least) p.blocks = least;
+    if (p.blocks < 1) p.blocks = 1;
+    p.lds = ((size_t)p.PH * WG_PW * a_row + 64 + (size_t)3 * (p.PH * shw + 2) * (WG_PW * shw + 2) * b_row + 64) * 2;
     return p;
 }
 }  // namespace
 
 extern "C" int64_t mvs_bf16_conv3d_wgrad_workspace_bytes(int nbatch, int CA, int CB, int Dp, int Hp, int Wp) {
     if (!chan_ok(CA) || !chan_ok(CB) || nbatch < 1 || Dp < 1 || Hp < 1 || Wp < 1) return -1;
-    return (int64_t)wgrad_plan(nbatch, CA, CB, Dp, Hp, Wp).chunks * CA * CB * 27 * (int64_t)sizeof(float);
+    // the stride only moves PH (not the block count), so the plan of stride 1 sizes the slabs for both
+    return (int64_t)wgrad_plan(nbatch, CA, CB, Dp, Hp, Wp, 1).blocks * CA * CB * 27 * (int64_t)sizeof(float);
 }
 
 extern "C" int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, void* workspace, int nbatch, int CA, int CB, int Dp, int Hp,
@@ -535,17 +615,27 @@ extern "C" int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, v
     MVS_REQUIRE((sd == 1 || sd == 2) && (shw == 1 || shw == 2), "mvs_bf16_conv3d_wgrad: bad stride");
     MVS_REQUIRE((int64_t)Dp * Hp * Wp * CA * 2 < ((int64_t)1 << 31) && (int64_t)Db * Hb * Wb * CB * 2 < ((int64_t)1 << 31),
                 "mvs_bf16_conv3d_wgrad: one sample exceeds the 2 GiB buffer range");
-    const WgradPlan p = wgrad_plan(nbatch, CA, CB, Dp, Hp, Wp);
+    const WgradPlan p = wgrad_plan(nbatch, CA, CB, Dp, Hp, Wp, shw);
+    const int b_row = CB < p.TB * 16 ? CB : p.TB * 16;
+    const int itemsB = 3 * (p.PH * shw + 2) * (WG_PW * shw + 2) * (b_row / 8);
+    MVS_REQUIRE(itemsB <= WG_MAXI * 256 && p.lds <= 64 * 1024, "mvs_bf16_conv3d_wgrad: Bt halo tile of %d pieces / %zu bytes does not fit (CB=%d stride %d)",
+                itemsB, p.lds, CB, shw);
     WgradArgs a{};
     a.A = reinterpret_cast<const __bf16*>(A), a.Bt = reinterpret_cast<const __bf16*>(Bt), a.part = reinterpret_cast<float*>(workspace);
     a.nb = nbatch, a.CA = CA, a.CB = CB, a.Dp = Dp, a.Hp = Hp, a.Wp = Wp, a.Db = Db, a.Hb = Hb, a.Wb = Wb, a.sd = sd, a.shw = shw;
-    a.nwc = p.nwc, a.seg = p.seg, a.nseg = p.nseg;
-    const int tiles = ((CA + 15) / 16) * ((CB + 15) / 16);
+    a.PH = p.PH, a.npr = p.npr, a.npc = p.npc, a.npatch = p.npatch;
     hipStream_t s = MVS_STREAM(stream);
-    hipLaunchKernelGGL(bf16_wgrad_kernel, dim3(p.chunks, tiles), dim3(256), 0, s, a);
+    const dim3 grid(p.blocks, p.gy);
+    if (p.TA == 1 && p.TB == 1) hipLaunchKernelGGL((bf16_wgrad_kernel<1, 1>), grid, dim3(256), p.lds, s, a);
+    else if (p.TA == 1 && p.TB == 2) hipLaunchKernelGGL((bf16_wgrad_kernel<1, 2>), grid, dim3(256), p.lds, s, a);
+    else if (p.TA == 2 && p.TB == 1) hipLaunchKernelGGL((bf16_wgrad_kernel<2, 1>), grid, dim3(256), p.lds, s, a);
+    else if (p.TA == 2 && p.TB == 2) hipLaunchKernelGGL((bf16_wgrad_kernel<2, 2>), grid, dim3(256), p.lds, s, a);
+    else if (p.TA == 1 && p.TB == 4) hipLaunchKernelGGL((bf16_wgrad_kernel<1, 4>), grid, dim3(256), p.lds, s, a);
+    else if (p.TA == 4 && p.TB == 1) hipLaunchKernelGGL((bf16_wgrad_kernel<4, 1>), grid, dim3(256), p.lds, s, a);
+    else MVS_REQUIRE(false, "mvs_bf16_conv3d_wgrad: no kernel for %d x %d channel tiles", p.TA, p.TB);
     if (int rc = mvs::finish_launch("mvs_bf16_conv3d_wgrad")) return rc;
     const int n = CA * CB * 27;
-    hipLaunchKernelGGL(bf16_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.part, p.chunks, n, dW);
+    hipLaunchKernelGGL(bf16_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, a.part, p.blocks, n, dW);
     return mvs::finish_launch("mvs_bf16_conv3d_wgrad");
 }
 
