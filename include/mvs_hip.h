@@ -272,6 +272,14 @@ int mvs_bf16_bn_bwd_apply(const void* dy, const void* x, const float* scale, con
 int mvs_cv_aggregate_bwd(const float* feat, const float* rt, const float* depth, const float* weight, const float* volume,
                          const float* gvolume, int B, int V, int C, int G, int D, int H, int W, float* dfeat, float* dweight,
                          mvs_stream_t stream);
+/* The same gradients with the bilinear scatter accumulated in LDS: a block owns a 16 x 8 tile of reference pixels and one channel
+ * octet, adds the taps of all D planes into a (1 << wx_log2) x wy texel window of the source view's gradient (ds_add_f32) and flushes
+ * the touched texels with one global atomic per value; taps outside the window go straight to global atomics, so the result is
+ * independent of the window.  gip_part [C/8][B][V-1][H][W]: d(loss)/d(vis weight) per channel octet - the caller adds the octets.
+ * stats: NULL, or 2 device counters (diagnostics): [0] += taps scattered, [1] += taps that missed the window. */
+int mvs_cv_aggregate_bwd_lds(const float* feat, const float* rt, const float* depth, const float* weight, const float* volume,
+                             const float* gvolume, int B, int V, int C, int G, int D, int H, int W, float* dfeat, float* gip_part,
+                             int wx_log2, int wy, unsigned* stats, mvs_stream_t stream);
 int mvs_softmax_bwd(const float* p, const float* dp, int B, int D, int64_t HW, float* dpre, mvs_stream_t stream);
 int mvs_prob1_bwd(const float* x, const float* w, const float* dlogits, int B, int C, int64_t N, float* dx, float* dwb,
                   mvs_stream_t stream);

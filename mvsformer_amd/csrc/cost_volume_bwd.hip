@@ -197,6 +197,185 @@ __global__ __launch_bounds__(64 * NW) void cv_aggregate_bwd_kernel(const float* 
     if (active) *reinterpret_cast<f32x4*>(dfeat + ((size_t)(b * V) * HW + pix) * C + cq * 4) = dref;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Second form: the bilinear scatter accumulated in LDS.  The kernel above spends ~90 % of its time in global fp32 atomics (one per
+// tap and channel whenever a lane's 2x2 texel block changes - plane spacing is 1-1.7 px, so nearly every sample).  But the samples of a
+// 16 x 8 tile of reference pixels over all D planes land on a few hundred source texels, each hit ~4*D times.  Here a block owns such
+// a tile and ONE channel octet, keeps a WX x WY texel window (8 channels, fp32) of the source view's gradient in LDS, adds every tap
+// that falls inside the window with ds_add_f32, and flushes the non-zero texels with one global atomic per value at the end of the
+// view; taps outside the window (rare for coherent hypotheses) go straight to global atomics, so the result does not depend on the
+// window at all.  C = 16/32/64 run as 2/4/8 independent octets (blockIdx.z) - more blocks on the small coarse stages, the same LDS
+// footprint - whose visibility-weight partial sums land in gip_part[octet] and are added by the caller.
+// ---------------------------------------------------------------------------------------------------------------------------
+#ifndef MVS_BWD_EXP
+#define MVS_BWD_EXP 0                                       // experiment switches (tools/exp_cv_bwd.py --build): 1 no LDS adds, 2 no outlier atomics,
+#endif                                                      // 4 constant coefficients instead of the gvol loads, 8 no tap gathers
+constexpr int LT_W = 16, LT_H = 8, LT_NW = 4;               // tile of reference pixels; wavefront = 2 rows x 16 pixels x 2 channel quads
+
+template <int C>
+__global__ __launch_bounds__(64 * LT_NW) void cv_aggregate_bwd_lds_kernel(const float* __restrict__ feat, const float* __restrict__ rt_all,
+                                                                          const float* __restrict__ depth, const float* __restrict__ weight,
+                                                                          const float* __restrict__ volume, const float* __restrict__ gvol,
+                                                                          int V, int D, int H, int W, float* __restrict__ dfeat,
+                                                                          float* __restrict__ gip_part, int wx_log2, int WY,
+                                                                          unsigned* __restrict__ stats) {
+    constexpr int CPG = C / G, NOCT = C / 8;                 // channels per correlation group, channel octets
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int WX = 1 << wx_log2;
+    // window = 8 channel planes of WY x WX texels.  Planar, not texel-major: for one tap and channel the 64 lanes of a ds_add_f32 then
+    // fall on neighbouring texels = neighbouring banks (texel-major put all of them on 8 of the 32 banks: 8-way conflicts on an
+    // instruction that already costs several cycles per access - measured 1.44 of 1.74 ms at stage 4).  Plane stride == 16 (mod 32)
+    // so that the two channel quads of a pixel (cq = 0 / 1, 4 planes apart) land on different bank halves.
+    const int WPL = WX * WY + 4;                             // 4 planes apart = 16 banks apart
+    float* win = reinterpret_cast<float*>(smem_raw);                                      // [8][WPL]
+    unsigned char* hand = smem_raw + (size_t)WPL * 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u32x4* taps_o = reinterpret_cast<u32x4*>(hand) + wave * 64;
+    f32x4* taps_w = reinterpret_cast<f32x4*>(hand + LT_NW * 64 * 16) + wave * 64;
+    int* taps_xy = reinterpret_cast<int*>(hand + LT_NW * 64 * 32) + wave * 64;
+    int* origin = reinterpret_cast<int*>(hand + LT_NW * 64 * 36);                        // [2]
+
+    const int oct = blockIdx.z % NOCT, b = blockIdx.z / NOCT;
+    const int tx0 = blockIdx.x * LT_W, ty0 = blockIdx.y * LT_H;
+    const size_t HW = (size_t)H * W;
+    const unsigned pix_bytes = C * 4u;
+    const int pg = lane >> 1, cq = lane & 1;
+    const int xi = tx0 + (pg & 15), yi = ty0 + wave * 2 + (pg >> 4);
+    const bool active = xi < W && yi < H;
+    const int xg = min(xi, W - 1), yg = min(yi, H - 1);
+    const size_t pix = (size_t)yg * W + xg;
+    const int cb = oct * 8 + cq * 4;                          // first of the lane's 4 channels
+    const f32x4 r = *reinterpret_cast<const f32x4*>(feat + ((size_t)(b * V) * HW + pix) * C + cb);
+    const float half_w = (float)((W - 1) / 2.0), half_h = (float)((H - 1) / 2.0);
+    const float* wp = weight + (size_t)(b * (V - 1)) * HW + pix;
+    float wsum = 0.0f;
+    for (int sv = 0; sv < V - 1; ++sv) wsum = wsum + wp[(size_t)sv * HW];
+    const float inv_s = 1.0f / (wsum + 1e-6f);
+    const int g0 = cb / CPG;                                  // CPG = 1: 4 groups cb..cb+3; 2: 2 groups; >= 4: the one group
+    const float* gp = gvol + ((size_t)(b * G + g0) * D) * HW + pix;
+
+    // T = sum_{g,d} G*vm over the pixel: once per pixel, by the octet-0 block (its two lanes take four groups each)
+    float tsum = 0.0f;
+    if (oct == 0) {
+        const float* ga = gvol + ((size_t)(b * G + cq * 4) * D) * HW + pix;
+        const float* va = volume + ((size_t)(b * G + cq * 4) * D) * HW + pix;
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tsum = fmaf(ga[((size_t)k * D + d) * HW], va[((size_t)k * D + d) * HW], tsum);
+        tsum += __shfl_xor(tsum, 1, 64);
+    }
+    for (int i = threadIdx.x; i < WPL * 2; i += 64 * LT_NW) reinterpret_cast<f32x4*>(win)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 dref = {0.f, 0.f, 0.f, 0.f};
+    for (int sv = 0; sv < V - 1; ++sv) {
+        const float* rt = rt_all + (size_t)(b * (V - 1) + sv) * 12;
+        const mvs::rsrc_t src = mvs::make_rsrc(feat + (size_t)(b * V + sv + 1) * HW * C, (unsigned)(HW * pix_bytes));
+        float* dsrc = dfeat + (size_t)(b * V + sv + 1) * HW * C + oct * 8;
+        const float wv = wp[(size_t)sv * HW];
+        // window origin: around the projection of the tile centre on its middle plane
+        if (threadIdx.x == 0) {
+            const int xc = min(tx0 + LT_W / 2, W - 1), yc = min(ty0 + LT_H / 2, H - 1);
+            float un, vn, z;
+            mvs::sweep_project(rt, (float)xc, (float)yc, depth[((size_t)b * D + D / 2) * HW + (size_t)yc * W + xc], half_w, half_h, &un, &vn, &z);
+            const float ix = (un + 1.0f) * half_w, iy = (vn + 1.0f) * half_h;
+            const bool ok = fabsf(ix) < 1e6f && fabsf(iy) < 1e6f;       // also false for NaN
+            origin[0] = ok ? (int)floorf(ix) - WX / 2 : 0;
+            origin[1] = ok ? (int)floorf(iy) - WY / 2 : 0;
+        }
+        __syncthreads();                                      // origin visible; window zeroed (first view) / flushed (later views)
+        const int ox = origin[0], oy = origin[1];
+        float gip = 0.0f;                                     // sum_{d, own channels} coef * ref * warp
+        for (int c0 = 0; c0 < D; c0 += 2) {
+            __builtin_amdgcn_wave_barrier();
+            {
+                const int p = lane & 31, dd = lane >> 5;
+                const int d = min(c0 + dd, D - 1);
+                const int x = min(tx0 + (p & 15), W - 1), y = min(ty0 + wave * 2 + (p >> 4), H - 1);
+                float un, vn, z;
+                mvs::sweep_project(rt, (float)x, (float)y, depth[((size_t)b * D + d) * HW + (size_t)y * W + x], half_w, half_h, &un, &vn, &z);
+                int x0, y0;
+                const mvs::Taps t = mvs::sweep_taps_xy(un, vn, H, W, half_w, half_h, &x0, &y0);
+                taps_o[lane] = u32x4{(unsigned)t.o00, (unsigned)t.o01, (unsigned)t.o10, (unsigned)t.o11};
+                taps_w[lane] = f32x4{t.w00, t.w01, t.w10, t.w11};
+                taps_xy[lane] = ((y0 - oy) << 16) | ((x0 - ox) & 0xFFFF);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd) {
+                const int d = c0 + dd;
+                if (d >= D) break;
+                const u32x4 o = taps_o[dd * 32 + pg];
+                const f32x4 w = taps_w[dd * 32 + pg];
+                const int xy = taps_xy[dd * 32 + pg];
+                f32x4 t4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t4[k] = (MVS_BWD_EXP & 8) ? f32x4{w[k], w[0], w[1], w[2]} : buf_load4(src, o[k] * pix_bytes + (unsigned)cb * 4u);
+                float coef[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = (CPG < 4) ? i / CPG : 0;
+                    coef[i] = ((MVS_BWD_EXP & 4) ? w[k] : gp[((size_t)k * D + d) * HW]) * inv_s * (1.0f / CPG);
+                }
+                float cr[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float g4 = t4[0][i] * w[0];
+                    g4 = fmaf(t4[1][i], w[1], g4);
+                    g4 = fmaf(t4[2][i], w[2], g4);
+                    g4 = fmaf(t4[3][i], w[3], g4);
+                    dref[i] = fmaf(coef[i] * wv, g4, dref[i]);
+                    gip = fmaf(coef[i] * r[i], g4, gip);
+                    cr[i] = coef[i] * wv * r[i];
+                }
+                if (active) {
+                    const int rx = (int)(short)(xy & 0xFFFF), ry = xy >> 16;      // tap (0,0) relative to the window
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (w[k] == 0.0f) continue;           // taps outside the image carry weight 0 (and a clamped offset)
+                        const int txx = rx + (k & 1), tyy = ry + (k >> 1);
+                        if ((unsigned)txx < (unsigned)WX && (unsigned)tyy < (unsigned)WY) {
+                            float* cell = win + (cq * 4) * WPL + (tyy << wx_log2) + txx;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (MVS_BWD_EXP & 16) atomicAdd(reinterpret_cast<int*>(cell + i * WPL), (int)(w[k] * cr[i] * 1048576.0f));
+                                else if (!(MVS_BWD_EXP & 1)) atomicAdd(cell + i * WPL, w[k] * cr[i]);
+                                else dref[i] += w[k] * cr[i] * (float)txx;
+                        } else {
+                            float* dst = dsrc + (size_t)o[k] * C + cq * 4;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (!(MVS_BWD_EXP & 2)) atomicAdd(dst + i, w[k] * cr[i]);
+                                else dref[i] += w[k] * cr[i] * (float)tyy;
+                            if (stats) atomicAdd(stats + 1, 1u);           // diagnostics only (tools/exp_cv_bwd.py)
+                        }
+                        if (stats) atomicAdd(stats, 1u);
+                    }
+                }
+            }
+        }
+        gip += __shfl_xor(gip, 1, 64);
+        if (active && cq == 0)
+            gip_part[((size_t)(oct * gridDim.z / NOCT + b) * (V - 1) + sv) * HW + pix] = oct == 0 ? gip - tsum * inv_s : gip;
+        __syncthreads();                                      // every tap of this view is in the window
+        // flush: a thread takes 4 consecutive texels of one channel plane (one ds_read_b128), touched values go out as global atomics
+        for (int i = threadIdx.x; i < WX * WY * 2; i += 64 * LT_NW) {
+            const int c = i / (WX * WY / 4), q = i % (WX * WY / 4);
+            f32x4* cellp = reinterpret_cast<f32x4*>(win + c * WPL) + q;
+            const f32x4 v = *cellp;
+            if (v[0] != 0.0f || v[1] != 0.0f || v[2] != 0.0f || v[3] != 0.0f) {
+                const int tex = q * 4, gx = ox + (tex & (WX - 1)), gy = oy + (tex >> wx_log2);
+                float* dst = dsrc + ((size_t)gy * W + gx) * C + c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] != 0.0f) atomicAdd(dst + (size_t)e * C, v[e]);
+                *cellp = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+    if (active) *reinterpret_cast<f32x4*>(dfeat + ((size_t)(b * V) * HW + pix) * C + cb) = dref;
+}
+
 }  // namespace
 
 extern "C" int mvs_cv_aggregate_bwd(const float* feat, const float* rt, const float* depth, const float* weight, const float* volume,
@@ -217,4 +396,35 @@ extern "C" int mvs_cv_aggregate_bwd(const float* feat, const float* rt, const fl
         default: hipLaunchKernelGGL(cv_aggregate_bwd_kernel<16>, grid, block, 0, s, feat, rt, depth, weight, volume, gvolume, V, D, H, W, dfeat, dweight); break;
     }
     return mvs::finish_launch("mvs_cv_aggregate_bwd");
+}
+
+// LDS-window form (see cv_aggregate_bwd_lds_kernel).  gip_part [C/8][B][V-1][H][W]: per channel octet partial d(loss)/d(vis weight);
+// the caller adds the octets (octet 0 already carries the -T/S term).  window = (log2 WX, WY) texels, WX*WY*32 bytes of LDS.
+// stats (optional, diagnostics): [0] += taps scattered, [1] += taps that missed the window.
+extern "C" int mvs_cv_aggregate_bwd_lds(const float* feat, const float* rt, const float* depth, const float* weight, const float* volume,
+                                        const float* gvolume, int B, int V, int C, int Gin, int D, int H, int W, float* dfeat,
+                                        float* gip_part, int wx_log2, int wy, unsigned* stats, mvs_stream_t stream) {
+    MVS_REQUIRE(feat && rt && depth && weight && volume && gvolume && dfeat && gip_part, "mvs_cv_aggregate_bwd_lds: null pointer");
+    MVS_REQUIRE(B >= 1 && V >= 2 && D >= 1 && H >= 1 && W >= 1, "mvs_cv_aggregate_bwd_lds: bad shape");
+    MVS_REQUIRE(Gin == G, "mvs_cv_aggregate_bwd_lds: only G=8 correlation groups are built (got %d)", Gin);
+    MVS_REQUIRE(C == 8 || C == 16 || C == 32 || C == 64, "mvs_cv_aggregate_bwd_lds: C must be 8, 16, 32 or 64 (got %d)", C);
+    MVS_REQUIRE((int64_t)C * H * W * 4 < ((int64_t)1 << 32), "mvs_cv_aggregate_bwd_lds: one view's feature block exceeds 4 GiB");
+    MVS_REQUIRE(wx_log2 >= 4 && wx_log2 <= 7 && wy >= 8 && wy <= 64 && wy % 4 == 0, "mvs_cv_aggregate_bwd_lds: window %d x %d out of range",
+                1 << wx_log2, wy);
+    const size_t lds = (((size_t)wy << wx_log2) + 4) * 32 + (size_t)LT_NW * 64 * 36 + 16;
+    MVS_REQUIRE(lds <= 64 * 1024, "mvs_cv_aggregate_bwd_lds: window needs %zu bytes of LDS (> 64 KiB)", lds);
+    const int noct = C / 8;
+    MVS_REQUIRE((int64_t)B * noct <= 65535 && mvs::ceil_div(H, LT_H) <= 65535, "mvs_cv_aggregate_bwd_lds: grid limits exceeded");
+    dim3 grid(mvs::ceil_div(W, LT_W), mvs::ceil_div(H, LT_H), B * noct), block(64 * LT_NW);
+    hipStream_t s = MVS_STREAM(stream);
+#define MVS_LAUNCH_BL(CC) \
+    hipLaunchKernelGGL(cv_aggregate_bwd_lds_kernel<CC>, grid, block, lds, s, feat, rt, depth, weight, volume, gvolume, V, D, H, W, dfeat, gip_part, wx_log2, wy, stats)
+    switch (C) {
+        case 8: MVS_LAUNCH_BL(8); break;
+        case 16: MVS_LAUNCH_BL(16); break;
+        case 32: MVS_LAUNCH_BL(32); break;
+        default: MVS_LAUNCH_BL(64); break;
+    }
+#undef MVS_LAUNCH_BL
+    return mvs::finish_launch("mvs_cv_aggregate_bwd_lds");
 }

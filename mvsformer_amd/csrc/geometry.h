@@ -63,6 +63,14 @@ __device__ __forceinline__ Taps sweep_taps(float un, float vn, int H, int W, flo
     return t;
 }
 
+// sweep_taps plus the integer position of tap (0,0), clamped to [-2, W+1] x [-2, H+1] (for callers that bin taps spatially)
+__device__ __forceinline__ Taps sweep_taps_xy(float un, float vn, int H, int W, float half_w, float half_h, int* x0, int* y0) {
+    const float ix = (un + 1.0f) * half_w, iy = (vn + 1.0f) * half_h;
+    *x0 = (int)fminf(fmaxf(floorf(ix), -2.0f), (float)W + 1.0f);       // fmaxf / fminf drop NaN
+    *y0 = (int)fminf(fmaxf(floorf(iy), -2.0f), (float)H + 1.0f);
+    return sweep_taps(un, vn, H, W, half_w, half_h);
+}
+
 // Fast form of sweep_project + sweep_taps for the fused sweeps (one reciprocal + Newton step instead of four IEEE divisions, no
 // normalize / un-normalize round trip, tap validity as four unsigned compares): the sampling position differs from the
 // reference's by ~1e-4 px (the reference's own coordinates carry that much rounding from the round trip through [-1, 1]), which

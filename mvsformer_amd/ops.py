@@ -8,6 +8,7 @@ launch stream to get per-kernel durations live.
 from __future__ import annotations
 
 import contextlib
+import os
 from collections import defaultdict
 from typing import Dict, List, Optional, Tuple
 
@@ -568,12 +569,21 @@ def conv3d_wgrad(A: torch.Tensor, Bt: torch.Tensor, stride) -> torch.Tensor:
     return dW
 
 
-def cv_aggregate_bwd(feat_cl, rt, depth, weight, volume, gvolume, G: int):
+def cv_aggregate_bwd(feat_cl, rt, depth, weight, volume, gvolume, G: int, stats: Optional[torch.Tensor] = None):
     for t, n in ((feat_cl, "features"), (rt, "rt"), (depth, "depth_values"), (weight, "vis_weight"), (volume, "volume"), (gvolume, "grad")):
         _chk(t, n)
     B, V, H, W, C = feat_cl.shape
     D = depth.shape[1]
     dfeat = torch.zeros_like(feat_cl)
+    mode = os.environ.get("MVS_CV_BWD", "direct")
+    if mode != "direct":
+        # LDS-window scatter (cost_volume_bwd.hip, second kernel; opt-in: measured no faster) with a
+        # MVS_CV_BWD_WINDOW="log2(WX),WY" texel window (default 64 x 24)
+        wxl, wy = (int(v) for v in os.environ.get("MVS_CV_BWD_WINDOW", "6,24").split(","))
+        part = torch.empty((C // 8,) + tuple(weight.shape), device=weight.device, dtype=torch.float32)
+        _call("mvs_cv_aggregate_bwd_lds", "cv_aggregate_bwd_lds_kernel<%d>" % C, _ptr(feat_cl), _ptr(rt), _ptr(depth), _ptr(weight),
+              _ptr(volume), _ptr(gvolume), B, V, C, G, D, H, W, _ptr(dfeat), _ptr(part), wxl, wy, _ptr(stats), _stream())
+        return dfeat, (part[0] if C == 8 else part.sum(0))
     dw = torch.empty_like(weight)
     _call("mvs_cv_aggregate_bwd", "cv_aggregate_bwd_kernel<%d>" % (C // 4), _ptr(feat_cl), _ptr(rt), _ptr(depth), _ptr(weight), _ptr(volume),
           _ptr(gvolume), B, V, C, G, D, H, W, _ptr(dfeat), _ptr(dw), _stream())
