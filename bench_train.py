@@ -34,6 +34,10 @@ def parse():
                     help="bf16 (BASELINE configs[2]): forward under torch.autocast(bfloat16) - the regularizer runs on bf16 channel-last "
                          "activations and v_mfma_f32_16x16x32_bf16, the cost volume, BatchNorm statistics, head and loss stay fp32, "
                          "master weights fp32 (what the reference's autocast training does); f32: everything fp32")
+    ap.add_argument("--graph", choices=["on", "off"], default="off",
+                    help="replay the whole step (forward + loss + backward + AdamW) as ONE hipGraph (mvsformer_amd/graphs.py): host cost per "
+                         "step 16 ms -> 1.2 ms; measured step time 17.0 -> 17.5 ms (the ~570 short kernels, not the host, are the limit), "
+                         "hence off by default")
     return ap.parse_args()
 
 
@@ -55,7 +59,8 @@ def main(args):
     if ddp:
         net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
         model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local])
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    use_graph = args.graph == "on" and not ddp
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=use_graph)
     feats, proj, dv, scene = synth.make_inputs(args.views, args.height, args.width, seed=rank, device=dev)
     feats = {k: v.requires_grad_(True) for k, v in feats.items()}
     from mvsformer_amd.losses import ce_loss_stage4
@@ -75,8 +80,25 @@ def main(args):
         opt.step()
         return loss
 
+    eager_step, graph_note = step, None
+    if use_graph:
+        try:
+            from mvsformer_amd.graphs import CapturedStep
+            step = CapturedStep(eager_step, warmup=3)
+        except Exception as e:                               # report, fall back to eager launches
+            if args.graph == "on":
+                raise
+            step, use_graph, graph_note = eager_step, False, "capture failed: %r" % (e,)
     for _ in range(args.warmup):
         loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    # host cost of ONE step measured against an idle GPU (launch queue empty, so nothing blocks): if it is close to ms_per_step
+    # the step is bound by the Python / autograd / launch path, not by the kernels
+    t0 = time.perf_counter()
+    loss = step()
+    t_enqueue = time.perf_counter() - t0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -92,7 +114,7 @@ def main(args):
     if rank == 0:
         print(json.dumps({"metric": "training samples/s (fwd+bwd+AdamW), 640x512, 5 views, cascade 32/16/8/8", "value": round(world * args.steps / dt.item(), 3),
                           "unit": "samples/s", "n_gpus": world, "steps": args.steps, "ms_per_step": round(dt.item() / args.steps * 1e3, 2),
-                          "dtype": args.dtype, "data": "synthetic", "scaling": "weak", "final_loss": round(float(loss.detach()), 4),
+                          "host_enqueue_ms_per_step": round(t_enqueue * 1e3, 2), "hip_graph": use_graph, "graph_note": graph_note, "dtype": args.dtype, "data": "synthetic", "scaling": "weak", "final_loss": round(float(loss.detach()), 4),
                           "parallelism": "DDP + SyncBatchNorm over RCCL" if ddp else "single GPU"}))
     if ddp:
         dist.destroy_process_group()

@@ -1,0 +1,42 @@
+"""hipGraph capture of a whole training step.
+
+One training step of the cascade is ~570 kernel launches, most of them a few microseconds long; driven from Python (autograd
+Functions -> ctypes -> hipLaunchKernel) the HOST needs ~16 ms per step, which is the step time - the GPU idles between launches
+(bench_train.py prints ``host_enqueue_ms_per_step``).  The step has no data-dependent control flow and no host synchronization
+(SyncBatchNorm counts stay on the device, the optimizer runs ``capturable``), so the whole of forward + loss + backward + optimizer
+step is recorded once into a hipGraph through ``torch.cuda.graph`` (stream capture sees the ctypes launches because every C-ABI call
+is enqueued on torch's current stream) and replayed with one ``hipGraphLaunch`` per step.
+
+The reference has no counterpart (eager PyTorch, trainer/mvsformer_trainer.py:82-165); the contract is the usual one of captured
+graphs: static shapes, inputs updated IN PLACE (``tensor.copy_``) between replays, everything the step allocates lives in the
+graph's private pool.
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import torch
+
+
+class CapturedStep:
+    """``step_fn()`` (no arguments, returns a tensor or a tuple of tensors) captured into a hipGraph after ``warmup`` eager runs on a
+    side stream (lazy initialisation - weight-pack caches, hipFuncSetAttribute, allocator growth - must not happen during capture)."""
+
+    def __init__(self, step_fn: Callable[[], object], warmup: int = 3):
+        if not torch.cuda.is_available():
+            raise RuntimeError("CapturedStep needs a GPU")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step_fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = step_fn()
+
+    def __call__(self):
+        """Replay; returns the (static) output tensors of the captured step - clone them if they must outlive the next replay."""
+        self.graph.replay()
+        return self.outputs
