@@ -34,8 +34,9 @@ def _sync_sums(sums: torch.Tensor, count: float, bn):
     if world <= 1:
         return sums, None
     if count == 0.0:
-        dist.all_reduce(sums, group=bn.process_group)
-        return sums, None
+        red = sums.clone()                         # out of place: the caller's tensor keeps this rank's values (dgamma / dbeta)
+        dist.all_reduce(red, group=bn.process_group)
+        return red, None
     n = int(count)
     packed = torch.cat([sums, sums.new_tensor([float(n // 4096), float(n % 4096)])])
     dist.all_reduce(packed, group=bn.process_group)
@@ -168,11 +169,12 @@ class BnActFn(torch.autograd.Function):
         dy = dy.contiguous().view(x.shape)
         sums = ops.bn_bwd_reduce(dy, x, scale, shift, mean, invstd, ctx.relu)
         C = x.shape[1]
-        local = sums.clone()                       # dgamma / dbeta stay per-rank (DDP averages parameter grads itself)
+        local = sums                               # dgamma / dbeta stay per-rank (DDP averages parameter grads itself); _sync_sums
+                                                   # all-reduces a packed COPY, so `sums` keeps this rank's values - no clone needed
         sums, _ = _sync_sums(sums, 0.0, ctx.bn)
         dx = ops.bn_bwd_apply(dy, x, scale, shift, mean, invstd, g, sums, ctx.count, ctx.relu, count_dev).view(ctx.shape)
-        dgamma = local[C:].clone() if ctx.needs_input_grad[1] else None
-        dbeta = local[:C].clone() if ctx.needs_input_grad[2] else None
+        dgamma = local[C:] if ctx.needs_input_grad[1] else None          # views of the 2C-float reduction result (48 BN layers x 3
+        dbeta = local[:C] if ctx.needs_input_grad[2] else None           # device copies per step otherwise)
         if ctx.groups > 1:                         # shared parameters: sum the groups' gradients
             dgamma = dgamma.view(ctx.groups, -1).sum(0) if dgamma is not None else None
             dbeta = dbeta.view(ctx.groups, -1).sum(0) if dbeta is not None else None
@@ -200,7 +202,7 @@ class Prob1Fn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dx, dwb = ops.prob1_bwd(x, w, dy.contiguous().reshape(x.shape[0], -1))
         C = x.shape[1]
-        return dx, dwb[:C].reshape(ctx.wshape).clone(), dwb[C:].clone()
+        return dx, dwb[:C].reshape(ctx.wshape), dwb[C:]
 
 
 class SigmoidFn(torch.autograd.Function):
@@ -409,9 +411,9 @@ class BnActBf16Fn(torch.autograd.Function):
         dy = dy.contiguous()
         sums = ops.bf16_bn_bwd_reduce(dy, x, scale, shift, mean, invstd, ctx.relu)
         C = x.shape[-1]
-        local = sums.clone()
+        local = sums
         sums, _ = _sync_sums(sums, 0.0, ctx.bn)
         dx = ops.bf16_bn_bwd_apply(dy, x, scale, shift, mean, invstd, g, sums, ctx.count, ctx.relu, count_dev)
-        dgamma = local[C:].clone() if ctx.needs_input_grad[1] else None
-        dbeta = local[:C].clone() if ctx.needs_input_grad[2] else None
+        dgamma = local[C:] if ctx.needs_input_grad[1] else None          # views of the 2C-float reduction result (48 BN layers x 3
+        dbeta = local[:C] if ctx.needs_input_grad[2] else None           # device copies per step otherwise)
         return dx, dgamma, dbeta, (dy if ctx.has_res else None), None, None
