@@ -27,7 +27,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 4
+#define MVS_ABI_VERSION 5
 
 typedef void* mvs_stream_t;
 
@@ -249,7 +249,11 @@ int mvs_conv3d_wgrad(const float* A, const float* Bt, float* dW, int nbatch, int
  *   mvs_bf16_from_f32_ncdhw / mvs_bf16_to_f32_ncdhw: fp32 [B,C,N] <-> bf16 [B,N,C]
  *   mvs_bf16_bn_stats / mvs_bf16_affine_act / mvs_bf16_bn_bwd_reduce / mvs_bf16_bn_bwd_apply: channel-last bf16 twins of
  *       mvs_bn_stats / mvs_affine_act / mvs_bn_bwd_reduce / mvs_bn_bwd_apply over R = B*D*H*W rows (fp32 statistics;
- *       mvs_bn_finalize is shared; partial rows in a workspace of mvs_bf16_bn_reduce_workspace_bytes, fixed-order sums)
+ *       mvs_bn_finalize is shared; partial rows in a workspace of mvs_bf16_bn_reduce_workspace_bytes, fixed-order sums).
+ *       groups > 1 = grouped BatchNorm over the batch dimension (the visibility CNN applied once per source view,
+ *       mvsformer_model.py:91, as ONE batch): sample n = rows [n*rows_per_sample, (n+1)*rows_per_sample) belongs to group
+ *       n % groups; statistics and every per-channel array are per (group, channel), laid out [groups*C] (sums: [sum | sum of
+ *       squares], each groups*C) - what mvs_bn_finalize_grouped consumes and produces.  groups = 1: rows_per_sample is ignored.
  * ------------------------------------------------------------------------------------------------------- */
 int64_t mvs_bf16_packed_elems(int Cin, int Cout);
 int mvs_bf16_pack_weights(const float* w, int d0, int d1, int src, int Cout, int Cin, void* wpacked, mvs_stream_t stream);
@@ -260,15 +264,17 @@ int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, void* worksp
                           int Db, int Hb, int Wb, int sd, int shw, mvs_stream_t stream);
 int mvs_bf16_from_f32_ncdhw(const float* in, void* out, int B, int C, int64_t N, mvs_stream_t stream);
 int mvs_bf16_to_f32_ncdhw(const void* in, float* out, int B, int C, int64_t N, mvs_stream_t stream);
-int64_t mvs_bf16_bn_reduce_workspace_bytes(int C, int64_t R);
-int mvs_bf16_bn_stats(const void* x, int C, int64_t R, float* sums, void* workspace, mvs_stream_t stream);
+int64_t mvs_bf16_bn_reduce_workspace_bytes(int C, int64_t R, int groups, int64_t rows_per_sample);
+int mvs_bf16_bn_stats(const void* x, int C, int64_t R, int groups, int64_t rows_per_sample, float* sums, void* workspace,
+                      mvs_stream_t stream);
 int mvs_bf16_affine_act(const void* x, const float* scale, const float* shift, const void* residual, int relu, int C, int64_t R,
-                        void* y, mvs_stream_t stream);
+                        int groups, int64_t rows_per_sample, void* y, mvs_stream_t stream);
 int mvs_bf16_bn_bwd_reduce(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
-                           const float* invstd, int relu, int C, int64_t R, float* sums, void* workspace, mvs_stream_t stream);
+                           const float* invstd, int relu, int C, int64_t R, int groups, int64_t rows_per_sample, float* sums,
+                           void* workspace, mvs_stream_t stream);
 int mvs_bf16_bn_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
                           const float* invstd, const float* gamma, const float* sums, double count, const float* count_dev,
-                          int relu, int C, int64_t R, void* dx, mvs_stream_t stream);
+                          int relu, int C, int64_t R, int groups, int64_t rows_per_sample, void* dx, mvs_stream_t stream);
 int mvs_cv_aggregate_bwd(const float* feat, const float* rt, const float* depth, const float* weight, const float* volume,
                          const float* gvolume, int B, int V, int C, int G, int D, int H, int W, float* dfeat, float* dweight,
                          mvs_stream_t stream);

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 from ctypes import c_double  # noqa: E402
 
@@ -58,11 +58,11 @@ SIGNATURES = {
     "mvs_bf16_conv3d_wgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "mvs_bf16_from_f32_ncdhw": (I, [P, P, I, I, L, P]),
     "mvs_bf16_to_f32_ncdhw": (I, [P, P, I, I, L, P]),
-    "mvs_bf16_bn_reduce_workspace_bytes": (L, [I, L]),
-    "mvs_bf16_bn_stats": (I, [P, I, L, P, P, P]),
-    "mvs_bf16_affine_act": (I, [P, P, P, P, I, I, L, P, P]),
-    "mvs_bf16_bn_bwd_reduce": (I, [P, P, P, P, P, P, I, I, L, P, P, P]),
-    "mvs_bf16_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, Dbl, P, I, I, L, P, P]),
+    "mvs_bf16_bn_reduce_workspace_bytes": (L, [I, L, I, L]),
+    "mvs_bf16_bn_stats": (I, [P, I, L, I, L, P, P, P]),
+    "mvs_bf16_affine_act": (I, [P, P, P, P, I, I, L, I, L, P, P]),
+    "mvs_bf16_bn_bwd_reduce": (I, [P, P, P, P, P, P, I, I, L, I, L, P, P, P]),
+    "mvs_bf16_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, Dbl, P, I, I, L, I, L, P, P]),
     "mvs_cv_aggregate_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P]),
     "mvs_cv_aggregate_bwd_lds": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, I, I, P, P]),
     "mvs_softmax_bwd": (I, [P, P, I, I, L, P, P]),

@@ -287,6 +287,19 @@ def vis_train_views(entropy: torch.Tensor, vis: nn.Sequential) -> torch.Tensor:
     B, Vs, H, W = entropy.shape
     if os.environ.get("MVS_VIS_PER_VIEW", "0") == "1" or Vs == 1:
         return torch.cat([vis_train(entropy[:, v:v + 1], vis) for v in range(Vs)], dim=1)
+    from .module import autocast_bf16
+    if autocast_bf16() and os.environ.get("MVS_VIS_BF16", "1") != "0":
+        # under autocast the reference runs this CNN in half precision too (it is inside the autocast region,
+        # trainer/mvsformer_trainer.py:104-106): bf16 channel-last kernels, fp32 statistics, the 1x1 conv + sigmoid in fp32
+        x16 = torch.zeros(B * Vs, 1, H, W, 8, device=entropy.device, dtype=torch.bfloat16)
+        x16[..., 0] = entropy.reshape(B * Vs, 1, H, W)                   # batch index b*Vs + v; entropy is detached (no gradient)
+        for i in range(3):
+            blk = vis[i]
+            cin_pad = 8 if i == 0 else blk.conv.in_channels
+            x16 = ConvBf16Fn.apply(x16, embed_conv2d_weight(blk.conv.weight, cin_pad), (1, 1))
+            x16 = BnActBf16Fn.apply(x16, blk.bn.weight, blk.bn.bias, None, blk.bn, True, Vs)
+        y = Prob1Fn.apply(FromBf16Fn.apply(x16), vis[3].weight, vis[3].bias)
+        return SigmoidFn.apply(y).reshape(B, Vs, H, W)
     x = torch.zeros(B * Vs, 4, 1, H, W, device=entropy.device, dtype=torch.float32)
     x[:, 0, 0] = entropy.reshape(B * Vs, H, W)                          # batch index b*Vs + v
     for i in range(3):
@@ -383,37 +396,52 @@ class DeconvBf16Fn(torch.autograd.Function):
 
 class BnActBf16Fn(torch.autograd.Function):
     """Training-mode BatchNorm (fp32 batch statistics of the bf16 conv output, running-stat update) + ReLU + optional skip,
-    channel-last bf16 in and out; SyncBatchNorm statistics ride the same all-reduce as in :class:`BnActFn`."""
+    channel-last bf16 in and out; SyncBatchNorm statistics ride the same all-reduce as in :class:`BnActFn`.  ``groups`` > 1: the
+    batch holds ``groups`` independent calls of the module (sample n -> group n % groups), statistics per (group, channel)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, bn, relu):
+    def forward(ctx, x, gamma, beta, residual, bn, relu, groups=1):
         x = x.contiguous()
         C = x.shape[-1]
-        count = float(x.numel() // C)
-        sums = ops.bf16_bn_stats(x)
+        if groups > 1 and residual is not None:
+            raise ops._lib.MvsHipError("grouped BatchNorm has no residual form")
+        count = float(x.numel() // (C * groups))
+        sums = ops.bf16_bn_stats(x, groups)
         sums, count_dev = _sync_sums(sums, count, bn)
         g = gamma.detach().to(torch.float32).contiguous() if gamma is not None else None
         b = beta.detach().to(torch.float32).contiguous() if beta is not None else None
         track = bn.track_running_stats and bn.running_mean is not None
         rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
-        scale, shift, mean, invstd = ops.bn_finalize(sums, g, b, rm, rv, _momentum(bn) if track else 0.0, bn.eps, count, count_dev)
+        if groups > 1:
+            if bn.momentum is None:
+                raise ops._lib.MvsHipError("grouped BatchNorm needs a fixed momentum (cumulative averaging changes per group)")
+            scale, shift, mean, invstd = ops.bn_finalize_grouped(sums, g, b, rm, rv, bn.momentum, bn.eps, count, groups, count_dev)
+        else:
+            scale, shift, mean, invstd = ops.bn_finalize(sums, g, b, rm, rv, _momentum(bn) if track else 0.0, bn.eps, count, count_dev)
         if track and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+            bn.num_batches_tracked.add_(groups)
         res = residual.contiguous() if residual is not None else None
-        y = ops.bf16_affine_act(x, scale, shift, res, relu)
-        ctx.save_for_backward(x, scale, shift, mean, invstd, g if g is not None else scale.new_ones(C), count_dev)
-        ctx.relu, ctx.count, ctx.bn, ctx.has_res = relu, count, bn, residual is not None
+        y = ops.bf16_affine_act(x, scale, shift, res, relu, groups)
+        gfull = g if g is not None else scale.new_ones(C)
+        if groups > 1:
+            gfull = gfull.repeat(groups)
+        ctx.save_for_backward(x, scale, shift, mean, invstd, gfull, count_dev)
+        ctx.relu, ctx.count, ctx.bn, ctx.has_res, ctx.groups = relu, count, bn, residual is not None, groups
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, scale, shift, mean, invstd, g, count_dev = ctx.saved_tensors
         dy = dy.contiguous()
-        sums = ops.bf16_bn_bwd_reduce(dy, x, scale, shift, mean, invstd, ctx.relu)
-        C = x.shape[-1]
+        G = ctx.groups
+        sums = ops.bf16_bn_bwd_reduce(dy, x, scale, shift, mean, invstd, ctx.relu, G)
+        CT = x.shape[-1] * G
         local = sums
         sums, _ = _sync_sums(sums, 0.0, ctx.bn)
-        dx = ops.bf16_bn_bwd_apply(dy, x, scale, shift, mean, invstd, g, sums, ctx.count, ctx.relu, count_dev)
-        dgamma = local[C:] if ctx.needs_input_grad[1] else None          # views of the 2C-float reduction result (48 BN layers x 3
-        dbeta = local[:C] if ctx.needs_input_grad[2] else None           # device copies per step otherwise)
-        return dx, dgamma, dbeta, (dy if ctx.has_res else None), None, None
+        dx = ops.bf16_bn_bwd_apply(dy, x, scale, shift, mean, invstd, g, sums, ctx.count, ctx.relu, count_dev, G)
+        dgamma = local[CT:] if ctx.needs_input_grad[1] else None         # views of the reduction result (no device copies)
+        dbeta = local[:CT] if ctx.needs_input_grad[2] else None
+        if G > 1:                                                        # shared parameters: sum the groups' gradients
+            dgamma = dgamma.view(G, -1).sum(0) if dgamma is not None else None
+            dbeta = dbeta.view(G, -1).sum(0) if dbeta is not None else None
+        return dx, dgamma, dbeta, (dy if ctx.has_res else None), None, None, None

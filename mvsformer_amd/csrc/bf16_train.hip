@@ -391,10 +391,13 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void bf16_bn_reduce_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
-                                                             int C, size_t R, float* __restrict__ part) {
+                                                             int C, size_t RS, int groups, float* __restrict__ part) {
+    // grid = (blocks per sample, samples); RS = rows per sample.  Plain BatchNorm: one "sample" of all R rows.  Grouped (the batch
+    // holds `groups` independent calls, sample n belongs to group n % groups): parameters of group g live at [g*C, (g+1)*C).
     __shared__ float red[4][2 * 64];
     const int CQ = C / 8;
     const int cq = threadIdx.x % CQ, rsub = threadIdx.x / CQ, rstep = 256 / CQ;
+    const int gofs = (int)(blockIdx.y % groups) * C;
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.0f;
@@ -402,13 +405,14 @@ __global__ __launch_bounds__(256) void bf16_bn_reduce_kernel(const __bf16* __res
     if (BWD) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            sc[e] = scale[cq * 8 + e];
-            sh[e] = shift[cq * 8 + e];
-            mu[e] = mean[cq * 8 + e];
-            is[e] = invstd[cq * 8 + e];
+            sc[e] = scale[gofs + cq * 8 + e];
+            sh[e] = shift[gofs + cq * 8 + e];
+            mu[e] = mean[gofs + cq * 8 + e];
+            is[e] = invstd[gofs + cq * 8 + e];
         }
     }
-    const size_t r0 = (size_t)blockIdx.x * ROWS_PER_BLOCK, r1 = min(r0 + ROWS_PER_BLOCK, R);
+    const size_t s0 = (size_t)blockIdx.y * RS;
+    const size_t r0 = s0 + (size_t)blockIdx.x * ROWS_PER_BLOCK, r1 = min(r0 + ROWS_PER_BLOCK, s0 + RS);
     for (size_t r = r0 + rsub; r < r1; r += rstep) {
         const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + r * C + cq * 8);
         if (!BWD) {
@@ -449,16 +453,17 @@ __global__ __launch_bounds__(256) void bf16_bn_reduce_kernel(const __bf16* __res
     }
     __syncthreads();
     if (threadIdx.x < 2 * C)
-        part[(size_t)blockIdx.x * 2 * C + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // y = [relu](x*scale[c] + shift[c]) [+ residual]
 __global__ __launch_bounds__(256) void bf16_affine_act_kernel(const __bf16* __restrict__ x, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const __bf16* __restrict__ res, int relu, int C,
-                                                              size_t total8, __bf16* __restrict__ y) {
+                                                              size_t total8, size_t RS, int groups, __bf16* __restrict__ y) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one channel octet
     if (i >= total8) return;
-    const int c0 = (int)(i % (C / 8)) * 8;
+    const int c0 = (int)(i % (C / 8)) * 8 + (groups > 1 ? (int)(((i / (C / 8)) / RS) % groups) * C : 0);
     const bf16x8 xv = reinterpret_cast<const bf16x8*>(x)[i];
     bf16x8 rv;
     if (res) rv = reinterpret_cast<const bf16x8*>(res)[i];
@@ -482,11 +487,12 @@ __global__ __launch_bounds__(256) void bf16_bn_bwd_apply_kernel(const __bf16* __
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ sums,
                                                                 double count_host, const float* __restrict__ count_dev, int relu, int C,
-                                                                size_t total8, __bf16* __restrict__ dx) {
+                                                                size_t total8, size_t RS, int groups, __bf16* __restrict__ dx) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total8) return;
     const double count = resolve_count(count_host, count_dev);
-    const int c0 = (int)(i % (C / 8)) * 8;
+    const int c0 = (int)(i % (C / 8)) * 8 + (groups > 1 ? (int)(((i / (C / 8)) / RS) % groups) * C : 0);
+    const int CT = C * groups;                              // sums = [sum g (groups*C)] [sum g*xhat (groups*C)]
     const bf16x8 xv = reinterpret_cast<const bf16x8*>(x)[i], gv = reinterpret_cast<const bf16x8*>(dy)[i];
     bf16x8 o;
 #pragma unroll
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(256) void bf16_bn_bwd_apply_kernel(const __bf16* __
         const float f = (float)xv[e];
         float g = (float)gv[e];
         if (relu && !(fmaf(f, scale[c], shift[c]) > 0.0f)) g = 0.0f;
-        const float m1 = (float)((double)sums[c] / count), m2 = (float)((double)sums[C + c] / count);
+        const float m1 = (float)((double)sums[c] / count), m2 = (float)((double)sums[CT + c] / count);
         const float gi = (gamma ? gamma[c] : 1.0f) * invstd[c];
         o[e] = (__bf16)(gi * (g - m1 - (f - mean[c]) * invstd[c] * m2));
     }
@@ -667,52 +673,75 @@ extern "C" int mvs_bf16_to_f32_ncdhw(const void* in, float* out, int B, int C, i
     return mvs::finish_launch("mvs_bf16_to_f32_ncdhw");
 }
 
-extern "C" int64_t mvs_bf16_bn_reduce_workspace_bytes(int C, int64_t R) {
-    if (!chan_ok(C) || R < 1) return -1;
-    return ((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * 2 * C * (int64_t)sizeof(float);
+namespace {
+// Grouped BatchNorm over a channel-last batch (groups independent calls of the same module interleaved in the batch dimension, sample n
+// -> group n % groups: the visibility CNN, applied once per source view by the reference): statistics per (group, channel); every
+// per-channel array is [groups*C], sums are [sum (groups*C)][sum sq (groups*C)] - the layout mvs_bn_finalize_grouped consumes.
+struct BnShape { int64_t RS; int nsamples; unsigned bps; };
+bool bn_shape(int C, int64_t R, int groups, int64_t rows_per_sample, BnShape* o) {
+    if (!chan_ok(C) || R < 1 || groups < 1) return false;
+    if (groups == 1) { o->RS = R; o->nsamples = 1; }
+    else {
+        if (rows_per_sample < 1 || R % rows_per_sample || (R / rows_per_sample) % groups || R / rows_per_sample > 65535) return false;
+        o->RS = rows_per_sample; o->nsamples = (int)(R / rows_per_sample);
+    }
+    o->bps = (unsigned)((o->RS + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+    return true;
+}
+}  // namespace
+
+extern "C" int64_t mvs_bf16_bn_reduce_workspace_bytes(int C, int64_t R, int groups, int64_t rows_per_sample) {
+    BnShape sh;
+    if (!bn_shape(C, R, groups, rows_per_sample, &sh)) return -1;
+    return (int64_t)sh.bps * sh.nsamples * 2 * C * (int64_t)sizeof(float);
 }
 
-extern "C" int mvs_bf16_bn_stats(const void* x, int C, int64_t R, float* sums, void* workspace, mvs_stream_t stream) {
-    MVS_REQUIRE(x && sums && workspace && chan_ok(C) && R >= 1, "mvs_bf16_bn_stats: bad arguments");
-    const unsigned nb = (unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+extern "C" int mvs_bf16_bn_stats(const void* x, int C, int64_t R, int groups, int64_t rows_per_sample, float* sums, void* workspace,
+                                 mvs_stream_t stream) {
+    BnShape sh;
+    MVS_REQUIRE(x && sums && workspace && bn_shape(C, R, groups, rows_per_sample, &sh), "mvs_bf16_bn_stats: bad arguments");
     float* part = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL(bf16_bn_reduce_kernel<false>, dim3(nb), dim3(256), 0, MVS_STREAM(stream),
+    hipLaunchKernelGGL(bf16_bn_reduce_kernel<false>, dim3(sh.bps, sh.nsamples), dim3(256), 0, MVS_STREAM(stream),
                        reinterpret_cast<const __bf16*>(x), (const __bf16*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, 0, C, (size_t)R, part);
-    mvs::launch_partials_reduce(part, (int)nb, 2 * C, sums, MVS_STREAM(stream));
+                       (const float*)nullptr, (const float*)nullptr, 0, C, (size_t)sh.RS, groups, part);
+    mvs::launch_partials_reduce_grouped(part, (int)sh.bps, sh.nsamples, groups, C, sums, MVS_STREAM(stream));
     return mvs::finish_launch("mvs_bf16_bn_stats");
 }
 
 extern "C" int mvs_bf16_affine_act(const void* x, const float* scale, const float* shift, const void* residual, int relu, int C, int64_t R,
-                                   void* y, mvs_stream_t stream) {
-    MVS_REQUIRE(x && scale && shift && y && chan_ok(C) && R >= 1, "mvs_bf16_affine_act: bad arguments");
+                                   int groups, int64_t rows_per_sample, void* y, mvs_stream_t stream) {
+    BnShape sh;
+    MVS_REQUIRE(x && scale && shift && y && bn_shape(C, R, groups, rows_per_sample, &sh), "mvs_bf16_affine_act: bad arguments");
     const size_t total8 = (size_t)R * (C / 8);
     hipLaunchKernelGGL(bf16_affine_act_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, MVS_STREAM(stream),
                        reinterpret_cast<const __bf16*>(x), scale, shift, reinterpret_cast<const __bf16*>(residual), relu, C, total8,
-                       reinterpret_cast<__bf16*>(y));
+                       (size_t)sh.RS, groups, reinterpret_cast<__bf16*>(y));
     return mvs::finish_launch("mvs_bf16_affine_act");
 }
 
 extern "C" int mvs_bf16_bn_bwd_reduce(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
-                                      const float* invstd, int relu, int C, int64_t R, float* sums, void* workspace,
-                                      mvs_stream_t stream) {
-    MVS_REQUIRE(dy && x && scale && shift && mean && invstd && sums && workspace && chan_ok(C) && R >= 1, "mvs_bf16_bn_bwd_reduce: bad arguments");
-    const unsigned nb = (unsigned)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+                                      const float* invstd, int relu, int C, int64_t R, int groups, int64_t rows_per_sample, float* sums,
+                                      void* workspace, mvs_stream_t stream) {
+    BnShape sh;
+    MVS_REQUIRE(dy && x && scale && shift && mean && invstd && sums && workspace && bn_shape(C, R, groups, rows_per_sample, &sh),
+                "mvs_bf16_bn_bwd_reduce: bad arguments");
     float* part = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL(bf16_bn_reduce_kernel<true>, dim3(nb), dim3(256), 0, MVS_STREAM(stream),
-                       reinterpret_cast<const __bf16*>(x), reinterpret_cast<const __bf16*>(dy), scale, shift, mean, invstd, relu, C, (size_t)R,
-                       part);
-    mvs::launch_partials_reduce(part, (int)nb, 2 * C, sums, MVS_STREAM(stream));
+    hipLaunchKernelGGL(bf16_bn_reduce_kernel<true>, dim3(sh.bps, sh.nsamples), dim3(256), 0, MVS_STREAM(stream),
+                       reinterpret_cast<const __bf16*>(x), reinterpret_cast<const __bf16*>(dy), scale, shift, mean, invstd, relu, C,
+                       (size_t)sh.RS, groups, part);
+    mvs::launch_partials_reduce_grouped(part, (int)sh.bps, sh.nsamples, groups, C, sums, MVS_STREAM(stream));
     return mvs::finish_launch("mvs_bf16_bn_bwd_reduce");
 }
 
 extern "C" int mvs_bf16_bn_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
                                      const float* invstd, const float* gamma, const float* sums, double count, const float* count_dev,
-                                     int relu, int C, int64_t R, void* dx, mvs_stream_t stream) {
-    MVS_REQUIRE(dy && x && scale && shift && mean && invstd && sums && dx && chan_ok(C) && R >= 1, "mvs_bf16_bn_bwd_apply: bad arguments");
+                                     int relu, int C, int64_t R, int groups, int64_t rows_per_sample, void* dx, mvs_stream_t stream) {
+    BnShape sh;
+    MVS_REQUIRE(dy && x && scale && shift && mean && invstd && sums && dx && bn_shape(C, R, groups, rows_per_sample, &sh),
+                "mvs_bf16_bn_bwd_apply: bad arguments");
     const size_t total8 = (size_t)R * (C / 8);
     hipLaunchKernelGGL(bf16_bn_bwd_apply_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, MVS_STREAM(stream),
                        reinterpret_cast<const __bf16*>(dy), reinterpret_cast<const __bf16*>(x), scale, shift, mean, invstd, gamma, sums, count,
-                       count_dev, relu, C, total8, reinterpret_cast<__bf16*>(dx));
+                       count_dev, relu, C, total8, (size_t)sh.RS, groups, reinterpret_cast<__bf16*>(dx));
     return mvs::finish_launch("mvs_bf16_bn_bwd_apply");
 }

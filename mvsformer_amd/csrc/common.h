@@ -24,6 +24,10 @@ inline int finish_launch(const char* what) {
 // The deterministic second stage of every block-partial reduction in the library (BatchNorm statistics and their backward).
 void launch_partials_reduce(const float* part, int nparts, int n, float* out, hipStream_t stream);
 
+// Grouped form over partial rows of width 2*C ([sum | sum of squares]) written by (block bx of sample n) at row n*bps + bx:
+// out[g*C + c] / out[groups*C + g*C + c] = sums over the samples n = g (mod groups) and their bps blocks, fixed order.
+void launch_partials_reduce_grouped(const float* part, int bps, int nsamples, int groups, int C, float* out, hipStream_t stream);
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline long long ceil_div(long long a, long long b) { return (a + b - 1) / b; }
 

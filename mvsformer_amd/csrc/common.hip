@@ -20,6 +20,27 @@ static __global__ __launch_bounds__(256) void partials_reduce_kernel(const float
     if (lane == 0) out[j] = s;
 }
 
+static __global__ __launch_bounds__(256) void partials_reduce_grouped_kernel(const float* __restrict__ part, int bps, int nsamples, int groups,
+                                                                             int C, float* __restrict__ out) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;          // output (g, j), j in [0, 2C)
+    if (o >= groups * 2 * C) return;
+    const int g = o / (2 * C), j = o % (2 * C);
+    const int per = (nsamples / groups) * bps;              // partial rows of this group
+    float s = 0.0f;
+    for (int q = lane; q < per; q += 64) {
+        const int n = g + (q / bps) * groups, bx = q % bps;
+        s += part[((size_t)n * bps + bx) * 2 * C + j];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) out[(j >= C ? groups * C : 0) + g * C + (j % C)] = s;
+}
+
+void launch_partials_reduce_grouped(const float* part, int bps, int nsamples, int groups, int C, float* out, hipStream_t stream) {
+    if (groups == 1 && nsamples == 1) return launch_partials_reduce(part, bps, 2 * C, out, stream);
+    hipLaunchKernelGGL(partials_reduce_grouped_kernel, dim3((groups * 2 * C + 3) / 4), dim3(256), 0, stream, part, bps, nsamples, groups, C, out);
+}
+
 void launch_partials_reduce(const float* part, int nparts, int n, float* out, hipStream_t stream) {
     hipLaunchKernelGGL(partials_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, part, nparts, n, out);
 }

@@ -826,39 +826,51 @@ def bf16_conv3d_wgrad(A: torch.Tensor, Bt: torch.Tensor, stride) -> torch.Tensor
     return dW
 
 
-def bf16_bn_stats(x: torch.Tensor) -> torch.Tensor:
-    _chk16(x, "x")
+def _bf16_bn_shape(x: torch.Tensor, groups: int):
+    """(C, R, rows per sample) of a channel-last bf16 batch ``[N,...,C]``; ``groups`` > 1 = grouped BatchNorm over the batch dimension
+    (sample n belongs to group n % groups)."""
     C = x.shape[-1]
-    sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
-    ws = _reduce_ws("mvs_bf16_bn_reduce_workspace_bytes", x.device, C, x.numel() // C)
-    _call("mvs_bf16_bn_stats", "bf16_bn_stats", _ptr(x), C, x.numel() // C, _ptr(sums), _ptr(ws), _stream())
+    R = x.numel() // C
+    if groups > 1 and x.shape[0] % groups:
+        raise _lib.MvsHipError("grouped BatchNorm: batch %d is not a multiple of %d groups" % (x.shape[0], groups))
+    return C, R, R // x.shape[0]
+
+
+def bf16_bn_stats(x: torch.Tensor, groups: int = 1) -> torch.Tensor:
+    """-> ``sums [2*groups*C]``: [sum | sum of squares] per (group, channel)."""
+    _chk16(x, "x")
+    C, R, rps = _bf16_bn_shape(x, groups)
+    sums = torch.empty(2 * groups * C, device=x.device, dtype=torch.float32)
+    ws = _reduce_ws("mvs_bf16_bn_reduce_workspace_bytes", x.device, C, R, groups, rps)
+    _call("mvs_bf16_bn_stats", "bf16_bn_stats", _ptr(x), C, R, groups, rps, _ptr(sums), _ptr(ws), _stream())
     return sums
 
 
-def bf16_affine_act(x, scale, shift, residual, relu):
+def bf16_affine_act(x, scale, shift, residual, relu, groups: int = 1):
     _chk16(x, "x"), _chk(scale, "scale"), _chk(shift, "shift")
     if residual is not None:
         _chk16(residual, "residual")
-    C = x.shape[-1]
+    C, R, rps = _bf16_bn_shape(x, groups)
     y = torch.empty_like(x)
-    _call("mvs_bf16_affine_act", "bf16_affine_act", _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), int(relu), C, x.numel() // C, _ptr(y), _stream())
+    _call("mvs_bf16_affine_act", "bf16_affine_act", _ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), int(relu), C, R, groups, rps, _ptr(y),
+          _stream())
     return y
 
 
-def bf16_bn_bwd_reduce(dy, x, scale, shift, mean, invstd, relu):
+def bf16_bn_bwd_reduce(dy, x, scale, shift, mean, invstd, relu, groups: int = 1):
     _chk16(dy, "dy"), _chk16(x, "x")
-    C = x.shape[-1]
-    sums = torch.empty(2 * C, device=x.device, dtype=torch.float32)
-    ws = _reduce_ws("mvs_bf16_bn_reduce_workspace_bytes", x.device, C, x.numel() // C)
+    C, R, rps = _bf16_bn_shape(x, groups)
+    sums = torch.empty(2 * groups * C, device=x.device, dtype=torch.float32)
+    ws = _reduce_ws("mvs_bf16_bn_reduce_workspace_bytes", x.device, C, R, groups, rps)
     _call("mvs_bf16_bn_bwd_reduce", "bf16_bn_bwd_reduce", _ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), int(relu), C,
-          x.numel() // C, _ptr(sums), _ptr(ws), _stream())
+          R, groups, rps, _ptr(sums), _ptr(ws), _stream())
     return sums
 
 
-def bf16_bn_bwd_apply(dy, x, scale, shift, mean, invstd, gamma, sums, count, relu, count_dev=None):
+def bf16_bn_bwd_apply(dy, x, scale, shift, mean, invstd, gamma, sums, count, relu, count_dev=None, groups: int = 1):
     _chk16(dy, "dy"), _chk16(x, "x"), _chk(sums, "sums"), _opt(gamma, "gamma"), _opt(count_dev, "count_dev")
-    C = x.shape[-1]
+    C, R, rps = _bf16_bn_shape(x, groups)
     dx = torch.empty_like(x)
     _call("mvs_bf16_bn_bwd_apply", "bf16_bn_bwd_apply", _ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _ptr(gamma),
-          _ptr(sums), float(count), _ptr(count_dev), int(relu), C, x.numel() // C, _ptr(dx), _stream())
+          _ptr(sums), float(count), _ptr(count_dev), int(relu), C, R, groups, rps, _ptr(dx), _stream())
     return dx

@@ -215,3 +215,66 @@ def test_regularizer_bf16_vs_cpu_autocast(dev, kind, D, H, W):
         worst[name] = ((a - b).norm() / (b.norm() + 1e-30)).item()
     bad = {k: v for k, v in worst.items() if v > 0.25}
     assert not bad, bad
+
+
+def test_bn_act_bf16_grouped_equals_per_group_calls(dev):
+    """Grouped BatchNorm over the batch dimension (sample n -> group n % groups) = the same module called once per group on that
+    group's samples: outputs, input gradients, parameter gradients (summed over the groups) and running statistics (updated once per
+    group, in group order)."""
+    from mvsformer_amd import autograd as ag
+    torch.manual_seed(5)
+    N, G, C = 6, 3, 16
+    x = (torch.randn(N, 1, 9, 130, C) * 2 + 0.5).to(torch.bfloat16).to(dev)        # 1170 rows per sample: not a block multiple
+    go = torch.randn(N, 1, 9, 130, C).to(torch.bfloat16).to(dev)
+
+    def make_bn():
+        bn = torch.nn.BatchNorm3d(C).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+        return bn
+    bn_a, bn_b = make_bn(), make_bn()
+    xa = x.clone().requires_grad_(True)
+    ya = ag.BnActBf16Fn.apply(xa, bn_a.weight, bn_a.bias, None, bn_a, True, G)
+    ya.backward(go)
+    xb = x.clone().requires_grad_(True)
+    outs = []
+    for g in range(G):
+        outs.append(ag.BnActBf16Fn.apply(xb[g::G], bn_b.weight, bn_b.bias, None, bn_b, True))
+    for g in range(G):
+        outs[g].backward(go[g::G])
+    for g in range(G):
+        relclose(ya[g::G].float(), outs[g].float(), 1e-2, "y group %d" % g)          # bf16 outputs: 2^-8 of scale
+        relclose(xa.grad[g::G].float(), xb.grad[g::G].float(), 1e-2, "dx group %d" % g)
+    relclose(bn_a.weight.grad, bn_b.weight.grad, 1e-4, "dgamma")
+    relclose(bn_a.bias.grad, bn_b.bias.grad, 1e-4, "dbeta")
+    relclose(bn_a.running_mean, bn_b.running_mean, 1e-5, "running_mean")
+    relclose(bn_a.running_var, bn_b.running_var, 1e-5, "running_var")
+    assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == G
+
+
+def test_vis_train_views_bf16_close_to_fp32(dev):
+    """The visibility CNN in training under autocast (bf16 channel-last kernels, grouped BatchNorm) against its fp32 path on the same
+    entropy maps: weights within bf16 noise of the sigmoid output, parameter gradients aligned (cosine)."""
+    import copy
+    import mvsformer_amd as m
+    from mvsformer_amd import autograd as ag
+    torch.manual_seed(2)
+    net = m.StageNet(dict(base_ch=8, fusion_type="cnn", depth_type="ce"), 8, 0).to(dev).train()
+    net2 = copy.deepcopy(net)
+    ent = (torch.rand(1, 3, 40, 56, device=dev) * 2.0).contiguous()
+    R = torch.randn(1, 3, 40, 56, device=dev)
+    w32 = ag.vis_train_views(ent, net.vis)
+    (w32 * R).sum().backward()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        w16 = ag.vis_train_views(ent, net2.vis)
+    assert w16.dtype == torch.float32 and w16.shape == w32.shape
+    (w16 * R).sum().backward()
+    assert (w16 - w32).abs().max().item() < 3e-2                          # sigmoid outputs in [0,1]
+    g32 = torch.cat([p.grad.flatten() for p in net.vis.parameters()])
+    g16 = torch.cat([p.grad.flatten() for p in net2.vis.parameters()])
+    cos = torch.dot(g32, g16) / (g32.norm() * g16.norm())
+    assert cos.item() > 0.98, cos.item()
+    for a, b in zip(net.vis.buffers(), net2.vis.buffers()):
+        if a.dtype.is_floating_point:
+            relclose(b, a, 3e-2, "running stat")
