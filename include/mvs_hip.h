@@ -257,6 +257,9 @@ int mvs_conv3d_wgrad(const float* A, const float* Bt, float* dW, int nbatch, int
  * ------------------------------------------------------------------------------------------------------- */
 int64_t mvs_bf16_packed_elems(int Cin, int Cout);
 int mvs_bf16_pack_weights(const float* w, int d0, int d1, int src, int Cout, int Cin, void* wpacked, mvs_stream_t stream);
+/* two layouts of one weight (the forward's and the data gradient's) in one launch */
+int mvs_bf16_pack_weights2(const float* w, int d0, int d1, int srcA, int CoutA, int CinA, void* packedA, int srcB, int CoutB, int CinB,
+                           void* packedB, mvs_stream_t stream);
 int mvs_bf16_conv3d(const void* x, const void* wpacked, const float* scale, const float* shift, const void* residual, void* y,
                     int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd, int shw, int relu, mvs_stream_t stream);
 int64_t mvs_bf16_conv3d_wgrad_workspace_bytes(int nbatch, int CA, int CB, int Dp, int Hp, int Wp);

@@ -346,23 +346,27 @@ class ConvBf16Fn(torch.autograd.Function):
         x = x.contiguous()
         w = weight.detach().to(torch.float32).contiguous()
         cout, cin = w.shape[0], w.shape[1]
-        y = ops.bf16_conv3d(x, ops.bf16_pack(w, 0, cin, cout), cin, cout, 0, stride)
-        ctx.save_for_backward(x, w)
-        ctx.stride = stride
+        if ctx.needs_input_grad[0]:     # the data gradient's layout (stride-1: channels swapped + taps mirrored; strided: transposed
+            wf, wb = ops.bf16_pack2(w, (0, cin, cout), (2 if stride[1] == 1 else 1, cout, cin))     # conv) in the same launch
+        else:
+            wf, wb = ops.bf16_pack(w, 0, cin, cout), None
+        y = ops.bf16_conv3d(x, wf, cin, cout, 0, stride)
+        ctx.save_for_backward(x, wb)
+        ctx.stride, ctx.wshape = stride, (cout, cin)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, wb = ctx.saved_tensors
         dy = dy.contiguous()
-        cout, cin = w.shape[0], w.shape[1]
+        cout, cin = ctx.wshape
         sd, shw = ctx.stride
         dx = None
         if ctx.needs_input_grad[0]:
             if shw == 1:        # stride-1 conv: the data gradient is the same conv with channels swapped and taps mirrored
-                dx = ops.bf16_conv3d(dy, ops.bf16_pack(w, 2, cout, cin), cout, cin, 0, (1, 1))
+                dx = ops.bf16_conv3d(dy, wb, cout, cin, 0, (1, 1))
             else:               # strided conv: the transposed conv of the same weight
-                dx = ops.bf16_conv3d(dy, ops.bf16_pack(w, 1, cout, cin), cout, cin, 1, (sd, shw))
+                dx = ops.bf16_conv3d(dy, wb, cout, cin, 1, (sd, shw))
             if dx.shape != x.shape:
                 raise ops._lib.MvsHipError("conv backward: input %s is not 2x the output grid %s" % (tuple(x.shape), tuple(dy.shape)))
         dw = ops.bf16_conv3d_wgrad(dy, x, (sd, shw)) if ctx.needs_input_grad[1] else None
@@ -377,19 +381,23 @@ class DeconvBf16Fn(torch.autograd.Function):
         x = x.contiguous()
         w = weight.detach().to(torch.float32).contiguous()          # [Cin,Cout,3,3,3]
         cin, cout = w.shape[0], w.shape[1]
-        y = ops.bf16_conv3d(x, ops.bf16_pack(w, 1, cin, cout), cin, cout, 1, (sd, 2))
-        ctx.save_for_backward(x, w)
-        ctx.sd = sd
+        if ctx.needs_input_grad[0]:     # data gradient = strided conv of dY with W read as [out = cin, in = cout]
+            wf, wb = ops.bf16_pack2(w, (1, cin, cout), (0, cout, cin))
+        else:
+            wf, wb = ops.bf16_pack(w, 1, cin, cout), None
+        y = ops.bf16_conv3d(x, wf, cin, cout, 1, (sd, 2))
+        ctx.save_for_backward(x, wb)
+        ctx.sd, ctx.wshape = sd, (cin, cout)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, wb = ctx.saved_tensors
         dy = dy.contiguous()
-        cin, cout = w.shape[0], w.shape[1]
+        cin, cout = ctx.wshape
         dx = None
         if ctx.needs_input_grad[0]:   # strided conv of dY with W read as [out = cin, in = cout]
-            dx = ops.bf16_conv3d(dy, ops.bf16_pack(w, 0, cout, cin), cout, cin, 0, (ctx.sd, 2))
+            dx = ops.bf16_conv3d(dy, wb, cout, cin, 0, (ctx.sd, 2))
         dw = ops.bf16_conv3d_wgrad(x, dy, (ctx.sd, 2)) if ctx.needs_input_grad[1] else None
         return dx, dw, None
 

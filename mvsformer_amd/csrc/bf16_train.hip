@@ -39,21 +39,29 @@ __device__ __forceinline__ void xcd_item(int total, int& logical, bool& valid) {
 // out[((step * NT + nt) * 64 + lane) * 8 + e] = A[m = nt*16 + (lane & 15)][k-block t = 4*step + (lane >> 4)][e]  as bf16, where k-block
 // t = (tap, channel octet cq) = (t / (KC/8), t % (KC/8)), channel c = cq*8 + e; zero beyond M rows / 27*KC/8 blocks.
 // src: 0 = w[m][c][tap], 1 = w[c][m][tap], 2 = w[c][m][26 - tap]   (w = [d0][d1][27] fp32)
-__global__ void bf16_pack_kernel(const float* __restrict__ w, int d1, int src, int M, int KC, int NT, int steps, __bf16* __restrict__ out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= steps * NT * 64) return;
-    const int lane = idx & 63, nt = (idx >> 6) % NT, step = idx / (64 * NT);
-    const int m = nt * 16 + (lane & 15), t = 4 * step + (lane >> 4), KQ = KC / 8;
+struct PackJob {
+    int d1, src, M, KC, NT, steps, nblocks;
+    __bf16* out;
+};
+// one launch packs up to two layouts of the same weight (the forward's and the data gradient's): blocks [0, a.nblocks) do job a
+__global__ void bf16_pack_kernel(const float* __restrict__ w, const PackJob a, const PackJob b) {
+    const bool first = (int)blockIdx.x < a.nblocks;
+    const PackJob& j = first ? a : b;
+    const int idx = ((int)blockIdx.x - (first ? 0 : a.nblocks)) * blockDim.x + threadIdx.x;
+    if (idx >= j.steps * j.NT * 64) return;
+    const int lane = idx & 63, nt = (idx >> 6) % j.NT, step = idx / (64 * j.NT);
+    const int m = nt * 16 + (lane & 15), t = 4 * step + (lane >> 4), KQ = j.KC / 8;
     const int tap = t / KQ, cq = t % KQ;
     bf16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = cq * 8 + e;
         float f = 0.0f;
-        if (m < M && t < 27 * KQ) f = src == 0 ? w[((size_t)m * d1 + c) * 27 + tap] : w[((size_t)c * d1 + m) * 27 + (src == 2 ? 26 - tap : tap)];
+        if (m < j.M && t < 27 * KQ)
+            f = j.src == 0 ? w[((size_t)m * j.d1 + c) * 27 + tap] : w[((size_t)c * j.d1 + m) * 27 + (j.src == 2 ? 26 - tap : tap)];
         v[e] = (__bf16)f;
     }
-    reinterpret_cast<bf16x8*>(out)[idx] = v;
+    reinterpret_cast<bf16x8*>(j.out)[idx] = v;
 }
 
 // ------------------------------------------------------------------------------------------------ convolution (forward and data gradients)
@@ -541,15 +549,34 @@ extern "C" int64_t mvs_bf16_packed_elems(int Cin, int Cout) {
     return (int64_t)steps * nt_of(Cout) * 64 * 8;
 }
 
+namespace {
+bool pack_job(int d0, int d1, int src, int Cout, int Cin, void* out, PackJob* j) {
+    if (!chan_ok(Cin) || !chan_ok(Cout) || src < 0 || src > 2 || !out) return false;
+    if (!((src == 0 && d0 == Cout && d1 == Cin) || (src != 0 && d0 == Cin && d1 == Cout))) return false;
+    j->d1 = d1, j->src = src, j->M = Cout, j->KC = Cin, j->NT = nt_of(Cout), j->steps = (27 * Cin / 8 + 3) / 4;
+    j->nblocks = (j->steps * j->NT * 64 + 255) / 256;
+    j->out = reinterpret_cast<__bf16*>(out);
+    return true;
+}
+}  // namespace
+
 extern "C" int mvs_bf16_pack_weights(const float* w, int d0, int d1, int src, int Cout, int Cin, void* wpacked, mvs_stream_t stream) {
-    MVS_REQUIRE(w && wpacked, "mvs_bf16_pack_weights: null pointer");
-    MVS_REQUIRE(chan_ok(Cin) && chan_ok(Cout) && src >= 0 && src <= 2, "mvs_bf16_pack_weights: Cin=%d Cout=%d src=%d", Cin, Cout, src);
-    MVS_REQUIRE((src == 0 && d0 == Cout && d1 == Cin) || (src != 0 && d0 == Cin && d1 == Cout), "mvs_bf16_pack_weights: weight is [%d][%d][27], "
-                "expected %s", d0, d1, src == 0 ? "[Cout][Cin]" : "[Cin][Cout]");
-    const int steps = (27 * Cin / 8 + 3) / 4, nt = nt_of(Cout), n = steps * nt * 64;
-    hipLaunchKernelGGL(bf16_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, MVS_STREAM(stream), w, d1, src, Cout, Cin, nt, steps,
-                       reinterpret_cast<__bf16*>(wpacked));
+    PackJob a{}, none{};
+    MVS_REQUIRE(w && pack_job(d0, d1, src, Cout, Cin, wpacked, &a), "mvs_bf16_pack_weights: weight [%d][%d][27] / src %d / Cin=%d Cout=%d", d0,
+                d1, src, Cin, Cout);
+    hipLaunchKernelGGL(bf16_pack_kernel, dim3(a.nblocks), dim3(256), 0, MVS_STREAM(stream), w, a, none);
     return mvs::finish_launch("mvs_bf16_pack_weights");
+}
+
+// the forward's and the data gradient's layout of one weight in ONE launch (a training step packs every layer twice)
+extern "C" int mvs_bf16_pack_weights2(const float* w, int d0, int d1, int srcA, int CoutA, int CinA, void* packedA, int srcB, int CoutB,
+                                      int CinB, void* packedB, mvs_stream_t stream) {
+    PackJob a{}, b{};
+    MVS_REQUIRE(w && pack_job(d0, d1, srcA, CoutA, CinA, packedA, &a) && pack_job(d0, d1, srcB, CoutB, CinB, packedB, &b),
+                "mvs_bf16_pack_weights2: weight [%d][%d][27] does not match (src %d: %d->%d) / (src %d: %d->%d)", d0, d1, srcA, CinA, CoutA,
+                srcB, CinB, CoutB);
+    hipLaunchKernelGGL(bf16_pack_kernel, dim3(a.nblocks + b.nblocks), dim3(256), 0, MVS_STREAM(stream), w, a, b);
+    return mvs::finish_launch("mvs_bf16_pack_weights2");
 }
 
 // gather: 0 = Conv3d (out = (in - 1)/stride + 1), 1 = ConvTranspose3d k3 p1 op(stride-1) (out = in*stride)

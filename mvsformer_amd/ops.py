@@ -788,6 +788,20 @@ def bf16_pack(weight: torch.Tensor, src: int, cin: int, cout: int) -> torch.Tens
     return packed
 
 
+def bf16_pack2(weight: torch.Tensor, a, b):
+    """Two layouts ``(src, cin, cout)`` of one weight in one launch (forward + data gradient): -> (packed_a, packed_b)."""
+    _chk(weight, "conv weight")
+    outs = []
+    for src, cin, cout in (a, b):
+        n = _lib.load().mvs_bf16_packed_elems(cin, cout)
+        if n <= 0:
+            raise _lib.MvsHipError("bf16 conv: channels must be 8/16/32/64 (Cin=%d Cout=%d)" % (cin, cout))
+        outs.append(torch.empty(n, device=weight.device, dtype=torch.bfloat16))
+    _call("mvs_bf16_pack_weights2", "mvs_bf16_pack_weights", _ptr(weight), weight.shape[0], weight.shape[1], int(a[0]), a[2], a[1],
+          _ptr(outs[0]), int(b[0]), b[2], b[1], _ptr(outs[1]), _stream())
+    return outs[0], outs[1]
+
+
 def bf16_conv3d(x, wpacked, cin, cout, gather: int, stride, scale=None, shift=None, residual=None, relu=False):
     """``x [B,D,H,W,cin]`` bf16 -> ``[B,Do,Ho,Wo,cout]`` bf16; ``gather`` 0 = Conv3d, 1 = ConvTranspose3d (k3, p1, op = stride-1)."""
     _chk16(x, "x"), _chk16(wpacked, "packed weights"), _opt(scale, "scale"), _opt(shift, "shift")
