@@ -1,4 +1,4 @@
-"""hipGraph capture of a whole training step (mvsformer_amd/graphs.py): replays must reproduce the eager step."""
+"""hipGraph capture of a whole training step (mvsformer_amd/graphs.py): a replay must do what the eager step does."""
 import pytest
 import torch
 
@@ -6,6 +6,9 @@ pytestmark = pytest.mark.gpu
 
 
 def test_captured_training_step_matches_eager():
+    """From one and the same state (parameters + BatchNorm buffers), one graph replay and one eager step must produce the same loss
+    and the same updated state up to the reordering of the backward's float atomics.  (Trajectories over several steps are not
+    compared: the training head is an arg-max, so rounding-level parameter differences flip pixels and grow.)"""
     import mvsformer_amd as m
     from mvsformer_amd import synth
     from mvsformer_amd.graphs import CapturedStep
@@ -14,30 +17,35 @@ def test_captured_training_step_matches_eager():
     feats, proj, dv, scene = synth.make_inputs(3, 128, 192, seed=4, device=dev)
     gts = {"stage%d" % (i + 1): synth.plane_depth(scene, s, device=dev)[None] for i, s in enumerate(synth.STAGE_SCALES)}
     masks = {k: torch.ones_like(v) for k, v in gts.items()}
+    torch.manual_seed(0)
+    net = m.CascadeMVS(dict(ndepths=[8, 8, 4, 4])).to(dev).train()
+    opt = torch.optim.SGD(net.parameters(), lr=1e-2)
 
-    def build():
-        torch.manual_seed(0)
-        net = m.CascadeMVS(dict(ndepths=[8, 8, 4, 4])).to(dev).train()
-        opt = torch.optim.AdamW(net.parameters(), lr=1e-3, capturable=True)
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = net(feats, proj, dv, tmp=[5.0, 5.0, 5.0, 1.0])
+        loss = sum(ce_loss_stage4(out, gts, masks, dlossw=[1, 1, 1, 1]).values())
+        loss.backward()
+        opt.step()
+        return loss
 
-        def step():
-            opt.zero_grad(set_to_none=True)
-            out = net(feats, proj, dv, tmp=[5.0, 5.0, 5.0, 1.0])
-            loss = sum(ce_loss_stage4(out, gts, masks, dlossw=[1, 1, 1, 1]).values())
-            loss.backward()
-            opt.step()
-            return loss
-        return net, step
+    graphed = CapturedStep(step, warmup=3)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
 
-    net_e, step_e = build()
-    losses_e = [step_e().item() for _ in range(3 + 4)]                  # 3 warm-up + capture pass count as steps in the graphed twin
-    net_g, step_g = build()
-    graphed = CapturedStep(step_g, warmup=3)                            # 3 eager steps + 1 captured (capture does not execute)
-    losses_g = [graphed().item() for _ in range(4)]
-    # the graphed model has taken 3 eager steps, then 4 replays: same trajectory as 7 eager steps (atomics reorder: 1e-4)
-    for a, b in zip(losses_e[3:], losses_g):
-        assert abs(a - b) <= 2e-4 * abs(a), (losses_e, losses_g)
-    # AdamW divides by sqrt(v): where a gradient is rounding noise (atomics reorder between the two runs) the update is +-lr
-    # whatever its size, so parameters agree to the 7 steps' worth of lr at worst and almost everywhere much better
-    diff = torch.cat([(p - q).abs().flatten() for p, q in zip(net_e.parameters(), net_g.parameters())])
-    assert diff.max().item() <= 7.5e-3 and (diff > 1e-4).float().mean().item() < 0.05, (diff.max().item(), (diff > 1e-4).float().mean().item())
+    def restore():
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                v.copy_(state[k])
+
+    loss_g = graphed().clone()
+    after_g = {k: v.clone() for k, v in net.state_dict().items()}
+    loss_g2 = graphed().clone()                              # a second replay really advances the state
+    assert not torch.equal(after_g["fusions.0.cost_reg.conv1.conv.weight"], net.state_dict()["fusions.0.cost_reg.conv1.conv.weight"])
+    restore()
+    loss_e = step().clone()
+    assert abs(loss_e.item() - loss_g.item()) <= 1e-6 * abs(loss_e.item()), (loss_e.item(), loss_g.item(), loss_g2.item())
+    for k, v in net.state_dict().items():
+        if v.dtype.is_floating_point:
+            assert (v - after_g[k]).abs().max().item() <= 1e-6 + 1e-4 * v.abs().max().item(), k
+        else:
+            assert torch.equal(v, after_g[k]), k
