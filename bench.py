@@ -184,8 +184,8 @@ def main(args):
                 ach = per_launch / (s["avg_ms"] * 1e-3) / 1e12
                 e.update(bound="mfma", achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s",
                          frac=round(ach / FP32_MFMA_PEAK_TF, 4), algorithmic_per_launch=per_launch)
-            tr = traffic_db.get(name)
-            e["traffic"] = tr["hbm_bytes_per_launch"] if tr else None
+            tr = traffic_db.get(name) or next((v for k, v in traffic_db.items() if k.startswith(name + "<")), None)   # bench tags drop
+            e["traffic"] = tr["hbm_bytes_per_launch"] if tr else None                                           # some template lists
         kernels.append(e)
     kernels.sort(key=lambda e: -e["ms_per_step"])
     dom = next(e for e in kernels if "bound" in e)
