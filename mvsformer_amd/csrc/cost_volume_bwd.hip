@@ -209,7 +209,8 @@ __global__ __launch_bounds__(64 * NW) void cv_aggregate_bwd_kernel(const float* 
 // ---------------------------------------------------------------------------------------------------------------------------
 #ifndef MVS_BWD_EXP
 #define MVS_BWD_EXP 0                                       // experiment switches (tools/exp_cv_bwd.py --build): 1 no LDS adds, 2 no outlier atomics,
-#endif                                                      // 4 constant coefficients instead of the gvol loads, 8 no tap gathers
+#endif                                                      // 4 constant coefficients instead of the gvol loads, 8 no tap gathers,
+                                                            // 16 ds_add_u32 (fixed point) / 32 ds_add_u64 (two channels per op) for timing
 constexpr int LT_W = 16, LT_H = 8, LT_NW = 4;               // tile of reference pixels; wavefront = 2 rows x 16 pixels x 2 channel quads
 
 template <int C>
@@ -336,6 +337,14 @@ __global__ __launch_bounds__(64 * LT_NW) void cv_aggregate_bwd_lds_kernel(const 
                         const int txx = rx + (k & 1), tyy = ry + (k >> 1);
                         if ((unsigned)txx < (unsigned)WX && (unsigned)tyy < (unsigned)WY) {
                             float* cell = win + (cq * 4) * WPL + (tyy << wx_log2) + txx;
+                            if (MVS_BWD_EXP & 32) {          // timing experiment: two channels per 64-bit integer LDS atomic
+                                unsigned long long* c64 = reinterpret_cast<unsigned long long*>(win) + ((cq * 2) * (WPL / 2) + (tyy << wx_log2) + txx);
+#pragma unroll
+                                for (int i = 0; i < 2; ++i) {
+                                    const long long lo = (long long)(int)(w[k] * cr[2 * i] * 1048576.0f), hi = (long long)(int)(w[k] * cr[2 * i + 1] * 1048576.0f);
+                                    atomicAdd(c64 + i * (WPL / 2), (unsigned long long)((hi << 32) + lo));
+                                }
+                            } else
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
                                 if (MVS_BWD_EXP & 16) atomicAdd(reinterpret_cast<int*>(cell + i * WPL), (int)(w[k] * cr[i] * 1048576.0f));

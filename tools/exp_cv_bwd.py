@@ -9,7 +9,7 @@ CSRC = os.path.join(REPO, "mvsformer_amd", "csrc")
 if "--build" in sys.argv:       # here (no GPU): full libraries with one experiment switch each -> csrc/exp/libmvs_hip_exp<N>.so
     os.makedirs(os.path.join(CSRC, "exp"), exist_ok=True)
     objs = [os.path.join(CSRC, o) for o in os.listdir(CSRC) if o.endswith(".o") and o != "cost_volume_bwd.o"]
-    for n in (1, 3, 15, 16):
+    for n in (1, 3, 15, 16, 32):
         obj = os.path.join(CSRC, "exp", "cvb_%d.o" % n)
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
                                "-DMVS_BWD_EXP=%d" % n, "-c", os.path.join(CSRC, "cost_volume_bwd.hip"), "-o", obj])
