@@ -289,6 +289,12 @@ int mvs_cv_aggregate_bwd(const float* feat, const float* rt, const float* depth,
 int mvs_cv_aggregate_bwd_lds(const float* feat, const float* rt, const float* depth, const float* weight, const float* volume,
                              const float* gvolume, int B, int V, int C, int G, int D, int H, int W, float* dfeat, float* gip_part,
                              int wx_log2, int wy, unsigned* stats, mvs_stream_t stream);
+/* Same contract, no atomics in the common case: a WAVEFRONT owns an 8 x 4 pixel tile and a private LDS window; lanes that target the
+ * same cell in one instruction are serialized by a tag byte (owner election), the add is a plain LDS read-modify-write; planes in
+ * chunks of 8, window re-centred and flushed (global atomics) per (view, chunk); taps outside the window use global atomics. */
+int mvs_cv_aggregate_bwd_own(const float* feat, const float* rt, const float* depth, const float* weight, const float* volume,
+                             const float* gvolume, int B, int V, int C, int G, int D, int H, int W, float* dfeat, float* gip_part,
+                             int wx_log2, int wy, unsigned* stats, mvs_stream_t stream);
 int mvs_softmax_bwd(const float* p, const float* dp, int B, int D, int64_t HW, float* dpre, mvs_stream_t stream);
 int mvs_prob1_bwd(const float* x, const float* w, const float* dlogits, int B, int C, int64_t N, float* dx, float* dwb,
                   mvs_stream_t stream);

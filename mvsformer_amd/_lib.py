@@ -66,6 +66,7 @@ SIGNATURES = {
     "mvs_bf16_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, Dbl, P, I, I, L, I, L, P, P]),
     "mvs_cv_aggregate_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P]),
     "mvs_cv_aggregate_bwd_lds": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, I, I, P, P]),
+    "mvs_cv_aggregate_bwd_own": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, I, I, P, P]),
     "mvs_softmax_bwd": (I, [P, P, I, I, L, P, P]),
     "mvs_prob1_bwd": (I, [P, P, P, I, I, L, P, P, P]),
     "mvs_sigmoid_fwd": (I, [P, L, P, P]),

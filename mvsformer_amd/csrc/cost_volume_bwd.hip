@@ -385,6 +385,223 @@ __global__ __launch_bounds__(64 * LT_NW) void cv_aggregate_bwd_lds_kernel(const 
     if (active) *reinterpret_cast<f32x4*>(dfeat + ((size_t)(b * V) * HW + pix) * C + cb) = dref;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Third form: the scatter WITHOUT atomics in the common case.  Float atomics retire one lane-operation every ~2.7 clocks per CU in
+// LDS and in the L2 alike (profiles/r02_cv_bwd_lds_ablation.txt), so the only way below the direct kernel is not to issue them.
+// A WAVEFRONT owns an 8 x 4 tile of reference pixels (32 pixels x 2 channel quads), one channel octet and a private window of the
+// source view's gradient in LDS.  Nobody else touches that window, and a wavefront's LDS operations execute in program order, so a tap
+// is added with a plain read-modify-write (ds_read_b128 / ds_write_b128 of the lane's four channels) once the lanes that target the
+// SAME cell in the same instruction have been serialized: every pending lane writes its lane id into a per-cell tag byte, reads it
+// back, and the lane that finds its own id owns the cell for this round; the others go round again (collisions need two pixels on
+// one texel for the same tap - rare).  Planes are walked in chunks of 8 with the window re-centred per chunk (a D = 32 sweep spans
+// 50+ texels along the epipolar line), the touched cells are flushed with global atomics per (view, chunk), taps outside the window
+// go straight to global atomics - so the result does not depend on the window.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int OW_TW = 8, OW_TH = 4, OW_NW = 2, OW_DCH = 8;   // wave tile, wavefronts per block (side by side in x), planes per chunk
+constexpr int OW_QCAP = 128;                                 // out-of-window taps queued per wavefront before they are issued
+
+template <int C>
+__global__ __launch_bounds__(64 * OW_NW) void cv_aggregate_bwd_own_kernel(const float* __restrict__ feat, const float* __restrict__ rt_all,
+                                                                          const float* __restrict__ depth, const float* __restrict__ weight,
+                                                                          const float* __restrict__ volume, const float* __restrict__ gvol,
+                                                                          int V, int D, int H, int W, float* __restrict__ dfeat,
+                                                                          float* __restrict__ gip_part, int wx_log2, int WY,
+                                                                          unsigned* __restrict__ stats) {
+    constexpr int CPG = C / G, NOCT = C / 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int WX = 1 << wx_log2, NCELL = WX * WY;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t per_wave = (size_t)NCELL * 32 + 64 * 36 + (size_t)OW_QCAP * 20 + (size_t)NCELL * 2;
+    unsigned char* base = smem_raw + wave * ((per_wave + 15) & ~(size_t)15);
+    f32x4* win = reinterpret_cast<f32x4*>(base);                                          // [NCELL][2 quads]
+    u32x4* taps_o = reinterpret_cast<u32x4*>(base + (size_t)NCELL * 32);
+    f32x4* taps_w = reinterpret_cast<f32x4*>(base + (size_t)NCELL * 32 + 64 * 16);
+    int* taps_xy = reinterpret_cast<int*>(base + (size_t)NCELL * 32 + 64 * 32);
+    // [2 quads][NCELL] owner tags; volatile (no store-to-load forwarding: the read must see the last writer) and explicitly in the LDS
+    // address space (a generic volatile pointer compiles to flat_store/flat_load with full memory waits)
+    typedef volatile __attribute__((address_space(3))) unsigned char lds_tag_t;
+    // Taps that miss the window are not issued one instruction per (plane, tap) - a global atomic instruction with one live lane
+    // costs what one with 64 does - but queued (slot = running count + rank among the missing lanes, no atomics) and issued 64 at a time.
+    f32x4* qval = reinterpret_cast<f32x4*>(base + (size_t)NCELL * 32 + 64 * 36);
+    unsigned* qoff = reinterpret_cast<unsigned*>(base + (size_t)NCELL * 32 + 64 * 36 + (size_t)OW_QCAP * 16);
+    lds_tag_t* tags = (lds_tag_t*)(base + (size_t)NCELL * 32 + 64 * 36 + (size_t)OW_QCAP * 20);
+    int qn = 0;                                               // queued taps (wave-uniform)
+
+    const int oct = blockIdx.z % NOCT, b = blockIdx.z / NOCT;
+    const int tx0 = (blockIdx.x * OW_NW + wave) * OW_TW, ty0 = blockIdx.y * OW_TH;
+    const size_t HW = (size_t)H * W;
+    const unsigned pix_bytes = C * 4u;
+    const int pg = lane >> 1, cq = lane & 1;
+    const int xi = tx0 + (pg & 7), yi = ty0 + (pg >> 3);
+    const bool active = xi < W && yi < H;
+    const int xg = min(xi, W - 1), yg = min(yi, H - 1);
+    const size_t pix = (size_t)yg * W + xg;
+    const int cb = oct * 8 + cq * 4;
+    const f32x4 r = *reinterpret_cast<const f32x4*>(feat + ((size_t)(b * V) * HW + pix) * C + cb);
+    const float half_w = (float)((W - 1) / 2.0), half_h = (float)((H - 1) / 2.0);
+    const float* wp = weight + (size_t)(b * (V - 1)) * HW + pix;
+    float wsum = 0.0f;
+    for (int sv = 0; sv < V - 1; ++sv) wsum = wsum + wp[(size_t)sv * HW];
+    const float inv_s = 1.0f / (wsum + 1e-6f);
+    const int g0 = cb / CPG;
+    const float* gp = gvol + ((size_t)(b * G + g0) * D) * HW + pix;
+
+    float tsum = 0.0f;
+    if (oct == 0) {
+        const float* ga = gvol + ((size_t)(b * G + cq * 4) * D) * HW + pix;
+        const float* va = volume + ((size_t)(b * G + cq * 4) * D) * HW + pix;
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tsum = fmaf(ga[((size_t)k * D + d) * HW], va[((size_t)k * D + d) * HW], tsum);
+        tsum += __shfl_xor(tsum, 1, 64);
+    }
+    for (int i = lane; i < NCELL * 2; i += 64) win[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int xc = min(tx0 + OW_TW / 2, W - 1), yc = min(ty0 + OW_TH / 2, H - 1);         // tile centre (wave-uniform)
+
+    f32x4 dref = {0.f, 0.f, 0.f, 0.f};
+    for (int sv = 0; sv < V - 1; ++sv) {
+        const float* rt = rt_all + (size_t)(b * (V - 1) + sv) * 12;
+        const mvs::rsrc_t src = mvs::make_rsrc(feat + (size_t)(b * V + sv + 1) * HW * C, (unsigned)(HW * pix_bytes));
+        float* dsrc = dfeat + (size_t)(b * V + sv + 1) * HW * C + oct * 8;
+        const float wv = wp[(size_t)sv * HW];
+        float gip = 0.0f;
+        auto drain = [&]() {
+            for (int e = lane; e < qn; e += 64) {
+                const f32x4 v = qval[e];
+                float* dst = dsrc + qoff[e];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (v[i] != 0.0f) atomicAdd(dst + i, v[i]);
+            }
+            qn = 0;
+        };
+        for (int dc = 0; dc < D; dc += OW_DCH) {
+            const int dend = min(dc + OW_DCH, D);
+            // window origin: around the tile centre's projection on the chunk's middle plane (same value in every lane)
+            int ox, oy;
+            {
+                float un, vn, z;
+                mvs::sweep_project(rt, (float)xc, (float)yc, depth[((size_t)b * D + (dc + dend) / 2) * HW + (size_t)yc * W + xc], half_w, half_h, &un,
+                                   &vn, &z);
+                const float ix = (un + 1.0f) * half_w, iy = (vn + 1.0f) * half_h;
+                const bool ok = fabsf(ix) < 1e6f && fabsf(iy) < 1e6f;
+                ox = ok ? (int)floorf(ix) - WX / 2 : 0;
+                oy = ok ? (int)floorf(iy) - WY / 2 : 0;
+            }
+            int clo = NCELL, chi = -1;                        // cells this lane touched in the chunk (the flush scans only the wave's range)
+            for (int c0 = dc; c0 < dend; c0 += 2) {
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const int p = lane & 31, dd = lane >> 5;
+                    const int d = min(c0 + dd, D - 1);
+                    const int x = min(tx0 + (p & 7), W - 1), y = min(ty0 + (p >> 3), H - 1);
+                    float un, vn, z;
+                    mvs::sweep_project(rt, (float)x, (float)y, depth[((size_t)b * D + d) * HW + (size_t)y * W + x], half_w, half_h, &un, &vn, &z);
+                    int x0, y0;
+                    const mvs::Taps t = mvs::sweep_taps_xy(un, vn, H, W, half_w, half_h, &x0, &y0);
+                    taps_o[lane] = u32x4{(unsigned)t.o00, (unsigned)t.o01, (unsigned)t.o10, (unsigned)t.o11};
+                    taps_w[lane] = f32x4{t.w00, t.w01, t.w10, t.w11};
+                    taps_xy[lane] = ((y0 - oy) << 16) | ((x0 - ox) & 0xFFFF);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int dd = 0; dd < 2; ++dd) {
+                    const int d = c0 + dd;
+                    if (d >= dend) break;
+                    const u32x4 o = taps_o[dd * 32 + pg];
+                    const f32x4 w = taps_w[dd * 32 + pg];
+                    const int xy = taps_xy[dd * 32 + pg];
+                    f32x4 t4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t4[k] = buf_load4(src, o[k] * pix_bytes + (unsigned)cb * 4u);
+                    float coef[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = (CPG < 4) ? i / CPG : 0;
+                        coef[i] = gp[((size_t)k * D + d) * HW] * inv_s * (1.0f / CPG);
+                    }
+                    f32x4 cr;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float g4 = t4[0][i] * w[0];
+                        g4 = fmaf(t4[1][i], w[1], g4);
+                        g4 = fmaf(t4[2][i], w[2], g4);
+                        g4 = fmaf(t4[3][i], w[3], g4);
+                        dref[i] = fmaf(coef[i] * wv, g4, dref[i]);
+                        gip = fmaf(coef[i] * r[i], g4, gip);
+                        cr[i] = coef[i] * wv * r[i];
+                    }
+                    const int rx = (int)(short)(xy & 0xFFFF), ry = xy >> 16;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool want = active && w[k] != 0.0f;             // taps outside the image carry weight 0
+                        const int txx = rx + (k & 1), tyy = ry + (k >> 1);
+                        const bool inwin = want && (unsigned)txx < (unsigned)WX && (unsigned)tyy < (unsigned)WY;
+                        const f32x4 add = {w[k] * cr[0], w[k] * cr[1], w[k] * cr[2], w[k] * cr[3]};
+                        const bool miss = want && !inwin;
+                        const unsigned long long mm = __builtin_amdgcn_ballot_w64(miss);
+                        if (mm != 0) {                                        // wave-uniform
+                            const int nm = __builtin_popcountll(mm);
+                            if (qn + nm > OW_QCAP) drain();
+                            if (miss) {
+                                const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
+                                qoff[slot] = o[k] * (unsigned)C + (unsigned)cq * 4u;
+                                qval[slot] = add;
+                            }
+                            qn += nm;
+                        }
+                        if (stats) {
+                            if (want) atomicAdd(stats, 1u);
+                            if (miss) atomicAdd(stats + 1, 1u);
+                        }
+                        const int cell = inwin ? (tyy << wx_log2) + txx : 0;
+                        if (inwin) {
+                            clo = min(clo, cell);
+                            chi = max(chi, cell);
+                        }
+                        bool pending = inwin;
+                        while (__builtin_amdgcn_ballot_w64(pending) != 0) {    // wave-uniform; one round unless two lanes share a cell
+                            if (pending) tags[cq * NCELL + cell] = (unsigned char)lane;
+                            const bool mine = pending && tags[cq * NCELL + cell] == (unsigned char)lane;
+                            if (mine) {
+                                f32x4 v = win[cell * 2 + cq];
+                                v += add;
+                                win[cell * 2 + cq] = v;
+                                pending = false;
+                            }
+                        }
+                    }
+                }
+            }
+            // flush this chunk's window: touched values -> global atomics, cells back to zero (wave-private: no barrier)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                clo = min(clo, __shfl_xor(clo, m, 64));
+                chi = max(chi, __shfl_xor(chi, m, 64));
+            }
+            for (int i = 2 * clo + lane; i <= 2 * chi + 1; i += 64) {
+                const f32x4 v = win[i];
+                if (v[0] != 0.0f || v[1] != 0.0f || v[2] != 0.0f || v[3] != 0.0f) {
+                    const int tex = i >> 1, gx = ox + (tex & (WX - 1)), gy = oy + (tex >> wx_log2);
+                    float* dst = dsrc + ((size_t)gy * W + gx) * C + (i & 1) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (v[e] != 0.0f) atomicAdd(dst + e, v[e]);
+                    win[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (qn) drain();                                      // the queue addresses this view's gradient
+        gip += __shfl_xor(gip, 1, 64);
+        if (active && cq == 0)
+            gip_part[((size_t)(oct * gridDim.z / NOCT + b) * (V - 1) + sv) * HW + pix] = oct == 0 ? gip - tsum * inv_s : gip;
+    }
+    if (active) *reinterpret_cast<f32x4*>(dfeat + ((size_t)(b * V) * HW + pix) * C + cb) = dref;
+}
+
 }  // namespace
 
 extern "C" int mvs_cv_aggregate_bwd(const float* feat, const float* rt, const float* depth, const float* weight, const float* volume,
@@ -436,4 +653,34 @@ extern "C" int mvs_cv_aggregate_bwd_lds(const float* feat, const float* rt, cons
     }
 #undef MVS_LAUNCH_BL
     return mvs::finish_launch("mvs_cv_aggregate_bwd_lds");
+}
+
+// Owner-election form (see cv_aggregate_bwd_own_kernel): same contract as mvs_cv_aggregate_bwd_lds; the window is per WAVEFRONT
+// (8 x 4 pixels, 8 planes at a time), (1 << wx_log2) x wy texels, wx*wy*34 + 2304 bytes of LDS per wavefront.
+extern "C" int mvs_cv_aggregate_bwd_own(const float* feat, const float* rt, const float* depth, const float* weight, const float* volume,
+                                        const float* gvolume, int B, int V, int C, int Gin, int D, int H, int W, float* dfeat,
+                                        float* gip_part, int wx_log2, int wy, unsigned* stats, mvs_stream_t stream) {
+    MVS_REQUIRE(feat && rt && depth && weight && volume && gvolume && dfeat && gip_part, "mvs_cv_aggregate_bwd_own: null pointer");
+    MVS_REQUIRE(B >= 1 && V >= 2 && D >= 1 && H >= 1 && W >= 1, "mvs_cv_aggregate_bwd_own: bad shape");
+    MVS_REQUIRE(Gin == G, "mvs_cv_aggregate_bwd_own: only G=8 correlation groups are built (got %d)", Gin);
+    MVS_REQUIRE(C == 8 || C == 16 || C == 32 || C == 64, "mvs_cv_aggregate_bwd_own: C must be 8, 16, 32 or 64 (got %d)", C);
+    MVS_REQUIRE((int64_t)C * H * W * 4 < ((int64_t)1 << 32), "mvs_cv_aggregate_bwd_own: one view's feature block exceeds 4 GiB");
+    MVS_REQUIRE(wx_log2 >= 3 && wx_log2 <= 7 && wy >= 4 && wy <= 64, "mvs_cv_aggregate_bwd_own: window %d x %d out of range", 1 << wx_log2, wy);
+    const size_t per_wave = ((((size_t)wy << wx_log2) * 34 + 64 * 36 + (size_t)OW_QCAP * 20) + 15) & ~(size_t)15;
+    const size_t lds = per_wave * OW_NW;
+    MVS_REQUIRE(lds <= 64 * 1024, "mvs_cv_aggregate_bwd_own: window needs %zu bytes of LDS (> 64 KiB)", lds);
+    const int noct = C / 8;
+    MVS_REQUIRE((int64_t)B * noct <= 65535 && mvs::ceil_div(H, OW_TH) <= 65535, "mvs_cv_aggregate_bwd_own: grid limits exceeded");
+    dim3 grid(mvs::ceil_div(W, OW_TW * OW_NW), mvs::ceil_div(H, OW_TH), B * noct), block(64 * OW_NW);
+    hipStream_t s = MVS_STREAM(stream);
+#define MVS_LAUNCH_BO(CC) \
+    hipLaunchKernelGGL(cv_aggregate_bwd_own_kernel<CC>, grid, block, lds, s, feat, rt, depth, weight, volume, gvolume, V, D, H, W, dfeat, gip_part, wx_log2, wy, stats)
+    switch (C) {
+        case 8: MVS_LAUNCH_BO(8); break;
+        case 16: MVS_LAUNCH_BO(16); break;
+        case 32: MVS_LAUNCH_BO(32); break;
+        default: MVS_LAUNCH_BO(64); break;
+    }
+#undef MVS_LAUNCH_BO
+    return mvs::finish_launch("mvs_cv_aggregate_bwd_own");
 }

@@ -575,13 +575,16 @@ def cv_aggregate_bwd(feat_cl, rt, depth, weight, volume, gvolume, G: int, stats:
     B, V, H, W, C = feat_cl.shape
     D = depth.shape[1]
     dfeat = torch.zeros_like(feat_cl)
-    mode = os.environ.get("MVS_CV_BWD", "direct")
+    mode = os.environ.get("MVS_CV_BWD", "own")
     if mode != "direct":
-        # LDS-window scatter (cost_volume_bwd.hip, second kernel; opt-in: measured no faster) with a
-        # MVS_CV_BWD_WINDOW="log2(WX),WY" texel window (default 64 x 24)
-        wxl, wy = (int(v) for v in os.environ.get("MVS_CV_BWD_WINDOW", "6,24").split(","))
+        # "own" (default): per-wavefront LDS windows with owner election - no atomics in the common case; "lds": block-shared window with
+        # LDS float atomics; "direct": global atomics with per-lane run merging (DESIGN.md §4.5 for the measurements).
+        # MVS_CV_BWD_WINDOW="log2(WX),WY" overrides the texel window.
+        own = mode == "own"
+        wxl, wy = (int(v) for v in os.environ.get("MVS_CV_BWD_WINDOW", "5,20" if own else "6,24").split(","))
         part = torch.empty((C // 8,) + tuple(weight.shape), device=weight.device, dtype=torch.float32)
-        _call("mvs_cv_aggregate_bwd_lds", "cv_aggregate_bwd_lds_kernel<%d>" % C, _ptr(feat_cl), _ptr(rt), _ptr(depth), _ptr(weight),
+        fn = "mvs_cv_aggregate_bwd_own" if own else "mvs_cv_aggregate_bwd_lds"
+        _call(fn, "cv_aggregate_bwd_%s_kernel<%d>" % (mode, C), _ptr(feat_cl), _ptr(rt), _ptr(depth), _ptr(weight),
               _ptr(volume), _ptr(gvolume), B, V, C, G, D, H, W, _ptr(dfeat), _ptr(part), wxl, wy, _ptr(stats), _stream())
         return dfeat, (part[0] if C == 8 else part.sum(0))
     dw = torch.empty_like(weight)
