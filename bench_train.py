@@ -34,10 +34,10 @@ def parse():
                     help="bf16 (BASELINE configs[2]): forward under torch.autocast(bfloat16) - the regularizer runs on bf16 channel-last "
                          "activations and v_mfma_f32_16x16x32_bf16, the cost volume, BatchNorm statistics, head and loss stay fp32, "
                          "master weights fp32 (what the reference's autocast training does); f32: everything fp32")
-    ap.add_argument("--graph", choices=["on", "off"], default="off",
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the whole step (forward + loss + backward + AdamW) as ONE hipGraph (mvsformer_amd/graphs.py): host cost per "
-                         "step 16 ms -> 1.2 ms; measured step time 17.0 -> 17.5 ms (the ~570 short kernels, not the host, are the limit), "
-                         "hence off by default")
+                         "step 13-22 ms (box dependent) -> 0.6 ms, so the step runs at the GPU's pace (13.2 ms) whatever the host does; "
+                         "auto = on for a single rank (eager fallback if capture fails), off under DistributedDataParallel")
     return ap.parse_args()
 
 
@@ -59,7 +59,7 @@ def main(args):
     if ddp:
         net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
         model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local])
-    use_graph = args.graph == "on" and not ddp
+    use_graph = args.graph == "on" or (args.graph == "auto" and not ddp)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=use_graph)
     feats, proj, dv, scene = synth.make_inputs(args.views, args.height, args.width, seed=rank, device=dev)
     feats = {k: v.requires_grad_(True) for k, v in feats.items()}
