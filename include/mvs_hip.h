@@ -262,6 +262,11 @@ int mvs_bf16_pack_weights2(const float* w, int d0, int d1, int srcA, int CoutA, 
                            void* packedB, mvs_stream_t stream);
 int mvs_bf16_conv3d(const void* x, const void* wpacked, const float* scale, const float* shift, const void* residual, void* y,
                     int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd, int shw, int relu, mvs_stream_t stream);
+/* raw convolution + the batch statistics of its bf16-rounded output in the same pass (what mvs_bf16_bn_stats(y, groups) returns):
+ * sums [2*groups*Cout]; workspace = mvs_bf16_conv3d_stats_workspace_bytes(B, Cout, Do, Ho, Wo) of the OUTPUT grid */
+int64_t mvs_bf16_conv3d_stats_workspace_bytes(int B, int Cout, int Do, int Ho, int Wo);
+int mvs_bf16_conv3d_stats(const void* x, const void* wpacked, void* y, int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd,
+                          int shw, int groups, float* sums, void* workspace, mvs_stream_t stream);
 int64_t mvs_bf16_conv3d_wgrad_workspace_bytes(int nbatch, int CA, int CB, int Dp, int Hp, int Wp);
 int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, void* workspace, int nbatch, int CA, int CB, int Dp, int Hp, int Wp,
                           int Db, int Hb, int Wb, int sd, int shw, mvs_stream_t stream);

@@ -55,6 +55,8 @@ SIGNATURES = {
     "mvs_bf16_pack_weights": (I, [P, I, I, I, I, I, P, P]),
     "mvs_bf16_pack_weights2": (I, [P, I, I, I, I, I, P, I, I, I, P, P]),
     "mvs_bf16_conv3d": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "mvs_bf16_conv3d_stats_workspace_bytes": (L, [I, I, I, I, I]),
+    "mvs_bf16_conv3d_stats": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, P, P, P]),
     "mvs_bf16_conv3d_wgrad_workspace_bytes": (L, [I, I, I, I, I, I]),
     "mvs_bf16_conv3d_wgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "mvs_bf16_from_f32_ncdhw": (I, [P, P, I, I, L, P]),

@@ -342,7 +342,9 @@ class ConvBf16Fn(torch.autograd.Function):
     """Raw 3x3x3 convolution on bf16 channel-last activations, fp32 master weight ``[Cout,Cin,3,3,3]`` cast per call."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride):
+    def forward(ctx, x, weight, stride, stats_groups=0):
+        """``stats_groups`` > 0: also return the batch statistics of the output (``sums [2*groups*Cout]``, non-differentiable) computed
+        in the convolution's epilogue, for the BatchNorm that follows (:class:`BnActBf16Fn` ``sums=``)."""
         x = x.contiguous()
         w = weight.detach().to(torch.float32).contiguous()
         cout, cin = w.shape[0], w.shape[1]
@@ -350,13 +352,16 @@ class ConvBf16Fn(torch.autograd.Function):
             wf, wb = ops.bf16_pack2(w, (0, cin, cout), (2 if stride[1] == 1 else 1, cout, cin))     # conv) in the same launch
         else:
             wf, wb = ops.bf16_pack(w, 0, cin, cout), None
-        y = ops.bf16_conv3d(x, wf, cin, cout, 0, stride)
         ctx.save_for_backward(x, wb)
         ctx.stride, ctx.wshape = stride, (cout, cin)
-        return y
+        if stats_groups:
+            y, sums = ops.bf16_conv3d_stats(x, wf, cin, cout, 0, stride, stats_groups)
+            ctx.mark_non_differentiable(sums)
+            return y, sums
+        return ops.bf16_conv3d(x, wf, cin, cout, 0, stride)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dsums=None):
         x, wb = ctx.saved_tensors
         dy = dy.contiguous()
         cout, cin = ctx.wshape
@@ -370,14 +375,14 @@ class ConvBf16Fn(torch.autograd.Function):
             if dx.shape != x.shape:
                 raise ops._lib.MvsHipError("conv backward: input %s is not 2x the output grid %s" % (tuple(x.shape), tuple(dy.shape)))
         dw = ops.bf16_conv3d_wgrad(dy, x, (sd, shw)) if ctx.needs_input_grad[1] else None
-        return dx, dw, None
+        return dx, dw, None, None
 
 
 class DeconvBf16Fn(torch.autograd.Function):
     """Raw ConvTranspose3d k3, stride (sd,2,2), padding 1, output_padding (sd-1,1,1) on bf16 channel-last activations."""
 
     @staticmethod
-    def forward(ctx, x, weight, sd):
+    def forward(ctx, x, weight, sd, stats_groups=0):
         x = x.contiguous()
         w = weight.detach().to(torch.float32).contiguous()          # [Cin,Cout,3,3,3]
         cin, cout = w.shape[0], w.shape[1]
@@ -385,13 +390,16 @@ class DeconvBf16Fn(torch.autograd.Function):
             wf, wb = ops.bf16_pack2(w, (1, cin, cout), (0, cout, cin))
         else:
             wf, wb = ops.bf16_pack(w, 1, cin, cout), None
-        y = ops.bf16_conv3d(x, wf, cin, cout, 1, (sd, 2))
         ctx.save_for_backward(x, wb)
         ctx.sd, ctx.wshape = sd, (cin, cout)
-        return y
+        if stats_groups:
+            y, sums = ops.bf16_conv3d_stats(x, wf, cin, cout, 1, (sd, 2), stats_groups)
+            ctx.mark_non_differentiable(sums)
+            return y, sums
+        return ops.bf16_conv3d(x, wf, cin, cout, 1, (sd, 2))
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dsums=None):
         x, wb = ctx.saved_tensors
         dy = dy.contiguous()
         cin, cout = ctx.wshape
@@ -399,7 +407,7 @@ class DeconvBf16Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:   # strided conv of dY with W read as [out = cin, in = cout]
             dx = ops.bf16_conv3d(dy, wb, cout, cin, 0, (ctx.sd, 2))
         dw = ops.bf16_conv3d_wgrad(x, dy, (ctx.sd, 2)) if ctx.needs_input_grad[1] else None
-        return dx, dw, None
+        return dx, dw, None, None
 
 
 class BnActBf16Fn(torch.autograd.Function):
@@ -408,13 +416,15 @@ class BnActBf16Fn(torch.autograd.Function):
     batch holds ``groups`` independent calls of the module (sample n -> group n % groups), statistics per (group, channel)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, bn, relu, groups=1):
+    def forward(ctx, x, gamma, beta, residual, bn, relu, groups=1, sums=None):
+        """``sums``: the statistics of ``x`` if the producing convolution already took them (``ConvBf16Fn(..., stats_groups)``)."""
         x = x.contiguous()
         C = x.shape[-1]
         if groups > 1 and residual is not None:
             raise ops._lib.MvsHipError("grouped BatchNorm has no residual form")
         count = float(x.numel() // (C * groups))
-        sums = ops.bf16_bn_stats(x, groups)
+        if sums is None:
+            sums = ops.bf16_bn_stats(x, groups)
         sums, count_dev = _sync_sums(sums, count, bn)
         g = gamma.detach().to(torch.float32).contiguous() if gamma is not None else None
         b = beta.detach().to(torch.float32).contiguous() if beta is not None else None
@@ -452,4 +462,4 @@ class BnActBf16Fn(torch.autograd.Function):
         if G > 1:                                                        # shared parameters: sum the groups' gradients
             dgamma = dgamma.view(G, -1).sum(0) if dgamma is not None else None
             dbeta = dbeta.view(G, -1).sum(0) if dbeta is not None else None
-        return dx, dgamma, dbeta, (dy if ctx.has_res else None), None, None, None
+        return dx, dgamma, dbeta, (dy if ctx.has_res else None), None, None, None, None

@@ -75,7 +75,8 @@ struct ConvArgs {
     int relu;
     int B, Di, Hi, Wi, Do, Ho, Wo, Cout;
     int nwchunks, items;
-};
+    float* stats_part;        // optional [items][2*Cout]: per work item, sum and sum of squares of the bf16-ROUNDED outputs per channel
+};                            // (the batch statistics of the BatchNorm that follows: no separate pass over y)
 
 // GATHER = 0: Conv3d, input voxel = out*stride - 1 + k.  GATHER = 1: ConvTranspose3d (k=3, padding 1, output_padding stride-1) as a
 // gather: input voxel = (out + 1 - k) / stride where divisible.
@@ -146,6 +147,11 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
         }
     }
     // D[i = co (4*kb + r inside the tile)][j = voxel]: a lane owns 4 consecutive output channels of one voxel -> one 8-byte store
+    float ssum[NT][4], ssq[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ssum[nt][r] = ssq[nt][r] = 0.0f;
 #pragma unroll
     for (int vt = 0; vt < VT; ++vt) {
         const int ow = ow0 + vt * 16 + j;
@@ -167,8 +173,37 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += (float)rs[r];
             }
-            *reinterpret_cast<bf16x4*>(a.y + vox * a.Cout + co0) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            *reinterpret_cast<bf16x4*>(a.y + vox * a.Cout + co0) = o;
+            if (a.stats_part) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float f = (float)o[r];          // what BatchNorm will see
+                    ssum[nt][r] += f;
+                    ssq[nt][r] = fmaf(f, f, ssq[nt][r]);
+                }
+            }
         }
+    }
+    if (a.stats_part) {
+        // the 16 lanes of a kb group hold the same 4 channels of different voxels: butterfly over j, lane j = 0 writes
+        float* row = a.stats_part + (size_t)item * 2 * a.Cout;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s1 = ssum[nt][r], s2 = ssq[nt][r];
+#pragma unroll
+                for (int m = 8; m >= 1; m >>= 1) {
+                    s1 += __shfl_xor(s1, m, 64);
+                    s2 += __shfl_xor(s2, m, 64);
+                }
+                const int co = nt * 16 + kb * 4 + r;
+                if (j == 0 && co < a.Cout) {
+                    row[co] = s1;
+                    row[a.Cout + co] = s2;
+                }
+            }
     }
 }
 
@@ -580,9 +615,34 @@ extern "C" int mvs_bf16_pack_weights2(const float* w, int d0, int d1, int srcA, 
 }
 
 // gather: 0 = Conv3d (out = (in - 1)/stride + 1), 1 = ConvTranspose3d k3 p1 op(stride-1) (out = in*stride)
+static int bf16_conv3d_impl(const void* x, const void* wpacked, const float* scale, const float* shift, const void* residual, void* y,
+                            int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd, int shw, int relu, float* stats_part,
+                            int groups, float* sums, mvs_stream_t stream);
+
 extern "C" int mvs_bf16_conv3d(const void* x, const void* wpacked, const float* scale, const float* shift, const void* residual, void* y,
                                int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd, int shw, int relu,
                                mvs_stream_t stream) {
+    return bf16_conv3d_impl(x, wpacked, scale, shift, residual, y, B, Cin, Cout, Di, Hi, Wi, gather, sd, shw, relu, nullptr, 1, nullptr, stream);
+}
+
+// Raw convolution + the batch statistics of its (bf16-rounded) output in the same pass: sums [2*groups*Cout] = [sum | sum of squares]
+// per (group, channel), sample b in group b % groups - exactly what mvs_bf16_bn_stats would return for y.  workspace:
+// mvs_bf16_conv3d_stats_workspace_bytes (one partial row per work item, then the fixed-order reduce).
+extern "C" int64_t mvs_bf16_conv3d_stats_workspace_bytes(int B, int Cout, int Do, int Ho, int Wo) {
+    if (!chan_ok(Cout) || B < 1 || Do < 1 || Ho < 1 || Wo < 1) return -1;
+    return (int64_t)B * Do * Ho * ((Wo + 63) / 64) * 2 * Cout * (int64_t)sizeof(float);
+}
+
+extern "C" int mvs_bf16_conv3d_stats(const void* x, const void* wpacked, void* y, int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather,
+                                     int sd, int shw, int groups, float* sums, void* workspace, mvs_stream_t stream) {
+    MVS_REQUIRE(sums && workspace && groups >= 1 && B % groups == 0, "mvs_bf16_conv3d_stats: bad statistics arguments (B=%d groups=%d)", B, groups);
+    return bf16_conv3d_impl(x, wpacked, nullptr, nullptr, nullptr, y, B, Cin, Cout, Di, Hi, Wi, gather, sd, shw, 0,
+                            reinterpret_cast<float*>(workspace), groups, sums, stream);
+}
+
+static int bf16_conv3d_impl(const void* x, const void* wpacked, const float* scale, const float* shift, const void* residual, void* y,
+                            int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd, int shw, int relu, float* stats_part,
+                            int groups, float* sums, mvs_stream_t stream) {
     MVS_REQUIRE(x && wpacked && y, "mvs_bf16_conv3d: null pointer");
     MVS_REQUIRE(chan_ok(Cin) && chan_ok(Cout), "mvs_bf16_conv3d: channels must be 8/16/32/64 (Cin=%d Cout=%d)", Cin, Cout);
     MVS_REQUIRE(B >= 1 && Di >= 1 && Hi >= 1 && Wi >= 1 && (gather == 0 || gather == 1), "mvs_bf16_conv3d: bad shape");
@@ -599,16 +659,23 @@ extern "C" int mvs_bf16_conv3d(const void* x, const void* wpacked, const float* 
     const int64_t items = (int64_t)B * a.Do * a.Ho * a.nwchunks;
     MVS_REQUIRE(items < ((int64_t)1 << 30), "mvs_bf16_conv3d: too many rows");
     a.items = (int)items;
+    a.stats_part = stats_part;
     hipStream_t s = MVS_STREAM(stream);
     const int nt = nt_of(Cout);
+    int rc;
     if (gather == 0) {
-        if (sd == 1 && shw == 1) return launch_conv<0, 1, 1>(a, Cin, nt, s);
-        if (sd == 2) return launch_conv<0, 2, 2>(a, Cin, nt, s);
-        return launch_conv<0, 1, 2>(a, Cin, nt, s);
+        if (sd == 1 && shw == 1) rc = launch_conv<0, 1, 1>(a, Cin, nt, s);
+        else if (sd == 2) rc = launch_conv<0, 2, 2>(a, Cin, nt, s);
+        else rc = launch_conv<0, 1, 2>(a, Cin, nt, s);
+    } else {
+        if (sd == 1 && shw == 1) rc = launch_conv<1, 1, 1>(a, Cin, nt, s);
+        else if (sd == 2) rc = launch_conv<1, 2, 2>(a, Cin, nt, s);
+        else rc = launch_conv<1, 1, 2>(a, Cin, nt, s);
     }
-    if (sd == 1 && shw == 1) return launch_conv<1, 1, 1>(a, Cin, nt, s);
-    if (sd == 2) return launch_conv<1, 2, 2>(a, Cin, nt, s);
-    return launch_conv<1, 1, 2>(a, Cin, nt, s);
+    if (rc != MVS_OK || !stats_part) return rc;
+    // work items are sample-major, so the rows of sample b are [b*bps, (b+1)*bps): the grouped fixed-order reduce applies as is
+    mvs::launch_partials_reduce_grouped(stats_part, a.Do * a.Ho * a.nwchunks, B, groups, Cout, sums, s);
+    return mvs::finish_launch("mvs_bf16_conv3d_stats");
 }
 
 namespace {

@@ -72,12 +72,16 @@ def _train_conv_bn_act(x, conv, bn, relu, residual, transposed_sd=None):
     if x.dtype == torch.bfloat16:
         if conv.bias is not None or bn is None:
             raise MvsHipError("bf16 training layer without BatchNorm / with bias is not built")
+        # MVS_BN_FUSED_STATS=1: the convolution's epilogue takes the batch statistics of its output instead of a separate pass over y.
+        # Measured 13.5 vs 13.3 ms per step (one partial row per wavefront makes the fixed-order reduce long): off by default.
+        fused = 1 if os.environ.get("MVS_BN_FUSED_STATS", "0") == "1" else 0
         if transposed_sd is None:
             s = tuple(conv.stride)
-            y = ag.ConvBf16Fn.apply(x, conv.weight, (s[0], s[1]))
+            out = ag.ConvBf16Fn.apply(x, conv.weight, (s[0], s[1]), fused)
         else:
-            y = ag.DeconvBf16Fn.apply(x, conv.weight, transposed_sd)
-        return ag.BnActBf16Fn.apply(y, bn.weight, bn.bias, residual, bn, bool(relu))
+            out = ag.DeconvBf16Fn.apply(x, conv.weight, transposed_sd, fused)
+        y, sums = out if fused else (out, None)
+        return ag.BnActBf16Fn.apply(y, bn.weight, bn.bias, residual, bn, bool(relu), 1, sums)
     if transposed_sd is None:
         s = tuple(conv.stride)
         y = ag.ConvFn.apply(x, conv.weight, (s[0], s[1]))

@@ -828,6 +828,29 @@ def bf16_conv3d(x, wpacked, cin, cout, gather: int, stride, scale=None, shift=No
     return y
 
 
+def bf16_conv3d_stats(x, wpacked, cin, cout, gather: int, stride, groups: int = 1):
+    """Raw convolution + the batch statistics of its bf16-rounded output in one pass -> ``(y, sums [2*groups*cout])``: the sums are
+    what :func:`bf16_bn_stats` ``(y, groups)`` would return, without the extra pass over ``y``."""
+    _chk16(x, "x"), _chk16(wpacked, "packed weights")
+    B, Di, Hi, Wi, C = x.shape
+    assert C == cin
+    sd, shw = stride
+    if gather == 0:
+        Do, Ho, Wo = (Di - 1) // sd + 1, (Hi - 1) // shw + 1, (Wi - 1) // shw + 1
+    else:
+        Do, Ho, Wo = Di * sd, Hi * shw, Wi * shw
+    if B % groups:
+        raise _lib.MvsHipError("grouped statistics: batch %d is not a multiple of %d groups" % (B, groups))
+    y = torch.empty(B, Do, Ho, Wo, cout, device=x.device, dtype=torch.bfloat16)
+    sums = torch.empty(2 * groups * cout, device=x.device, dtype=torch.float32)
+    ws = _reduce_ws("mvs_bf16_conv3d_stats_workspace_bytes", x.device, B, cout, Do, Ho, Wo)
+    flops = 2.0 * 27 * cin * cout * B * (Do * Ho * Wo if gather == 0 else Di * Hi * Wi)
+    tag = ("bf16_conv_kernel<%d,%d,g%d,s%d%d>" % (cin, cout, gather, sd, shw), "flops", flops)
+    _call("mvs_bf16_conv3d_stats", tag, _ptr(x), _ptr(wpacked), _ptr(y), B, cin, cout, Di, Hi, Wi, int(gather), sd, shw, int(groups),
+          _ptr(sums), _ptr(ws), _stream())
+    return y, sums
+
+
 def bf16_conv3d_wgrad(A: torch.Tensor, Bt: torch.Tensor, stride) -> torch.Tensor:
     """``dW[a][b][27] = sum A[p][a] * Bt[p*s-1+k][b]`` (fp32); ``A [N,Dp,Hp,Wp,CA]`` lives on the grid the stride divides."""
     _chk16(A, "A"), _chk16(Bt, "Bt")
@@ -838,7 +861,9 @@ def bf16_conv3d_wgrad(A: torch.Tensor, Bt: torch.Tensor, stride) -> torch.Tensor
     if nws <= 0:
         raise _lib.MvsHipError("bf16 wgrad: channels must be 8/16/32/64 (CA=%d CB=%d)" % (CA, CB))
     ws = torch.empty(nws, device=A.device, dtype=torch.uint8)
-    tag = ("bf16_wgrad_kernel", "flops", 2.0 * 27 * CA * CB * N * Dp * Hp * Wp)
+    name = "bf16_wgrad_kernel" if os.environ.get("MVS_TAG_SHAPES", "0") != "1" else \
+        "bf16_wgrad<%d,%d,s%d%d,%dx%dx%dx%d>" % (CA, CB, stride[0], stride[1], N, Dp, Hp, Wp)
+    tag = (name, "flops", 2.0 * 27 * CA * CB * N * Dp * Hp * Wp)
     _call("mvs_bf16_conv3d_wgrad", tag, _ptr(A), _ptr(Bt), _ptr(dW), _ptr(ws), N, CA, CB, Dp, Hp, Wp, Db, Hb, Wb, stride[0], stride[1], _stream())
     return dW
 

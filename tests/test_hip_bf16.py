@@ -278,3 +278,25 @@ def test_vis_train_views_bf16_close_to_fp32(dev):
     for a, b in zip(net.vis.buffers(), net2.vis.buffers()):
         if a.dtype.is_floating_point:
             relclose(b, a, 3e-2, "running stat")
+
+
+@pytest.mark.parametrize("cin,cout,gather,stride,N,D,H,W,groups", [(16, 16, 0, (1, 1), 1, 3, 9, 70, 1), (8, 16, 0, (1, 1), 4, 1, 12, 130, 2),
+                                                                   (32, 64, 0, (1, 2), 2, 2, 8, 36, 1), (64, 32, 1, (1, 2), 1, 2, 5, 33, 1),
+                                                                   (16, 8, 1, (2, 2), 2, 2, 3, 20, 2)])
+def test_conv_bf16_epilogue_statistics(dev, cin, cout, gather, stride, N, D, H, W, groups):
+    """The batch statistics taken in the convolution's epilogue (mvs_bf16_conv3d_stats) = a separate mvs_bf16_bn_stats pass over the
+    same output, per (group, channel); the output itself is bit-identical to the plain convolution's."""
+    from mvsformer_amd import ops
+    torch.manual_seed(cin + cout)
+    x = torch.randn(N, D, H, W, cin).to(torch.bfloat16).to(dev)
+    w = (torch.randn(cout, cin, 3, 3, 3) * 0.1) if gather == 0 else (torch.randn(cin, cout, 3, 3, 3) * 0.1)
+    wp = ops.bf16_pack(w.to(dev), 0 if gather == 0 else 1, cin, cout)
+    y0 = ops.bf16_conv3d(x, wp, cin, cout, gather, stride)
+    y1, sums = ops.bf16_conv3d_stats(x, wp, cin, cout, gather, stride, groups)
+    assert torch.equal(y0, y1)
+    ref = ops.bf16_bn_stats(y0, groups)
+    relclose(sums, ref, 2e-5, "sums")
+    # and against plain torch on the rounded output
+    yf = y0.float().reshape(N // groups, groups, -1, cout)
+    relclose(sums[:groups * cout].view(groups, cout), yf.sum(dim=(0, 2)), 1e-4, "sum vs torch")
+    relclose(sums[groups * cout:].view(groups, cout), (yf * yf).sum(dim=(0, 2)), 1e-4, "sumsq vs torch")
