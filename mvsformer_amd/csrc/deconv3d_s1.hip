@@ -36,6 +36,9 @@ __device__ __forceinline__ float group8_sum(float v) {
     return dpp_add<0x141>(v);
 }
 
+#ifndef MVS_DS1_EXP
+#define MVS_DS1_EXP 0          // timing experiments (tools/exp_tail.py --build): 1 = no MFMA loop, 2 = no input staging loads, 4 = one chunk only, 8 = no epilogue
+#endif
 constexpr int npd_of(int NC) { return NC == 8 ? 80 : (NC == 16 ? 144 : 304); }       // 9*NC padded to == 16 (mod 32)
 constexpr int ntiles_of(int NC) { return NC == 8 ? 5 : 9 * NC / 16; }
 
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void deconv3d_s1_kernel(const float* __restric
         const int cleft = min(CC, CIN - ch * CC);
         const rsrc_t xin = make_rsrc(x + (size_t)(b * CIN + ch * CC) * Di * plane, (unsigned)((size_t)cleft * Di * plane * 4));
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) sreg[i] = buf_load(xin, voff[i], 0);
+        for (int i = 0; i < EPT; ++i) sreg[i] = (MVS_DS1_EXP & 2) ? (float)voff[i] : buf_load(xin, voff[i], 0);
         const f32x4* src = reinterpret_cast<const f32x4*>(wp + (size_t)ch * (CC / 4) * WSLAB);
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void deconv3d_s1_kernel(const float* __restric
     const float* abase = s_in + kk * CS + hp * IW + i16;     // + ks*4*CS + (dz*IH + oy)*IW + m*16 + ox
     const float* bbase = s_w + kk * NPD + i16;               // + ks*WSLAB + kd*4*NPD + tile*16
 
-    const int nchunks = (CIN + CC - 1) / CC;
+    const int nchunks = (MVS_DS1_EXP & 4) ? 1 : (CIN + CC - 1) / CC;
     prefetch(0);
     for (int ch = 0; ch < nchunks; ++ch) {
         __syncthreads();
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256) void deconv3d_s1_kernel(const float* __restric
         __syncthreads();
         if (ch + 1 < nchunks) prefetch(ch + 1);
 #pragma unroll
-        for (int ks = 0; ks < CC / 4; ++ks) {
+        for (int ks = 0; ks < ((MVS_DS1_EXP & 1) ? 0 : CC / 4); ++ks) {
 #pragma unroll
             for (int kd = 0; kd < 3; ++kd) {
                 const int dz = dl + 2 - kd;                  // input depth do + 1 - kd, tile origin d0 - 1
@@ -190,6 +193,15 @@ __global__ __launch_bounds__(256) void deconv3d_s1_kernel(const float* __restric
     // ---- epilogue ----
     const int od = d0 + dl, hi = hi0 + hp;
     if (od >= Do || hi >= Hi) return;
+    if (MVS_DS1_EXP & 8) {                                   // timing experiment: no epilogue (one store keeps the accumulators alive)
+        float t = 0.0f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < NACC; ++q) t += acc[m][q][0] + acc[m][q][1] + acc[m][q][2] + acc[m][q][3];
+        if (t == 123.456f) y[0] = t;
+        return;
+    }
     const bool vec_ok = (Wi % 4) == 0;
     auto store_row = [&](int co, int oh, f32x4 e, f32x4 o, int wi) {
         const float sc = scale ? scale[co] : 1.0f, sh = shift ? shift[co] : 0.0f;

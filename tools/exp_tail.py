@@ -1,8 +1,25 @@
 #!/usr/bin/env python
 """Where the time of the CostRegNet3D tail (conv11 + BN + ReLU + skip + 1x1x1 prob in one launch) and of conv1 goes at stage-4 shape:
 with / without the skip read, against the two-launch form, and a float4 copy of the same bytes for scale.  (GPU box)"""
-import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os, subprocess, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+CSRC = os.path.join(REPO, "mvsformer_amd", "csrc")
+if "--build" in sys.argv:       # here (no GPU): full libraries with one experiment switch each -> csrc/exp/libmvs_hip_ds1_<N>.so
+    os.makedirs(os.path.join(CSRC, "exp"), exist_ok=True)
+    srcs = open(os.path.join(CSRC, "Makefile")).read().split("SRCS =")[1].split("\n")[0].split()
+    objs = [os.path.join(CSRC, f.replace(".hip", ".o")) for f in srcs if f != "deconv3d_s1.hip"]
+    for n in (1, 2, 4, 8, 9):
+        obj = os.path.join(CSRC, "exp", "ds1_%d.o" % n)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
+                               "-DMVS_DS1_EXP=%d" % n, "-c", os.path.join(CSRC, "deconv3d_s1.hip"), "-o", obj])
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", obj] + objs +
+                              ["-o", os.path.join(CSRC, "exp", "libmvs_hip_ds1_%d.so" % n)])
+    sys.exit(0)
+import torch
+from mvsformer_amd import _lib
+if os.environ.get("MVS_EXP_LIB"):
+    _lib.LIB_PATH = os.path.join(CSRC, "exp", "libmvs_hip_ds1_%s.so" % os.environ["MVS_EXP_LIB"])
 import mvsformer_amd as m
 from mvsformer_amd import ops
 dev = torch.device("cuda:0")
