@@ -277,6 +277,11 @@ int mvs_bf16_bn_stats(const void* x, int C, int64_t R, int groups, int64_t rows_
                       mvs_stream_t stream);
 int mvs_bf16_affine_act(const void* x, const float* scale, const float* shift, const void* residual, int relu, int C, int64_t R,
                         int groups, int64_t rows_per_sample, void* y, mvs_stream_t stream);
+/* training-mode BatchNorm forward in one call / three launches when no cross-rank reduction sits between statistics and finalize:
+ * = mvs_bf16_bn_stats + mvs_bn_finalize(_grouped) + mvs_bf16_affine_act; stats4 = [scale | shift | mean | invstd], each groups*C */
+int mvs_bf16_bn_train_fwd(const void* x, const void* residual, int relu, int C, int64_t R, int groups, int64_t rows_per_sample,
+                          const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                          float* stats4, void* y, void* workspace, mvs_stream_t stream);
 int mvs_bf16_bn_bwd_reduce(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
                            const float* invstd, int relu, int C, int64_t R, int groups, int64_t rows_per_sample, float* sums,
                            void* workspace, mvs_stream_t stream);

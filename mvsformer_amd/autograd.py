@@ -423,23 +423,30 @@ class BnActBf16Fn(torch.autograd.Function):
         if groups > 1 and residual is not None:
             raise ops._lib.MvsHipError("grouped BatchNorm has no residual form")
         count = float(x.numel() // (C * groups))
-        if sums is None:
-            sums = ops.bf16_bn_stats(x, groups)
-        sums, count_dev = _sync_sums(sums, count, bn)
         g = gamma.detach().to(torch.float32).contiguous() if gamma is not None else None
         b = beta.detach().to(torch.float32).contiguous() if beta is not None else None
         track = bn.track_running_stats and bn.running_mean is not None
         rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
-        if groups > 1:
-            if bn.momentum is None:
-                raise ops._lib.MvsHipError("grouped BatchNorm needs a fixed momentum (cumulative averaging changes per group)")
-            scale, shift, mean, invstd = ops.bn_finalize_grouped(sums, g, b, rm, rv, bn.momentum, bn.eps, count, groups, count_dev)
+        if groups > 1 and bn.momentum is None:
+            raise ops._lib.MvsHipError("grouped BatchNorm needs a fixed momentum (cumulative averaging changes per group)")
+        res = residual.contiguous() if residual is not None else None
+        synced = isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size(bn.process_group) > 1
+        if sums is None and not synced:
+            # no collective between statistics and finalize: one call, three launches
+            mom = bn.momentum if groups > 1 else (_momentum(bn) if track else 0.0)
+            y, scale, shift, mean, invstd = ops.bf16_bn_train_fwd(x, res, relu, g, b, rm, rv, mom, bn.eps, groups)
+            count_dev = None
         else:
-            scale, shift, mean, invstd = ops.bn_finalize(sums, g, b, rm, rv, _momentum(bn) if track else 0.0, bn.eps, count, count_dev)
+            if sums is None:
+                sums = ops.bf16_bn_stats(x, groups)
+            sums, count_dev = _sync_sums(sums, count, bn)
+            if groups > 1:
+                scale, shift, mean, invstd = ops.bn_finalize_grouped(sums, g, b, rm, rv, bn.momentum, bn.eps, count, groups, count_dev)
+            else:
+                scale, shift, mean, invstd = ops.bn_finalize(sums, g, b, rm, rv, _momentum(bn) if track else 0.0, bn.eps, count, count_dev)
+            y = ops.bf16_affine_act(x, scale, shift, res, relu, groups)
         if track and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(groups)
-        res = residual.contiguous() if residual is not None else None
-        y = ops.bf16_affine_act(x, scale, shift, res, relu, groups)
         gfull = g if g is not None else scale.new_ones(C)
         if groups > 1:
             gfull = gfull.repeat(groups)

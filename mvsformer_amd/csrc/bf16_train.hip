@@ -827,6 +827,77 @@ extern "C" int mvs_bf16_bn_bwd_reduce(const void* dy, const void* x, const float
     return mvs::finish_launch("mvs_bf16_bn_bwd_reduce");
 }
 
+namespace {
+// partial rows -> per-(group, channel) sums -> mean / invstd / scale / shift and the running-statistics update, in ONE launch: the
+// arithmetic of partials_reduce_grouped followed by bn_finalize(_grouped) of train.hip (same order, same double-precision steps).
+// One wavefront per base channel walks the groups in order (the running statistics take the groups' updates in order).
+__global__ __launch_bounds__(256) void bf16_bn_reduce_finalize_kernel(const float* __restrict__ part, int bps, int nsamples, int groups, int C,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                      float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                      float momentum, float eps, double count, float* __restrict__ out4) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    const int CT = C * groups, per = (nsamples / groups) * bps;
+    const float g = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
+    float rm = running_mean ? running_mean[c] : 0.0f, rv = running_var ? running_var[c] : 0.0f;
+    for (int q = 0; q < groups; ++q) {
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int i = lane; i < per; i += 64) {
+            const size_t row = (size_t)(q + (i / bps) * groups) * bps + (i % bps);
+            s1 += part[row * 2 * C + c];
+            s2 += part[row * 2 * C + C + c];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            s1 += __shfl_xor(s1, m, 64);
+            s2 += __shfl_xor(s2, m, 64);
+        }
+        const int cc = q * C + c;
+        const double mean = (double)s1 / count;
+        double var = (double)s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (lane == 0) {
+            out4[cc] = g * invstd;                           // scale
+            out4[CT + cc] = bt - (float)mean * g * invstd;   // shift
+            out4[2 * CT + cc] = (float)mean;
+            out4[3 * CT + cc] = invstd;
+        }
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        rm = (1.0f - momentum) * rm + momentum * (float)mean;
+        rv = (1.0f - momentum) * rv + momentum * (float)unbiased;
+    }
+    if (running_mean && lane == 0) {
+        running_mean[c] = rm;
+        running_var[c] = rv;
+    }
+}
+}  // namespace
+
+// Training-mode BatchNorm forward of a channel-last bf16 tensor in one call and three launches (statistics partials; reduce + finalize;
+// normalize + ReLU + skip) - what mvs_bf16_bn_stats + mvs_bn_finalize(_grouped) + mvs_bf16_affine_act do in four, for the case without a
+// cross-rank reduction in between.  stats4 = [scale | shift | mean | invstd], each groups*C.
+extern "C" int mvs_bf16_bn_train_fwd(const void* x, const void* residual, int relu, int C, int64_t R, int groups, int64_t rows_per_sample,
+                                     const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                                     float eps, float* stats4, void* y, void* workspace, mvs_stream_t stream) {
+    BnShape sh;
+    MVS_REQUIRE(x && stats4 && y && workspace && bn_shape(C, R, groups, rows_per_sample, &sh), "mvs_bf16_bn_train_fwd: bad arguments");
+    MVS_REQUIRE((!running_mean) == (!running_var), "mvs_bf16_bn_train_fwd: running_mean and running_var come together");
+    hipStream_t s = MVS_STREAM(stream);
+    float* part = reinterpret_cast<float*>(workspace);
+    const int CT = C * groups;
+    hipLaunchKernelGGL(bf16_bn_reduce_kernel<false>, dim3(sh.bps, sh.nsamples), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x),
+                       (const __bf16*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, C,
+                       (size_t)sh.RS, groups, part);
+    hipLaunchKernelGGL(bf16_bn_reduce_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, (int)sh.bps, sh.nsamples, groups, C, gamma, beta,
+                       running_mean, running_var, momentum, eps, (double)(R / groups), stats4);
+    const size_t total8 = (size_t)R * (C / 8);
+    hipLaunchKernelGGL(bf16_affine_act_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x),
+                       stats4, stats4 + CT, reinterpret_cast<const __bf16*>(residual), relu, C, total8, (size_t)sh.RS, groups,
+                       reinterpret_cast<__bf16*>(y));
+    return mvs::finish_launch("mvs_bf16_bn_train_fwd");
+}
+
 extern "C" int mvs_bf16_bn_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
                                      const float* invstd, const float* gamma, const float* sums, double count, const float* count_dev,
                                      int relu, int C, int64_t R, int groups, int64_t rows_per_sample, void* dx, mvs_stream_t stream) {
