@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1536)
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph of the cascade per stream instead of launching its ~60 kernels")
     ap.add_argument("--cpu-sample-div", type=int, default=3, help="CPU baseline runs on about (H/div)x(W/div)")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short config-4 / config-5 runs reported as extra keys")
@@ -105,9 +106,34 @@ def time_steps(run, steps, world, dev):
     return float(tt.item()), out
 
 
-def make_runner(net, feats, proj, dv, tmp, streams):
+def make_runner(net, feats, proj, dv, tmp, streams, graphs=False):
     def step():
         return net(feats, proj, dv, tmp=tmp)
+
+    if graphs:
+        # one captured cascade per stream (mvsformer_amd/graphs.py): a step = one hipGraphLaunch instead of ~60 kernel launches; same
+        # kernels, same inputs, bit-identical outputs (tests/test_hip_graph.py::test_captured_eval_cascade_is_bit_equal)
+        from mvsformer_amd.graphs import CapturedStep
+
+        def nograd_step():
+            with torch.no_grad():
+                return step()
+        caps = []
+        for st in (streams or [torch.cuda.current_stream()]):
+            with torch.cuda.stream(st):
+                caps.append(CapturedStep(nograd_step, warmup=1))
+        torch.cuda.synchronize()
+
+        def run_g(n):
+            out = None
+            for i in range(n):
+                if streams is None:
+                    out = caps[0]()
+                else:
+                    with torch.cuda.stream(streams[i % len(streams)]):
+                        out = caps[i % len(streams)]()
+            return out
+        return step, run_g
 
     def run(n):
         out = None
@@ -152,8 +178,9 @@ def main(args):
     tmp = [5.0, 5.0, 5.0, 1.0]
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
     step, run = make_runner(net, feats, proj, dv, tmp, streams)
-
     step()                                               # first call builds the weight caches (synchronizes once)
+    if args.graph:                                       # measured: 1 stream 188.7 vs 189.1 depth maps/s eager, 3 streams 203 vs 215
+        _, run = make_runner(net, feats, proj, dv, tmp, streams, graphs=True)
     run(max(args.warmup, args.streams))
     dt, out = time_steps(run, args.steps, world, dev)
     assert torch.isfinite(out["refined_depth"]).all()
