@@ -457,7 +457,6 @@ __global__ __launch_bounds__(64 * OW_NW) void cv_aggregate_bwd_own_kernel(const 
         tsum += __shfl_xor(tsum, 1, 64);
     }
     for (int i = lane; i < NCELL * 2; i += 64) win[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int xc = min(tx0 + OW_TW / 2, W - 1), yc = min(ty0 + OW_TH / 2, H - 1);         // tile centre (wave-uniform)
 
     f32x4 dref = {0.f, 0.f, 0.f, 0.f};
     for (int sv = 0; sv < V - 1; ++sv) {
@@ -478,16 +477,25 @@ __global__ __launch_bounds__(64 * OW_NW) void cv_aggregate_bwd_own_kernel(const 
         };
         for (int dc = 0; dc < D; dc += OW_DCH) {
             const int dend = min(dc + OW_DCH, D);
-            // window origin: around the tile centre's projection on the chunk's middle plane (same value in every lane)
+            // window origin: around the MEAN projection of the tile's pixels on the chunk's middle plane (a single pixel - say the tile
+            // centre - can carry an outlier hypothesis and drag the whole window away: 8.8 % of the taps missed at stage 4 with the
+            // centre pixel, 6.3 % with the mean of the 32; a second, trimmed pass changed nothing)
             int ox, oy;
             {
                 float un, vn, z;
-                mvs::sweep_project(rt, (float)xc, (float)yc, depth[((size_t)b * D + (dc + dend) / 2) * HW + (size_t)yc * W + xc], half_w, half_h, &un,
-                                   &vn, &z);
-                const float ix = (un + 1.0f) * half_w, iy = (vn + 1.0f) * half_h;
-                const bool ok = fabsf(ix) < 1e6f && fabsf(iy) < 1e6f;
-                ox = ok ? (int)floorf(ix) - WX / 2 : 0;
-                oy = ok ? (int)floorf(iy) - WY / 2 : 0;
+                mvs::sweep_project(rt, (float)xg, (float)yg, depth[((size_t)b * D + (dc + dend) / 2) * HW + pix], half_w, half_h, &un, &vn, &z);
+                float ix = (un + 1.0f) * half_w, iy = (vn + 1.0f) * half_h;
+                float ok = (fabsf(ix) < 1e6f && fabsf(iy) < 1e6f) ? 1.0f : 0.0f;     // also 0 for NaN
+                ix = ok != 0.0f ? ix : 0.0f;
+                iy = ok != 0.0f ? iy : 0.0f;
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    ix += __shfl_xor(ix, m, 64);
+                    iy += __shfl_xor(iy, m, 64);
+                    ok += __shfl_xor(ok, m, 64);
+                }
+                ox = ok > 0.0f ? (int)floorf(ix / ok) - WX / 2 : 0;
+                oy = ok > 0.0f ? (int)floorf(iy / ok) - WY / 2 : 0;
             }
             int clo = NCELL, chi = -1;                        // cells this lane touched in the chunk (the flush scans only the wave's range)
             for (int c0 = dc; c0 < dend; c0 += 2) {

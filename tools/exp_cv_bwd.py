@@ -61,7 +61,7 @@ for i in (1, 2, 3, 4):
         t0 = timeit(lambda: ops.cv_aggregate_bwd(f, rt, hyp, w, vol, g, 8))
         fwd = timeit(lambda: ops.cv_aggregate(f, rt, hyp, w, 8, False, exact=True))
         line = "stage%d C=%d D=%d %dx%d %-7s fwd %.3f direct %.3f |" % (i, C, D, H, W, hname, fwd, t0)
-        for mode, win in [("lds", w_) for w_ in WINDOWS] + ([] if os.environ.get("MVS_EXP_LIB") else [("own", w_) for w_ in ("5,12", "5,16", "5,20", "5,24")]):
+        for mode, win in [("lds", w_) for w_ in WINDOWS] + ([] if os.environ.get("MVS_EXP_LIB") else [("own", w_) for w_ in ("5,12", "5,16", "5,20")]):
             os.environ["MVS_CV_BWD"] = mode
             os.environ["MVS_CV_BWD_WINDOW"] = win
             st = torch.zeros(2, dtype=torch.int32, device=dev)
