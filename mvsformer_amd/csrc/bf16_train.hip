@@ -214,19 +214,21 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
 // [4 voxels][16 channels] block whose 16 lanes each supplied the address of 4 contiguous channels of one voxel (any row stride;
 // tools/probe/tr16.hip pins the mapping) - two such reads are one v_mfma_f32_16x16x32_bf16 operand (K = 32 voxels, 8 per lane).
 //
-// Block = a patch of PH x 16 voxels of one (n, d) plane of A (PH = 2, 4 or 8 rows: what keeps the Bt halo tile under ~40 KB of LDS)
-// and TA x TB channel tiles (16 x 16 each; TA*TB <= 4).  Per patch the block stages the A tile [PH*16 voxels][CA block] and the Bt
-// halo tile [3 kd][PH*s + 2][16*s + 2][CB] as they are (16-byte global loads -> registers -> LDS, the next patch's loads in flight
-// under this patch's MFMAs; out-of-image cells arrive as zeros from out-of-range buffer loads), then every K step (2 rows x 16
-// columns of A) wave w runs taps w, w+4, ... for all its tiles: the A fragments are read once per K step, a Bt fragment once per
-// (tap, tb).  A block walks patches blockIdx.x, blockIdx.x + gridDim.x, ... with its partial sums in registers and writes ONE slab
+// Block = a patch of PH x 16 voxels of one (n, d) plane of A (PH = 2, 4 or 8 rows: what keeps the Bt plane ring under 56 KB of LDS)
+// and TA x TB channel tiles (16 x 16 each; TA*TB <= 4).  A work item is a COLUMN of such patches over a depth segment: per depth the
+// block stages the A tile [PH*16 voxels][CA block] and only the sd NEW Bt plane tiles [PH*s + 2][16*s + 2][CB] into a ring of four
+// depth planes (the other two of the three planes a depth needs were staged by the previous depth) - 16-byte global loads -> registers
+// -> LDS, the next depth's loads in flight under this depth's MFMAs; out-of-volume cells arrive as zeros from out-of-range buffer
+// loads.  Every K step (2 rows x 16 columns of A) wave w runs taps w, w+4, ... for all its tiles: the A fragments are read once per K
+// step, a Bt fragment once per (tap, tb).  A block keeps its partial sums in registers over all its work items and writes ONE slab
 // at the end; bf16_wgrad_reduce_kernel adds the slabs in a fixed order (no float atomics: the weight gradient is bit-reproducible).
 struct WgradArgs {
     const __bf16* A;
     const __bf16* Bt;
     float* part;              // [gridDim.x][CA][CB][27]
     int nb, CA, CB, Dp, Hp, Wp, Db, Hb, Wb, sd, shw;
-    int PH, npr, npc, npatch; // patch rows, patches per column / row of a plane, patches in total
+    int PH, npr, npc, npatch; // patch rows, patches per column / row of a plane, work items (columns of patches) in total
+    int dseg, nseg;           // depths per work item, depth segments per column
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -240,12 +242,11 @@ __device__ __forceinline__ bf16x8 frag_tr(const unsigned short* p0, const unsign
 }
 
 constexpr int WG_PW = 16;                                   // patch columns
-constexpr int WG_MAXI = 12;                                 // 16-byte Bt pieces per thread and patch, at most
-constexpr int WG_LDS_B = 42 * 1024;                         // Bt halo tile budget (bytes)
 
 template <int TA, int TB>                                   // channel tiles per block
 __global__ __launch_bounds__(256, 2) void bf16_wgrad_kernel(const WgradArgs a) {
     constexpr int TT = TA * TB;
+    constexpr int NIB = 4;                                  // 16-byte pieces of ONE Bt plane tile per thread, at most
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -256,18 +257,18 @@ __global__ __launch_bounds__(256, 2) void bf16_wgrad_kernel(const WgradArgs a) {
     const int a_row = min(CAB, a.CA), b_row = min(CBB, a.CB);            // stored channels per voxel
     const int ca0 = blockIdx.y * CAB;                       // TB covers all of CB
     unsigned short* sA = smem;                              // [PH*16][a_row]
-    unsigned short* sB = smem + a.PH * WG_PW * a_row + 64;  // [3][BH][BW][b_row] (+ slack: an 8-channel tile is read as 16 wide)
-    const int nvoxB = 3 * BH * BW, pcsB = b_row / 8, itemsB = nvoxB * pcsB;
+    unsigned short* sB = smem + a.PH * WG_PW * a_row + 64;  // ring of 4 depth planes [slot][BH][BW][b_row] (+ slack: 8-channel tiles)
+    const int plane_elems = BH * BW * b_row;
+    const int pcsB = b_row / 8, itemsB = BH * BW * pcsB;    // 16-byte pieces of one plane tile
     const int nvoxA = a.PH * WG_PW, pcsA = a_row / 8, itemsA = nvoxA * pcsA;
 
-    // patch-invariant staging maps: item -> (kd, row, col, piece) relative to the patch origin
-    int relB[WG_MAXI];
+    // column-invariant staging maps: item -> (row, col, piece) relative to the tile origin
+    int relB[NIB];
 #pragma unroll
-    for (int i = 0; i < WG_MAXI; ++i) {
+    for (int i = 0; i < NIB; ++i) {
         const int it = tid + i * 256;
         const int pc = it % pcsB, v = it / pcsB;
-        const int bc = v % BW, br = (v / BW) % BH, kd = v / (BW * BH);
-        relB[i] = it < itemsB ? (kd << 24) | (br << 16) | (bc << 8) | pc : -1;
+        relB[i] = it < itemsB ? ((v / BW) << 16) | ((v % BW) << 8) | pc : -1;
     }
     int relA[2];
 #pragma unroll
@@ -276,42 +277,7 @@ __global__ __launch_bounds__(256, 2) void bf16_wgrad_kernel(const WgradArgs a) {
         const int pc = it % pcsA, v = it / pcsA;
         relA[i] = it < itemsA ? ((v / WG_PW) << 16) | ((v % WG_PW) << 8) | pc : -1;
     }
-    u32x4 pfB[WG_MAXI], pfA[2];
-    auto fetch = [&](int patch) {
-        int r = patch;
-        const int pcx = r % a.npc;
-        r /= a.npc;
-        const int pry = r % a.npr;
-        r /= a.npr;
-        const int dp = r % a.Dp, n = r / a.Dp;
-        const int h0 = pry * a.PH, w0 = pcx * WG_PW;
-        const rsrc_t ra = make_rsrc(a.A + (size_t)n * a.Dp * a.Hp * a.Wp * a.CA, (unsigned)((size_t)a.Dp * a.Hp * a.Wp * a.CA * 2));
-        const rsrc_t rb = make_rsrc(a.Bt + (size_t)n * a.Db * a.Hb * a.Wb * a.CB, (unsigned)((size_t)a.Db * a.Hb * a.Wb * a.CB * 2));
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rel = relA[i];
-            const int hh = h0 + ((rel >> 16) & 0xFF), ww = w0 + ((rel >> 8) & 0xFF), pc = rel & 0xFF;
-            const bool ok = rel >= 0 && hh < a.Hp && ww < a.Wp;
-            const unsigned off = (unsigned)((((dp * a.Hp + hh) * a.Wp + ww) * a.CA + ca0 + pc * 8) * 2);
-            pfA[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? off : OOB, 0, 0));
-        }
-#pragma unroll
-        for (int i = 0; i < WG_MAXI; ++i) {
-            const int rel = relB[i];
-            const int db = dp * a.sd - 1 + (rel >> 24), hb = h0 * s - 1 + ((rel >> 16) & 0xFF), wb = w0 * s - 1 + ((rel >> 8) & 0xFF);
-            const bool ok = rel >= 0 && (unsigned)db < (unsigned)a.Db && (unsigned)hb < (unsigned)a.Hb && (unsigned)wb < (unsigned)a.Wb;
-            const unsigned off = (unsigned)((((db * a.Hb + hb) * a.Wb + wb) * a.CB + (rel & 0xFF) * 8) * 2);
-            if (i * 256 < itemsB) pfB[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, ok ? off : OOB, 0, 0));
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            if (relA[i] >= 0) *reinterpret_cast<u32x4*>(sA + (tid + i * 256) * 8) = pfA[i];
-#pragma unroll
-        for (int i = 0; i < WG_MAXI; ++i)
-            if (relB[i] >= 0) *reinterpret_cast<u32x4*>(sB + (tid + i * 256) * 8) = pfB[i];
-    };
+    u32x4 pfB[2][NIB], pfA[2];
 
     constexpr int NTAP = 7;
     f32x4 acc[NTAP][TT];
@@ -319,42 +285,101 @@ __global__ __launch_bounds__(256, 2) void bf16_wgrad_kernel(const WgradArgs a) {
     for (int q = 0; q < NTAP; ++q)
 #pragma unroll
         for (int t = 0; t < TT; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int vsub = t16 >> 2, csub = (t16 & 3) * 4;        // transpose-read lane roles: voxel (8*kb + 4*r + t16/4), channels 4*(t16%4)..+3
 
-    // lane-invariant parts of the transpose-read addresses: lane t16 of group kb supplies voxel (8*kb + 4*r + t16/4), channels 4*(t16%4)..+3
-    const int vsub = t16 >> 2, csub = (t16 & 3) * 4;
-    int patch = blockIdx.x;
-    if (patch < a.npatch) fetch(patch);
-    for (; patch < a.npatch; patch += gridDim.x) {
-        __syncthreads();                                    // previous patch's fragments consumed
-        commit();
-        __syncthreads();
-        if (patch + (int)gridDim.x < a.npatch) fetch(patch + gridDim.x);
-        for (int ks = 0; ks < a.PH / 2; ++ks) {
-            // the lane's two voxel quartets of this K step: v = ks*32 + 8*kb + 4*r + vsub -> (row, col) inside the patch
-            int arow[2], acol[2];
+    // Work item = a COLUMN of patches: (n, patch row, patch column, depth segment [d0, d1)).  Consecutive depths of A need the Bt
+    // planes (dp*sd - 1 .. dp*sd + 1): all but sd of them are already in the ring (slot = plane & 3), so a step stages sd new
+    // planes instead of three - the Bt halo tile was 3/4 of the kernel's staging traffic.
+    for (int col = blockIdx.x; col < a.npatch; col += gridDim.x) {
+        int r = col;
+        const int seg = r % a.nseg;
+        r /= a.nseg;
+        const int pcx = r % a.npc;
+        r /= a.npc;
+        const int pry = r % a.npr, n = r / a.npr;
+        const int h0 = pry * a.PH, w0 = pcx * WG_PW;
+        const int d0 = seg * a.dseg, d1 = min(d0 + a.dseg, a.Dp);
+        const rsrc_t ra = make_rsrc(a.A + (size_t)n * a.Dp * a.Hp * a.Wp * a.CA, (unsigned)((size_t)a.Dp * a.Hp * a.Wp * a.CA * 2));
+        const rsrc_t rb = make_rsrc(a.Bt + (size_t)n * a.Db * a.Hb * a.Wb * a.CB, (unsigned)((size_t)a.Db * a.Hb * a.Wb * a.CB * 2));
+        auto fetch_a = [&](int dp) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int v = 8 * kb + 4 * r + vsub;
-                arow[r] = 2 * ks + (v >> 4);
-                acol[r] = v & 15;
+            for (int i = 0; i < 2; ++i) {
+                const int rel = relA[i];
+                const int hh = h0 + ((rel >> 16) & 0xFF), ww = w0 + ((rel >> 8) & 0xFF), pc = rel & 0xFF;
+                const bool ok = rel >= 0 && hh < a.Hp && ww < a.Wp;
+                const unsigned off = (unsigned)((((dp * a.Hp + hh) * a.Wp + ww) * a.CA + ca0 + pc * 8) * 2);
+                pfA[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? off : OOB, 0, 0));
             }
-            bf16x8 fa[TA];
+        };
+        auto fetch_b = [&](int j, int db) {                 // Bt plane db (possibly outside the volume: zeros) -> register set j
 #pragma unroll
-            for (int t = 0; t < TA; ++t)
+            for (int i = 0; i < NIB; ++i) {
+                const int rel = relB[i];
+                const int hb = h0 * s - 1 + ((rel >> 16) & 0xFF), wb = w0 * s - 1 + ((rel >> 8) & 0xFF);
+                const bool ok = rel >= 0 && (unsigned)db < (unsigned)a.Db && (unsigned)hb < (unsigned)a.Hb && (unsigned)wb < (unsigned)a.Wb;
+                const unsigned off = (unsigned)((((db * a.Hb + hb) * a.Wb + wb) * a.CB + (rel & 0xFF) * 8) * 2);
+                if (i * 256 < itemsB) pfB[j][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, ok ? off : OOB, 0, 0));
+            }
+        };
+        auto commit_a = [&]() {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (relA[i] >= 0) *reinterpret_cast<u32x4*>(sA + (tid + i * 256) * 8) = pfA[i];
+        };
+        auto commit_b = [&](int j, int db) {
+            unsigned short* dst = sB + ((db + 4) & 3) * plane_elems;
+#pragma unroll
+            for (int i = 0; i < NIB; ++i)
+                if (relB[i] >= 0) *reinterpret_cast<u32x4*>(dst + (tid + i * 256) * 8) = pfB[j][i];
+        };
+        // column prologue: the first depth's three planes (the last sd of them through the steady-state path below)
+        __syncthreads();                                    // the previous column's fragments are consumed
+        fetch_b(0, d0 * a.sd - 1);                          // one round trip for the prologue planes (one plane if sd == 2)
+        if (a.sd == 1) fetch_b(1, d0);
+        commit_b(0, d0 * a.sd - 1);
+        if (a.sd == 1) commit_b(1, d0);
+        fetch_a(d0);
+        fetch_b(0, d0 * a.sd + 2 - a.sd);                   // literal register-set indices: the sets must stay in registers
+        if (a.sd == 2) fetch_b(1, d0 * a.sd + 1);
+        for (int dp = d0; dp < d1; ++dp) {
+            __syncthreads();                                // previous depth's fragments consumed
+            commit_a();
+            commit_b(0, dp * a.sd + 2 - a.sd);
+            if (a.sd == 2) commit_b(1, dp * a.sd + 1);
+            __syncthreads();
+            if (dp + 1 < d1) {                              // next depth's A tile and its sd new Bt planes, in flight under the MFMAs
+                fetch_a(dp + 1);
+                fetch_b(0, (dp + 1) * a.sd + 2 - a.sd);
+                if (a.sd == 2) fetch_b(1, (dp + 1) * a.sd + 1);
+            }
+            const int dbase = dp * a.sd - 1;                // Bt plane of depth tap kd = dbase + kd
+            for (int ks = 0; ks < a.PH / 2; ++ks) {
+                int arow[2], acol[2];
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int v = 8 * kb + 4 * rr + vsub;
+                    arow[rr] = 2 * ks + (v >> 4);
+                    acol[rr] = v & 15;
+                }
+                bf16x8 fa[TA];
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
                     fa[t] = frag_tr(sA + (arow[0] * WG_PW + acol[0]) * a_row + t * 16 + csub, sA + (arow[1] * WG_PW + acol[1]) * a_row + t * 16 + csub);
 #pragma unroll
-            for (int q = 0; q < NTAP; ++q) {
-                const int tap = wave + 4 * q;
-                if (tap >= 27) break;                       // wave-uniform
-                const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-                const unsigned short* b0 = sB + (((kd * BH + arow[0] * s + kh) * BW + acol[0] * s + kw) * b_row) + csub;
-                const unsigned short* b1 = sB + (((kd * BH + arow[1] * s + kh) * BW + acol[1] * s + kw) * b_row) + csub;
+                for (int q = 0; q < NTAP; ++q) {
+                    const int tap = wave + 4 * q;
+                    if (tap >= 27) break;                   // wave-uniform
+                    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                    const unsigned short* pl = sB + ((dbase + kd + 4) & 3) * plane_elems;
+                    const unsigned short* b0 = pl + (((arow[0] * s + kh) * BW + acol[0] * s + kw) * b_row) + csub;
+                    const unsigned short* b1 = pl + (((arow[1] * s + kh) * BW + acol[1] * s + kw) * b_row) + csub;
 #pragma unroll
-                for (int tb = 0; tb < TB; ++tb) {
-                    const bf16x8 fb = frag_tr(b0 + tb * 16, b1 + tb * 16);
+                    for (int tb = 0; tb < TB; ++tb) {
+                        const bf16x8 fb = frag_tr(b0 + tb * 16, b1 + tb * 16);
 #pragma unroll
-                    for (int ta = 0; ta < TA; ++ta)
-                        acc[q][ta * TB + tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ta], fb, acc[q][ta * TB + tb], 0, 0, 0);
+                        for (int ta = 0; ta < TA; ++ta)
+                            acc[q][ta * TB + tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ta], fb, acc[q][ta * TB + tb], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -679,7 +704,14 @@ static int bf16_conv3d_impl(const void* x, const void* wpacked, const float* sca
 }
 
 namespace {
-struct WgradPlan { int PH, npr, npc, npatch, TA, TB, gy, blocks; size_t lds; };
+struct WgradPlan { int PH, npr, npc, npatch, dseg, nseg, TA, TB, gy, blocks; size_t lds; };
+constexpr size_t WG_RING_B = 56 * 1024;                      // budget of the 4-plane Bt ring (bytes)
+int wgrad_nseg(int columns, int Dp, int target) {            // depth segments per column: enough work items, >= 2 depths each
+    int nseg = (target + columns - 1) / columns;
+    const int cap = Dp / 2 > 1 ? Dp / 2 : 1;
+    if (nseg > cap) nseg = cap;
+    return nseg < 1 ? 1 : nseg;
+}
 WgradPlan wgrad_plan(int nbatch, int CA, int CB, int Dp, int Hp, int Wp, int shw) {
     WgradPlan p;
     const int nA = (CA + 15) / 16, nB = (CB + 15) / 16;
@@ -689,15 +721,21 @@ WgradPlan wgrad_plan(int nbatch, int CA, int CB, int Dp, int Hp, int Wp, int shw
     p.gy = (nA + p.TA - 1) / p.TA;
     const int b_row = CB < p.TB * 16 ? CB : p.TB * 16, a_row = CA < p.TA * 16 ? CA : p.TA * 16;
     p.PH = 8;
-    while (p.PH > 2 && (size_t)3 * (p.PH * shw + 2) * (WG_PW * shw + 2) * b_row * 2 > (size_t)WG_LDS_B) p.PH >>= 1;
+    while (p.PH > 2 && (size_t)4 * (p.PH * shw + 2) * (WG_PW * shw + 2) * b_row * 2 > WG_RING_B) p.PH >>= 1;
     p.npr = (Hp + p.PH - 1) / p.PH;
     p.npc = (Wp + WG_PW - 1) / WG_PW;
-    p.npatch = nbatch * Dp * p.npr * p.npc;
-    p.blocks = 512 / p.gy;                                   // two resident blocks per CU over all channel groups; never more than the
-    const int least = nbatch * Dp * ((Hp + 7) / 8) * p.npc;  // patch count at PH = 8, so the slab count does not depend on the stride
-    if (p.blocks > least) p.blocks = least;
+    const int target = 512 / p.gy;                           // two resident blocks per CU over all channel groups
+    p.nseg = wgrad_nseg(nbatch * p.npr * p.npc, Dp, target);
+    p.dseg = (Dp + p.nseg - 1) / p.nseg;
+    p.nseg = (Dp + p.dseg - 1) / p.dseg;
+    p.npatch = nbatch * p.npr * p.npc * p.nseg;
+    // the slab (= block) count must not depend on the stride (the workspace is sized without it): the count at PH = 8
+    const int col8 = nbatch * ((Hp + 7) / 8) * p.npc;
+    const int seg8 = wgrad_nseg(col8, Dp, target), d8 = (Dp + seg8 - 1) / seg8;
+    const int least = col8 * ((Dp + d8 - 1) / d8);
+    p.blocks = target < least ? target : least;
     if (p.blocks < 1) p.blocks = 1;
-    p.lds = ((size_t)p.PH * WG_PW * a_row + 64 + (size_t)3 * (p.PH * shw + 2) * (WG_PW * shw + 2) * b_row + 64) * 2;
+    p.lds = ((size_t)p.PH * WG_PW * a_row + 64 + (size_t)4 * (p.PH * shw + 2) * (WG_PW * shw + 2) * b_row + 64) * 2;
     return p;
 }
 }  // namespace
@@ -717,13 +755,13 @@ extern "C" int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, v
                 "mvs_bf16_conv3d_wgrad: one sample exceeds the 2 GiB buffer range");
     const WgradPlan p = wgrad_plan(nbatch, CA, CB, Dp, Hp, Wp, shw);
     const int b_row = CB < p.TB * 16 ? CB : p.TB * 16;
-    const int itemsB = 3 * (p.PH * shw + 2) * (WG_PW * shw + 2) * (b_row / 8);
-    MVS_REQUIRE(itemsB <= WG_MAXI * 256 && p.lds <= 64 * 1024, "mvs_bf16_conv3d_wgrad: Bt halo tile of %d pieces / %zu bytes does not fit (CB=%d stride %d)",
+    const int itemsB = (p.PH * shw + 2) * (WG_PW * shw + 2) * (b_row / 8);          // one plane tile
+    MVS_REQUIRE(itemsB <= 4 * 256 && p.lds <= 64 * 1024, "mvs_bf16_conv3d_wgrad: Bt halo tile of %d pieces / %zu bytes does not fit (CB=%d stride %d)",
                 itemsB, p.lds, CB, shw);
     WgradArgs a{};
     a.A = reinterpret_cast<const __bf16*>(A), a.Bt = reinterpret_cast<const __bf16*>(Bt), a.part = reinterpret_cast<float*>(workspace);
     a.nb = nbatch, a.CA = CA, a.CB = CB, a.Dp = Dp, a.Hp = Hp, a.Wp = Wp, a.Db = Db, a.Hb = Hb, a.Wb = Wb, a.sd = sd, a.shw = shw;
-    a.PH = p.PH, a.npr = p.npr, a.npc = p.npc, a.npatch = p.npatch;
+    a.PH = p.PH, a.npr = p.npr, a.npc = p.npc, a.npatch = p.npatch, a.dseg = p.dseg, a.nseg = p.nseg;
     hipStream_t s = MVS_STREAM(stream);
     const dim3 grid(p.blocks, p.gy);
     if (p.TA == 1 && p.TB == 1) hipLaunchKernelGGL((bf16_wgrad_kernel<1, 1>), grid, dim3(256), p.lds, s, a);
