@@ -281,7 +281,8 @@ int mvs_bf16_affine_act(const void* x, const float* scale, const float* shift, c
  * = mvs_bf16_bn_stats + mvs_bn_finalize(_grouped) + mvs_bf16_affine_act; stats4 = [scale | shift | mean | invstd], each groups*C */
 int mvs_bf16_bn_train_fwd(const void* x, const void* residual, int relu, int C, int64_t R, int groups, int64_t rows_per_sample,
                           const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                          float* stats4, void* y, void* workspace, mvs_stream_t stream);
+                          int64_t* num_batches_tracked /* NULL, or nn.BatchNorm's counter: += groups */, float* stats4, void* y,
+                          void* workspace, mvs_stream_t stream);
 int mvs_bf16_bn_bwd_reduce(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
                            const float* invstd, int relu, int C, int64_t R, int groups, int64_t rows_per_sample, float* sums,
                            void* workspace, mvs_stream_t stream);

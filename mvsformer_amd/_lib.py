@@ -64,7 +64,7 @@ SIGNATURES = {
     "mvs_bf16_bn_reduce_workspace_bytes": (L, [I, L, I, L]),
     "mvs_bf16_bn_stats": (I, [P, I, L, I, L, P, P, P]),
     "mvs_bf16_affine_act": (I, [P, P, P, P, I, I, L, I, L, P, P]),
-    "mvs_bf16_bn_train_fwd": (I, [P, P, I, I, L, I, L, P, P, P, P, F, F, P, P, P, P]),
+    "mvs_bf16_bn_train_fwd": (I, [P, P, I, I, L, I, L, P, P, P, P, F, F, P, P, P, P, P]),
     "mvs_bf16_bn_bwd_reduce": (I, [P, P, P, P, P, P, I, I, L, I, L, P, P, P]),
     "mvs_bf16_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, Dbl, P, I, I, L, I, L, P, P]),
     "mvs_cv_aggregate_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P]),

@@ -434,8 +434,10 @@ class BnActBf16Fn(torch.autograd.Function):
         if sums is None and not synced:
             # no collective between statistics and finalize: one call, three launches
             mom = bn.momentum if groups > 1 else (_momentum(bn) if track else 0.0)
-            y, scale, shift, mean, invstd = ops.bf16_bn_train_fwd(x, res, relu, g, b, rm, rv, mom, bn.eps, groups)
+            nbt = bn.num_batches_tracked if track and bn.num_batches_tracked is not None else None       # incremented by the kernel
+            y, scale, shift, mean, invstd = ops.bf16_bn_train_fwd(x, res, relu, g, b, rm, rv, mom, bn.eps, groups, nbt)
             count_dev = None
+            track = False
         else:
             if sums is None:
                 sums = ops.bf16_bn_stats(x, groups)
@@ -464,9 +466,10 @@ class BnActBf16Fn(torch.autograd.Function):
         local = sums
         sums, _ = _sync_sums(sums, 0.0, ctx.bn)
         dx = ops.bf16_bn_bwd_apply(dy, x, scale, shift, mean, invstd, g, sums, ctx.count, ctx.relu, count_dev, G)
-        dgamma = local[CT:] if ctx.needs_input_grad[1] else None         # views of the reduction result (no device copies)
-        dbeta = local[:CT] if ctx.needs_input_grad[2] else None
-        if G > 1:                                                        # shared parameters: sum the groups' gradients
-            dgamma = dgamma.view(G, -1).sum(0) if dgamma is not None else None
-            dbeta = dbeta.view(G, -1).sum(0) if dbeta is not None else None
-        return dx, dgamma, dbeta, (dy if ctx.has_res else None), None, None, None, None
+        if G > 1:                                                        # shared parameters: sum the groups' gradients (one launch)
+            both = local.view(2, G, -1).sum(1)
+            dbeta, dgamma = both[0], both[1]
+        else:
+            dbeta, dgamma = local[:CT], local[CT:]                       # views of the reduction result (no device copies)
+        return dx, (dgamma if ctx.needs_input_grad[1] else None), (dbeta if ctx.needs_input_grad[2] else None), \
+            (dy if ctx.has_res else None), None, None, None, None

@@ -872,9 +872,11 @@ namespace {
 __global__ __launch_bounds__(256) void bf16_bn_reduce_finalize_kernel(const float* __restrict__ part, int bps, int nsamples, int groups, int C,
                                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                       float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                                      float momentum, float eps, double count, float* __restrict__ out4) {
+                                                                      float momentum, float eps, double count, float* __restrict__ out4,
+                                                                      long long* __restrict__ num_batches_tracked) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
+    if (num_batches_tracked && c == 0 && lane == 0) num_batches_tracked[0] += groups;       // nn.BatchNorm's counter: one call per group
     const int CT = C * groups, per = (nsamples / groups) * bps;
     const float g = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
     float rm = running_mean ? running_mean[c] : 0.0f, rv = running_var ? running_var[c] : 0.0f;
@@ -917,7 +919,7 @@ __global__ __launch_bounds__(256) void bf16_bn_reduce_finalize_kernel(const floa
 // cross-rank reduction in between.  stats4 = [scale | shift | mean | invstd], each groups*C.
 extern "C" int mvs_bf16_bn_train_fwd(const void* x, const void* residual, int relu, int C, int64_t R, int groups, int64_t rows_per_sample,
                                      const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
-                                     float eps, float* stats4, void* y, void* workspace, mvs_stream_t stream) {
+                                     float eps, int64_t* num_batches_tracked, float* stats4, void* y, void* workspace, mvs_stream_t stream) {
     BnShape sh;
     MVS_REQUIRE(x && stats4 && y && workspace && bn_shape(C, R, groups, rows_per_sample, &sh), "mvs_bf16_bn_train_fwd: bad arguments");
     MVS_REQUIRE((!running_mean) == (!running_var), "mvs_bf16_bn_train_fwd: running_mean and running_var come together");
@@ -928,7 +930,8 @@ extern "C" int mvs_bf16_bn_train_fwd(const void* x, const void* residual, int re
                        (const __bf16*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, C,
                        (size_t)sh.RS, groups, part);
     hipLaunchKernelGGL(bf16_bn_reduce_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, (int)sh.bps, sh.nsamples, groups, C, gamma, beta,
-                       running_mean, running_var, momentum, eps, (double)(R / groups), stats4);
+                       running_mean, running_var, momentum, eps, (double)(R / groups), stats4,
+                       reinterpret_cast<long long*>(num_batches_tracked));
     const size_t total8 = (size_t)R * (C / 8);
     hipLaunchKernelGGL(bf16_affine_act_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x),
                        stats4, stats4 + CT, reinterpret_cast<const __bf16*>(residual), relu, C, total8, (size_t)sh.RS, groups,

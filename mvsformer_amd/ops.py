@@ -888,17 +888,19 @@ def bf16_bn_stats(x: torch.Tensor, groups: int = 1) -> torch.Tensor:
     return sums
 
 
-def bf16_bn_train_fwd(x, residual, relu, gamma, beta, running_mean, running_var, momentum, eps, groups: int = 1):
+def bf16_bn_train_fwd(x, residual, relu, gamma, beta, running_mean, running_var, momentum, eps, groups: int = 1, num_batches_tracked=None):
     """Statistics + finalize (running-stat update) + normalize / ReLU / skip in one call -> ``(y, scale, shift, mean, invstd)``."""
     _chk16(x, "x"), _opt(gamma, "bn.weight"), _opt(beta, "bn.bias"), _opt(running_mean, "bn.running_mean"), _opt(running_var, "bn.running_var")
     if residual is not None:
         _chk16(residual, "residual")
+    if num_batches_tracked is not None:
+        _chk(num_batches_tracked, "bn.num_batches_tracked", dtype=torch.int64)
     C, R, rps = _bf16_bn_shape(x, groups)
     y = torch.empty_like(x)
     st = torch.empty(4, groups * C, device=x.device, dtype=torch.float32)
     ws = _reduce_ws("mvs_bf16_bn_reduce_workspace_bytes", x.device, C, R, groups, rps)
     _call("mvs_bf16_bn_train_fwd", "bf16_bn_train_fwd", _ptr(x), _ptr(residual), int(relu), C, R, groups, rps, _ptr(gamma), _ptr(beta),
-          _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), _ptr(st), _ptr(y), _ptr(ws), _stream())
+          _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), _ptr(num_batches_tracked), _ptr(st), _ptr(y), _ptr(ws), _stream())
     return y, st[0], st[1], st[2], st[3]
 
 
