@@ -256,13 +256,27 @@ class HeadFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------------------
+class _EmbedConv2dWeightFn(torch.autograd.Function):
+    """``[Cout,Cin,3,3]`` -> ``[Cout,cin_pad,3,3,3]`` with the 2-D kernel in the centre depth tap, zeros elsewhere: one fill + one strided
+    copy forward, a view backward (two ``F.pad`` calls are four launches forward and two more backward, 12 layers per step)."""
+
+    @staticmethod
+    def forward(ctx, w2d, cin_pad):
+        cout, cin = w2d.shape[0], w2d.shape[1]
+        w = w2d.new_zeros(cout, max(cin_pad, cin), 3, 3, 3)
+        w[:, :cin, 1] = w2d
+        ctx.cin = cin
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        return dw[:, :ctx.cin, 1], None
+
+
 def embed_conv2d_weight(w2d: torch.Tensor, cin_pad: int) -> torch.Tensor:
     """``[Cout,Cin,3,3]`` -> ``[Cout,cin_pad,3,3,3]`` with the 2-D kernel in the centre depth tap (so the 2-D convs of
     ``StageNet.vis`` run, forward and backward, on the same MFMA conv3d kernels at D = 1).  Pure padding: differentiable."""
-    w = F.pad(w2d.unsqueeze(2), (0, 0, 0, 0, 1, 1))                      # kd = 0, 2 are zero
-    if cin_pad > w.shape[1]:
-        w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, cin_pad - w.shape[1]))
-    return w
+    return _EmbedConv2dWeightFn.apply(w2d, cin_pad)
 
 
 def vis_train(entropy: torch.Tensor, vis: nn.Sequential) -> torch.Tensor:
