@@ -27,7 +27,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 5
+#define MVS_ABI_VERSION 6
 
 typedef void* mvs_stream_t;
 

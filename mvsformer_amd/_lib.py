@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 from ctypes import c_double  # noqa: E402
 
