@@ -21,6 +21,7 @@ float16-exact values to halve the files):
   stage_costregnet3d.npz   StageNet with ndepth=4 (CostRegNet3D), eval + train, intermediate taps
   cascade_v3.npz, cascade_v5.npz   4-stage inverse-depth cascade, 64x64, tmp=[5,5,5,1]
   train_costregnet.npz, train_costregnet3d.npz   train-mode StageNet (B=2): forward, loss=sum(pre*R), all gradients
+  fpn_decoder.npz          FPNDecoder (the step before the path), eval BatchNorm: state_dict, encoder outputs, the 4 feature maps
 """
 import json
 import os
@@ -536,3 +537,26 @@ def gen_ce_loss():
 
 if __name__ == "__main__" and os.environ.get("GEN_LOSS", "1") == "1":
     gen_ce_loss()
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_fpn_decoder():
+    """FPNDecoder (models/module.py:242-270), eval mode, default-initialized weights under a seed + randomized BatchNorm.
+    Coarsest level 5x6 -> 10x12, 20x24, 40x48: every level has partial 4x32 tiles; N=1 keeps the file small."""
+    from models.module import FPNDecoder
+    from oracle import ref_fpn
+    torch.manual_seed(7)
+    dec = FPNDecoder([8, 16, 32, 64])
+    ref_fpn.randomize_bn(dec, 8)
+    dec.eval()
+    conv01, conv11, conv21, conv31 = ref_fpn.make_case(9, 1, 5, 6)
+    with torch.no_grad():
+        outs = dec(conv01, conv11, conv21, conv31)
+    arrs = {"sd." + k: np32(v) for k, v in dec.state_dict().items() if v.dtype.is_floating_point}
+    arrs.update(conv01=np32(conv01), conv11=np32(conv11), conv21=np32(conv21), conv31=np32(conv31))
+    arrs.update({"out%d" % i: np32(o) for i, o in enumerate(outs)})
+    save("fpn_decoder.npz", **arrs)
+
+
+if __name__ == "__main__" and os.environ.get("GEN_FPN", "1") == "1":
+    gen_fpn_decoder()

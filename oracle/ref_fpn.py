@@ -1,0 +1,56 @@
+"""TEST INFRASTRUCTURE — CPU oracle for the FPN decoder (the step that hands features to the path).
+
+Restates reference models/module.py:242-270 (``FPNDecoder``: lateral 1x1 convolutions, bilinear x2 upsampling with
+align_corners=True, 3x3 output convolutions followed by BatchNorm2d and Swish, module.py:200-206) as a function of the
+module's ``state_dict``, eval-mode BatchNorm.  Pinned by tests/golden/fpn_decoder.npz (outputs of the real module, made
+by oracle/gen_golden.py).  Never imported by the product path.
+"""
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5   # nn.BatchNorm2d default, module.py:246-255 constructs it without arguments
+
+
+def swish(x):
+    """module.py:205-206"""
+    return x * torch.sigmoid(x)
+
+
+def _bn_eval(x, sd, prefix):
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"], sd[prefix + ".bias"],
+                        False, 0.0, BN_EPS)
+
+
+def _out(x, sd, name, padding):
+    """nn.Sequential(Conv2d, BatchNorm2d, Swish) — module.py:246,249,252,255"""
+    y = F.conv2d(x, sd[name + ".0.weight"], sd[name + ".0.bias"], padding=padding)
+    return swish(_bn_eval(y, sd, name + ".1"))
+
+
+def fpn_decoder_forward(sd, conv01, conv11, conv21, conv31):
+    """module.py:257-270 -> [out0 (1/8), out1 (1/4), out2 (1/2), out3 (full)], all [N,C,H,W]."""
+    intra = conv31
+    out0 = _out(intra, sd, "out0", 0)
+    outs = [out0]
+    for k, lateral in ((1, conv21), (2, conv11), (3, conv01)):
+        intra = F.interpolate(intra, scale_factor=2, mode="bilinear", align_corners=True) + \
+            F.conv2d(lateral, sd["inner%d.weight" % k], sd["inner%d.bias" % k])
+        outs.append(_out(intra, sd, "out%d" % k, 1))
+    return outs
+
+
+def make_case(seed, N, h, w, feat_chs=(8, 16, 32, 64)):
+    """Seeded encoder outputs for a decoder whose coarsest level is h x w: (conv01, conv11, conv21, conv31)."""
+    g = torch.Generator().manual_seed(seed)
+    return tuple(torch.randn(N, feat_chs[i], h * 2 ** (3 - i), w * 2 ** (3 - i), generator=g) for i in range(4))
+
+
+def randomize_bn(module, seed):
+    """Give every BatchNorm2d non-trivial affine parameters and running statistics (a fresh module has 1/0/0/1)."""
+    g = torch.Generator().manual_seed(seed)
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = 0.5 + torch.rand(m.num_features, generator=g)
+            m.bias.data = 0.2 * torch.randn(m.num_features, generator=g)
+            m.running_mean = 0.3 * torch.randn(m.num_features, generator=g)
+            m.running_var = 0.5 + torch.rand(m.num_features, generator=g)

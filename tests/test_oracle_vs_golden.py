@@ -213,3 +213,19 @@ def test_ce_loss_oracle_vs_reference(tag, inverse):
     for k in inputs:
         assert abs(losses[k].item() - float(g["%s_%s_loss" % (tag, k)])) < 1e-6
         assert max_abs(inputs[k]["prob_volume_pre"].grad, g["%s_%s_grad" % (tag, k)]) < 1e-8
+
+
+def fpn_golden():
+    g = load_golden("fpn_decoder.npz")
+    sd = {k[3:]: t(v) for k, v in g.items() if k.startswith("sd.")}
+    return g, sd, [t(g[k]) for k in ("conv01", "conv11", "conv21", "conv31")]
+
+
+def test_fpn_decoder_oracle_vs_reference():
+    """oracle/ref_fpn.py against the real FPNDecoder (models/module.py:242-270), eval BatchNorm."""
+    from oracle import ref_fpn
+    g, sd, feats = fpn_golden()
+    outs = ref_fpn.fpn_decoder_forward(sd, *feats)
+    assert [tuple(o.shape) for o in outs] == [(1, 64, 5, 6), (1, 32, 10, 12), (1, 16, 20, 24), (1, 8, 40, 48)]
+    for i, o in enumerate(outs):
+        assert max_abs(o, g["out%d" % i]) < TOL * max(1.0, float(np.abs(g["out%d" % i]).max())), i
