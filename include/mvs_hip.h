@@ -342,6 +342,23 @@ int mvs_schedule_inverse_range(const float* prev_depth, const float* prev_hyp, i
 int mvs_conf_accumulate(const float* conf, int B, int H, int W, float* acc, int Hf, int Wf, float weight, mvs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Row before the path: FPNDecoder.forward, models/module.py:242-270, eval-mode BatchNorm.  Inputs and the
+ * top-down intermediates are NCHW like the reference's tensors; the four feature maps come out CHANNEL-LAST [N,H,W,C], the layout
+ * the sweeps read (mvs_cv_*: feat [B,V,H,W,C] with N = B*V) - no nchw_to_nhwc pass.  scale/shift fold BatchNorm2d and the conv bias:
+ * scale = gamma / sqrt(var + eps), shift = beta + (bias - mean) * scale; the activation is Swish (module.py:200-206).
+ *   pack:   w [Cout,64,3,3] (out_k.0.weight, Cout = 8 | 16 | 32) -> packed, mvs_fpn_packed_floats(Cout) floats
+ *   out0:   x = conv31 [N,64,h,w], w [64,64] (out0.0.weight) -> out [N,h,w,64]
+ *   level:  intra_prev [N,64,h,w], lateral [N,Ck,2h,2w], w_inner [64,Ck] + b_inner [64] (inner_k), packed out_k weights ->
+ *           intra_out [N,64,2h,2w] (NULL for the last level: it is only ever consumed inside this kernel) and out [N,2h,2w,Ck] */
+int64_t mvs_fpn_packed_floats(int Cout);
+int mvs_fpn_pack_weights(const float* w, int Cout, float* packed, mvs_stream_t stream);
+int mvs_fpn_out0(const float* x, const float* w, const float* scale, const float* shift, int N, int h, int wd, float* out,
+                 mvs_stream_t stream);
+int mvs_fpn_level(const float* intra_prev, const float* lateral, const float* w_inner, const float* b_inner, const float* w_packed,
+                  const float* scale, const float* shift, int N, int Ck, int h, int w, float* intra_out, float* out,
+                  mvs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Next row after the path: geometric consistency filtering of the depth maps, misc/fusion.py:79-122
  * (get_reproj / project_img, vis_filter, ave_fusion) as driven by test.py:404-438, in one pass per reference pixel.
  *   ref_depth [n,1,H,W]   src_depths [n,v,1,H,W]   ref_cam [n,2,4,4]   src_cams [n,v,2,4,4]  (cam[0]=extrinsic, cam[1][:3,:3]=K)

@@ -12,7 +12,7 @@ from . import synth  # noqa: F401
 
 __all__ = ["synth", "StageNet", "DepthNet", "CostRegNet", "CostRegNet3D", "CascadeMVS", "homo_warping_3D_with_mask",
            "homo_warping_3D", "homo_warping", "depth_regression", "conf_regression", "init_inverse_range",
-           "schedule_inverse_range", "install", "fusion"]
+           "schedule_inverse_range", "install", "fusion", "FPNDecoder"]
 
 
 def __getattr__(name):
@@ -29,6 +29,9 @@ def __getattr__(name):
     if name in ("CascadeMVS", "randomize_bn_"):
         from . import cascade
         return getattr(cascade, name)
+    if name == "FPNDecoder":
+        from . import fpn
+        return fpn.FPNDecoder
     if name == "fusion":
         import importlib
         return importlib.import_module(".fusion", __name__)

@@ -97,6 +97,10 @@ SIGNATURES = {
     "mvs_init_inverse_range": (I, [P, I, I, I, I, I, P, P]),
     "mvs_schedule_inverse_range": (I, [P, P, I, F, I, I, I, I, P, P]),
     "mvs_conf_accumulate": (I, [P, I, I, I, P, I, I, F, P]),
+    "mvs_fpn_packed_floats": (L, [I]),
+    "mvs_fpn_pack_weights": (I, [P, I, P, P]),
+    "mvs_fpn_out0": (I, [P, P, P, P, I, I, I, P, P]),
+    "mvs_fpn_level": (I, [P, P, P, P, P, P, P, I, I, I, I, P, P, P]),
 }
 
 _lib = None

@@ -1,0 +1,282 @@
+// FPN decoder (models/module.py:242-270), eval mode: the step that hands the four feature maps to the plane sweeps
+// (SURVEY.md §8 f1/f4).  Reference per level k = 1..3:
+//     intra_k = interpolate(intra_{k-1}, x2, bilinear, align_corners=True) + inner_k(lateral_k)        (1x1 conv, C_k -> 64)
+//     out_k   = Swish(BatchNorm2d(conv3x3(intra_k)))                                                     (64 -> C_k)
+// materializes intra_3 = [N,64,H,W] (453 MB per 1152x1536 view) only to convolve it down to 8 channels.  Here one kernel per
+// level builds the intra tile in LDS (bilinear taps from an LDS-staged window of intra_{k-1}, the lateral 1x1 convolution on
+// the VALU with wave-uniform weights in SGPRs), runs the 3x3 convolution from LDS on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32, same fragment conventions as conv3d.hip) and stores out_k CHANNEL-LAST [N,H,W,C_k] - the layout the
+// sweeps gather from, so the four nchw_to_nhwc passes of the reference layout disappear.  intra_k goes back to HBM only for
+// k < 3 (the next level upsamples it); intra_3 never exists.
+//
+// Layouts: every input (encoder outputs, intra) is NCHW like the reference's tensors; outputs out_k are NHWC.
+// Work split: block = 4 x 32 output pixels, 4 wavefronts; the 64 top-down channels are processed in 4 chunks of 16 so the LDS
+// footprint stays at 30-50 KB (3-5 blocks per CU).  GEMM view per chunk: M = 16 pixels along x, K = taps x 16 channels,
+// N = output channels.  C_k = 8 would fill half of the 16-wide N tile, so there N = (2 output rows) x (8 channels): the four
+// input rows that feed an output row pair are each multiplied against a 16-column weight matrix holding tap row j for the upper
+// output row and tap row j-1 for the lower one (zero where that tap does not exist) - 12 MFMAs per 4 channels for two rows
+// instead of 18.
+//
+// Algorithmic FLOPs per output pixel of level k: 2*64*(C_k + 9*C_k); bytes: 4*(C_k in + C_k out + 64/4 upsampled source).
+#include "conv_common.h"
+
+namespace {
+using namespace mvsconv;
+
+constexpr int FC = 64;                       // channels of the top-down path (feat_chs[-1])
+constexpr int TH = 4, TW = 32;               // output tile
+constexpr int HR = TH + 2, HC = TW + 2;      // intra tile with the 3x3 halo
+constexpr int NPIX = HR * HC;                // 204 <= 256 threads: one thread per halo pixel
+constexpr int CCH = 16;                      // top-down channels per chunk
+constexpr int CS = pad_cs(NPIX, 1);          // 208: channel stride of the LDS tile (== 16 mod 32, see conv_common.h)
+constexpr int SH = 6, SW = 20, SS = SH * SW; // LDS window of the coarser level: (TH+1)/2 + 2 (+1 slack) rows, (TW+1)/2 + 2 (+1) columns
+
+__host__ __device__ constexpr int fpn_nt(int ck) { return ck == 32 ? 2 : 1; }
+__host__ __device__ constexpr int fpn_taps(int ck) { return ck == 8 ? 12 : 9; }
+__host__ __device__ constexpr int fpn_chunk_floats(int ck) { return 4 * fpn_taps(ck) * 4 * np_of(fpn_nt(ck)); }
+
+__device__ __forceinline__ float swish(float v) { return v / (1.0f + expf(-v)); }
+
+// packed image: [slab = cin/4 (16)][tap (9 | 12)][cin%4][NP]; a chunk of 16 input channels = 4 consecutive slabs
+__global__ void fpn_pack_kernel(const float* __restrict__ w /*[Cout,64,3,3]*/, int Cout, float* __restrict__ out) {
+    const int T = fpn_taps(Cout), NP = np_of(fpn_nt(Cout));
+    const int total = (FC / 4) * T * 4 * NP;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int n = idx % NP, kk = (idx / NP) % 4, tap = (idx / (4 * NP)) % T, slab = idx / (4 * NP * T);
+        const int c = slab * 4 + kk;
+        float v = 0.0f;
+        if (Cout == 8) {                     // tap = j*3 + kx over the 4 input rows j of an output row pair; n = h*8 + co
+            const int j = tap / 3, kx = tap % 3, h = n >> 3, co = n & 7, ky = j - h;
+            if (n < 16 && ky >= 0 && ky <= 2) v = w[((size_t)(co * FC + c) * 3 + ky) * 3 + kx];
+        } else if (n < Cout) {
+            v = w[(size_t)(n * FC + c) * 9 + tap];
+        }
+        out[idx] = v;
+    }
+}
+
+// out0 = Swish(BN(conv1x1 64->64 (conv31)))  (module.py:246,259): one thread per pixel, weights wave-uniform
+__global__ __launch_bounds__(64) void fpn_out0_kernel(const float* __restrict__ x /*[N,64,hw]*/, const float* __restrict__ w /*[64,64]*/,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift, int hw,
+                                                      float* __restrict__ out /*[N,hw,64]*/) {
+    const int pix = blockIdx.x * 64 + threadIdx.x, img = blockIdx.y;
+    if (pix >= hw) return;
+    const float* xp = x + (size_t)img * FC * hw + pix;
+    float acc[FC];
+#pragma unroll
+    for (int co = 0; co < FC; ++co) acc[co] = 0.0f;
+    for (int ci = 0; ci < FC; ++ci) {
+        const float xv = xp[(size_t)ci * hw];
+#pragma unroll
+        for (int co = 0; co < FC; ++co) acc[co] = fmaf(w[co * FC + ci], xv, acc[co]);
+    }
+    f32x4* o = reinterpret_cast<f32x4*>(out + ((size_t)img * hw + pix) * FC);
+#pragma unroll
+    for (int q = 0; q < FC / 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = swish(fmaf(acc[q * 4 + i], scale[q * 4 + i], shift[q * 4 + i]));
+        o[q] = v;
+    }
+}
+
+template <int CK>
+__global__ __launch_bounds__(256) void fpn_level_kernel(const float* __restrict__ prev /*[N,64,h,w]*/, const float* __restrict__ lat /*[N,CK,2h,2w]*/,
+                                                        const float* __restrict__ w_in /*[64,CK]*/, const float* __restrict__ b_in /*[64]*/,
+                                                        const float* __restrict__ wp, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int h, int w,
+                                                        float* __restrict__ intra_out /*[N,64,2h,2w] or null*/,
+                                                        float* __restrict__ out /*[N,2h,2w,CK]*/) {
+    constexpr bool ROWS2 = (CK == 8);
+    constexpr int NT = fpn_nt(CK), NP = np_of(NT), T = fpn_taps(CK), WCH = fpn_chunk_floats(CK);
+    constexpr int MT = ROWS2 ? 1 : 2;        // M tiles (16 pixels) per wavefront
+    __shared__ __attribute__((aligned(16))) float s_src[CCH * SS];
+    __shared__ __attribute__((aligned(16))) float s_tile[CCH * CS];
+    __shared__ __attribute__((aligned(16))) float s_w[WCH];
+
+    unsigned bx, by, bz;
+    xcd_block_coords(bx, by, bz);
+    const int H = 2 * h, W = 2 * w;
+    const int x0 = (int)bx * TW, y0 = (int)by * TH, img = (int)bz;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kk = lane >> 4;
+
+    // ---- this thread's halo pixel: bilinear taps into the coarse window (ATen upsample_bilinear2d, align_corners=True) ----
+    const int p = tid;
+    const int gy = y0 - 1 + p / HC, gx = x0 - 1 + p % HC;
+    const bool inimg = (p < NPIX) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const float sy = (float)(h - 1) / (float)(H - 1), sx = (float)(w - 1) / (float)(W - 1);
+    const int wy0 = (int)(sy * (float)max(y0 - 1, 0)), wx0 = (int)(sx * (float)max(x0 - 1, 0));
+    int o00 = 0, o01 = 0, o10 = 0, o11 = 0;
+    float ly0 = 0.f, ly1 = 0.f, lx0 = 0.f, lx1 = 0.f;
+    float lv[CK];
+#pragma unroll
+    for (int j = 0; j < CK; ++j) lv[j] = 0.0f;
+    if (inimg) {
+        const float fy = sy * (float)gy, fx = sx * (float)gx;
+        const int iy0 = (int)fy, ix0 = (int)fx;
+        const int iy1 = iy0 + (iy0 < h - 1 ? 1 : 0), ix1 = ix0 + (ix0 < w - 1 ? 1 : 0);
+        ly1 = fy - (float)iy0;
+        lx1 = fx - (float)ix0;
+        ly0 = 1.0f - ly1;
+        lx0 = 1.0f - lx1;
+        const int ry0 = min(iy0 - wy0, SH - 1), ry1 = min(iy1 - wy0, SH - 1), rx0 = min(ix0 - wx0, SW - 1), rx1 = min(ix1 - wx0, SW - 1);
+        o00 = ry0 * SW + rx0;
+        o01 = ry0 * SW + rx1;
+        o10 = ry1 * SW + rx0;
+        o11 = ry1 * SW + rx1;
+        const float* lp = lat + ((size_t)img * CK * H + gy) * W + gx;
+#pragma unroll
+        for (int j = 0; j < CK; ++j) lv[j] = lp[(size_t)j * H * W];
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int cc = 0; cc < FC / CCH; ++cc) {
+        __syncthreads();                                    // the previous chunk's MFMA phase has finished reading LDS
+        // ---- stage the coarse window of this chunk's 16 channels + this chunk's packed 3x3 weights ----
+        for (int idx = tid; idx < CCH * SS; idx += 256) {
+            const int c = idx / SS, r = idx % SS;
+            const int py = wy0 + r / SW, px = wx0 + r % SW;
+            float v = 0.0f;
+            if (py < h && px < w) v = prev[(((size_t)img * FC + cc * CCH + c) * h + py) * w + px];
+            s_src[idx] = v;
+        }
+        {
+            const f32x4* src = reinterpret_cast<const f32x4*>(wp + (size_t)cc * WCH);
+            f32x4* dst = reinterpret_cast<f32x4*>(s_w);
+            for (int idx = tid; idx < WCH / 4; idx += 256) dst[idx] = src[idx];
+        }
+        __syncthreads();
+        // ---- intra tile: upsampled coarse level + lateral 1x1 convolution; zero outside the image (the 3x3 conv's padding) ----
+        if (p < NPIX) {
+#pragma unroll
+            for (int c = 0; c < CCH; ++c) {
+                const int ch = cc * CCH + c;
+                float v = 0.0f;
+                if (inimg) {
+                    float lin = b_in[ch];
+#pragma unroll
+                    for (int j = 0; j < CK; ++j) lin = fmaf(w_in[ch * CK + j], lv[j], lin);
+                    const float* S = s_src + c * SS;
+                    const float up = ly0 * (lx0 * S[o00] + lx1 * S[o01]) + ly1 * (lx0 * S[o10] + lx1 * S[o11]);
+                    v = up + lin;
+                }
+                s_tile[c * CS + p] = v;
+            }
+        }
+        __syncthreads();
+        if (intra_out) {                                    // interior of the tile -> NCHW, 128-byte row segments
+#pragma unroll
+            for (int i = 0; i < CCH * TH * TW / 256; ++i) {
+                const int idx = tid + i * 256;
+                const int col = idx % TW, row = (idx / TW) % TH, c = idx / (TW * TH);
+                const int yy = y0 + row, xx = x0 + col;
+                if (yy < H && xx < W)
+                    intra_out[(((size_t)img * FC + cc * CCH + c) * H + yy) * W + xx] = s_tile[c * CS + (row + 1) * HC + col + 1];
+            }
+        }
+        // ---- 3x3 convolution of this chunk on the matrix cores ----
+#pragma unroll
+        for (int ks = 0; ks < CCH / 4; ++ks) {
+            const float* abase = s_tile + (ks * 4 + kk) * CS + i16;
+            const float* bbase = s_w + (size_t)(ks * T * 4 + kk) * NP + i16;
+            if constexpr (ROWS2) {
+                const int pq = wv >> 1, mt = wv & 1;        // output row pair, 16-column half
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float a = abase[(2 * pq + j) * HC + mt * 16 + kx];
+                        const float b = bbase[(j * 3 + kx) * 4 * NP];
+                        acc[0][0] = mfma4(a, b, acc[0][0]);
+                    }
+            } else {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float a[MT];
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) a[t] = abase[(wv + ky) * HC + t * 16 + kx];
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            const float b = bbase[(ky * 3 + kx) * 4 * NP + n * 16];
+#pragma unroll
+                            for (int t = 0; t < MT; ++t) acc[t][n] = mfma4(a[t], b, acc[t][n]);
+                        }
+                    }
+            }
+        }
+    }
+
+    // ---- epilogue: BatchNorm (folded with the conv bias) + Swish, channel-last store ----
+    if constexpr (ROWS2) {
+        const int pq = wv >> 1, mt = wv & 1, co = i16 & 7, yy = y0 + 2 * pq + (i16 >> 3);
+        const float sc = scale[co], sh = shift[co];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int xx = x0 + mt * 16 + 4 * kk + r;
+            if (yy < H && xx < W) out[(((size_t)img * H + yy) * W + xx) * CK + co] = swish(fmaf(acc[0][0][r], sc, sh));
+        }
+    } else {
+        const int yy = y0 + wv;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = n * 16 + i16;
+            const float sc = scale[co], sh = shift[co];
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int xx = x0 + t * 16 + 4 * kk + r;
+                    if (yy < H && xx < W) out[(((size_t)img * H + yy) * W + xx) * CK + co] = swish(fmaf(acc[t][n][r], sc, sh));
+                }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int64_t mvs_fpn_packed_floats(int Cout) {
+    if (Cout != 8 && Cout != 16 && Cout != 32) return -1;
+    return (int64_t)(FC / CCH) * fpn_chunk_floats(Cout);
+}
+
+extern "C" int mvs_fpn_pack_weights(const float* w, int Cout, float* packed, mvs_stream_t stream) {
+    MVS_REQUIRE(w && packed, "mvs_fpn_pack_weights: null pointer");
+    MVS_REQUIRE(Cout == 8 || Cout == 16 || Cout == 32, "mvs_fpn_pack_weights: Cout must be 8, 16 or 32 (got %d)", Cout);
+    const int total = (int)mvs_fpn_packed_floats(Cout);
+    hipLaunchKernelGGL(fpn_pack_kernel, dim3(mvs::ceil_div(total, 256)), dim3(256), 0, MVS_STREAM(stream), w, Cout, packed);
+    return mvs::finish_launch("mvs_fpn_pack_weights");
+}
+
+extern "C" int mvs_fpn_out0(const float* x, const float* w, const float* scale, const float* shift, int N, int h, int wd, float* out,
+                            mvs_stream_t stream) {
+    MVS_REQUIRE(x && w && scale && shift && out, "mvs_fpn_out0: null pointer");
+    MVS_REQUIRE(N >= 1 && N <= 65535 && h >= 1 && wd >= 1, "mvs_fpn_out0: bad shape N=%d h=%d w=%d", N, h, wd);
+    const int hw = h * wd;
+    hipLaunchKernelGGL(fpn_out0_kernel, dim3(mvs::ceil_div(hw, 64), N), dim3(64), 0, MVS_STREAM(stream), x, w, scale, shift, hw, out);
+    return mvs::finish_launch("mvs_fpn_out0");
+}
+
+extern "C" int mvs_fpn_level(const float* intra_prev, const float* lateral, const float* w_inner, const float* b_inner,
+                             const float* w_packed, const float* scale, const float* shift, int N, int Ck, int h, int w,
+                             float* intra_out, float* out, mvs_stream_t stream) {
+    MVS_REQUIRE(intra_prev && lateral && w_inner && b_inner && w_packed && scale && shift && out, "mvs_fpn_level: null pointer");
+    MVS_REQUIRE(Ck == 8 || Ck == 16 || Ck == 32, "mvs_fpn_level: lateral channels must be 8, 16 or 32 (got %d)", Ck);
+    MVS_REQUIRE(N >= 1 && N <= 65535 && h >= 1 && w >= 1 && (int64_t)2 * h <= 4 * 65535, "mvs_fpn_level: bad shape N=%d h=%d w=%d", N, h, w);
+    const dim3 grid(mvs::ceil_div(2 * w, TW), mvs::ceil_div(2 * h, TH), N), block(256);
+    hipStream_t s = MVS_STREAM(stream);
+    if (Ck == 8)
+        hipLaunchKernelGGL(fpn_level_kernel<8>, grid, block, 0, s, intra_prev, lateral, w_inner, b_inner, w_packed, scale, shift, h, w, intra_out, out);
+    else if (Ck == 16)
+        hipLaunchKernelGGL(fpn_level_kernel<16>, grid, block, 0, s, intra_prev, lateral, w_inner, b_inner, w_packed, scale, shift, h, w, intra_out, out);
+    else
+        hipLaunchKernelGGL(fpn_level_kernel<32>, grid, block, 0, s, intra_prev, lateral, w_inner, b_inner, w_packed, scale, shift, h, w, intra_out, out);
+    return mvs::finish_launch("mvs_fpn_level");
+}

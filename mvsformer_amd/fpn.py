@@ -1,0 +1,82 @@
+"""``FPNDecoder`` with the reference's interface (models/module.py:242-270) on the MI355X path — the step that hands the four
+feature maps to the plane sweeps.
+
+Same constructor argument, same parameter / buffer names (``out0.0.weight``, ``out0.1.running_mean``, ``inner1.bias`` ...), so
+``load_state_dict`` of a reference checkpoint's ``decoder.*`` keys works unchanged.  ``forward`` is different code: one HIP
+kernel per level (``csrc/fpn.hip``) fuses the bilinear x2 upsampling, the lateral 1x1 convolution, the 3x3 output convolution,
+eval-mode BatchNorm and Swish; the full-resolution 64-channel ``intra_feat`` of the reference is never written.
+
+The returned maps have the reference's logical shape ``[N,C,H,W]`` but CHANNEL-LAST memory (they are ``permute`` views of
+``[N,H,W,C]`` buffers), which is what the sweeps gather from: ``ops.to_channels_last`` passes such a tensor through without a
+copy, so the reference's ``features['stageK'] = feat.reshape(B,V,C,H,W)`` hand-over costs nothing.
+
+Eval mode only: training the 2-D feature extractor is outside the hot path; ``forward`` in training mode raises.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .module import _publish_cache, _versions
+
+
+class Swish(nn.Module):
+    """Parameterless placeholder (models/module.py:200-206) so that ``nn.Sequential`` indices match the reference's keys; the
+    activation itself runs in the kernels' epilogues."""
+
+    def forward(self, x):
+        raise _lib.MvsHipError("Swish is a structural placeholder of FPNDecoder: call the decoder")
+
+
+class FPNDecoder(nn.Module):
+    def __init__(self, feat_chs):
+        super().__init__()
+        feat_chs = list(feat_chs)
+        if feat_chs != [8, 16, 32, 64]:
+            raise _lib.MvsHipError("FPNDecoder: the HIP path is built for feat_chs=[8,16,32,64] (every shipped config), got %s" % feat_chs)
+        final_ch = feat_chs[-1]
+        self.out0 = nn.Sequential(nn.Conv2d(final_ch, feat_chs[3], kernel_size=1), nn.BatchNorm2d(feat_chs[3]), Swish())
+        self.inner1 = nn.Conv2d(feat_chs[2], final_ch, 1)
+        self.out1 = nn.Sequential(nn.Conv2d(final_ch, feat_chs[2], kernel_size=3, padding=1), nn.BatchNorm2d(feat_chs[2]), Swish())
+        self.inner2 = nn.Conv2d(feat_chs[1], final_ch, 1)
+        self.out2 = nn.Sequential(nn.Conv2d(final_ch, feat_chs[1], kernel_size=3, padding=1), nn.BatchNorm2d(feat_chs[1]), Swish())
+        self.inner3 = nn.Conv2d(feat_chs[0], final_ch, 1)
+        self.out3 = nn.Sequential(nn.Conv2d(final_ch, feat_chs[0], kernel_size=3, padding=1), nn.BatchNorm2d(feat_chs[0]), Swish())
+        self._cache = None
+
+    @staticmethod
+    def _fold(seq: nn.Sequential):
+        """BatchNorm2d (eval) + conv bias -> per-channel (scale, shift), in float64 on the way."""
+        conv, bn = seq[0], seq[1]
+        scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.double() + bn.eps)
+        shift = bn.bias.detach().double() + (conv.bias.detach().double() - bn.running_mean.double()) * scale
+        return scale.float().contiguous(), shift.float().contiguous()
+
+    def _prepared(self):
+        key = _versions(self)
+        if self._cache is None or self._cache[0] != key:
+            levels = []
+            for k in (1, 2, 3):
+                inner, seq = getattr(self, "inner%d" % k), getattr(self, "out%d" % k)
+                scale, shift = self._fold(seq)
+                levels.append((inner.weight.detach().reshape(ops.FPN_CH, -1).contiguous(), inner.bias.detach().contiguous(),
+                               ops.fpn_pack_weights(seq[0].weight.detach().contiguous()), scale, shift))
+            s0, h0 = self._fold(self.out0)
+            _publish_cache()
+            self._cache = (key, (self.out0[0].weight.detach().reshape(ops.FPN_CH, ops.FPN_CH).contiguous(), s0, h0), levels)
+        return self._cache[1], self._cache[2]
+
+    def forward(self, conv01, conv11, conv21, conv31):
+        if self.training:
+            raise _lib.MvsHipError("FPNDecoder: only eval mode is built on the HIP path (training the 2-D feature extractor is "
+                                   "outside the hot path, SURVEY.md §8); call .eval()")
+        with torch.no_grad():
+            (w0, s0, h0), levels = self._prepared()
+            intra = conv31.float().contiguous()
+            outs = [ops.fpn_out0(intra, w0, s0, h0)]
+            for i, lateral in enumerate((conv21, conv11, conv01)):
+                w_in, b_in, packed, scale, shift = levels[i]
+                intra, out = ops.fpn_level(intra, lateral.float().contiguous(), w_in, b_in, packed, scale, shift, want_intra=(i < 2))
+                outs.append(out)
+        return [o.permute(0, 3, 1, 2) for o in outs]

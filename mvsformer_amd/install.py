@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import importlib
 
+from . import fpn as _f
 from . import module as _m
 from . import stagenet as _s
 from . import warping as _w
@@ -25,6 +26,7 @@ _SYMBOLS = {
     "init_inverse_range": _m.init_inverse_range,
     "schedule_inverse_range": _m.schedule_inverse_range,
     "homo_warping_3D_with_mask": _w.homo_warping_3D_with_mask,
+    "FPNDecoder": _f.FPNDecoder,
 }
 
 

@@ -932,3 +932,51 @@ def bf16_bn_bwd_apply(dy, x, scale, shift, mean, invstd, gamma, sums, count, rel
     _call("mvs_bf16_bn_bwd_apply", "bf16_bn_bwd_apply", _ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _ptr(gamma),
           _ptr(sums), float(count), _ptr(count_dev), int(relu), C, R, groups, rps, _ptr(dx), _stream())
     return dx
+
+
+# ----------------------------------------------------------------------------------------------- FPN decoder (row before the path)
+FPN_CH = 64
+
+
+def fpn_pack_weights(w: torch.Tensor) -> torch.Tensor:
+    """``out_k.0.weight [Cout,64,3,3]`` (Cout 8 | 16 | 32) -> the MFMA-fragment image ``mvs_fpn_level`` stages through LDS."""
+    _chk(w, "fpn 3x3 weight")
+    Cout = w.shape[0]
+    if w.shape[1:] != (FPN_CH, 3, 3) or Cout not in (8, 16, 32):
+        raise _lib.MvsHipError("fpn 3x3 weight must be [8|16|32,64,3,3], got %s" % (tuple(w.shape),))
+    packed = torch.empty(int(_lib.load().mvs_fpn_packed_floats(Cout)), device=w.device, dtype=torch.float32)
+    _call("mvs_fpn_pack_weights", None, _ptr(w), Cout, _ptr(packed), _stream())
+    return packed
+
+
+def fpn_out0(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+    """``conv31 [N,64,h,w]`` -> ``Swish(BN(conv1x1)) [N,h,w,64]`` channel-last (reference models/module.py:246,259)."""
+    _chk(x, "conv31"), _chk(w, "out0 weight"), _chk(scale, "scale"), _chk(shift, "shift")
+    N, C, h, wd = x.shape
+    if C != FPN_CH or w.numel() != FPN_CH * FPN_CH or scale.numel() != FPN_CH or shift.numel() != FPN_CH:
+        raise _lib.MvsHipError("fpn_out0: expects 64 channels, got x %s w %s" % (tuple(x.shape), tuple(w.shape)))
+    out = torch.empty(N, h, wd, FPN_CH, device=x.device, dtype=torch.float32)
+    tag = ("fpn_out0_kernel", "flops", 2.0 * FPN_CH * FPN_CH * N * h * wd)
+    _call("mvs_fpn_out0", tag, _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), N, h, wd, _ptr(out), _stream())
+    return out
+
+
+def fpn_level(intra_prev: torch.Tensor, lateral: torch.Tensor, w_inner: torch.Tensor, b_inner: torch.Tensor, packed: torch.Tensor,
+              scale: torch.Tensor, shift: torch.Tensor, want_intra: bool):
+    """One top-down level (models/module.py:262-268): ``(intra_out [N,64,2h,2w] | None, out [N,2h,2w,Ck] channel-last)``."""
+    _chk(intra_prev, "intra_prev"), _chk(lateral, "lateral"), _chk(w_inner, "inner weight"), _chk(b_inner, "inner bias")
+    _chk(packed, "packed weights"), _chk(scale, "scale"), _chk(shift, "shift")
+    N, C, h, w = intra_prev.shape
+    Ck = lateral.shape[1]
+    if C != FPN_CH or lateral.shape != (N, Ck, 2 * h, 2 * w):
+        raise _lib.MvsHipError("fpn_level: intra_prev %s needs a lateral [N,Ck,2h,2w], got %s" % (tuple(intra_prev.shape), tuple(lateral.shape)))
+    if w_inner.numel() != FPN_CH * Ck or b_inner.numel() != FPN_CH or scale.numel() != Ck or shift.numel() != Ck:
+        raise _lib.MvsHipError("fpn_level: parameter sizes do not match Ck=%d" % Ck)
+    if Ck not in (8, 16, 32) or packed.numel() != int(_lib.load().mvs_fpn_packed_floats(Ck)):
+        raise _lib.MvsHipError("fpn_level: Ck=%d / packed weights of %d floats are not a supported pair" % (Ck, packed.numel()))
+    intra = torch.empty(N, FPN_CH, 2 * h, 2 * w, device=lateral.device, dtype=torch.float32) if want_intra else None
+    out = torch.empty(N, 2 * h, 2 * w, Ck, device=lateral.device, dtype=torch.float32)
+    tag = ("fpn_level_kernel<%d>" % Ck, "flops", 2.0 * FPN_CH * Ck * 10 * N * 4 * h * w)
+    _call("mvs_fpn_level", tag, _ptr(intra_prev), _ptr(lateral), _ptr(w_inner), _ptr(b_inner), _ptr(packed), _ptr(scale), _ptr(shift),
+          N, Ck, h, w, _ptr(intra), _ptr(out), _stream())
+    return intra, out
