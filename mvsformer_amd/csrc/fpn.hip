@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void fpn_level_kernel(const float* __restrict_
     const float sy = (float)(h - 1) / (float)(H - 1), sx = (float)(w - 1) / (float)(W - 1);
     const int wy0 = (int)(sy * (float)max(y0 - 1, 0)), wx0 = (int)(sx * (float)max(x0 - 1, 0));
     int o00 = 0, o01 = 0, o10 = 0, o11 = 0;
-    float ly0 = 0.f, ly1 = 0.f, lx0 = 0.f, lx1 = 0.f;
+    float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
     float lv[CK];
 #pragma unroll
     for (int j = 0; j < CK; ++j) lv[j] = 0.0f;
@@ -117,10 +117,11 @@ __global__ __launch_bounds__(256) void fpn_level_kernel(const float* __restrict_
         const float fy = sy * (float)gy, fx = sx * (float)gx;
         const int iy0 = (int)fy, ix0 = (int)fx;
         const int iy1 = iy0 + (iy0 < h - 1 ? 1 : 0), ix1 = ix0 + (ix0 < w - 1 ? 1 : 0);
-        ly1 = fy - (float)iy0;
-        lx1 = fx - (float)ix0;
-        ly0 = 1.0f - ly1;
-        lx0 = 1.0f - lx1;
+        const float ly1 = fy - (float)iy0, lx1 = fx - (float)ix0, ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+        w00 = ly0 * lx0;
+        w01 = ly0 * lx1;
+        w10 = ly1 * lx0;
+        w11 = ly1 * lx1;
         const int ry0 = min(iy0 - wy0, SH - 1), ry1 = min(iy1 - wy0, SH - 1), rx0 = min(ix0 - wx0, SW - 1), rx1 = min(ix1 - wx0, SW - 1);
         o00 = ry0 * SW + rx0;
         o01 = ry0 * SW + rx1;
@@ -131,28 +132,49 @@ __global__ __launch_bounds__(256) void fpn_level_kernel(const float* __restrict_
         for (int j = 0; j < CK; ++j) lv[j] = lp[(size_t)j * H * W];
     }
 
+    // ---- staging roles: thread = (window slot r, channel parity); the slot's global offset is the same for every chunk ----
+    const int sr = tid & 127, shalf = tid >> 7;
+    const int spy = wy0 + sr / SW, spx = wx0 + sr % SW;
+    const bool svalid = sr < SS && spy < h && spx < w;
+    const float* sbase = prev + (size_t)img * FC * h * w + (svalid ? (size_t)spy * w + spx : 0);
+    constexpr int NSR = CCH / 2, NWV = (WCH / 4 + 255) / 256;
+    float sreg[NSR];
+    f32x4 wreg[NWV];
+    auto prefetch = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < NSR; ++i) sreg[i] = svalid ? sbase[(size_t)(cc * CCH + 2 * i + shalf) * h * w] : 0.0f;
+        const f32x4* src = reinterpret_cast<const f32x4*>(wp + (size_t)cc * WCH);
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + i * 256;
+            wreg[i] = (idx < WCH / 4) ? src[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&]() {
+        if (sr < SS) {
+#pragma unroll
+            for (int i = 0; i < NSR; ++i) s_src[(2 * i + shalf) * SS + sr] = sreg[i];
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(s_w);
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < WCH / 4) dst[idx] = wreg[i];
+        }
+    };
+
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    prefetch(0);
     for (int cc = 0; cc < FC / CCH; ++cc) {
         __syncthreads();                                    // the previous chunk's MFMA phase has finished reading LDS
-        // ---- stage the coarse window of this chunk's 16 channels + this chunk's packed 3x3 weights ----
-        for (int idx = tid; idx < CCH * SS; idx += 256) {
-            const int c = idx / SS, r = idx % SS;
-            const int py = wy0 + r / SW, px = wx0 + r % SW;
-            float v = 0.0f;
-            if (py < h && px < w) v = prev[(((size_t)img * FC + cc * CCH + c) * h + py) * w + px];
-            s_src[idx] = v;
-        }
-        {
-            const f32x4* src = reinterpret_cast<const f32x4*>(wp + (size_t)cc * WCH);
-            f32x4* dst = reinterpret_cast<f32x4*>(s_w);
-            for (int idx = tid; idx < WCH / 4; idx += 256) dst[idx] = src[idx];
-        }
+        commit();                                           // coarse window of this chunk's 16 channels + its packed 3x3 weights
         __syncthreads();
+        if (cc + 1 < FC / CCH) prefetch(cc + 1);            // in flight during this chunk's two phases
         // ---- intra tile: upsampled coarse level + lateral 1x1 convolution; zero outside the image (the 3x3 conv's padding) ----
         if (p < NPIX) {
 #pragma unroll
@@ -164,8 +186,7 @@ __global__ __launch_bounds__(256) void fpn_level_kernel(const float* __restrict_
 #pragma unroll
                     for (int j = 0; j < CK; ++j) lin = fmaf(w_in[ch * CK + j], lv[j], lin);
                     const float* S = s_src + c * SS;
-                    const float up = ly0 * (lx0 * S[o00] + lx1 * S[o01]) + ly1 * (lx0 * S[o10] + lx1 * S[o11]);
-                    v = up + lin;
+                    v = fmaf(w11, S[o11], fmaf(w10, S[o10], fmaf(w01, S[o01], fmaf(w00, S[o00], lin))));
                 }
                 s_tile[c * CS + p] = v;
             }
