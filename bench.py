@@ -253,6 +253,30 @@ def main(args):
             del f2, p2, d2, o2
             torch.cuda.empty_cache()
 
+    # ---- the row before the path: FPN decoder emitting channel-last features, timed beside the path (extra key) ----
+    before = None
+    if rank == 0 and world == 1 and not args.no_other_configs:
+        from mvsformer_amd import FPNDecoder
+        torch.manual_seed(0)
+        dec = FPNDecoder([8, 16, 32, 64]).eval().to(dev)
+        enc = [torch.randn(args.views, c, args.height >> i, args.width >> i, device=dev) for i, c in enumerate((8, 16, 32, 64))]
+        for _ in range(3):
+            dec(*enc)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            outs = dec(*enc)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        flops = sum(2.0 * 64 * c * 10 * args.views * (args.height >> i) * (args.width >> i) for i, c in enumerate((8, 16, 32)))
+        ms = e0.elapsed_time(e1) / 20
+        before = {"fpn_decoder_ms_per_depth_map": round(ms, 3), "algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 1),
+                  "peak_tflops_fp32_mfma": 157.3, "outputs": "channel-last [N,H,W,C]: consumed by the sweeps without nchw_to_nhwc",
+                  "note": "FPNDecoder.forward (models/module.py:257-270), eval BatchNorm, %d views, random encoder outputs; not in `value`" % args.views}
+        del dec, enc, outs
+        torch.cuda.empty_cache()
+
     if rank == 0:
         total = world * args.steps * args.batch
         line = {
@@ -266,7 +290,7 @@ def main(args):
                        "streams_per_gpu": args.streams, "features_layout": args.features_layout,
                        "reference_views_per_step": args.batch},
             "roofline": roofline, "roofline_cost_volume": roofline_cv, "cpu_baseline": cpu,
-            "kernel_ms_sum": round(sum(e["ms_per_step"] for e in kernels), 3), "other_configs": other, "kernels": kernels,
+            "kernel_ms_sum": round(sum(e["ms_per_step"] for e in kernels), 3), "other_configs": other, "before_the_path": before, "kernels": kernels,
         }
         print(json.dumps(line))
     if world > 1:

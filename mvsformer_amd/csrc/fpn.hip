@@ -170,6 +170,13 @@ __global__ __launch_bounds__(256) void fpn_level_kernel(const float* __restrict_
         for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     prefetch(0);
+    {   // consume the lateral values once BEFORE the loop: otherwise the wait-count pass keeps them "pending" around the back edge
+        // and every chunk's first use waits vmcnt down to 0 - which also drains the (younger) prefetch of the next chunk
+        float guard = 0.0f;
+#pragma unroll
+        for (int j = 0; j < CK; ++j) guard += lv[j];
+        asm volatile("" ::"v"(guard));
+    }
     for (int cc = 0; cc < FC / CCH; ++cc) {
         __syncthreads();                                    // the previous chunk's MFMA phase has finished reading LDS
         commit();                                           // coarse window of this chunk's 16 channels + its packed 3x3 weights

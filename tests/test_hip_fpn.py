@@ -100,3 +100,25 @@ def test_fpn_decoder_full_size_vs_torch_on_gpu():
         err = float((o - ww).abs().max() / ww.abs().max())
         assert err < 1e-4, (i, err)
     assert np.isfinite(float(outs[3].sum()))
+
+
+@pytest.mark.gpu
+def test_decoder_to_cascade_hand_over_is_bit_identical():
+    """Decoder -> reference-style reshape -> 4-stage cascade: the channel-last maps give exactly the depth that NCHW-contiguous
+    copies of the same values give, with no transpose kernel launched."""
+    import mvsformer_amd as m
+    from mvsformer_amd import ops, synth
+    from oracle import ref_fpn
+    dev = torch.device("cuda:0")
+    B, V, H, W = 1, 3, 64, 128                        # stage 1 (1/8 res) needs H, W divisible by 8 for CostRegNet
+    _, proj, dv, _ = synth.make_inputs(V, H, W, seed=2, device=dev)
+    dec = build_decoder(seed=9).to(dev)
+    outs = dec(*[f.to(dev) for f in ref_fpn.make_case(10, B * V, H // 8, W // 8)])
+    feats = {"stage%d" % (i + 1): o.reshape(B, V, o.shape[1], o.shape[2], o.shape[3]) for i, o in enumerate(outs)}
+    net = m.CascadeMVS().to(dev).eval()
+    m.randomize_bn_(net, seed=1)
+    with ops.kernel_timer() as kt:
+        a = net(feats, proj, dv, tmp=[5.0, 5.0, 5.0, 1.0])
+    assert not any("nchw_to_nhwc" in k for k in kt.events)
+    b = net({k: v.contiguous() for k, v in feats.items()}, proj, dv, tmp=[5.0, 5.0, 5.0, 1.0])
+    assert torch.equal(a["refined_depth"], b["refined_depth"]) and torch.isfinite(a["refined_depth"]).all()
