@@ -348,13 +348,14 @@ int mvs_conf_accumulate(const float* conf, int B, int H, int W, float* acc, int 
  * scale = gamma / sqrt(var + eps), shift = beta + (bias - mean) * scale; the activation is Swish (module.py:200-206).
  *   pack:   w [Cout,64,3,3] (out_k.0.weight, Cout = 8 | 16 | 32) -> packed, mvs_fpn_packed_floats(Cout) floats
  *   out0:   x = conv31 [N,64,h,w], w [64,64] (out0.0.weight) -> out [N,h,w,64]
- *   level:  intra_prev [N,64,h,w], lateral [N,Ck,2h,2w], w_inner [64,Ck] + b_inner [64] (inner_k), packed out_k weights ->
+ *   level:  intra_prev [N,64,h,w], lateral [N,Ck,2h,2w], w_inner_p [32,Ck,2] (inner_k.weight [64,Ck] regrouped by output-channel PAIR:
+ *           w_inner_p[q][j][e] = weight[2q+e][j], one scalar load per pair for the packed fp32 pipe) + b_inner [64], packed out_k weights ->
  *           intra_out [N,64,2h,2w] (NULL for the last level: it is only ever consumed inside this kernel) and out [N,2h,2w,Ck] */
 int64_t mvs_fpn_packed_floats(int Cout);
 int mvs_fpn_pack_weights(const float* w, int Cout, float* packed, mvs_stream_t stream);
 int mvs_fpn_out0(const float* x, const float* w, const float* scale, const float* shift, int N, int h, int wd, float* out,
                  mvs_stream_t stream);
-int mvs_fpn_level(const float* intra_prev, const float* lateral, const float* w_inner, const float* b_inner, const float* w_packed,
+int mvs_fpn_level(const float* intra_prev, const float* lateral, const float* w_inner_p, const float* b_inner, const float* w_packed,
                   const float* scale, const float* shift, int N, int Ck, int h, int w, float* intra_out, float* out,
                   mvs_stream_t stream);
 

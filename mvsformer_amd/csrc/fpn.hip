@@ -4,7 +4,7 @@
 //     out_k   = Swish(BatchNorm2d(conv3x3(intra_k)))                                                     (64 -> C_k)
 // materializes intra_3 = [N,64,H,W] (453 MB per 1152x1536 view) only to convolve it down to 8 channels.  Here one kernel per
 // level builds the intra tile in LDS (bilinear taps from an LDS-staged window of intra_{k-1}, the lateral 1x1 convolution on
-// the VALU with wave-uniform weights in SGPRs), runs the 3x3 convolution from LDS on the fp32 matrix cores
+// the packed fp32 VALU with wave-uniform weights in SGPRs), runs the 3x3 convolution from LDS on the fp32 matrix cores
 // (v_mfma_f32_16x16x4_f32, same fragment conventions as conv3d.hip) and stores out_k CHANNEL-LAST [N,H,W,C_k] - the layout the
 // sweeps gather from, so the four nchw_to_nhwc passes of the reference layout disappear.  intra_k goes back to HBM only for
 // k < 3 (the next level upsamples it); intra_3 never exists.
@@ -36,6 +36,8 @@ __host__ __device__ constexpr int fpn_taps(int ck) { return ck == 8 ? 12 : 9; }
 __host__ __device__ constexpr int fpn_chunk_floats(int ck) { return 4 * fpn_taps(ck) * 4 * np_of(fpn_nt(ck)); }
 
 __device__ __forceinline__ float swish(float v) { return v / (1.0f + expf(-v)); }
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
 
 // packed image: [slab = cin/4 (16)][tap (9 | 12)][cin%4][NP]; a chunk of 16 input channels = 4 consecutive slabs
 __global__ void fpn_pack_kernel(const float* __restrict__ w /*[Cout,64,3,3]*/, int Cout, float* __restrict__ out) {
@@ -81,8 +83,8 @@ __global__ __launch_bounds__(64) void fpn_out0_kernel(const float* __restrict__ 
 }
 
 template <int CK>
-__global__ __launch_bounds__(256) void fpn_level_kernel(const float* __restrict__ prev /*[N,64,h,w]*/, const float* __restrict__ lat /*[N,CK,2h,2w]*/,
-                                                        const float* __restrict__ w_in /*[64,CK]*/, const float* __restrict__ b_in /*[64]*/,
+__global__ __launch_bounds__(256, (CK == 32 ? 2 : (CK == 16 ? 3 : 4))) void fpn_level_kernel(const float* __restrict__ prev /*[N,64,h,w]*/, const float* __restrict__ lat /*[N,CK,2h,2w]*/,
+                                                        const float* __restrict__ w_in_p /*[32,CK,2]*/, const float* __restrict__ b_in /*[64]*/,
                                                         const float* __restrict__ wp, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int h, int w,
                                                         float* __restrict__ intra_out /*[N,64,2h,2w] or null*/,
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(256) void fpn_level_kernel(const float* __restrict_
     const int wy0 = (int)(sy * (float)max(y0 - 1, 0)), wx0 = (int)(sx * (float)max(x0 - 1, 0));
     int o00 = 0, o01 = 0, o10 = 0, o11 = 0;
     float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
+    const float gate = inimg ? 1.0f : 0.0f;
     float lv[CK];
 #pragma unroll
     for (int j = 0; j < CK; ++j) lv[j] = 0.0f;
@@ -183,19 +186,23 @@ __global__ __launch_bounds__(256) void fpn_level_kernel(const float* __restrict_
         __syncthreads();
         if (cc + 1 < FC / CCH) prefetch(cc + 1);            // in flight during this chunk's two phases
         // ---- intra tile: upsampled coarse level + lateral 1x1 convolution; zero outside the image (the 3x3 conv's padding) ----
+        // two channels per step on the packed fp32 pipe (v_pk_fma_f32): the pair's lateral weights are 2*CK consecutive floats of w_in_p, the pair's
+        // window values arrive as one ds_read2_b32.  Branch-free: a pixel outside the image has zero taps, zero lateral values, gate 0.
         if (p < NPIX) {
 #pragma unroll
-            for (int c = 0; c < CCH; ++c) {
+            for (int c = 0; c < CCH; c += 2) {
                 const int ch = cc * CCH + c;
-                float v = 0.0f;
-                if (inimg) {
-                    float lin = b_in[ch];
+                f32x2 v = f32x2{b_in[ch], b_in[ch + 1]} * f32x2{gate, gate};
 #pragma unroll
-                    for (int j = 0; j < CK; ++j) lin = fmaf(w_in[ch * CK + j], lv[j], lin);
-                    const float* S = s_src + c * SS;
-                    v = fmaf(w11, S[o11], fmaf(w10, S[o10], fmaf(w01, S[o01], fmaf(w00, S[o00], lin))));
-                }
-                s_tile[c * CS + p] = v;
+                for (int j = 0; j < CK; ++j) v = pk_fma(f32x2{w_in_p[(ch * CK) + 2 * j], w_in_p[(ch * CK) + 2 * j + 1]}, f32x2{lv[j], lv[j]}, v);
+                const float* S = s_src + c * SS;
+                v = pk_fma(f32x2{w00, w00}, f32x2{S[o00], S[SS + o00]}, v);
+                v = pk_fma(f32x2{w01, w01}, f32x2{S[o01], S[SS + o01]}, v);
+                v = pk_fma(f32x2{w10, w10}, f32x2{S[o10], S[SS + o10]}, v);
+                v = pk_fma(f32x2{w11, w11}, f32x2{S[o11], S[SS + o11]}, v);
+                s_tile[c * CS + p] = v.x;
+                s_tile[(c + 1) * CS + p] = v.y;
+                if (c % 4 == 2) __builtin_amdgcn_sched_barrier(0);      // else all 16 channels' window reads are hoisted (187 VGPRs)
             }
         }
         __syncthreads();
@@ -292,19 +299,19 @@ extern "C" int mvs_fpn_out0(const float* x, const float* w, const float* scale, 
     return mvs::finish_launch("mvs_fpn_out0");
 }
 
-extern "C" int mvs_fpn_level(const float* intra_prev, const float* lateral, const float* w_inner, const float* b_inner,
+extern "C" int mvs_fpn_level(const float* intra_prev, const float* lateral, const float* w_inner_p, const float* b_inner,
                              const float* w_packed, const float* scale, const float* shift, int N, int Ck, int h, int w,
                              float* intra_out, float* out, mvs_stream_t stream) {
-    MVS_REQUIRE(intra_prev && lateral && w_inner && b_inner && w_packed && scale && shift && out, "mvs_fpn_level: null pointer");
+    MVS_REQUIRE(intra_prev && lateral && w_inner_p && b_inner && w_packed && scale && shift && out, "mvs_fpn_level: null pointer");
     MVS_REQUIRE(Ck == 8 || Ck == 16 || Ck == 32, "mvs_fpn_level: lateral channels must be 8, 16 or 32 (got %d)", Ck);
     MVS_REQUIRE(N >= 1 && N <= 65535 && h >= 1 && w >= 1 && (int64_t)2 * h <= 4 * 65535, "mvs_fpn_level: bad shape N=%d h=%d w=%d", N, h, w);
     const dim3 grid(mvs::ceil_div(2 * w, TW), mvs::ceil_div(2 * h, TH), N), block(256);
     hipStream_t s = MVS_STREAM(stream);
     if (Ck == 8)
-        hipLaunchKernelGGL(fpn_level_kernel<8>, grid, block, 0, s, intra_prev, lateral, w_inner, b_inner, w_packed, scale, shift, h, w, intra_out, out);
+        hipLaunchKernelGGL(fpn_level_kernel<8>, grid, block, 0, s, intra_prev, lateral, w_inner_p, b_inner, w_packed, scale, shift, h, w, intra_out, out);
     else if (Ck == 16)
-        hipLaunchKernelGGL(fpn_level_kernel<16>, grid, block, 0, s, intra_prev, lateral, w_inner, b_inner, w_packed, scale, shift, h, w, intra_out, out);
+        hipLaunchKernelGGL(fpn_level_kernel<16>, grid, block, 0, s, intra_prev, lateral, w_inner_p, b_inner, w_packed, scale, shift, h, w, intra_out, out);
     else
-        hipLaunchKernelGGL(fpn_level_kernel<32>, grid, block, 0, s, intra_prev, lateral, w_inner, b_inner, w_packed, scale, shift, h, w, intra_out, out);
+        hipLaunchKernelGGL(fpn_level_kernel<32>, grid, block, 0, s, intra_prev, lateral, w_inner_p, b_inner, w_packed, scale, shift, h, w, intra_out, out);
     return mvs::finish_launch("mvs_fpn_level");
 }

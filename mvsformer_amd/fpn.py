@@ -60,7 +60,7 @@ class FPNDecoder(nn.Module):
             for k in (1, 2, 3):
                 inner, seq = getattr(self, "inner%d" % k), getattr(self, "out%d" % k)
                 scale, shift = self._fold(seq)
-                levels.append((inner.weight.detach().reshape(ops.FPN_CH, -1).contiguous(), inner.bias.detach().contiguous(),
+                levels.append((inner.weight.detach().reshape(ops.FPN_CH // 2, 2, -1).permute(0, 2, 1).contiguous(), inner.bias.detach().contiguous(),
                                ops.fpn_pack_weights(seq[0].weight.detach().contiguous()), scale, shift))
             s0, h0 = self._fold(self.out0)
             _publish_cache()

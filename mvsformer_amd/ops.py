@@ -961,22 +961,23 @@ def fpn_out0(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift: torch
     return out
 
 
-def fpn_level(intra_prev: torch.Tensor, lateral: torch.Tensor, w_inner: torch.Tensor, b_inner: torch.Tensor, packed: torch.Tensor,
+def fpn_level(intra_prev: torch.Tensor, lateral: torch.Tensor, w_inner_p: torch.Tensor, b_inner: torch.Tensor, packed: torch.Tensor,
               scale: torch.Tensor, shift: torch.Tensor, want_intra: bool):
-    """One top-down level (models/module.py:262-268): ``(intra_out [N,64,2h,2w] | None, out [N,2h,2w,Ck] channel-last)``."""
-    _chk(intra_prev, "intra_prev"), _chk(lateral, "lateral"), _chk(w_inner, "inner weight"), _chk(b_inner, "inner bias")
+    """One top-down level (models/module.py:262-268): ``(intra_out [N,64,2h,2w] | None, out [N,2h,2w,Ck] channel-last)``.
+    ``w_inner_p`` is ``inner_k.weight [64,Ck]`` regrouped by output-channel pair: ``[32,Ck,2]`` (include/mvs_hip.h)."""
+    _chk(intra_prev, "intra_prev"), _chk(lateral, "lateral"), _chk(w_inner_p, "inner weight"), _chk(b_inner, "inner bias")
     _chk(packed, "packed weights"), _chk(scale, "scale"), _chk(shift, "shift")
     N, C, h, w = intra_prev.shape
     Ck = lateral.shape[1]
     if C != FPN_CH or lateral.shape != (N, Ck, 2 * h, 2 * w):
         raise _lib.MvsHipError("fpn_level: intra_prev %s needs a lateral [N,Ck,2h,2w], got %s" % (tuple(intra_prev.shape), tuple(lateral.shape)))
-    if w_inner.numel() != FPN_CH * Ck or b_inner.numel() != FPN_CH or scale.numel() != Ck or shift.numel() != Ck:
+    if w_inner_p.shape != (FPN_CH // 2, Ck, 2) or b_inner.numel() != FPN_CH or scale.numel() != Ck or shift.numel() != Ck:
         raise _lib.MvsHipError("fpn_level: parameter sizes do not match Ck=%d" % Ck)
     if Ck not in (8, 16, 32) or packed.numel() != int(_lib.load().mvs_fpn_packed_floats(Ck)):
         raise _lib.MvsHipError("fpn_level: Ck=%d / packed weights of %d floats are not a supported pair" % (Ck, packed.numel()))
     intra = torch.empty(N, FPN_CH, 2 * h, 2 * w, device=lateral.device, dtype=torch.float32) if want_intra else None
     out = torch.empty(N, 2 * h, 2 * w, Ck, device=lateral.device, dtype=torch.float32)
     tag = ("fpn_level_kernel<%d>" % Ck, "flops", 2.0 * FPN_CH * Ck * 10 * N * 4 * h * w)
-    _call("mvs_fpn_level", tag, _ptr(intra_prev), _ptr(lateral), _ptr(w_inner), _ptr(b_inner), _ptr(packed), _ptr(scale), _ptr(shift),
+    _call("mvs_fpn_level", tag, _ptr(intra_prev), _ptr(lateral), _ptr(w_inner_p), _ptr(b_inner), _ptr(packed), _ptr(scale), _ptr(shift),
           N, Ck, h, w, _ptr(intra), _ptr(out), _stream())
     return intra, out
