@@ -35,7 +35,8 @@ __host__ __device__ constexpr int fpn_nt(int ck) { return ck == 32 ? 2 : 1; }
 __host__ __device__ constexpr int fpn_taps(int ck) { return ck == 8 ? 12 : 9; }
 __host__ __device__ constexpr int fpn_chunk_floats(int ck) { return 4 * fpn_taps(ck) * 4 * np_of(fpn_nt(ck)); }
 
-__device__ __forceinline__ float swish(float v) { return v / (1.0f + expf(-v)); }
+// x * sigmoid(x) with the hardware exp2 / reciprocal (a few ulp; the epilogue shares the fp32 pipe with the MFMAs, an IEEE divide costs 10 slots)
+__device__ __forceinline__ float swish(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
 
@@ -130,22 +131,25 @@ __global__ __launch_bounds__(256, (CK == 32 ? 2 : (CK == 16 ? 3 : 4))) void fpn_
         o01 = ry0 * SW + rx1;
         o10 = ry1 * SW + rx0;
         o11 = ry1 * SW + rx1;
-        const float* lp = lat + ((size_t)img * CK * H + gy) * W + gx;
+        // wave-uniform 64-bit base + 32-bit lane offset: the loads take the saddr form, no per-lane 64-bit address arithmetic
+        const float* lat_img = lat + (size_t)img * CK * H * W;
+        const unsigned lo = (unsigned)(gy * W + gx), HW = (unsigned)(H * W);
 #pragma unroll
-        for (int j = 0; j < CK; ++j) lv[j] = lp[(size_t)j * H * W];
+        for (int j = 0; j < CK; ++j) lv[j] = lat_img[j * HW + lo];
     }
 
     // ---- staging roles: thread = (window slot r, channel parity); the slot's global offset is the same for every chunk ----
     const int sr = tid & 127, shalf = tid >> 7;
     const int spy = wy0 + sr / SW, spx = wx0 + sr % SW;
     const bool svalid = sr < SS && spy < h && spx < w;
-    const float* sbase = prev + (size_t)img * FC * h * w + (svalid ? (size_t)spy * w + spx : 0);
+    const float* prev_img = prev + (size_t)img * FC * h * w;
+    const unsigned hw = (unsigned)(h * w), soff = svalid ? (unsigned)(shalf * (h * w) + spy * w + spx) : 0u;
     constexpr int NSR = CCH / 2, NWV = (WCH / 4 + 255) / 256;
     float sreg[NSR];
     f32x4 wreg[NWV];
     auto prefetch = [&](int cc) {
 #pragma unroll
-        for (int i = 0; i < NSR; ++i) sreg[i] = svalid ? sbase[(size_t)(cc * CCH + 2 * i + shalf) * h * w] : 0.0f;
+        for (int i = 0; i < NSR; ++i) sreg[i] = svalid ? prev_img[(unsigned)(cc * CCH + 2 * i) * hw + soff] : 0.0f;
         const f32x4* src = reinterpret_cast<const f32x4*>(wp + (size_t)cc * WCH);
 #pragma unroll
         for (int i = 0; i < NWV; ++i) {
@@ -213,14 +217,14 @@ __global__ __launch_bounds__(256, (CK == 32 ? 2 : (CK == 16 ? 3 : 4))) void fpn_
                 const int col = idx % TW, row = (idx / TW) % TH, c = idx / (TW * TH);
                 const int yy = y0 + row, xx = x0 + col;
                 if (yy < H && xx < W)
-                    intra_out[(((size_t)img * FC + cc * CCH + c) * H + yy) * W + xx] = s_tile[c * CS + (row + 1) * HC + col + 1];
+                    intra_out[(size_t)img * FC * H * W + (unsigned)(((cc * CCH + c) * H + yy) * W + xx)] = s_tile[c * CS + (row + 1) * HC + col + 1];
             }
         }
         // ---- 3x3 convolution of this chunk on the matrix cores ----
 #pragma unroll
         for (int ks = 0; ks < CCH / 4; ++ks) {
             const float* abase = s_tile + (ks * 4 + kk) * CS + i16;
-            const float* bbase = s_w + (size_t)(ks * T * 4 + kk) * NP + i16;
+            const float* bbase = s_w + (ks * T * 4 + kk) * NP + i16;
             if constexpr (ROWS2) {
                 const int pq = wv >> 1, mt = wv & 1;        // output row pair, 16-column half
 #pragma unroll
@@ -251,13 +255,14 @@ __global__ __launch_bounds__(256, (CK == 32 ? 2 : (CK == 16 ? 3 : 4))) void fpn_
     }
 
     // ---- epilogue: BatchNorm (folded with the conv bias) + Swish, channel-last store ----
+    float* out_img = out + (size_t)img * H * W * CK;
     if constexpr (ROWS2) {
         const int pq = wv >> 1, mt = wv & 1, co = i16 & 7, yy = y0 + 2 * pq + (i16 >> 3);
         const float sc = scale[co], sh = shift[co];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int xx = x0 + mt * 16 + 4 * kk + r;
-            if (yy < H && xx < W) out[(((size_t)img * H + yy) * W + xx) * CK + co] = swish(fmaf(acc[0][0][r], sc, sh));
+            if (yy < H && xx < W) out_img[(unsigned)((yy * W + xx) * CK + co)] = swish(fmaf(acc[0][0][r], sc, sh));
         }
     } else {
         const int yy = y0 + wv;
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(256, (CK == 32 ? 2 : (CK == 16 ? 3 : 4))) void fpn_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int xx = x0 + t * 16 + 4 * kk + r;
-                    if (yy < H && xx < W) out[(((size_t)img * H + yy) * W + xx) * CK + co] = swish(fmaf(acc[t][n][r], sc, sh));
+                    if (yy < H && xx < W) out_img[(unsigned)((yy * W + xx) * CK + co)] = swish(fmaf(acc[t][n][r], sc, sh));
                 }
         }
     }
@@ -305,6 +310,7 @@ extern "C" int mvs_fpn_level(const float* intra_prev, const float* lateral, cons
     MVS_REQUIRE(intra_prev && lateral && w_inner_p && b_inner && w_packed && scale && shift && out, "mvs_fpn_level: null pointer");
     MVS_REQUIRE(Ck == 8 || Ck == 16 || Ck == 32, "mvs_fpn_level: lateral channels must be 8, 16 or 32 (got %d)", Ck);
     MVS_REQUIRE(N >= 1 && N <= 65535 && h >= 1 && w >= 1 && (int64_t)2 * h <= 4 * 65535, "mvs_fpn_level: bad shape N=%d h=%d w=%d", N, h, w);
+    MVS_REQUIRE((int64_t)FC * 4 * h * w < ((int64_t)1 << 31), "mvs_fpn_level: one image's 64-channel level exceeds 2^31 elements (32-bit in-image offsets)");
     const dim3 grid(mvs::ceil_div(2 * w, TW), mvs::ceil_div(2 * h, TH), N), block(256);
     hipStream_t s = MVS_STREAM(stream);
     if (Ck == 8)
