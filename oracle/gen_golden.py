@@ -22,6 +22,7 @@ float16-exact values to halve the files):
   cascade_v3.npz, cascade_v5.npz   4-stage inverse-depth cascade, 64x64, tmp=[5,5,5,1]
   train_costregnet.npz, train_costregnet3d.npz   train-mode StageNet (B=2): forward, loss=sum(pre*R), all gradients
   fpn_decoder.npz          FPNDecoder (the step before the path), eval BatchNorm: state_dict, encoder outputs, the 4 feature maps
+  fpn_encoder.npz          FPNEncoder, eval BatchNorm: state_dict (conv weights float16-exact), image, the 4 encoder outputs
 """
 import json
 import os
@@ -560,3 +561,32 @@ def gen_fpn_decoder():
 
 if __name__ == "__main__" and os.environ.get("GEN_FPN", "1") == "1":
     gen_fpn_decoder()
+
+
+def gen_fpn_encoder():
+    """FPNEncoder (models/module.py:208-240, norm_type='BN'), eval mode, seeded default init with the convolution weights rounded to
+    float16-exact values (halves the file; both sides use exactly these values) + randomized BatchNorm.  40x48 image."""
+    from models.module import FPNEncoder
+    from oracle import ref_fpn
+    torch.manual_seed(11)
+    enc = FPNEncoder([8, 16, 32, 64])
+    ref_fpn.randomize_bn(enc, 12)
+    with torch.no_grad():
+        for name, p in enc.named_parameters():
+            if name.endswith("conv.weight"):
+                p.copy_(f16exact(p))
+    enc.eval()
+    x = torch.randn(1, 3, 40, 48, generator=torch.Generator().manual_seed(13))
+    with torch.no_grad():
+        outs = enc(x)
+    arrs = {}
+    for k, v in enc.state_dict().items():
+        if v.dtype.is_floating_point:
+            arrs["sd." + k] = np32(v).astype(np.float16) if k.endswith("conv.weight") else np32(v)
+    arrs["x"] = np32(x)
+    arrs.update({"out%d" % i: np32(o) for i, o in enumerate(outs)})
+    save("fpn_encoder.npz", **arrs)
+
+
+if __name__ == "__main__" and os.environ.get("GEN_FPN", "1") == "1":
+    gen_fpn_encoder()

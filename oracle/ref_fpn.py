@@ -1,9 +1,9 @@
-"""TEST INFRASTRUCTURE — CPU oracle for the FPN decoder (the step that hands features to the path).
+"""TEST INFRASTRUCTURE — CPU oracle for the FPN decoder and encoder (the steps that hand features to the path).
 
 Restates reference models/module.py:242-270 (``FPNDecoder``: lateral 1x1 convolutions, bilinear x2 upsampling with
 align_corners=True, 3x3 output convolutions followed by BatchNorm2d and Swish, module.py:200-206) as a function of the
-module's ``state_dict``, eval-mode BatchNorm.  Pinned by tests/golden/fpn_decoder.npz (outputs of the real module, made
-by oracle/gen_golden.py).  Never imported by the product path.
+module's ``state_dict``, eval-mode BatchNorm, and models/module.py:208-240 (``FPNEncoder``) likewise.  Pinned by
+tests/golden/fpn_decoder.npz and fpn_encoder.npz (outputs of the real modules, made by oracle/gen_golden.py).  Never imported by the product path.
 """
 import torch
 import torch.nn.functional as F
@@ -54,3 +54,28 @@ def randomize_bn(module, seed):
             m.bias.data = 0.2 * torch.randn(m.num_features, generator=g)
             m.running_mean = 0.3 * torch.randn(m.num_features, generator=g)
             m.running_var = 0.5 + torch.rand(m.num_features, generator=g)
+
+
+# --------------------------------------------------------------------------------------------- FPNEncoder (module.py:208-240)
+ENCODER_LAYERS = (  # name, cin, cout, kernel, stride  (module.py:211-224; padding = kernel // 2 everywhere)
+    ("conv00", 3, 8, 7, 1), ("conv01", 8, 8, 5, 1),
+    ("downsample1", 8, 16, 5, 2), ("conv10", 16, 16, 3, 1), ("conv11", 16, 16, 3, 1),
+    ("downsample2", 16, 32, 5, 2), ("conv20", 32, 32, 3, 1), ("conv21", 32, 32, 3, 1),
+    ("downsample3", 32, 64, 3, 2), ("conv30", 64, 64, 3, 1), ("conv31", 64, 64, 3, 1))
+
+
+def conv_bn_lrelu(x, sd, name, stride, padding):
+    """models/module.py:40-73 ``Conv2d`` with norm_type='BN': conv (no bias) -> BatchNorm2d (eval) -> leaky_relu(0.1)."""
+    y = F.conv2d(x, sd[name + ".conv.weight"], None, stride=stride, padding=padding)
+    y = F.batch_norm(y, sd[name + ".bn.running_mean"], sd[name + ".bn.running_var"], sd[name + ".bn.weight"], sd[name + ".bn.bias"],
+                     False, 0.0, BN_EPS)
+    return F.leaky_relu(y, 0.1)
+
+
+def fpn_encoder_forward(sd, x):
+    """module.py:226-240 -> [conv01 (full), conv11 (1/2), conv21 (1/4), conv31 (1/8)]."""
+    feats = {}
+    for name, _, _, k, s in ENCODER_LAYERS:
+        x = conv_bn_lrelu(x, sd, name, s, k // 2)
+        feats[name] = x
+    return [feats["conv01"], feats["conv11"], feats["conv21"], feats["conv31"]]

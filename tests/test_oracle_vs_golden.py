@@ -229,3 +229,18 @@ def test_fpn_decoder_oracle_vs_reference():
     assert [tuple(o.shape) for o in outs] == [(1, 64, 5, 6), (1, 32, 10, 12), (1, 16, 20, 24), (1, 8, 40, 48)]
     for i, o in enumerate(outs):
         assert max_abs(o, g["out%d" % i]) < TOL * max(1.0, float(np.abs(g["out%d" % i]).max())), i
+
+
+def fpn_encoder_golden():
+    g = load_golden("fpn_encoder.npz")
+    return g, {k[3:]: t(v) for k, v in g.items() if k.startswith("sd.")}
+
+
+def test_fpn_encoder_oracle_vs_reference():
+    """oracle/ref_fpn.py against the real FPNEncoder (models/module.py:208-240), eval BatchNorm."""
+    from oracle import ref_fpn
+    g, sd = fpn_encoder_golden()
+    outs = ref_fpn.fpn_encoder_forward(sd, t(g["x"]))
+    assert [tuple(o.shape) for o in outs] == [(1, 8, 40, 48), (1, 16, 20, 24), (1, 32, 10, 12), (1, 64, 5, 6)]
+    for i, o in enumerate(outs):
+        assert max_abs(o, g["out%d" % i]) < TOL * max(1.0, float(np.abs(g["out%d" % i]).max())), i
