@@ -256,25 +256,39 @@ def main(args):
     # ---- the row before the path: FPN decoder emitting channel-last features, timed beside the path (extra key) ----
     before = None
     if rank == 0 and world == 1 and not args.no_other_configs:
-        from mvsformer_amd import FPNDecoder
+        from mvsformer_amd import FPNDecoder, FPNEncoder
         torch.manual_seed(0)
         dec = FPNDecoder([8, 16, 32, 64]).eval().to(dev)
+        fenc = FPNEncoder([8, 16, 32, 64]).eval().to(dev)
+        img = torch.randn(args.views, 3, args.height, args.width, device=dev)
         enc = [torch.randn(args.views, c, args.height >> i, args.width >> i, device=dev) for i, c in enumerate((8, 16, 32, 64))]
         for _ in range(3):
             dec(*enc)
+            fenc(img)
         torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
         for _ in range(20):
             outs = dec(*enc)
         e1.record()
+        for _ in range(20):
+            fenc(img)
+        e2.record()
         torch.cuda.synchronize(dev)
         flops = sum(2.0 * 64 * c * 10 * args.views * (args.height >> i) * (args.width >> i) for i, c in enumerate((8, 16, 32)))
         ms = e0.elapsed_time(e1) / 20
+        eflops = 0.0
+        hh, ww, cin = args.height, args.width, 3
+        for (_, k, st), cout in zip(FPNEncoder.LAYERS, (8, 8, 16, 16, 16, 32, 32, 32, 64, 64, 64)):
+            hh, ww = (hh - 1) // st + 1, (ww - 1) // st + 1
+            eflops += 2.0 * k * k * cin * cout * args.views * hh * ww
+            cin = cout
+        ems = e1.elapsed_time(e2) / 20
         before = {"fpn_decoder_ms_per_depth_map": round(ms, 3), "algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 1),
+                  "fpn_encoder_ms_per_depth_map": round(ems, 3), "encoder_algorithmic_tflops": round(eflops / (ems * 1e-3) / 1e12, 1),
                   "peak_tflops_fp32_mfma": 157.3, "outputs": "channel-last [N,H,W,C]: consumed by the sweeps without nchw_to_nhwc",
-                  "note": "FPNDecoder.forward (models/module.py:257-270), eval BatchNorm, %d views, random encoder outputs; not in `value`" % args.views}
-        del dec, enc, outs
+                  "note": "FPNEncoder / FPNDecoder.forward (models/module.py:226-270), eval BatchNorm, %d views, random inputs; not in `value`" % args.views}
+        del dec, enc, outs, fenc, img
         torch.cuda.empty_cache()
 
     if rank == 0:

@@ -351,6 +351,15 @@ int mvs_conf_accumulate(const float* conf, int B, int H, int W, float* acc, int 
  *   level:  intra_prev [N,64,h,w], lateral [N,Ck,2h,2w], w_inner_p [32,Ck,2] (inner_k.weight [64,Ck] regrouped by output-channel PAIR:
  *           w_inner_p[q][j][e] = weight[2q+e][j], one scalar load per pair for the packed fp32 pipe) + b_inner [64], packed out_k weights ->
  *           intra_out [N,64,2h,2w] (NULL for the last level: it is only ever consumed inside this kernel) and out [N,2h,2w,Ck] */
+/* FPNEncoder layers, models/module.py:40-73,208-240: y = leaky_relu(BatchNorm2d_eval(conv2d(x, w, stride, padding = K/2)), slope), NCHW.
+ * Built for the encoder's eight layer shapes (Cin,Cout,K,stride) = (3,8,7,1) (8,8,5,1) (8,16,5,2) (16,16,3,1) (16,32,5,2) (32,32,3,1)
+ * (32,64,3,2) (64,64,3,1); anything else returns MVS_EINVAL.  scale = gamma / sqrt(var + eps), shift = beta - mean * scale.
+ *   pack: w [Cout,Cin,K,K] -> packed, mvs_conv2d_packed_floats(Cin, Cout, K) floats
+ *   x [N,Cin,H,W] -> y [N,Cout,(H-1)/stride+1,(W-1)/stride+1] */
+int64_t mvs_conv2d_packed_floats(int Cin, int Cout, int K);
+int mvs_conv2d_pack_weights(const float* w, int Cin, int Cout, int K, float* packed, mvs_stream_t stream);
+int mvs_conv2d_bn_lrelu(const float* x, const float* packed, const float* scale, const float* shift, int N, int Cin, int Cout, int K,
+                        int stride, int H, int W, float slope, float* y, mvs_stream_t stream);
 int64_t mvs_fpn_packed_floats(int Cout);
 int mvs_fpn_pack_weights(const float* w, int Cout, float* packed, mvs_stream_t stream);
 int mvs_fpn_out0(const float* x, const float* w, const float* scale, const float* shift, int N, int h, int wd, float* out,

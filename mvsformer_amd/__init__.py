@@ -12,7 +12,7 @@ from . import synth  # noqa: F401
 
 __all__ = ["synth", "StageNet", "DepthNet", "CostRegNet", "CostRegNet3D", "CascadeMVS", "homo_warping_3D_with_mask",
            "homo_warping_3D", "homo_warping", "depth_regression", "conf_regression", "init_inverse_range",
-           "schedule_inverse_range", "install", "fusion", "FPNDecoder"]
+           "schedule_inverse_range", "install", "fusion", "FPNDecoder", "FPNEncoder"]
 
 
 def __getattr__(name):
@@ -29,9 +29,9 @@ def __getattr__(name):
     if name in ("CascadeMVS", "randomize_bn_"):
         from . import cascade
         return getattr(cascade, name)
-    if name == "FPNDecoder":
+    if name in ("FPNDecoder", "FPNEncoder"):
         from . import fpn
-        return fpn.FPNDecoder
+        return getattr(fpn, name)
     if name == "fusion":
         import importlib
         return importlib.import_module(".fusion", __name__)

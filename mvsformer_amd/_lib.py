@@ -97,6 +97,9 @@ SIGNATURES = {
     "mvs_init_inverse_range": (I, [P, I, I, I, I, I, P, P]),
     "mvs_schedule_inverse_range": (I, [P, P, I, F, I, I, I, I, P, P]),
     "mvs_conf_accumulate": (I, [P, I, I, I, P, I, I, F, P]),
+    "mvs_conv2d_packed_floats": (L, [I, I, I]),
+    "mvs_conv2d_pack_weights": (I, [P, I, I, I, P, P]),
+    "mvs_conv2d_bn_lrelu": (I, [P, P, P, P, I, I, I, I, I, I, I, F, P, P]),
     "mvs_fpn_packed_floats": (L, [I]),
     "mvs_fpn_pack_weights": (I, [P, I, P, P]),
     "mvs_fpn_out0": (I, [P, P, P, P, I, I, I, P, P]),

@@ -1,5 +1,5 @@
-"""``FPNDecoder`` with the reference's interface (models/module.py:242-270) on the MI355X path — the step that hands the four
-feature maps to the plane sweeps.
+"""``FPNEncoder`` / ``FPNDecoder`` with the reference's interface (models/module.py:208-270) on the MI355X path — the steps that hand
+the four feature maps to the plane sweeps.
 
 Same constructor argument, same parameter / buffer names (``out0.0.weight``, ``out0.1.running_mean``, ``inner1.bias`` ...), so
 ``load_state_dict`` of a reference checkpoint's ``decoder.*`` keys works unchanged.  ``forward`` is different code: one HIP
@@ -9,6 +9,9 @@ eval-mode BatchNorm and Swish; the full-resolution 64-channel ``intra_feat`` of 
 The returned maps have the reference's logical shape ``[N,C,H,W]`` but CHANNEL-LAST memory (they are ``permute`` views of
 ``[N,H,W,C]`` buffers), which is what the sweeps gather from: ``ops.to_channels_last`` passes such a tensor through without a
 copy, so the reference's ``features['stageK'] = feat.reshape(B,V,C,H,W)`` hand-over costs nothing.
+
+``FPNEncoder`` is eleven fused conv + BatchNorm + leaky-ReLU launches (``csrc/conv2d.hip``), NCHW like the reference, so its
+outputs (and a ViT branch added to ``conv31``, mvsformer_model.py:229) feed the decoder unchanged.
 
 Eval mode only: training the 2-D feature extractor is outside the hot path; ``forward`` in training mode raises.
 """
@@ -80,3 +83,71 @@ class FPNDecoder(nn.Module):
                 intra, out = ops.fpn_level(intra, lateral.float().contiguous(), w_in, b_in, packed, scale, shift, want_intra=(i < 2))
                 outs.append(out)
         return [o.permute(0, 3, 1, 2) for o in outs]
+
+
+class Conv2d(nn.Module):
+    """Parameter holder with the reference's attribute names (models/module.py:40-73: ``conv`` without bias, ``bn``); the
+    arithmetic runs in ``FPNEncoder.forward``."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, norm_type="BN"):
+        super().__init__()
+        if norm_type != "BN" or padding != kernel_size // 2:
+            raise _lib.MvsHipError("Conv2d: the HIP path is built for norm_type='BN' and padding = kernel_size // 2 (FPNEncoder's layers)")
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=False)
+        self.bn = nn.BatchNorm2d(out_channels, momentum=0.1)
+        self.kernel_size, self.stride = kernel_size, stride
+
+    def forward(self, x):
+        raise _lib.MvsHipError("Conv2d is a parameter holder of FPNEncoder: call the encoder")
+
+
+class FPNEncoder(nn.Module):
+    """models/module.py:208-240.  ``forward(x [N,3,H,W]) -> [conv01 (full res), conv11 (1/2), conv21 (1/4), conv31 (1/8)]``."""
+
+    LAYERS = (("conv00", 7, 1), ("conv01", 5, 1), ("downsample1", 5, 2), ("conv10", 3, 1), ("conv11", 3, 1), ("downsample2", 5, 2),
+              ("conv20", 3, 1), ("conv21", 3, 1), ("downsample3", 3, 2), ("conv30", 3, 1), ("conv31", 3, 1))
+
+    def __init__(self, feat_chs, norm_type="BN"):
+        super().__init__()
+        feat_chs = list(feat_chs)
+        if feat_chs != [8, 16, 32, 64]:
+            raise _lib.MvsHipError("FPNEncoder: the HIP path is built for feat_chs=[8,16,32,64] (every shipped config), got %s" % feat_chs)
+        c = feat_chs
+        self.conv00 = Conv2d(3, c[0], 7, 1, padding=3, norm_type=norm_type)
+        self.conv01 = Conv2d(c[0], c[0], 5, 1, padding=2, norm_type=norm_type)
+        self.downsample1 = Conv2d(c[0], c[1], 5, stride=2, padding=2, norm_type=norm_type)
+        self.conv10 = Conv2d(c[1], c[1], 3, 1, padding=1, norm_type=norm_type)
+        self.conv11 = Conv2d(c[1], c[1], 3, 1, padding=1, norm_type=norm_type)
+        self.downsample2 = Conv2d(c[1], c[2], 5, stride=2, padding=2, norm_type=norm_type)
+        self.conv20 = Conv2d(c[2], c[2], 3, 1, padding=1, norm_type=norm_type)
+        self.conv21 = Conv2d(c[2], c[2], 3, 1, padding=1, norm_type=norm_type)
+        self.downsample3 = Conv2d(c[2], c[3], 3, stride=2, padding=1, norm_type=norm_type)
+        self.conv30 = Conv2d(c[3], c[3], 3, 1, padding=1, norm_type=norm_type)
+        self.conv31 = Conv2d(c[3], c[3], 3, 1, padding=1, norm_type=norm_type)
+        self._cache = None
+
+    def _prepared(self):
+        key = _versions(self)
+        if self._cache is None or self._cache[0] != key:
+            layers = []
+            for name, k, stride in self.LAYERS:
+                m = getattr(self, name)
+                scale = m.bn.weight.detach().double() / torch.sqrt(m.bn.running_var.double() + m.bn.eps)
+                shift = m.bn.bias.detach().double() - m.bn.running_mean.double() * scale
+                layers.append((ops.conv2d_pack_weights(m.conv.weight.detach().contiguous()), scale.float().contiguous(),
+                               shift.float().contiguous(), m.conv.out_channels, k, stride))
+            _publish_cache()
+            self._cache = (key, layers)
+        return self._cache[1]
+
+    def forward(self, x):
+        if self.training:
+            raise _lib.MvsHipError("FPNEncoder: only eval mode is built on the HIP path (training the 2-D feature extractor is "
+                                   "outside the hot path, SURVEY.md §8); call .eval()")
+        with torch.no_grad():
+            x = x.float().contiguous()
+            outs = {}
+            for (name, _, _), (packed, scale, shift, cout, k, stride) in zip(self.LAYERS, self._prepared()):
+                x = ops.conv2d_bn_lrelu(x, packed, scale, shift, cout, k, stride, 0.1)
+                outs[name] = x
+        return [outs["conv01"], outs["conv11"], outs["conv21"], outs["conv31"]]

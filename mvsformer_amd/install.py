@@ -26,20 +26,24 @@ _SYMBOLS = {
     "init_inverse_range": _m.init_inverse_range,
     "schedule_inverse_range": _m.schedule_inverse_range,
     "homo_warping_3D_with_mask": _w.homo_warping_3D_with_mask,
-    "FPNDecoder": _f.FPNDecoder,
 }
+# the rows before the path: eval-only on the HIP path, so they are rebound only on request
+_FEATURE_SYMBOLS = {"FPNDecoder": _f.FPNDecoder, "FPNEncoder": _f.FPNEncoder}
 
 
-def install(model_module: str = "models.mvsformer_model", also=("models.module", "models.warping")) -> dict:
-    """Rebind the hot-path names inside the reference's modules.  Returns ``{module: [names rebound]}``."""
+def install(model_module: str = "models.mvsformer_model", also=("models.module", "models.warping"), features: bool = False) -> dict:
+    """Rebind the hot-path names inside the reference's modules.  Returns ``{module: [names rebound]}``.
+    ``features=True`` (inference deployments) also rebinds ``FPNEncoder`` / ``FPNDecoder``, which are eval-only here: their ``forward``
+    raises in training mode, so leave it off for a model that will be trained."""
     done = {}
+    symbols = dict(_SYMBOLS, **(_FEATURE_SYMBOLS if features else {}))
     for name in (model_module,) + tuple(also):
         try:
             mod = importlib.import_module(name)
         except ImportError:
             continue
         hit = []
-        for sym, obj in _SYMBOLS.items():
+        for sym, obj in symbols.items():
             if hasattr(mod, sym):
                 setattr(mod, sym, obj)
                 hit.append(sym)

@@ -981,3 +981,31 @@ def fpn_level(intra_prev: torch.Tensor, lateral: torch.Tensor, w_inner_p: torch.
     _call("mvs_fpn_level", tag, _ptr(intra_prev), _ptr(lateral), _ptr(w_inner_p), _ptr(b_inner), _ptr(packed), _ptr(scale), _ptr(shift),
           N, Ck, h, w, _ptr(intra), _ptr(out), _stream())
     return intra, out
+
+
+# ----------------------------------------------------------------------------------------------- FPN encoder layers
+def conv2d_pack_weights(w: torch.Tensor) -> torch.Tensor:
+    """``conv.weight [Cout,Cin,K,K]`` of an FPN encoder layer -> the MFMA-fragment image ``mvs_conv2d_bn_lrelu`` stages through LDS."""
+    _chk(w, "conv2d weight")
+    Cout, Cin, K, K2 = w.shape
+    n = int(_lib.load().mvs_conv2d_packed_floats(Cin, Cout, K)) if K == K2 else -1
+    if n <= 0:
+        raise _lib.MvsHipError("conv2d weight %s is not an FPN encoder layer shape" % (tuple(w.shape),))
+    packed = torch.empty(n, device=w.device, dtype=torch.float32)
+    _call("mvs_conv2d_pack_weights", None, _ptr(w), Cin, Cout, K, _ptr(packed), _stream())
+    return packed
+
+
+def conv2d_bn_lrelu(x: torch.Tensor, packed: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, cout: int, k: int, stride: int,
+                    slope: float = 0.1) -> torch.Tensor:
+    """``leaky_relu(BatchNorm2d_eval(conv2d(x, w, stride, padding=k//2)), slope)`` (reference models/module.py:40-73), NCHW."""
+    _chk(x, "x"), _chk(packed, "packed weights"), _chk(scale, "scale"), _chk(shift, "shift")
+    N, Cin, H, W = x.shape
+    if scale.numel() != cout or shift.numel() != cout or packed.numel() != int(_lib.load().mvs_conv2d_packed_floats(Cin, cout, k)):
+        raise _lib.MvsHipError("conv2d_bn_lrelu: parameter sizes do not match (Cin,Cout,K)=(%d,%d,%d)" % (Cin, cout, k))
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty(N, cout, Ho, Wo, device=x.device, dtype=torch.float32)
+    tag = ("conv2d_kernel<%d,%d,%d,%d>" % (Cin, cout, k, stride), "flops", 2.0 * k * k * Cin * cout * N * Ho * Wo)
+    _call("mvs_conv2d_bn_lrelu", tag, _ptr(x), _ptr(packed), _ptr(scale), _ptr(shift), N, Cin, cout, k, stride, H, W, float(slope), _ptr(y),
+          _stream())
+    return y

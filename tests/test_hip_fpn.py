@@ -122,3 +122,69 @@ def test_decoder_to_cascade_hand_over_is_bit_identical():
     assert not any("nchw_to_nhwc" in k for k in kt.events)
     b = net({k: v.contiguous() for k, v in feats.items()}, proj, dv, tmp=[5.0, 5.0, 5.0, 1.0])
     assert torch.equal(a["refined_depth"], b["refined_depth"]) and torch.isfinite(a["refined_depth"]).all()
+
+
+# ------------------------------------------------------------------------------------------------ FPNEncoder (csrc/conv2d.hip)
+def build_encoder(sd=None, seed=0):
+    from mvsformer_amd import FPNEncoder
+    from oracle import ref_fpn
+    torch.manual_seed(seed)
+    enc = FPNEncoder([8, 16, 32, 64])
+    if sd is None:
+        ref_fpn.randomize_bn(enc, seed + 1)
+    else:
+        missing, unexpected = enc.load_state_dict(sd, strict=False)
+        assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+    return enc.eval()
+
+
+def test_fpn_encoder_is_eval_only_and_checkpoint_compatible():
+    g = load_golden("fpn_encoder.npz")
+    enc = build_encoder({k[3:]: t(v) for k, v in g.items() if k.startswith("sd.")})
+    assert sorted(k for k in enc.state_dict() if not k.endswith("num_batches_tracked")) == sorted(k[3:] for k in g if k.startswith("sd."))
+    from mvsformer_amd._lib import MvsHipError
+    with pytest.raises(MvsHipError):
+        enc.train()(t(g["x"]))
+
+
+@pytest.mark.gpu
+def test_fpn_encoder_vs_golden():
+    g = load_golden("fpn_encoder.npz")
+    dev = torch.device("cuda:0")
+    enc = build_encoder({k[3:]: t(v) for k, v in g.items() if k.startswith("sd.")}).to(dev)
+    outs = enc(t(g["x"], dev))
+    for i, o in enumerate(outs):
+        assert tuple(o.shape) == g["out%d" % i].shape and o.is_contiguous()
+        assert scale_err(o.cpu(), g["out%d" % i]) < TOL, i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W", [(2, 37, 51), (1, 8, 8), (3, 64, 200)])
+def test_fpn_encoder_vs_oracle(N, H, W):
+    """Odd sizes (stride-2 layers round up, partial tiles, scalar stores), a tile-less 8x8 image, several images and tiles."""
+    from oracle import ref_fpn
+    enc = build_encoder(seed=21)
+    x = torch.randn(N, 3, H, W, generator=torch.Generator().manual_seed(22))
+    want = ref_fpn.fpn_encoder_forward({k: v.detach() for k, v in enc.state_dict().items()}, x)
+    outs = enc.to("cuda:0")(x.to("cuda:0"))
+    for i, (o, ww) in enumerate(zip(outs, want)):
+        assert o.shape == ww.shape
+        assert scale_err(o.cpu(), ww) < TOL, i
+
+
+@pytest.mark.gpu
+def test_fpn_encoder_decoder_full_size_vs_torch_on_gpu():
+    """Encoder + decoder chained at BASELINE configs[1] size (5 views, 1152x1536) against the oracle's torch ops on the GPU."""
+    from oracle import ref_fpn
+    dev = torch.device("cuda:0")
+    enc, dec = build_encoder(seed=31).to(dev), build_decoder(seed=32).to(dev)
+    x = torch.randn(5, 3, 1152, 1536, generator=torch.Generator().manual_seed(33)).to(dev)
+    feats = enc(x)
+    outs = dec(*feats)
+    with torch.no_grad():
+        wf = ref_fpn.fpn_encoder_forward({k: v.detach() for k, v in enc.state_dict().items()}, x)
+        wo = ref_fpn.fpn_decoder_forward({k: v.detach() for k, v in dec.state_dict().items()}, *wf)
+    for i, (o, ww) in enumerate(zip(list(feats) + list(outs), list(wf) + list(wo))):
+        assert o.shape == ww.shape
+        err = float((o - ww).abs().max() / ww.abs().max())
+        assert err < 1e-4, (i, err)

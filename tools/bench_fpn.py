@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Times the FPN decoder (csrc/fpn.hip) on BASELINE configs[1]'s geometry (5 views, 1152x1536) with HIP events per launch, next to
+"""Times the FPN encoder (csrc/conv2d.hip) and decoder (csrc/fpn.hip) on BASELINE configs[1]'s geometry (5 views, 1152x1536) with HIP events per launch, next to
 the same ops in plain PyTorch (MIOpen convolutions + ATen upsampling) on the same GPU.  Prints one JSON object.
 
     python tools/bench_fpn.py [--views 5] [--height 1152] [--width 1536] [--iters 20]
@@ -12,7 +12,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mvsformer_amd import FPNDecoder, ops  # noqa: E402
+from mvsformer_amd import FPNDecoder, FPNEncoder, ops  # noqa: E402
 
 
 def torch_decoder(sd, conv01, conv11, conv21, conv31):
@@ -30,6 +30,18 @@ def torch_decoder(sd, conv01, conv11, conv21, conv31):
         intra = F.interpolate(intra, scale_factor=2, mode="bilinear", align_corners=True) + F.conv2d(lat, sd["inner%d.weight" % k], sd["inner%d.bias" % k])
         outs.append(out(intra, "out%d" % k, 1))
     return outs
+
+
+def torch_encoder(sd, x):
+    """models/module.py:226-240 in plain torch - the comparison leg."""
+    import torch.nn.functional as F
+    outs = {}
+    for name, k, s in FPNEncoder.LAYERS:
+        x = F.conv2d(x, sd[name + ".conv.weight"], None, stride=s, padding=k // 2)
+        x = F.batch_norm(x, sd[name + ".bn.running_mean"], sd[name + ".bn.running_var"], sd[name + ".bn.weight"], sd[name + ".bn.bias"], False, 0.0, 1e-5)
+        x = F.leaky_relu(x, 0.1)
+        outs[name] = x
+    return [outs["conv01"], outs["conv11"], outs["conv21"], outs["conv31"]]
 
 
 def main():
@@ -59,11 +71,18 @@ def main():
         torch.cuda.synchronize()
         return s.elapsed_time(e) / iters
 
+    enc = FPNEncoder([8, 16, 32, 64]).eval().to(dev)
+    esd = {k: v.detach() for k, v in enc.state_dict().items()}
+    img = torch.randn(a.views, 3, a.height, a.width, generator=g).to(dev)
+    ms_enc = timed(lambda: enc(img), a.iters)
+    with torch.no_grad():
+        ms_enc_torch = timed(lambda: torch_encoder(esd, img), max(3, a.iters // 4))
     ms_hip = timed(lambda: dec(*feats), a.iters)
     with torch.no_grad():
         ms_torch = timed(lambda: torch_decoder(sd, *feats), max(3, a.iters // 4))
     with ops.kernel_timer() as kt:
         for _ in range(a.iters):
+            enc(img)
             dec(*feats)
     kernels = {}
     for name, s in kt.summary().items():
@@ -71,10 +90,16 @@ def main():
         kernels[name] = {"avg_ms": round(s["avg_ms"], 4), "calls": s["calls"]}
         if wk:
             kernels[name]["tflops"] = round(wk["amount"] / s["calls"] / (s["avg_ms"] * 1e-3) / 1e12, 2)
-    flops = sum(kt.work[k]["amount"] / kt.summary()[k]["calls"] for k in kt.work)
-    print(json.dumps({"workload": "FPNDecoder eval, %d views %dx%d, fp32" % (a.views, a.height, a.width), "hip_ms": round(ms_hip, 3),
-                      "torch_miopen_ms": round(ms_torch, 3), "speedup": round(ms_torch / ms_hip, 2),
-                      "algorithmic_tflops": round(flops / (ms_hip * 1e-3) / 1e12, 2), "fp32_mfma_peak_tflops": 157.3, "kernels": kernels}))
+    summ = kt.summary()
+    fl = {True: 0.0, False: 0.0}
+    for k in kt.work:
+        fl[k.startswith("conv2d")] += kt.work[k]["amount"] / a.iters      # per forward (two layers share some kernel names)
+    print(json.dumps({"workload": "FPNEncoder + FPNDecoder eval, %d views %dx%d, fp32" % (a.views, a.height, a.width),
+                      "decoder": {"hip_ms": round(ms_hip, 3), "torch_miopen_ms": round(ms_torch, 3), "speedup": round(ms_torch / ms_hip, 2),
+                                  "algorithmic_tflops": round(fl[False] / (ms_hip * 1e-3) / 1e12, 2)},
+                      "encoder": {"hip_ms": round(ms_enc, 3), "torch_miopen_ms": round(ms_enc_torch, 3), "speedup": round(ms_enc_torch / ms_enc, 2),
+                                  "algorithmic_tflops": round(fl[True] / (ms_enc * 1e-3) / 1e12, 2)},
+                      "fp32_mfma_peak_tflops": 157.3, "kernels": kernels}))
 
 
 if __name__ == "__main__":
