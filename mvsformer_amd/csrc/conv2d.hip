@@ -83,21 +83,51 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const float* __restrict__ x
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- staging roles: element i of this thread is tile slot tid + i*256; its LDS slot and its in-image offset do not depend on
+    // the chunk, so both are computed once.  A chunk's loads are all issued before any is consumed, and the NEXT chunk's loads are in
+    // flight during the current chunk's MFMA phase (a rolled load -> wait -> store loop serializes one global latency per element).
+    constexpr int NIT = (CC * C::IR * IC + 255) / 256, NWV = (WCH / 4 + 255) / 256;
+    int goff[NIT], loff[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int idx = tid + i * 256;
+        const int c = idx / (C::IR * IC), r = idx % (C::IR * IC);
+        const int gy = iy0 + r / IC, gx = ix0 + r % IC;
+        const bool slot = idx < CC * C::IR * IC;
+        loff[i] = slot ? c * CS + r : -1;
+        goff[i] = (slot && c < CIN && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (c * H + gy) * W + gx : -1;
+    }
+    float sreg[NIT];
+    f32x4 wreg[NWV];
+    auto prefetch = [&](int ch) {
+        const float* xc = x_img + (size_t)ch * CC * H * W;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) sreg[i] = goff[i] >= 0 ? xc[(unsigned)goff[i]] : 0.0f;
+        const f32x4* src = reinterpret_cast<const f32x4*>(wp + (size_t)ch * WCH);
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + i * 256;
+            wreg[i] = idx < WCH / 4 ? src[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+            if (loff[i] >= 0) s_in[loff[i]] = sreg[i];
+        f32x4* dst = reinterpret_cast<f32x4*>(s_w);
+#pragma unroll
+        for (int i = 0; i < NWV; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < WCH / 4) dst[idx] = wreg[i];
+        }
+    };
+
+    prefetch(0);
     for (int ch = 0; ch < C::CP / CC; ++ch) {
         if (ch) __syncthreads();                            // the previous chunk's MFMA phase has finished reading LDS
-        for (int idx = tid; idx < CC * C::IR * IC; idx += 256) {
-            const int c = idx / (C::IR * IC), r = idx % (C::IR * IC);
-            const int gy = iy0 + r / IC, gx = ix0 + r % IC, cin = ch * CC + c;
-            float v = 0.0f;
-            if (cin < CIN && gy >= 0 && gy < H && gx >= 0 && gx < W) v = x_img[(unsigned)((cin * H + gy) * W + gx)];
-            s_in[c * CS + r] = v;
-        }
-        {
-            const f32x4* src = reinterpret_cast<const f32x4*>(wp + (size_t)ch * WCH);
-            f32x4* dst = reinterpret_cast<f32x4*>(s_w);
-            for (int idx = tid; idx < WCH / 4; idx += 256) dst[idx] = src[idx];
-        }
+        commit();
         __syncthreads();
+        if (ch + 1 < C::CP / CC) prefetch(ch + 1);
 #pragma unroll
         for (int ks = 0; ks < CC / 4; ++ks) {
             const float* abase = s_in + (ks * 4 + kk) * CS + S * i16;
