@@ -351,6 +351,15 @@ int mvs_conf_accumulate(const float* conf, int B, int H, int W, float* acc, int 
  *   level:  intra_prev [N,64,h,w], lateral [N,Ck,2h,2w], w_inner_p [32,Ck,2] (inner_k.weight [64,Ck] regrouped by output-channel PAIR:
  *           w_inner_p[q][j][e] = weight[2q+e][j], one scalar load per pair for the packed fp32 pipe) + b_inner [64], packed out_k weights ->
  *           intra_out [N,64,2h,2w] (NULL for the last level: it is only ever consumed inside this kernel) and out [N,2h,2w,Ck] */
+/* Last decoder level (Ck = 8, no intra_out) with the 3x3 convolution on the bf16 matrix cores in SPLIT form: each fp32 operand is
+ * hi + lo (two bf16), the product is accumulated in fp32 as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi (error <= ~2^-16 relative per product;
+ * measured 4e-6 of the output scale against 6e-7 for the fp32 MFMA form).  Same arguments as mvs_fpn_level otherwise.
+ *   pack: w [8,64,3,3] (out3.0.weight) -> packed, mvs_fpn_split_packed_bytes() bytes */
+int64_t mvs_fpn_split_packed_bytes(void);
+int mvs_fpn_pack_weights_split(const float* w, void* packed, mvs_stream_t stream);
+int mvs_fpn_level_split(const float* intra_prev, const float* lateral, const float* w_inner_p, const float* b_inner, const void* w_split,
+                        const float* scale, const float* shift, int N, int h, int w, float* out, mvs_stream_t stream);
+
 /* FPNEncoder layers, models/module.py:40-73,208-240: y = leaky_relu(BatchNorm2d_eval(conv2d(x, w, stride, padding = K/2)), slope), NCHW.
  * Built for the encoder's eight layer shapes (Cin,Cout,K,stride) = (3,8,7,1) (8,8,5,1) (8,16,5,2) (16,16,3,1) (16,32,5,2) (32,32,3,1)
  * (32,64,3,2) (64,64,3,1); anything else returns MVS_EINVAL.  scale = gamma / sqrt(var + eps), shift = beta - mean * scale.

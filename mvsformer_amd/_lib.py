@@ -104,6 +104,9 @@ SIGNATURES = {
     "mvs_fpn_pack_weights": (I, [P, I, P, P]),
     "mvs_fpn_out0": (I, [P, P, P, P, I, I, I, P, P]),
     "mvs_fpn_level": (I, [P, P, P, P, P, P, P, I, I, I, I, P, P, P]),
+    "mvs_fpn_split_packed_bytes": (L, []),
+    "mvs_fpn_pack_weights_split": (I, [P, P, P]),
+    "mvs_fpn_level_split": (I, [P, P, P, P, P, P, P, I, I, I, P, P]),
 }
 
 _lib = None

@@ -983,6 +983,34 @@ def fpn_level(intra_prev: torch.Tensor, lateral: torch.Tensor, w_inner_p: torch.
     return intra, out
 
 
+def fpn_pack_weights_split(w: torch.Tensor) -> torch.Tensor:
+    """``out3.0.weight [8,64,3,3]`` -> per-lane bf16 hi/lo fragments for :func:`fpn_level_split` (uint8 storage)."""
+    _chk(w, "fpn 3x3 weight")
+    if tuple(w.shape) != (8, FPN_CH, 3, 3):
+        raise _lib.MvsHipError("fpn_pack_weights_split: weight must be [8,64,3,3], got %s" % (tuple(w.shape),))
+    packed = torch.empty(int(_lib.load().mvs_fpn_split_packed_bytes()), device=w.device, dtype=torch.uint8)
+    _call("mvs_fpn_pack_weights_split", None, _ptr(w), _ptr(packed), _stream())
+    return packed
+
+
+def fpn_level_split(intra_prev: torch.Tensor, lateral: torch.Tensor, w_inner_p: torch.Tensor, b_inner: torch.Tensor, w_split: torch.Tensor,
+                    scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+    """The last top-down level (Ck = 8) with its 3x3 convolution on the bf16 matrix cores in hi/lo split form (include/mvs_hip.h):
+    ``out [N,2h,2w,8]`` channel-last; ``intra`` is not produced."""
+    _chk(intra_prev, "intra_prev"), _chk(lateral, "lateral"), _chk(w_inner_p, "inner weight"), _chk(b_inner, "inner bias")
+    _chk(w_split, "split weights", torch.uint8), _chk(scale, "scale"), _chk(shift, "shift")
+    N, C, h, w = intra_prev.shape
+    if C != FPN_CH or lateral.shape != (N, 8, 2 * h, 2 * w) or w_inner_p.shape != (FPN_CH // 2, 8, 2) or b_inner.numel() != FPN_CH:
+        raise _lib.MvsHipError("fpn_level_split: shapes %s / %s do not form the Ck=8 level" % (tuple(intra_prev.shape), tuple(lateral.shape)))
+    if w_split.numel() != int(_lib.load().mvs_fpn_split_packed_bytes()) or scale.numel() != 8 or shift.numel() != 8:
+        raise _lib.MvsHipError("fpn_level_split: parameter sizes do not match")
+    out = torch.empty(N, 2 * h, 2 * w, 8, device=lateral.device, dtype=torch.float32)
+    tag = ("fpn_level8_split_kernel", "flops", 2.0 * FPN_CH * 8 * 10 * N * 4 * h * w)
+    _call("mvs_fpn_level_split", tag, _ptr(intra_prev), _ptr(lateral), _ptr(w_inner_p), _ptr(b_inner), _ptr(w_split), _ptr(scale), _ptr(shift),
+          N, h, w, _ptr(out), _stream())
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- FPN encoder layers
 def conv2d_pack_weights(w: torch.Tensor) -> torch.Tensor:
     """``conv.weight [Cout,Cin,K,K]`` of an FPN encoder layer -> the MFMA-fragment image ``mvs_conv2d_bn_lrelu`` stages through LDS."""
