@@ -427,8 +427,15 @@ __global__ __launch_bounds__(256, 3) void fpn_level8_split_kernel(const float* _
                     hi8[e] = hi;
                     lo8[e] = (__bf16)(v8[e] - (float)hi);
                 }
-                *reinterpret_cast<bf16x8*>(s_hi + p * SP_PS + g * 8) = hi8;
-                *reinterpret_cast<bf16x8*>(s_lo + p * SP_PS + g * 8) = lo8;
+                // UNTESTED hypothesis for the sporadic wrong strips (lanes 48..63 = the last quarter a 4-cycle vector op finishes): the
+                // ds_write_b128 below issues right behind the v_cvt_pk_bf16_f32 that produces its last data register; if that conversion
+                // has a longer result latency than the hazard tables of this compiler assume, the last quarter stores a stale
+                // register.  Draining the stores AFTER them (tried on the box) cannot help against that; idling BEFORE them would.
+                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                u32x4_t hq = __builtin_bit_cast(u32x4_t, hi8), lq = __builtin_bit_cast(u32x4_t, lo8);
+                asm volatile("s_nop 7\n\ts_nop 7" : "+v"(hq), "+v"(lq));          // ordered after the conversions by its operands
+                *reinterpret_cast<u32x4_t*>(s_hi + p * SP_PS + g * 8) = hq;
+                *reinterpret_cast<u32x4_t*>(s_lo + p * SP_PS + g * 8) = lq;
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
