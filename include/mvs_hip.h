@@ -27,7 +27,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 6
+#define MVS_ABI_VERSION 7
 
 typedef void* mvs_stream_t;
 
@@ -101,6 +101,25 @@ int mvs_vis_fwd(const float* entropy, const float* params, int N, int H, int W, 
 int mvs_cv_aggregate_fwd(const float* feat, const float* rt, const float* depth, const float* weight,
                          int B, int V, int C, int G, int D, int H, int W,
                          float* volume, float* sim_depth, int flags, mvs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Stored-correlation form of the two sweeps for the coarse cascade stages (C = 32 | 64), same reference lines
+ * (models/mvsformer_model.py:73-105,151-158).  There the V-1 per-view correlation volumes [G,D,H,W] fit the 256 MB
+ * Infinity Cache (113 / 226 MB at stages 1 / 2 of BASELINE configs[1]), so sweep A' keeps them - and the per-view eval
+ * similarity - in `store`, and sweep B' is a pure stream over the store: no second gather sweep.
+ *   mvs_cv_corr_store_bytes  size of `store` for a shape (-1 if the shape is not built: C must be 32 or 64, G 8)
+ *   mvs_cv_corr_fwd   feat [B,V,H,W,C], rt, depth as in mvs_cv_entropy_fwd -> entropy [B,V-1,H,W] (bit-identical to
+ *                     mvs_cv_entropy_fwd's) + store; flags as above
+ *   mvs_cv_merge_fwd  store + weight [B,V-1,H,W] + depth -> volume [B,G,D,H,W] (bit-identical to mvs_cv_aggregate_fwd's on the
+ *                     same flags) and, if sim_depth != NULL, the similarity arg-max depth [B,H,W] (the sums over groups are taken in
+ *                     a different order than mvs_cv_aggregate_fwd's: equal up to arg-max ties)
+ * `store` is caller-owned scratch, 16-byte aligned, layout private to the pair (pixel-group tiles, cost_volume.hip).
+ * ------------------------------------------------------------------------------------------------------- */
+int64_t mvs_cv_corr_store_bytes(int B, int V, int C, int G, int D, int H, int W);
+int mvs_cv_corr_fwd(const float* feat, const float* rt, const float* depth, int B, int V, int C, int G, int D, int H, int W,
+                    float* entropy, void* store, int flags, mvs_stream_t stream);
+int mvs_cv_merge_fwd(const void* store, const float* depth, const float* weight, int B, int V, int C, int G, int D, int H, int W,
+                     float* volume, float* sim_depth, mvs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * LDS-tiled form of the same two sweeps (cost_volume_tiled.hip) - the default eval path of StageNet.  Same math as
@@ -351,15 +370,6 @@ int mvs_conf_accumulate(const float* conf, int B, int H, int W, float* acc, int 
  *   level:  intra_prev [N,64,h,w], lateral [N,Ck,2h,2w], w_inner_p [32,Ck,2] (inner_k.weight [64,Ck] regrouped by output-channel PAIR:
  *           w_inner_p[q][j][e] = weight[2q+e][j], one scalar load per pair for the packed fp32 pipe) + b_inner [64], packed out_k weights ->
  *           intra_out [N,64,2h,2w] (NULL for the last level: it is only ever consumed inside this kernel) and out [N,2h,2w,Ck] */
-/* Last decoder level (Ck = 8, no intra_out) with the 3x3 convolution on the bf16 matrix cores in SPLIT form: each fp32 operand is
- * hi + lo (two bf16), the product is accumulated in fp32 as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi (error <= ~2^-16 relative per product;
- * measured 4e-6 of the output scale against 6e-7 for the fp32 MFMA form).  Same arguments as mvs_fpn_level otherwise.
- *   pack: w [8,64,3,3] (out3.0.weight) -> packed, mvs_fpn_split_packed_bytes() bytes */
-int64_t mvs_fpn_split_packed_bytes(void);
-int mvs_fpn_pack_weights_split(const float* w, void* packed, mvs_stream_t stream);
-int mvs_fpn_level_split(const float* intra_prev, const float* lateral, const float* w_inner_p, const float* b_inner, const void* w_split,
-                        const float* scale, const float* shift, int N, int h, int w, float* out, mvs_stream_t stream);
-
 /* FPNEncoder layers, models/module.py:40-73,208-240: y = leaky_relu(BatchNorm2d_eval(conv2d(x, w, stride, padding = K/2)), slope), NCHW.
  * Built for the encoder's eight layer shapes (Cin,Cout,K,stride) = (3,8,7,1) (8,8,5,1) (8,16,5,2) (16,16,3,1) (16,32,5,2) (32,32,3,1)
  * (32,64,3,2) (64,64,3,1); anything else returns MVS_EINVAL.  scale = gamma / sqrt(var + eps), shift = beta - mean * scale.

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 from ctypes import c_double  # noqa: E402
 
@@ -34,6 +34,9 @@ SIGNATURES = {
     "mvs_cv_entropy_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, I, P]),
     "mvs_vis_fwd": (I, [P, P, I, I, I, P, P]),
     "mvs_cv_aggregate_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, I, P]),
+    "mvs_cv_corr_store_bytes": (L, [I, I, I, I, I, I, I]),
+    "mvs_cv_corr_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, P]),
+    "mvs_cv_merge_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P, P]),
     "mvs_cv_tiled_workspace_bytes": (L, [I, I, I, I, I, I]),
     "mvs_cv_tiled_entropy_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, I, P, P]),
     "mvs_cv_tiled_aggregate_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, P, I, P, P]),
@@ -104,9 +107,6 @@ SIGNATURES = {
     "mvs_fpn_pack_weights": (I, [P, I, P, P]),
     "mvs_fpn_out0": (I, [P, P, P, P, I, I, I, P, P]),
     "mvs_fpn_level": (I, [P, P, P, P, P, P, P, I, I, I, I, P, P, P]),
-    "mvs_fpn_split_packed_bytes": (L, []),
-    "mvs_fpn_pack_weights_split": (I, [P, P, P]),
-    "mvs_fpn_level_split": (I, [P, P, P, P, P, P, P, I, I, I, P, P]),
 }
 
 _lib = None

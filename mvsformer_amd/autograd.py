@@ -37,16 +37,38 @@ def _sync_sums(sums: torch.Tensor, count: float, bn):
         red = sums.clone()                         # out of place: the caller's tensor keeps this rank's values (dgamma / dbeta)
         dist.all_reduce(red, group=bn.process_group)
         return red, None
-    n = int(count)
-    packed = torch.cat([sums, sums.new_tensor([float(n // 4096), float(n % 4096)])])
+    packed = torch.cat([sums, _count_halves(sums.device, int(count))])
     dist.all_reduce(packed, group=bn.process_group)
     return packed[:-2], packed[-2:]
+
+
+_COUNT_HALVES = {}
+
+
+def _capturing(device) -> bool:
+    return device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+
+
+def _count_halves(device, n: int) -> torch.Tensor:
+    """``[n / 4096, n % 4096]`` as a device tensor, cached per (device, n): the host-to-device copy happens once, OUTSIDE any hipGraph
+    capture (a pageable copy inside a capture would either fail or bake a stale host pointer into the graph); ``CapturedStep`` warms
+    every layer up eagerly first, so a capture only ever finds the cached tensor."""
+    key = (str(device), n)
+    t = _COUNT_HALVES.get(key)
+    if t is None:
+        if _capturing(device):
+            raise ops._lib.MvsHipError("SyncBatchNorm element count %d first seen inside a hipGraph capture: run the step eagerly once" % n)
+        t = torch.tensor([float(n // 4096), float(n % 4096)], dtype=torch.float32, device=device)
+        _COUNT_HALVES[key] = t
+    return t
 
 
 def _momentum(bn) -> float:
     """``momentum=None`` is torch's cumulative moving average: factor 1/(num_batches_tracked + 1) for this update."""
     if bn.momentum is not None:
         return float(bn.momentum)
+    if bn.num_batches_tracked is not None and _capturing(bn.num_batches_tracked.device):
+        raise ops._lib.MvsHipError("BatchNorm(momentum=None) reads num_batches_tracked on the host and cannot be captured in a hipGraph")
     seen = int(bn.num_batches_tracked.item()) if bn.num_batches_tracked is not None else 0
     return 1.0 / float(seen + 1)
 

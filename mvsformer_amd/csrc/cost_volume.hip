@@ -478,6 +478,231 @@ __global__ __launch_bounds__(64 * NW) void cv_aggregate_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Stored-correlation form of the two sweeps for the COARSE stages (C >= 32: few pixels, many channels and planes).
+//
+// There the (V-1) per-view correlation volumes [G,D,H,W] are small enough to stay in the 256 MB Infinity Cache (113 MB at config-2
+// stage 1, 226 MB at stage 2), so sweep A' keeps them (and the per-view similarity it computes on the way) and sweep B' becomes a pure
+// stream: no second gather sweep, no second geometry pass.  cv_corr_kernel = cv_entropy_kernel + the group means and the eval
+// similarity of cv_aggregate_kernel, operation for operation, so entropy and volume come out BIT-IDENTICAL to the recomputing pair.
+//
+// Store layout (private to this pair): pixel-group tiles, one per wavefront of sweep A' (TPX = 256/C consecutive pixels of a row):
+//   corr [B*(V-1)][H][XG][D][G][TPX]    simv [B*(V-1)][H][XG][D][TPX]      XG = ceil(W / TPX)
+// a wavefront's output for a chunk of LPP planes is one contiguous 2 KB run (staged through LDS, written as 16-byte stores).
+//
+// The similarity's sums over the 8 groups (an 8-lane all-reduce of 8 values per lane: 24 DPP additions, half-rate instructions, in
+// cv_aggregate_kernel) go through LDS here: every lane drops its 8 partial values, lane k of a pixel picks up the 8 partials of
+// value k (two ds_read_b128) and adds them - 7 full-rate additions instead of 24 half-rate ones.
+// ---------------------------------------------------------------------------------------------------------
+template <int LPP>
+struct CorrCfg {
+    static constexpr int C = 4 * LPP, CPG = C / G, PPW = 64 / LPP;
+    static constexpr int UNITS = PPW * (LPP / 8);          // all-reduce units per wavefront: (pixel) or (pixel, lane parity)
+    static constexpr int RED_FLOATS = UNITS * 72;          // unit stride 72 floats: 64 used, padded so a 32-lane store group hits 32 banks
+    static constexpr int STAGE_FLOATS = LPP * G * PPW;     // one chunk of group means (512 floats)
+    static constexpr int SSTAGE_FLOATS = LPP * PPW;        // one chunk of similarities (64 floats)
+    static constexpr size_t lds_bytes(int D) { return (size_t)NW * (128 * 32 + (PPW * D + RED_FLOATS + STAGE_FLOATS + SSTAGE_FLOATS) * sizeof(float)); }
+};
+
+template <int LPP, bool FAST>
+__global__ __launch_bounds__(64 * NW) void cv_corr_kernel(const float* __restrict__ feat /*[B,V,H,W,C]*/, const float* __restrict__ rt_all,
+                                                          const float* __restrict__ depth, int V, int D, int H, int W, float* __restrict__ entropy,
+                                                          float* __restrict__ corr, float* __restrict__ simv, int gx, int total) {
+    using Cfg = CorrCfg<LPP>;
+    constexpr int C = Cfg::C, CPG = Cfg::CPG, PPW = Cfg::PPW;
+    static_assert(LPP == 8 || LPP == 16, "stored-correlation sweeps are built for C = 32 and C = 64");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u32x4* taps_o = reinterpret_cast<u32x4*>(smem) + wave * 64;
+    f32x4* taps_w = reinterpret_cast<f32x4*>(smem + NW * 64 * 16) + wave * 64;
+    float* fbase = reinterpret_cast<float*>(smem + NW * 128 * 16);
+    float* sims = fbase + (size_t)wave * PPW * D;                                            // [D][PPW]
+    float* red = fbase + (size_t)NW * PPW * D + wave * Cfg::RED_FLOATS;
+    float* stage = fbase + (size_t)NW * (PPW * D + Cfg::RED_FLOATS) + wave * Cfg::STAGE_FLOATS;   // [LPP][G][PPW]
+    float* sstage = fbase + (size_t)NW * (PPW * D + Cfg::RED_FLOATS + Cfg::STAGE_FLOATS) + wave * Cfg::SSTAGE_FLOATS;   // [LPP][PPW]
+
+    const BlockId bid = xcd_block(gx, H, total);
+    if (!bid.valid) return;
+    const int xgi = bid.x * NW + wave;                      // pixel group of this wavefront
+    const int x0 = xgi * PPW, y = bid.y;
+    const int b = bid.z / (V - 1), sv = bid.z % (V - 1);
+    if (x0 >= W) return;                                   // wave-uniform; only wavefront-level barriers below
+    const int XG = (W + PPW - 1) / PPW;
+    const size_t HW = (size_t)H * W;
+    const unsigned pix_bytes = C * 4u;
+    const int pg = lane / LPP, cq = lane % LPP;
+    const int xg = min(x0 + pg, W - 1);
+    const f32x4 r = *reinterpret_cast<const f32x4*>(feat + ((size_t)(b * V) * HW + (size_t)y * W + xg) * C + cq * 4);
+    const mvs::rsrc_t src = mvs::make_rsrc(feat + (size_t)(b * V + sv + 1) * HW * C, (unsigned)(HW * pix_bytes));
+    const float* rt = rt_all + (size_t)(b * (V - 1) + sv) * 12;
+    const float* depth_row = depth + (size_t)b * D * HW + (size_t)y * W;
+    const float half_w = (float)((W - 1) / 2.0), half_h = (float)((H - 1) / 2.0);
+    const size_t tile = ((size_t)(b * (V - 1) + sv) * H + y) * XG + xgi;
+    float* ctile = corr + tile * ((size_t)D * G * PPW);
+    float* stile = simv + tile * ((size_t)D * PPW);
+
+    // F.normalize(ref_volume, dim=1), exactly as in cv_aggregate_kernel
+    f32x4 rn;
+    {
+        f32x4 n2 = {r[0] * r[0], r[1] * r[1], r[2] * r[2], r[3] * r[3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) n2[i] = (CPG == 8) ? parity_sum16(n2[i]) : pixel_sum<LPP>(n2[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rn[i] = r[i] / fmaxf(sqrtf(n2[i]), 1e-12f);
+    }
+    // all-reduce addressing.  Writer: this lane's values for j = 4*par + i go to unit (pixel, par), slot k' = 2*i + t (t = 0: q, 1: ||w||^2),
+    // position gi (its group).  Reader: lane (pixel, cq) owns unit par_r = cq / 8 (C = 64) and slot k' = cq % 8.
+    const int par_w = (LPP == 16) ? (cq & 1) : 0, gi = (LPP == 16) ? (cq >> 1) : cq;
+    float* red_w = red + (pg * (LPP / 8) + par_w) * 72 + gi;
+    const float* red_r = red + (pg * (LPP / 8) + (cq >> 3)) * 72 + (cq & 7) * 8;
+
+    for (int c0 = 0; c0 < D; c0 += LPP) {
+        geometry_pass<PPW, FAST>(rt, depth_row, HW, c0, D, x0, y, H, W, half_w, half_h, lane, taps_o, taps_w);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int dd = 0; dd < LPP; ++dd) {
+            // per-step uniform branch as in cv_aggregate_kernel: one step's loads in flight per wavefront, 4 wavefronts per SIMD
+            if (c0 + dd < D) {
+                const u32x4 o = taps_o[dd * PPW + pg];
+                const f32x4 w = taps_w[dd * PPW + pg];
+                const f32x4 g4 = gather4(src, pix_bytes, cq * 16u, o, w);
+                const f32x4 p = {r[0] * g4[0], r[1] * g4[1], r[2] * g4[2], r[3] * g4[3]};
+                const float h = ((p[0] + p[1]) + p[2]) + p[3];
+                // sim_vol = sum over groups (cv_entropy_kernel's expression) and this lane's group mean (cv_aggregate_kernel's)
+                const float s = pixel_sum<LPP>(h) * (1.0f / CPG);
+                if (cq == 0) sims[(c0 + dd) * PPW + pg] = s;
+                if (CPG == 4) {
+                    stage[(dd * G + cq) * PPW + pg] = h * 0.25f;
+                } else {
+                    const float h2 = dpp_add<DPP_XOR1>(h);
+                    if ((cq & 1) == 0) stage[(dd * G + (cq >> 1)) * PPW + pg] = h2 * 0.125f;
+                }
+                // eval similarity: sum_j (sum_g refn[g,j]*warp[g,j]) / max(||warp[:,j]||, 1e-12), mean over j
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    red_w[(2 * i) * 8] = rn[i] * g4[i];
+                    red_w[(2 * i + 1) * 8] = g4[i] * g4[i];
+                }
+                __builtin_amdgcn_wave_barrier();
+                const f32x4 ra = *reinterpret_cast<const f32x4*>(red_r), rb = *reinterpret_cast<const f32x4*>(red_r + 4);
+                __builtin_amdgcn_wave_barrier();
+                const float tot = ((((((ra[0] + ra[1]) + ra[2]) + ra[3]) + rb[0]) + rb[1]) + rb[2]) + rb[3];
+                // even lanes hold q_j, their odd neighbours ||w_j||^2
+                const float nrm = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tot), DPP_XOR1, 0xF, 0xF, true));
+                float term = (cq & 1) ? 0.0f : tot * __builtin_amdgcn_rsqf(fmaxf(nrm, 1e-24f));
+                term = pixel_sum<LPP>(term);
+                if (cq == 0) sstage[dd * PPW + pg] = term * (1.0f / CPG);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // this chunk's 2 KB of group means and 256 B of similarities: contiguous in the tile
+        {
+            const int nd = min(LPP, D - c0);
+#pragma unroll
+            for (int it = 0; it < Cfg::STAGE_FLOATS / 256; ++it) {
+                const int f = it * 64 + lane;                                   // float4 index inside the chunk
+                if (f * 4 < nd * G * PPW)
+                    *reinterpret_cast<f32x4*>(ctile + (size_t)c0 * G * PPW + f * 4) = *reinterpret_cast<const f32x4*>(stage + f * 4);
+            }
+            if (lane * 4 < nd * PPW) *reinterpret_cast<f32x4*>(stile + (size_t)c0 * PPW + lane * 4) = *reinterpret_cast<const f32x4*>(sstage + lane * 4);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // entropy of softmax_d - cv_entropy_kernel's epilogue
+    {
+        const int p = lane % PPW, k = lane / PPW;
+        float m = -INFINITY;
+        for (int d = k; d < D; d += LPP) m = fmaxf(m, sims[d * PPW + p]);
+#pragma unroll
+        for (int s = PPW; s < 64; s <<= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+        float sum = 0.0f;
+        for (int d = k; d < D; d += LPP) sum += FAST ? __expf(sims[d * PPW + p] - m) : expf(sims[d * PPW + p] - m);
+#pragma unroll
+        for (int s = PPW; s < 64; s <<= 1) sum += __shfl_xor(sum, s, 64);
+        const float inv_sum = __builtin_amdgcn_rcpf(sum);
+        float ent = 0.0f;
+        for (int d = k; d < D; d += LPP) {
+            const float pr = FAST ? __expf(sims[d * PPW + p] - m) * inv_sum : expf(sims[d * PPW + p] - m) / sum;
+            ent = ent + (-pr) * (FAST ? __logf(pr + 1e-7f) : logf(pr + 1e-7f));
+        }
+#pragma unroll
+        for (int s = PPW; s < 64; s <<= 1) ent += __shfl_xor(ent, s, 64);
+        if (k == 0 && x0 + p < W) entropy[((size_t)(b * (V - 1) + sv) * H + y) * W + x0 + p] = ent;
+    }
+}
+
+// sweep B' over the stored correlation: volume_mean = sum_v w_v*corr_v / (sum_v w_v + 1e-6) (mvsformer_model.py:101-105) in
+// cv_aggregate_kernel's order of operations, and sim_depth = depth[argmax_d sum_v similarity_v] (mvsformer_model.py:151-158).
+// One wavefront per pixel group; every load is a contiguous 1 KB run.
+template <int TPX>
+__global__ __launch_bounds__(64 * NW) void cv_merge_kernel(const float* __restrict__ corr, const float* __restrict__ simv, const float* __restrict__ depth,
+                                                           const float* __restrict__ weight, int V, int D, int H, int W, float* __restrict__ volume,
+                                                           float* __restrict__ sim_depth, int gx, int total) {
+    constexpr int LPR = TPX / 4;                          // lanes (float4s) per (plane, group) row
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const BlockId bid = xcd_block(gx, H, total);
+    if (!bid.valid) return;
+    const int XG = (W + TPX - 1) / TPX;
+    const int xgi = bid.x * NW + wave, y = bid.y, b = bid.z;
+    if (xgi >= XG) return;
+    const int x0 = xgi * TPX;
+    const size_t HW = (size_t)H * W;
+    const int nv = V - 1;
+    const size_t vstride_c = (size_t)H * XG * D * G * TPX, vstride_s = (size_t)H * XG * D * TPX;
+    const float* ct = corr + (size_t)(b * nv) * vstride_c + ((size_t)y * XG + xgi) * ((size_t)D * G * TPX);
+    const float* stl = simv + (size_t)(b * nv) * vstride_s + ((size_t)y * XG + xgi) * ((size_t)D * TPX);
+    const float* wp = weight + (size_t)(b * nv) * HW + (size_t)y * W;
+    {
+        const int part = lane % LPR, xs = x0 + part * 4;
+        f32x4 wsum = {0.f, 0.f, 0.f, 0.f};
+        for (int v = 0; v < nv; ++v)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wsum[i] = wsum[i] + wp[(size_t)v * HW + min(xs + i, W - 1)];
+        f32x4 denom;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) denom[i] = wsum[i] + 1e-6f;
+        const bool vec = ((W & 3) == 0) && xs < W;          // whole float4 inside the row, 16-byte aligned
+        const int rows = D * G;
+        for (int row = lane / LPR; row < rows; row += 64 / LPR) {
+            const int f = row * LPR + part;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int v = 0; v < nv; ++v) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(ct + (size_t)v * vstride_c + (size_t)f * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = acc[i] + c4[i] * wp[(size_t)v * HW + min(xs + i, W - 1)];
+            }
+            const int d = row / G, g = row % G;
+            float* o = volume + ((size_t)(b * G + g) * D + d) * HW + (size_t)y * W + xs;
+            if (vec) {
+                *reinterpret_cast<f32x4*>(o) = f32x4{acc[0] / denom[0], acc[1] / denom[1], acc[2] / denom[2], acc[3] / denom[3]};
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (xs + i < W) o[i] = acc[i] / denom[i];
+            }
+        }
+    }
+    if (sim_depth) {
+        const int px = lane % TPX, ds = lane / TPX;
+        float best = -INFINITY;
+        int besti = 0;
+        for (int d = ds; d < D; d += 64 / TPX) {
+            float s = 0.0f;
+            for (int v = 0; v < nv; ++v) s = s + stl[(size_t)v * vstride_s + (size_t)d * TPX + px];
+            if (s > best) { best = s; besti = d; }
+        }
+#pragma unroll
+        for (int m = TPX; m < 64; m <<= 1) {                // first maximum wins, as a sequential scan over d would have it
+            const float ob = __shfl_xor(best, m, 64);
+            const int oi = __shfl_xor(besti, m, 64);
+            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+        }
+        if (ds == 0 && x0 + px < W) sim_depth[(size_t)b * HW + (size_t)y * W + x0 + px] = depth[((size_t)b * D + besti) * HW + (size_t)y * W + x0 + px];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // NCHW -> NHWC feature transpose ([N,C,HW] -> [N,HW,C]) through an LDS tile of TP pixels: reads are 16 bytes per lane along a
 // channel row (a wavefront reads 1 KB contiguous), writes are one contiguous TP*C-float run per block (dwordx4 per lane).  VEC = false
 // (HW not a multiple of 4, or a ragged last block) falls back to dword reads.
@@ -598,4 +823,71 @@ extern "C" int mvs_cv_aggregate_fwd(const float* feat, const float* rt, const fl
 #undef MVS_LAUNCH_AGG
 #undef MVS_LAUNCH_AGG2
     return mvs::finish_launch("mvs_cv_aggregate_fwd");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// stored-correlation sweeps (coarse stages)
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct StoreLayout { int64_t corr_floats, sim_floats; int TPX, XG; };
+StoreLayout store_layout(int B, int V, int C, int D, int H, int W) {
+    StoreLayout l;
+    l.TPX = 256 / C;
+    l.XG = mvs::ceil_div(W, l.TPX);
+    l.corr_floats = (int64_t)B * (V - 1) * H * l.XG * D * G * l.TPX;
+    l.sim_floats = (int64_t)B * (V - 1) * H * l.XG * D * l.TPX;
+    return l;
+}
+}  // namespace
+
+extern "C" int64_t mvs_cv_corr_store_bytes(int B, int V, int C, int Gin, int D, int H, int W) {
+    if (B < 1 || V < 2 || D < 1 || H < 1 || W < 1 || Gin != G || (C != 32 && C != 64)) return -1;
+    const StoreLayout l = store_layout(B, V, C, D, H, W);
+    return (l.corr_floats + l.sim_floats) * (int64_t)sizeof(float);
+}
+
+extern "C" int mvs_cv_corr_fwd(const float* feat, const float* rt, const float* depth, int B, int V, int C, int Gin, int D, int H, int W,
+                               float* entropy, void* store, int flags, mvs_stream_t stream) {
+    MVS_REQUIRE(feat && rt && depth && entropy && store, "mvs_cv_corr_fwd: null pointer");
+    if (int rc = check_shapes("mvs_cv_corr_fwd", B, V, C, Gin, D, H, W)) return rc;
+    MVS_REQUIRE(C == 32 || C == 64, "mvs_cv_corr_fwd: the stored-correlation sweeps are built for C = 32 and C = 64 (got %d)", C);
+    MVS_REQUIRE((reinterpret_cast<uintptr_t>(store) & 15) == 0, "mvs_cv_corr_fwd: store must be 16-byte aligned");
+    const int LPP = C / 4, PPW = 64 / LPP;
+    const size_t lds = LPP == 16 ? CorrCfg<16>::lds_bytes(D) : CorrCfg<8>::lds_bytes(D);
+    MVS_REQUIRE(lds <= 64 * 1024, "mvs_cv_corr_fwd: D=%d with C=%d needs %zu bytes of LDS (> 64 KiB)", D, C, lds);
+    const StoreLayout l = store_layout(B, V, C, D, H, W);
+    float* corr = static_cast<float*>(store);
+    float* simv = corr + l.corr_floats;
+    const int gx = mvs::ceil_div(W, NW * PPW);
+    const int64_t total64 = (int64_t)gx * H * B * (V - 1);
+    MVS_REQUIRE(total64 < ((int64_t)1 << 30), "mvs_cv_corr_fwd: too many blocks");
+    const int total = (int)total64;
+    dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(64 * NW);
+    hipStream_t s = MVS_STREAM(stream);
+    const bool fast = !(flags & 1);
+#define MVS_LAUNCH_CORR(L)                                                                                                                 \
+    if (fast) hipLaunchKernelGGL((cv_corr_kernel<L, true>), grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy, corr, simv, gx, total); \
+    else hipLaunchKernelGGL((cv_corr_kernel<L, false>), grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy, corr, simv, gx, total)
+    if (LPP == 16) { MVS_LAUNCH_CORR(16); } else { MVS_LAUNCH_CORR(8); }
+#undef MVS_LAUNCH_CORR
+    return mvs::finish_launch("mvs_cv_corr_fwd");
+}
+
+extern "C" int mvs_cv_merge_fwd(const void* store, const float* depth, const float* weight, int B, int V, int C, int Gin, int D, int H, int W,
+                                float* volume, float* sim_depth, mvs_stream_t stream) {
+    MVS_REQUIRE(store && depth && weight && volume, "mvs_cv_merge_fwd: null pointer");
+    if (int rc = check_shapes("mvs_cv_merge_fwd", B, V, C, Gin, D, H, W)) return rc;
+    MVS_REQUIRE(C == 32 || C == 64, "mvs_cv_merge_fwd: the stored-correlation sweeps are built for C = 32 and C = 64 (got %d)", C);
+    const StoreLayout l = store_layout(B, V, C, D, H, W);
+    const float* corr = static_cast<const float*>(store);
+    const float* simv = corr + l.corr_floats;
+    const int gx = mvs::ceil_div(l.XG, NW);
+    const int64_t total64 = (int64_t)gx * H * B;
+    MVS_REQUIRE(total64 < ((int64_t)1 << 30), "mvs_cv_merge_fwd: too many blocks");
+    const int total = (int)total64;
+    dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(64 * NW);
+    hipStream_t s = MVS_STREAM(stream);
+    if (l.TPX == 4) hipLaunchKernelGGL((cv_merge_kernel<4>), grid, block, 0, s, corr, simv, depth, weight, V, D, H, W, volume, sim_depth, gx, total);
+    else hipLaunchKernelGGL((cv_merge_kernel<8>), grid, block, 0, s, corr, simv, depth, weight, V, D, H, W, volume, sim_depth, gx, total);
+    return mvs::finish_launch("mvs_cv_merge_fwd");
 }

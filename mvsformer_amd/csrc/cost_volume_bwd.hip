@@ -281,8 +281,9 @@ __global__ __launch_bounds__(64 * LT_NW) void cv_aggregate_bwd_lds_kernel(const 
             mvs::sweep_project(rt, (float)xc, (float)yc, depth[((size_t)b * D + D / 2) * HW + (size_t)yc * W + xc], half_w, half_h, &un, &vn, &z);
             const float ix = (un + 1.0f) * half_w, iy = (vn + 1.0f) * half_h;
             const bool ok = fabsf(ix) < 1e6f && fabsf(iy) < 1e6f;       // also false for NaN
-            origin[0] = ok ? (int)floorf(ix) - WX / 2 : 0;
-            origin[1] = ok ? (int)floorf(iy) - WY / 2 : 0;
+            // clamped to where a window can still hold an in-image tap: the packed 16-bit window coordinates below must not wrap
+            origin[0] = ok ? min(max((int)floorf(ix) - WX / 2, -WX), W + 1) : 0;
+            origin[1] = ok ? min(max((int)floorf(iy) - WY / 2, -WY), H + 1) : 0;
         }
         __syncthreads();                                      // origin visible; window zeroed (first view) / flushed (later views)
         const int ox = origin[0], oy = origin[1];
@@ -494,8 +495,11 @@ __global__ __launch_bounds__(64 * OW_NW) void cv_aggregate_bwd_own_kernel(const 
                     iy += __shfl_xor(iy, m, 64);
                     ok += __shfl_xor(ok, m, 64);
                 }
-                ox = ok > 0.0f ? (int)floorf(ix / ok) - WX / 2 : 0;
-                oy = ok > 0.0f ? (int)floorf(iy / ok) - WY / 2 : 0;
+                // the mean of projections that are each only bounded by 1e6 px can land anywhere: clamp the origin to where a window can
+                // still hold an in-image tap, so that (x0 - ox, y0 - oy) with x0 in [-2, W+1] stays far inside the signed 16-bit fields
+                // packed below (a wrapped coordinate would alias into the window and be flushed OUTSIDE the image)
+                ox = ok > 0.0f ? min(max((int)floorf(ix / ok) - WX / 2, -WX), W + 1) : 0;
+                oy = ok > 0.0f ? min(max((int)floorf(iy / ok) - WY / 2, -WY), H + 1) : 0;
             }
             int clo = NCELL, chi = -1;                        // cells this lane touched in the chunk (the flush scans only the wave's range)
             for (int c0 = dc; c0 < dend; c0 += 2) {

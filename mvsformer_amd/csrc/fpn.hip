@@ -281,190 +281,6 @@ __global__ __launch_bounds__(256, (CK == 32 ? 2 : (CK == 16 ? 3 : 4))) void fpn_
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Last level (C_k = 8) with the 3x3 convolution on the BF16 matrix cores in split form: every fp32 operand is written as
-// hi + lo with hi = bf16(v), lo = bf16(v - hi) (v - hi is exact in fp32), and a*b is accumulated in fp32 as
-// a_lo*b_hi + a_hi*b_lo + a_hi*b_hi (the dropped lo*lo term and the third-order residuals are <= 2^-16 relative per product).
-// Why: on gfx950 the fp32 MFMA shares the fp32 VALU pipe (same 157 TFLOP/s peak), v_mfma_f32_16x16x32_bf16 runs at 16x that
-// rate - three of them with K = 32 replace eight fp32 MFMAs with K = 4 at 1/2 the cycles each: 5.3x fewer matrix cycles for ~2.5
-// extra vector instructions per intra value (the split).  Layout follows bf16_train.hip: the intra tile is CHANNEL-LAST bf16 in LDS
-// ([halo pixel][32 channels], 80-byte pixel stride so the 16 pixels of a fragment read hit distinct banks), a lane's A operand = 8
-// consecutive channels of its pixel = one ds_read_b128; the B operand (weights, N = 2 output rows x 8 channels as in the fp32 form) is
-// pre-packed per lane and read straight from L1/L2.  64 channels = 2 chunks of 32.
-//
-// STATUS: EXPERIMENTAL, OFF by default (MVS_FPN_SPLIT=1 selects it).  Parity-green on every small shape (4e-6 of scale, as the numpy
-// walk-through predicts) and 1.29 ms against 1.45 ms for the fp32 form at 5 x 1152x1536 - but at that size 0.06 % of the pixels come
-// out wrong, differently from run to run: always the intra values of 16 consecutive halo pixels that lanes 48..63 of wavefront 0 or 1
-// produced (tools/diag_fpn_split.py prints the maps).  Draining the LDS stores before their source registers are reused did not
-// change it; the cause is open.  No test exercises this kernel until it is found.
-// ---------------------------------------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int SP_CH = 32;                    // top-down channels per chunk (= K of one MFMA)
-constexpr int SP_PS = 40;                    // bf16 elements per halo pixel in LDS (32 used)
-constexpr int SP_UNITS = (FC / SP_CH) * 12 * 2 * 64;   // bf16x8 units of the packed weights: [chunk][tap 12][hi|lo][lane]
-
-__global__ void fpn_pack_split_kernel(const float* __restrict__ w /*[8,64,3,3]*/, bf16x8* __restrict__ out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= SP_UNITS) return;
-    const int l = idx & 63, part = (idx >> 6) & 1, t = (idx >> 7) % 12, cq = idx / (128 * 12);
-    const int n = l & 15, kk = l >> 4, hh = n >> 3, co = n & 7, j = t / 3, kx = t % 3, ky = j - hh;
-    bf16x8 v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = cq * SP_CH + kk * 8 + e;
-        const float f = (ky >= 0 && ky <= 2) ? w[((size_t)(co * FC + c) * 3 + ky) * 3 + kx] : 0.0f;
-        const __bf16 hi = (__bf16)f;
-        v[e] = part ? (__bf16)(f - (float)hi) : hi;
-    }
-    out[idx] = v;
-}
-
-__global__ __launch_bounds__(256, 3) void fpn_level8_split_kernel(const float* __restrict__ prev /*[N,64,h,w]*/, const float* __restrict__ lat /*[N,8,2h,2w]*/,
-                                                                   const float* __restrict__ w_in_p /*[32,8,2]*/, const float* __restrict__ b_in,
-                                                                   const bf16x8* __restrict__ wsp, const float* __restrict__ scale,
-                                                                   const float* __restrict__ shift, int h, int w, float* __restrict__ out /*[N,2h,2w,8]*/) {
-    constexpr int CK = 8;
-    __shared__ __attribute__((aligned(16))) float s_src[SP_CH * SS];
-    __shared__ __attribute__((aligned(16))) __bf16 s_hi[NPIX * SP_PS];
-    __shared__ __attribute__((aligned(16))) __bf16 s_lo[NPIX * SP_PS];
-
-    unsigned bx, by, bz;
-    xcd_block_coords(bx, by, bz);
-    const int H = 2 * h, W = 2 * w;
-    const int x0 = (int)bx * TW, y0 = (int)by * TH, img = (int)bz;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i16 = lane & 15, kk = lane >> 4;
-
-    // ---- this thread's halo pixel (identical to fpn_level_kernel) ----
-    const int p = tid;
-    const int gy = y0 - 1 + p / HC, gx = x0 - 1 + p % HC;
-    const bool inimg = (p < NPIX) && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    const float sy = (float)(h - 1) / (float)(H - 1), sx = (float)(w - 1) / (float)(W - 1);
-    const int wy0 = (int)(sy * (float)max(y0 - 1, 0)), wx0 = (int)(sx * (float)max(x0 - 1, 0));
-    int o00 = 0, o01 = 0, o10 = 0, o11 = 0;
-    float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
-    const float gate = inimg ? 1.0f : 0.0f;
-    float lv[CK];
-#pragma unroll
-    for (int j = 0; j < CK; ++j) lv[j] = 0.0f;
-    if (inimg) {
-        const float fy = sy * (float)gy, fx = sx * (float)gx;
-        const int iy0 = (int)fy, ix0 = (int)fx;
-        const int iy1 = iy0 + (iy0 < h - 1 ? 1 : 0), ix1 = ix0 + (ix0 < w - 1 ? 1 : 0);
-        const float ly1 = fy - (float)iy0, lx1 = fx - (float)ix0, ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
-        w00 = ly0 * lx0;
-        w01 = ly0 * lx1;
-        w10 = ly1 * lx0;
-        w11 = ly1 * lx1;
-        const int ry0 = min(iy0 - wy0, SH - 1), ry1 = min(iy1 - wy0, SH - 1), rx0 = min(ix0 - wx0, SW - 1), rx1 = min(ix1 - wx0, SW - 1);
-        o00 = ry0 * SW + rx0;
-        o01 = ry0 * SW + rx1;
-        o10 = ry1 * SW + rx0;
-        o11 = ry1 * SW + rx1;
-        const float* lat_img = lat + (size_t)img * CK * H * W;
-        const unsigned lo = (unsigned)(gy * W + gx), HW = (unsigned)(H * W);
-#pragma unroll
-        for (int j = 0; j < CK; ++j) lv[j] = lat_img[j * HW + lo];
-    }
-
-    const int sr = tid & 127, shalf = tid >> 7;
-    const int spy = wy0 + sr / SW, spx = wx0 + sr % SW;
-    const bool svalid = sr < SS && spy < h && spx < w;
-    const float* prev_img = prev + (size_t)img * FC * h * w;
-    const unsigned hw = (unsigned)(h * w), soff = svalid ? (unsigned)(shalf * (h * w) + spy * w + spx) : 0u;
-    constexpr int NSR = SP_CH / 2;
-    float sreg[NSR];
-    auto prefetch = [&](int cc) {
-#pragma unroll
-        for (int i = 0; i < NSR; ++i) sreg[i] = svalid ? prev_img[(unsigned)(cc * SP_CH + 2 * i) * hw + soff] : 0.0f;
-    };
-    auto commit = [&]() {
-        if (sr < SS) {
-#pragma unroll
-            for (int i = 0; i < NSR; ++i) s_src[(2 * i + shalf) * SS + sr] = sreg[i];
-        }
-    };
-
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int pq = wv >> 1, mt = wv & 1;                    // output row pair, 16-column half
-
-    prefetch(0);
-    {
-        float guard = 0.0f;                                 // see fpn_level_kernel: keeps the wait-count pass from draining the prefetch
-#pragma unroll
-        for (int j = 0; j < CK; ++j) guard += lv[j];
-        asm volatile("" ::"v"(guard));
-    }
-    for (int cc = 0; cc < FC / SP_CH; ++cc) {
-        __syncthreads();
-        commit();
-        __syncthreads();
-        if (cc + 1 < FC / SP_CH) prefetch(cc + 1);
-        // ---- intra tile for 32 channels: packed fp32 math as in fpn_level_kernel, then the hi/lo split, 8 channels per 16-byte store ----
-        if (p < NPIX) {
-#pragma unroll
-            for (int g = 0; g < SP_CH / 8; ++g) {
-                float v8[8];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = g * 8 + 2 * q, ch = cc * SP_CH + c;
-                    f32x2 v = f32x2{b_in[ch], b_in[ch + 1]} * f32x2{gate, gate};
-#pragma unroll
-                    for (int j = 0; j < CK; ++j) v = pk_fma(f32x2{w_in_p[(ch * CK) + 2 * j], w_in_p[(ch * CK) + 2 * j + 1]}, f32x2{lv[j], lv[j]}, v);
-                    const float* S = s_src + c * SS;
-                    v = pk_fma(f32x2{w00, w00}, f32x2{S[o00], S[SS + o00]}, v);
-                    v = pk_fma(f32x2{w01, w01}, f32x2{S[o01], S[SS + o01]}, v);
-                    v = pk_fma(f32x2{w10, w10}, f32x2{S[o10], S[SS + o10]}, v);
-                    v = pk_fma(f32x2{w11, w11}, f32x2{S[o11], S[SS + o11]}, v);
-                    v8[2 * q] = v.x;
-                    v8[2 * q + 1] = v.y;
-                }
-                bf16x8 hi8, lo8;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const __bf16 hi = (__bf16)v8[e];
-                    hi8[e] = hi;
-                    lo8[e] = (__bf16)(v8[e] - (float)hi);
-                }
-                // UNTESTED hypothesis for the sporadic wrong strips (lanes 48..63 = the last quarter a 4-cycle vector op finishes): the
-                // ds_write_b128 below issues right behind the v_cvt_pk_bf16_f32 that produces its last data register; if that conversion
-                // has a longer result latency than the hazard tables of this compiler assume, the last quarter stores a stale
-                // register.  Draining the stores AFTER them (tried on the box) cannot help against that; idling BEFORE them would.
-                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-                u32x4_t hq = __builtin_bit_cast(u32x4_t, hi8), lq = __builtin_bit_cast(u32x4_t, lo8);
-                asm volatile("s_nop 7\n\ts_nop 7" : "+v"(hq), "+v"(lq));          // ordered after the conversions by its operands
-                *reinterpret_cast<u32x4_t*>(s_hi + p * SP_PS + g * 8) = hq;
-                *reinterpret_cast<u32x4_t*>(s_lo + p * SP_PS + g * 8) = lq;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __syncthreads();
-        // ---- 3x3 convolution of this chunk: 12 (input row, kx) taps x 3 split products ----
-        const bf16x8* wl = wsp + (size_t)cc * 12 * 2 * 64 + lane;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int pa = (2 * pq + j) * HC + mt * 16 + i16 + kx;
-                const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(s_hi + pa * SP_PS + kk * 8);
-                const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(s_lo + pa * SP_PS + kk * 8);
-                const bf16x8 b_hi = wl[((j * 3 + kx) * 2 + 0) * 64], b_lo = wl[((j * 3 + kx) * 2 + 1) * 64];
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, b_hi, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_lo, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, b_hi, acc, 0, 0, 0);
-            }
-    }
-
-    float* out_img = out + (size_t)img * H * W * CK;
-    const int co = i16 & 7, yy = y0 + 2 * pq + (i16 >> 3);
-    const float sc = scale[co], sh = shift[co];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int xx = x0 + mt * 16 + 4 * kk + r;
-        if (yy < H && xx < W) out_img[(unsigned)((yy * W + xx) * CK + co)] = swish(fmaf(acc[r], sc, sh));
-    }
-}
 }  // namespace
 
 extern "C" int64_t mvs_fpn_packed_floats(int Cout) {
@@ -505,24 +321,4 @@ extern "C" int mvs_fpn_level(const float* intra_prev, const float* lateral, cons
     else
         hipLaunchKernelGGL(fpn_level_kernel<32>, grid, block, 0, s, intra_prev, lateral, w_inner_p, b_inner, w_packed, scale, shift, h, w, intra_out, out);
     return mvs::finish_launch("mvs_fpn_level");
-}
-
-extern "C" int64_t mvs_fpn_split_packed_bytes(void) { return (int64_t)SP_UNITS * 16; }
-
-extern "C" int mvs_fpn_pack_weights_split(const float* w, void* packed, mvs_stream_t stream) {
-    MVS_REQUIRE(w && packed, "mvs_fpn_pack_weights_split: null pointer");
-    hipLaunchKernelGGL(fpn_pack_split_kernel, dim3(mvs::ceil_div(SP_UNITS, 256)), dim3(256), 0, MVS_STREAM(stream), w, reinterpret_cast<bf16x8*>(packed));
-    return mvs::finish_launch("mvs_fpn_pack_weights_split");
-}
-
-extern "C" int mvs_fpn_level_split(const float* intra_prev, const float* lateral, const float* w_inner_p, const float* b_inner,
-                                   const void* w_split, const float* scale, const float* shift, int N, int h, int w, float* out,
-                                   mvs_stream_t stream) {
-    MVS_REQUIRE(intra_prev && lateral && w_inner_p && b_inner && w_split && scale && shift && out, "mvs_fpn_level_split: null pointer");
-    MVS_REQUIRE(N >= 1 && N <= 65535 && h >= 1 && w >= 1 && (int64_t)2 * h <= 4 * 65535, "mvs_fpn_level_split: bad shape N=%d h=%d w=%d", N, h, w);
-    MVS_REQUIRE((int64_t)FC * 4 * h * w < ((int64_t)1 << 31), "mvs_fpn_level_split: one image's 64-channel level exceeds 2^31 elements");
-    const dim3 grid(mvs::ceil_div(2 * w, TW), mvs::ceil_div(2 * h, TH), N), block(256);
-    hipLaunchKernelGGL(fpn_level8_split_kernel, grid, block, 0, MVS_STREAM(stream), intra_prev, lateral, w_inner_p, b_inner,
-                       reinterpret_cast<const bf16x8*>(w_split), scale, shift, h, w, out);
-    return mvs::finish_launch("mvs_fpn_level_split");
 }

@@ -68,28 +68,21 @@ class FPNDecoder(nn.Module):
                 levels.append((inner.weight.detach().reshape(ops.FPN_CH // 2, 2, -1).permute(0, 2, 1).contiguous(), inner.bias.detach().contiguous(),
                                ops.fpn_pack_weights(seq[0].weight.detach().contiguous()), scale, shift))
             s0, h0 = self._fold(self.out0)
-            split = ops.fpn_pack_weights_split(self.out3[0].weight.detach().contiguous())
             _publish_cache()
-            self._cache = (key, (self.out0[0].weight.detach().reshape(ops.FPN_CH, ops.FPN_CH).contiguous(), s0, h0), levels, split)
-        return self._cache[1], self._cache[2], self._cache[3]
+            self._cache = (key, (self.out0[0].weight.detach().reshape(ops.FPN_CH, ops.FPN_CH).contiguous(), s0, h0), levels)
+        return self._cache[1], self._cache[2]
 
     def forward(self, conv01, conv11, conv21, conv31):
         if self.training:
             raise _lib.MvsHipError("FPNDecoder: only eval mode is built on the HIP path (training the 2-D feature extractor is "
                                    "outside the hot path, SURVEY.md §8); call .eval()")
         with torch.no_grad():
-            (w0, s0, h0), levels, split = self._prepared()
-            # MVS_FPN_SPLIT=1: EXPERIMENTAL bf16 hi/lo split form of the last level - sporadically wrong pixels at full size, cause
-            # open (csrc/fpn.hip); the default is the fp32 MFMA form
-            use_split = os.environ.get("MVS_FPN_SPLIT", "0") == "1"
+            (w0, s0, h0), levels = self._prepared()
             intra = conv31.float().contiguous()
             outs = [ops.fpn_out0(intra, w0, s0, h0)]
             for i, lateral in enumerate((conv21, conv11, conv01)):
                 w_in, b_in, packed, scale, shift = levels[i]
-                if i == 2 and use_split:
-                    out = ops.fpn_level_split(intra, lateral.float().contiguous(), w_in, b_in, split, scale, shift)
-                else:
-                    intra, out = ops.fpn_level(intra, lateral.float().contiguous(), w_in, b_in, packed, scale, shift, want_intra=(i < 2))
+                intra, out = ops.fpn_level(intra, lateral.float().contiguous(), w_in, b_in, packed, scale, shift, want_intra=(i < 2))
                 outs.append(out)
         return [o.permute(0, 3, 1, 2) for o in outs]
 

@@ -237,6 +237,43 @@ def cv_aggregate(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, weig
     return vol, sim
 
 
+def cv_store_bytes(feat: torch.Tensor, D: int, G: int) -> int:
+    """Bytes of the per-view correlation store of the stored-correlation sweeps for channel-last ``feat [B,V,H,W,C]`` (-1: not built
+    for this shape - C must be 32 or 64)."""
+    B, V, H, W, C = feat.shape
+    return int(_lib.load().mvs_cv_corr_store_bytes(B, V, C, G, D, H, W))
+
+
+def cv_corr(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, G: int, exact: Optional[bool] = None):
+    """Sweep A', coarse stages: entropy ``[B,V-1,H,W]`` as :func:`cv_entropy` plus the per-view correlation store for :func:`cv_merge`."""
+    _chk(feat, "features"), _chk(rt, "rt"), _chk(depth, "depth_values")
+    B, V, H, W, C = feat.shape
+    D = depth.shape[1]
+    if depth.shape != (B, D, H, W):
+        raise _lib.MvsHipError("depth_values must be [B,D,H,W]=%s, got %s" % ((B, D, H, W), tuple(depth.shape)))
+    nbytes = cv_store_bytes(feat, D, G)
+    if nbytes <= 0:
+        raise _lib.MvsHipError("stored-correlation sweeps are built for C = 32 | 64, G = 8 (got C=%d, G=%d)" % (C, G))
+    ent = torch.empty(B, V - 1, H, W, device=feat.device, dtype=torch.float32)
+    store = torch.empty(nbytes // 4, device=feat.device, dtype=torch.float32)
+    tag = ("cv_corr_kernel<%d>" % (C // 4), "bytes", 4.0 * B * H * W * (V * C + D))
+    _call("mvs_cv_corr_fwd", tag, _ptr(feat), _ptr(rt), _ptr(depth), B, V, C, G, D, H, W, _ptr(ent), _ptr(store), _cv_flags(exact), _stream())
+    return ent, store
+
+
+def cv_merge(store: torch.Tensor, depth: torch.Tensor, weight: torch.Tensor, V: int, C: int, G: int, want_sim_depth: bool):
+    """Sweep B' over the store of :func:`cv_corr`: ``volume [B,G,D,H,W]`` and the similarity arg-max depth."""
+    _chk(store, "correlation store"), _chk(depth, "depth_values"), _chk(weight, "vis_weight")
+    B, D, H, W = depth.shape
+    if weight.shape != (B, V - 1, H, W) or store.numel() * 4 != int(_lib.load().mvs_cv_corr_store_bytes(B, V, C, G, D, H, W)):
+        raise _lib.MvsHipError("cv_merge: weight %s / store size do not match the shape" % (tuple(weight.shape),))
+    vol = torch.empty(B, G, D, H, W, device=depth.device, dtype=torch.float32)
+    sim = torch.empty(B, H, W, device=depth.device, dtype=torch.float32) if want_sim_depth else None
+    tag = ("cv_merge_kernel<%d>" % (256 // C), "bytes", 4.0 * B * H * W * (G * D))     # the rest of SURVEY 8d's bytes is credited to sweep A'
+    _call("mvs_cv_merge_fwd", tag, _ptr(store), _ptr(depth), _ptr(weight), B, V, C, G, D, H, W, _ptr(vol), _ptr(sim), _stream())
+    return vol, sim
+
+
 def cv_tiled_supported(feat: torch.Tensor) -> bool:
     """The LDS-tiled sweeps take the FPN decoder's NCHW ``[B,V,C,H,W]`` maps directly (C in 8/16/32/64, contiguous fp32)."""
     return (isinstance(feat, torch.Tensor) and feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 5 and feat.is_contiguous()
@@ -576,6 +613,8 @@ def cv_aggregate_bwd(feat_cl, rt, depth, weight, volume, gvolume, G: int, stats:
     D = depth.shape[1]
     dfeat = torch.zeros_like(feat_cl)
     mode = os.environ.get("MVS_CV_BWD", "own")
+    if mode not in ("own", "lds", "direct"):
+        raise _lib.MvsHipError("MVS_CV_BWD=%r: expected 'own', 'lds' or 'direct'" % mode)
     if mode != "direct":
         # "own" (default): per-wavefront LDS windows with owner election - no atomics in the common case; "lds": block-shared window with
         # LDS float atomics; "direct": global atomics with per-lane run merging (DESIGN.md §4.5 for the measurements).
@@ -981,34 +1020,6 @@ def fpn_level(intra_prev: torch.Tensor, lateral: torch.Tensor, w_inner_p: torch.
     _call("mvs_fpn_level", tag, _ptr(intra_prev), _ptr(lateral), _ptr(w_inner_p), _ptr(b_inner), _ptr(packed), _ptr(scale), _ptr(shift),
           N, Ck, h, w, _ptr(intra), _ptr(out), _stream())
     return intra, out
-
-
-def fpn_pack_weights_split(w: torch.Tensor) -> torch.Tensor:
-    """``out3.0.weight [8,64,3,3]`` -> per-lane bf16 hi/lo fragments for :func:`fpn_level_split` (uint8 storage)."""
-    _chk(w, "fpn 3x3 weight")
-    if tuple(w.shape) != (8, FPN_CH, 3, 3):
-        raise _lib.MvsHipError("fpn_pack_weights_split: weight must be [8,64,3,3], got %s" % (tuple(w.shape),))
-    packed = torch.empty(int(_lib.load().mvs_fpn_split_packed_bytes()), device=w.device, dtype=torch.uint8)
-    _call("mvs_fpn_pack_weights_split", None, _ptr(w), _ptr(packed), _stream())
-    return packed
-
-
-def fpn_level_split(intra_prev: torch.Tensor, lateral: torch.Tensor, w_inner_p: torch.Tensor, b_inner: torch.Tensor, w_split: torch.Tensor,
-                    scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
-    """The last top-down level (Ck = 8) with its 3x3 convolution on the bf16 matrix cores in hi/lo split form (include/mvs_hip.h):
-    ``out [N,2h,2w,8]`` channel-last; ``intra`` is not produced."""
-    _chk(intra_prev, "intra_prev"), _chk(lateral, "lateral"), _chk(w_inner_p, "inner weight"), _chk(b_inner, "inner bias")
-    _chk(w_split, "split weights", torch.uint8), _chk(scale, "scale"), _chk(shift, "shift")
-    N, C, h, w = intra_prev.shape
-    if C != FPN_CH or lateral.shape != (N, 8, 2 * h, 2 * w) or w_inner_p.shape != (FPN_CH // 2, 8, 2) or b_inner.numel() != FPN_CH:
-        raise _lib.MvsHipError("fpn_level_split: shapes %s / %s do not form the Ck=8 level" % (tuple(intra_prev.shape), tuple(lateral.shape)))
-    if w_split.numel() != int(_lib.load().mvs_fpn_split_packed_bytes()) or scale.numel() != 8 or shift.numel() != 8:
-        raise _lib.MvsHipError("fpn_level_split: parameter sizes do not match")
-    out = torch.empty(N, 2 * h, 2 * w, 8, device=lateral.device, dtype=torch.float32)
-    tag = ("fpn_level8_split_kernel", "flops", 2.0 * FPN_CH * 8 * 10 * N * 4 * h * w)
-    _call("mvs_fpn_level_split", tag, _ptr(intra_prev), _ptr(lateral), _ptr(w_inner_p), _ptr(b_inner), _ptr(w_split), _ptr(scale), _ptr(shift),
-          N, h, w, _ptr(out), _stream())
-    return out
 
 
 # ----------------------------------------------------------------------------------------------- FPN encoder layers

@@ -6,9 +6,14 @@
 Where the reference runs ~40 ATen launches per source view over materialized [B,C,D,H,W] temporaries, this
 forward is 5 + 10 hand-written HIP launches per stage:
 
-    mvs_proj_prepare -> mvs_cv_tiled_entropy_fwd -> mvs_vis_wino_fwd -> mvs_cv_tiled_aggregate_fwd
-    (MVS_CV_TILED=0 or channel-last inputs: mvs_nchw_to_nhwc -> mvs_cv_entropy_fwd -> ... -> mvs_cv_aggregate_fwd)
+    mvs_proj_prepare -> mvs_nchw_to_nhwc (skipped for channel-last inputs) -> sweep A -> mvs_vis_wino_fwd -> sweep B
     -> 9 fused conv/deconv MFMA layers -> (mvs_prob3_fwd) -> mvs_head_fwd
+
+The sweeps are chosen per stage (``_cv_plan``): coarse stages keep the per-view correlation volumes sweep A computes
+(``mvs_cv_corr_fwd``), so that sweep B is a pure stream over them (``mvs_cv_merge_fwd``); fine stages recompute the
+correlation in sweep B (``mvs_cv_entropy_fwd`` / ``mvs_cv_aggregate_fwd``) because their per-view volumes no longer fit the
+Infinity Cache.  ``MVS_CV_TILED=1`` opts into the LDS-tiled sweeps of cost_volume_tiled.hip (they lose on the noisy
+hypotheses a random-weight cascade predicts).
 
 ``DepthNet`` is the name BASELINE.json uses for the same thing.
 """
@@ -22,6 +27,14 @@ import torch.nn as nn
 from . import ops
 from ._lib import MvsHipError
 from .module import ConvBnReLU, CostRegNet, CostRegNet3D, _versions, pack_vis_params
+
+
+def _store_plan(feat_cl, D, G) -> bool:
+    """True when the stage should keep its per-view correlation volumes (stored-correlation sweeps): built for C = 32 | 64 and only
+    worth it while the store stays Infinity-Cache sized (MVS_CV_STORE_MAX_MB, default 256; 0 disables the path)."""
+    limit = float(os.environ.get("MVS_CV_STORE_MAX_MB", "256"))
+    nbytes = ops.cv_store_bytes(feat_cl, D, G)
+    return 0 < nbytes <= limit * 2 ** 20
 
 
 class StageNet(nn.Module):
@@ -54,6 +67,10 @@ class StageNet(nn.Module):
             self._vis_cache = (key, params, prepared)
         return self._vis_cache[1:]
 
+    @staticmethod
+    def _vis_weight(entropy, vis_params, vis_prepared):
+        return ops.vis_wino(entropy, vis_params, vis_prepared) if vis_prepared is not None else ops.vis(entropy, vis_params)
+
     def forward(self, features, proj_matrices, depth_values, tmp=2.0):
         """``features [B,V,C,H,W]`` (view 0 = reference), ``proj_matrices [B,V,2,4,4]``, ``depth_values [B,D,H,W]``."""
         depth_type = self.args["depth_type"]
@@ -71,19 +88,24 @@ class StageNet(nn.Module):
         # step 2 of the reference forward: fused warp + group correlation + visibility-weighted aggregation
         rt = ops.proj_prepare(proj)
         vis_params, vis_prepared = self._vis_params()
-        # MVS_CV_TILED=1: the LDS-tiled sweeps (cost_volume_tiled.hip).  Measured: they win on spatially coherent
-        # hypotheses, lose on the noisy ones a random-weight cascade predicts, so the direct sweeps stay the default.
+        # Sweep plan per stage: MVS_CV_TILED=1 opts into the LDS-tiled sweeps (they lose on the noisy hypotheses a
+        # random-weight cascade predicts); coarse stages whose per-view correlation volumes fit the Infinity Cache keep them
+        # (mvs_cv_corr_fwd) and merge by streaming (mvs_cv_merge_fwd); everything else recomputes the correlation in sweep B.
         tiled = os.environ.get("MVS_CV_TILED", "0") == "1" and ops.cv_tiled_supported(feat)
         if tiled:                                               # LDS-tiled sweeps straight from the decoder's NCHW maps
             entropy = ops.cv_tiled_entropy(feat, rt, hyp, G)
+            weight = self._vis_weight(entropy, vis_params, vis_prepared)
+            volume, sim_depth = ops.cv_tiled_aggregate(feat, rt, hyp, weight, G, want_sim_depth=True)
         else:                                                   # direct gather sweeps over channel-last maps (zero-copy if NHWC already)
             feat = ops.to_channels_last(feat)
-            entropy = ops.cv_entropy(feat, rt, hyp, G)
-        weight = ops.vis_wino(entropy, vis_params, vis_prepared) if vis_prepared is not None else ops.vis(entropy, vis_params)
-        if tiled:
-            volume, sim_depth = ops.cv_tiled_aggregate(feat, rt, hyp, weight, G, want_sim_depth=True)
-        else:
-            volume, sim_depth = ops.cv_aggregate(feat, rt, hyp, weight, G, want_sim_depth=True)
+            if _store_plan(feat, hyp.shape[1], G):
+                entropy, store = ops.cv_corr(feat, rt, hyp, G)
+                weight = self._vis_weight(entropy, vis_params, vis_prepared)
+                volume, sim_depth = ops.cv_merge(store, hyp, weight, feat.shape[1], feat.shape[4], G, want_sim_depth=True)
+            else:
+                entropy = ops.cv_entropy(feat, rt, hyp, G)
+                weight = self._vis_weight(entropy, vis_params, vis_prepared)
+                volume, sim_depth = ops.cv_aggregate(feat, rt, hyp, weight, G, want_sim_depth=True)
 
         # step 3: regularization + head
         if type(tmp) == list:

@@ -44,7 +44,6 @@ def test_fpn_decoder_is_eval_only_and_checkpoint_compatible():
 
 @pytest.mark.gpu
 def test_fpn_decoder_vs_golden(monkeypatch):
-    monkeypatch.delenv("MVS_FPN_SPLIT", raising=False)       # the experimental split form of the last level is not under test
     g = load_golden("fpn_decoder.npz")
     dev = torch.device("cuda:0")
     dec = build_decoder({k[3:]: t(v) for k, v in g.items() if k.startswith("sd.")}).to(dev)
@@ -59,7 +58,6 @@ def test_fpn_decoder_vs_golden(monkeypatch):
 @pytest.mark.parametrize("N,h,w", [(3, 7, 9), (1, 1, 1), (2, 2, 17)])
 def test_fpn_decoder_vs_oracle(N, h, w, monkeypatch):
     """Partial tiles in both directions, several images, the degenerate 1x1 coarsest level (upsampling scale 0)."""
-    monkeypatch.delenv("MVS_FPN_SPLIT", raising=False)
     from oracle import ref_fpn
     dec = build_decoder(seed=3)
     feats = ref_fpn.make_case(4, N, h, w)

@@ -95,6 +95,16 @@ def _sweeps(impl, exact):
     if impl == "direct":
         return (lambda f, rt, hyp: ops.cv_entropy(ops.to_channels_last(f), rt, hyp, 8, exact=exact),
                 lambda f, rt, hyp, w, sim: ops.cv_aggregate(ops.to_channels_last(f), rt, hyp, w, 8, sim, exact=exact))
+    if impl == "stored":                          # coarse stages: per-view correlation kept by sweep A', streamed by sweep B'
+        box = {}
+
+        def sweep_a(f, rt, hyp):
+            ent, box["store"] = ops.cv_corr(ops.to_channels_last(f), rt, hyp, 8, exact=exact)
+            return ent
+
+        def sweep_b(f, rt, hyp, w, sim):
+            return ops.cv_merge(box["store"], hyp, w, f.shape[1], f.shape[2], 8, sim)
+        return sweep_a, sweep_b
     return (lambda f, rt, hyp: ops.cv_tiled_entropy(f.contiguous(), rt, hyp, 8, exact=exact),
             lambda f, rt, hyp, w, sim: ops.cv_tiled_aggregate(f.contiguous(), rt, hyp, w, 8, sim, exact=exact))
 
@@ -141,6 +151,17 @@ def test_cost_volume_taps(dev, kind, impl, exact, tol):
 def test_cost_volume_vs_oracle_odd_sizes(dev, C, D, H, W, V, impl, exact, tol):
     """Ragged sizes (W not a multiple of 64 or of 4, odd D, D not divisible by the planes per pass, up to 7 source views) against
     the CPU oracle."""
+    _odd_sizes_case(dev, C, D, H, W, V, impl, exact, tol)
+
+
+@pytest.mark.parametrize("exact,tol", [(True, 5e-5), (False, 3e-4)])
+@pytest.mark.parametrize("C,D,H,W,V", [(64, 6, 9, 70, 3), (32, 5, 17, 33, 2), (64, 48, 8, 16, 2), (32, 16, 12, 44, 8), (64, 33, 5, 7, 3), (32, 9, 6, 129, 5)])
+def test_stored_correlation_sweeps_vs_oracle_odd_sizes(dev, C, D, H, W, V, exact, tol):
+    """The coarse stages' stored-correlation pair (mvs_cv_corr_fwd / mvs_cv_merge_fwd) on the same ragged cases, against the CPU oracle."""
+    _odd_sizes_case(dev, C, D, H, W, V, "stored", exact, tol)
+
+
+def _odd_sizes_case(dev, C, D, H, W, V, impl, exact, tol):
     from mvsformer_amd import ops, synth
     from oracle import ref_torch
     gen = torch.Generator().manual_seed(C * 131 + D)
@@ -201,6 +222,39 @@ def test_tiled_sweeps_equal_direct_sweeps_exactly(dev):
     # both kinds of round were exercised: coherent hypotheses always fit the LDS tile, wild ones (on images larger than a tile's
     # capacity) take the direct-gather rounds
     assert seen[False] == 0.0 and seen[True] > 0.5, seen
+
+
+def test_stored_correlation_sweeps_equal_recomputing_sweeps_exactly(dev):
+    """mvs_cv_corr_fwd + mvs_cv_merge_fwd are the recomputing sweeps with the per-view correlation parked in memory: entropy and
+    volume BIT FOR BIT (both arithmetic modes), the similarity arg-max up to ties (its sums over groups run in another order);
+    coherent and wild hypotheses (behind the camera, far outside the frustum), a batch of 2, ragged widths, D not a multiple of
+    the planes per pass."""
+    from mvsformer_amd import ops, synth
+    for C, D, H, W, V, wild in ((32, 16, 24, 32, 3, False), (64, 32, 16, 24, 5, True), (64, 7, 9, 37, 2, False), (32, 19, 11, 50, 4, True),
+                                (64, 32, 36, 48, 5, False)):
+        scale = {64: 8, 32: 4}[C]
+        scene = synth.make_scene(V, H * scale, W * scale, seed=C + D)
+        feat = synth.render_features(scene, scale, C, batch=2, device=dev).contiguous()
+        proj = synth.proj_matrices(scene, (scale,), 2, device=dev)["stage1"]
+        g = torch.Generator().manual_seed(C + D)
+        if wild:
+            hyp = (torch.rand(2, D, H, W, generator=g) * 1500.0 - 200.0).to(dev)
+        else:
+            z = synth.plane_depth(scene, scale, device=dev)
+            hyp = (1.0 / (1.0 / z[None, None] + torch.linspace(1, -1, D, device=dev).view(1, D, 1, 1) * (1e-5 * D))).repeat(2, 1, 1, 1).contiguous()
+        w = torch.rand(2, V - 1, H, W, generator=g).to(dev)
+        rt = ops.proj_prepare(proj)
+        fcl = ops.to_channels_last(feat)
+        for exact in (True, False):
+            e0, (v0, s0) = ops.cv_entropy(fcl, rt, hyp, 8, exact=exact), ops.cv_aggregate(fcl, rt, hyp, w, 8, True, exact=exact)
+            e1, store = ops.cv_corr(fcl, rt, hyp, 8, exact=exact)
+            v1, s1 = ops.cv_merge(store, hyp, w, V, C, 8, True)
+            v2, none = ops.cv_merge(store, hyp, w, V, C, 8, False)
+            assert torch.equal(e0, e1), (C, D, exact, (e0 - e1).abs().max().item())
+            assert torch.equal(v0, v1), (C, D, exact, (v0 - v1).abs().max().item())
+            assert none is None and torch.equal(v1, v2)
+            assert ((hyp - s1.unsqueeze(1)) == 0).any(1).all(), "sim_depth is not one of the hypotheses"
+            assert (s0 != s1).double().mean().item() < 0.01, (C, D, exact)
 
 
 # ------------------------------------------------------------------------------------------------ a5/a6
