@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph of the cascade per stream instead of launching its ~60 kernels")
-    ap.add_argument("--cpu-sample-div", type=int, default=3, help="CPU baseline runs on about (H/div)x(W/div)")
+    ap.add_argument("--cpu-runs", type=int, default=1, help="timed full-size CPU cascades of the cpu_baseline leg (each 1-2 minutes)")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short config-4 / config-5 runs reported as extra keys")
     ap.add_argument("--batch", type=int, default=1, help="reference views per step (B of the [B,V,C,H,W] inputs)")
@@ -60,31 +60,71 @@ def parse():
 
 
 def cpu_baseline(net, args):
-    """The oracle (torch CPU, all host cores) on a bounded sample: same cascade, same views/depths, about 1/div^2 of the pixels;
-    1 warm-up + 2 timed cascades, scaled by the pixel ratio and SAID to be scaled."""
+    """The oracle (torch CPU, all host cores) on the WHOLE config-2 workload: the same inputs the GPU is timed on (seed 0),
+    `--cpu-runs` timed cascades (default 1; each is 1-2 minutes on the GPU box's host) after one warm-up cascade on a 512x384 sample
+    that only warms the thread pool and the allocator.  Returns the JSON object, the CPU inputs and the oracle's outputs (the
+    reference the `parity` object is computed against)."""
     from mvsformer_amd import synth
     from oracle import ref_torch
-    div = args.cpu_sample_div
-    H, W = args.height // div, args.width // div
-    H, W = max(64, H - H % 64), max(64, W - W % 64)
     cores = min(os.cpu_count() or 1, 64)       # torch's intra-op pool stops scaling (and oversubscribes) beyond this
     torch.set_num_threads(cores)
-    feats, proj, dv, _ = synth.make_inputs(args.views, H, W, seed=0)
     sds = [{k: v.detach().cpu() for k, v in f.state_dict().items()} for f in net.fusions]
-    times = []
+    kw = dict(ndepths=net.ndepths, depth_interals_ratio=net.depth_interals_ratio, tmp=[5.0, 5.0, 5.0, 1.0])
     with torch.no_grad():
-        for _ in range(3):
+        wf, wp, wd, _ = synth.make_inputs(args.views, 384, 512, seed=0)
+        t0 = time.time()
+        ref_torch.cascade_forward(wf, wp, wd, sds, **kw)
+        warm = time.time() - t0
+        del wf, wp, wd
+        inputs = synth.make_inputs(args.views, args.height, args.width, seed=0, batch=args.batch)[:3]
+        times = []
+        for _ in range(max(1, args.cpu_runs)):
             t0 = time.time()
-            ref_torch.cascade_forward(feats, proj, dv, sds, ndepths=net.ndepths, depth_interals_ratio=net.depth_interals_ratio,
-                                      tmp=[5.0, 5.0, 5.0, 1.0])
+            ref = ref_torch.cascade_forward(*inputs, sds, **kw)
             times.append(time.time() - t0)
-    dt = sum(times[1:]) / 2.0
-    scale = (args.height * args.width) / float(H * W)
-    return {"value": 1.0 / (dt * scale), "unit": "depth maps/s", "cores": cores, "kind": "port", "scaled_from_sample": True,
-            "sample_seconds": [round(t, 2) for t in times],
-            "sample": "oracle/ref_torch.cascade_forward (torch %s CPU, %d threads): 1 warm-up + 2 timed cascades on %dx%d x %d views = "
-                      "1/%.1f of the config-2 pixels, mean %.2f s; value = 1/(t*%.1f) (linear in pixels; a sample this small is "
-                      "partly cache-resident, so this flatters the CPU)" % (torch.__version__, cores, W, H, args.views, scale, dt, scale)}
+    dt = sum(times) / len(times)
+    cpu = {"value": args.batch / dt, "unit": "depth maps/s", "cores": cores, "kind": "port", "scaled_from_sample": False,
+           "seconds_per_cascade": [round(t, 2) for t in times], "warmup_seconds_512x384": round(warm, 2),
+           "sample": "oracle/ref_torch.cascade_forward (torch %s CPU, %d threads) on the full workload: %d timed cascade(s) at %dx%d x %d views "
+                     "(the inputs the GPU runs, seed 0) after one warm-up cascade on a 512x384 sample; unscaled" % (
+                         torch.__version__, cores, len(times), args.width, args.height, args.views)}
+    return cpu, inputs, ref
+
+
+def rel_stats(got, want):
+    rel = ((got - want).abs() / want.abs()).flatten().float()
+    k = max(1, int(round(rel.numel() * 0.999)))
+    return {"max": float(rel.max()), "p99.9": float(rel.kthvalue(k).values), "median": float(rel.median())}
+
+
+def depth_parity(net, feats, proj, dv, tmp, ref, dev):
+    """The second half of the BASELINE metric at the benched size: max per-pixel |depth - ref| / |ref| of the HIP cascade against the
+    CPU oracle on identical inputs - free-running (each stage consumes the HIP cascade's own hypotheses) and stage by stage with the
+    oracle's hypotheses fed to the HIP stage (pure kernel error), as tools/report_parity.py does at small sizes."""
+    with torch.no_grad():
+        out = net(feats, proj, dv, tmp=tmp)
+        free, fed = {}, {}
+        for i in range(4):
+            k = "stage%d" % (i + 1)
+            want = ref[k]["depth"].to(dev)
+            free[k] = rel_stats(out[k]["depth"], want)
+            st = net.fusions[i](feats[k], proj[k], ref[k]["depth_values"].to(dev), tmp=tmp)
+            fed[k] = rel_stats(st["depth"], want)
+        final = rel_stats(out["refined_depth"], ref["refined_depth"].to(dev))
+    return {"max_rel_depth_err": final["max"], "p99.9_rel_depth_err": final["p99.9"], "median_rel_depth_err": final["median"], "tolerance": 1e-3,
+            "free_running_cascade": free, "stage_with_oracle_hypotheses": fed,
+            "reference": "oracle/ref_torch.cascade_forward (the reference's formulation on torch CPU) on the timed inputs, full size"}
+
+
+def csrc_digest():
+    """sha256[:16] over the kernel sources: profiles/traffic_by_kernel.json records the digest it was collected at, and the per-kernel
+    `traffic` is only reported while the sources are still those."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(REPO, "mvsformer_amd", "csrc", "*.hip")) + glob.glob(os.path.join(REPO, "mvsformer_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def time_steps(run, steps, world, dev):
@@ -103,6 +143,7 @@ def time_steps(run, steps, world, dev):
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    time_steps.own_seconds = dt                          # this rank's own wall time (the returned one is the MAX over ranks)
     return float(tt.item()), out
 
 
@@ -166,13 +207,17 @@ def main(args):
     torch.manual_seed(0)
     net = m.CascadeMVS().eval()
     m.randomize_bn_(net, seed=1)
-    cpu = None
+    cpu, ref = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(net, args)
+        cpu, cpu_inputs, ref = cpu_baseline(net, args)
     net = net.to(dev)
 
     # each rank owns its reference view(s): different scene seed per rank, inputs resident in HBM before timing
-    feats, proj, dv, _ = synth.make_inputs(args.views, args.height, args.width, seed=rank, batch=args.batch, device=dev)
+    if ref is not None:                                  # the very tensors the oracle ran on
+        feats, proj, dv = ({k: v.to(dev) for k, v in cpu_inputs[0].items()}, {k: v.to(dev) for k, v in cpu_inputs[1].items()}, cpu_inputs[2].to(dev))
+        del cpu_inputs
+    else:
+        feats, proj, dv, _ = synth.make_inputs(args.views, args.height, args.width, seed=rank, batch=args.batch, device=dev)
     if args.features_layout == "nhwc":
         feats = {k: v.reshape(-1, *v.shape[2:]).contiguous(memory_format=torch.channels_last).view(v.shape) for k, v in feats.items()}
     tmp = [5.0, 5.0, 5.0, 1.0]
@@ -183,7 +228,13 @@ def main(args):
         _, run = make_runner(net, feats, proj, dv, tmp, streams, graphs=True)
     run(max(args.warmup, args.streams))
     dt, out = time_steps(run, args.steps, world, dev)
+    own_dt = time_steps.own_seconds
     assert torch.isfinite(out["refined_depth"]).all()
+    with torch.no_grad():                                # the timed steps computed what a fresh single-stream call computes
+        again = step()
+    assert torch.equal(out["refined_depth"], again["refined_depth"]), "timed step and a fresh call disagree"
+    parity = depth_parity(net, feats, proj, dv, tmp, ref, dev) if ref is not None else None
+    del ref
 
     # ---- per-kernel durations: HIP events around every launch, on the launch stream (single stream, after the timed region) ----
     torch.cuda.synchronize()
@@ -192,10 +243,15 @@ def main(args):
             step()
     ksum = timer.summary()
     work = timer.work
-    traffic_db = {}
+    traffic_db, traffic_source = {}, None
     if os.path.exists(TRAFFIC_FILE):
         with open(TRAFFIC_FILE) as f:
-            traffic_db = json.load(f).get("kernels", {})
+            tj = json.load(f)
+        if tj.get("csrc_digest") == csrc_digest():
+            traffic_db = tj.get("kernels", {})
+            traffic_source = "profiles/traffic_by_kernel.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_traffic.py) at kernel sources %s = the sources of this run; not re-measured in this run" % tj["csrc_digest"]
+        else:
+            traffic_source = "none: profiles/traffic_by_kernel.json was collected at kernel sources %s, this run has %s" % (tj.get("csrc_digest"), csrc_digest())
     kernels = []
     for name, s in ksum.items():
         w = work.get(name)
@@ -211,8 +267,8 @@ def main(args):
                 ach = per_launch / (s["avg_ms"] * 1e-3) / 1e12
                 e.update(bound="mfma", achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s",
                          frac=round(ach / FP32_MFMA_PEAK_TF, 4), algorithmic_per_launch=per_launch)
-            tr = traffic_db.get(name) or next((v for k, v in traffic_db.items() if k.startswith(name + "<")), None)   # bench tags drop
-            e["traffic"] = tr["hbm_bytes_per_launch"] if tr else None                                           # some template lists
+            tr = traffic_db.get(name)
+            e["traffic"] = tr["hbm_bytes_per_launch"] if tr else None
         kernels.append(e)
     kernels.sort(key=lambda e: -e["ms_per_step"])
     dom = next(e for e in kernels if "bound" in e)
@@ -236,6 +292,16 @@ def main(args):
                    "traffic": (sum(t * e["calls_per_step"] for t, e in zip(cv_traffic, cv)) if cv and all(t is not None for t in cv_traffic) else None),
                    "launches": {e["kernel"]: e["ms_per_step"] for e in cv},
                    "note": "sum over the 4 stages of 4*H*W*(V*C + D + G*D) bytes / summed time of the sweeps (+ feature transposes)"}
+    # the measured ceiling of the gathering sweeps: tools/gather_bound.py fetches the same taps with no arithmetic (profiles/r03_gather_bound.json)
+    gb_file = os.path.join(REPO, "profiles", "r03_gather_bound.json")
+    if os.path.exists(gb_file) and (args.height, args.width, args.views, args.batch) == (1152, 1536, 5, 1):
+        gb = {(r["C"], r["hyp"]): r["gather_regs_ms"] for r in json.load(open(gb_file))}
+        gathering = [e for e in cv if e["kernel"].startswith(("cv_entropy", "cv_aggregate", "cv_corr"))]
+        bound = sum(gb[(4 * int(e["kernel"].split("<")[1].split(",")[0].rstrip(">")), "cascade")] * e["calls_per_step"] for e in gathering)
+        roofline_cv["gather_only_ms_per_depth_map"] = round(bound, 4)
+        roofline_cv["frac_of_gather_bound"] = round(bound / sum(e["ms_per_step"] for e in gathering), 4)
+        roofline_cv["gather_bound_source"] = ("profiles/r03_gather_bound.json (tools/gather_bound.py: the same tap addresses, no arithmetic, one launch per "
+                                              "gathering sweep); measured on another box of the pool, not in this run")
 
     # ---- BASELINE configs[3] / configs[4] shapes through the same cascade (short runs, extra keys; not the judged metric) ----
     other = None
@@ -291,6 +357,28 @@ def main(args):
         del dec, enc, outs, fenc, img
         torch.cuda.empty_cache()
 
+    # ---- the same workload with channel-last features (what mvsformer_amd.FPNDecoder emits): no nchw_to_nhwc launches (extra key) ----
+    nhwc = None
+    if rank == 0 and world == 1 and not args.no_other_configs and args.features_layout == "nchw":
+        f2 = {k: v.reshape(-1, *v.shape[2:]).contiguous(memory_format=torch.channels_last).view(v.shape) for k, v in feats.items()}
+        _, run2 = make_runner(net, f2, proj, dv, tmp, streams)
+        run2(args.streams + 1)
+        n2 = 60
+        dt2, o2 = time_steps(run2, n2, 1, dev)
+        assert torch.equal(o2["refined_depth"], out["refined_depth"])      # same numbers: the sweeps read the same NHWC bytes either way
+        nhwc = {"depth_maps_per_s": round(n2 * args.batch / dt2, 2), "ms_per_step": round(dt2 / n2 * 1e3, 3), "steps": n2,
+                "note": "features handed over channel-last in memory (zero-copy into the sweeps); not `value`: the reference's decoder emits NCHW"}
+        del f2, o2
+
+    # ---- who ran: one record per rank (device, its own wall time), so that a scaling run shows N distinct GPUs ----
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "local_rank": local_rank, "device": props.name, "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
+            "ms_per_step": round(own_dt / args.steps * 1e3, 3)}
+    ranks = [mine]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+
     if rank == 0:
         total = world * args.steps * args.batch
         line = {
@@ -304,6 +392,8 @@ def main(args):
                        "streams_per_gpu": args.streams, "features_layout": args.features_layout,
                        "reference_views_per_step": args.batch},
             "roofline": roofline, "roofline_cost_volume": roofline_cv, "cpu_baseline": cpu,
+            "max_rel_depth_err": parity["max_rel_depth_err"] if parity else None, "parity": parity, "traffic_source": traffic_source,
+            "ranks_seen": dist.get_world_size() if world > 1 else 1, "ranks": ranks, "features_layout_nhwc": nhwc,
             "kernel_ms_sum": round(sum(e["ms_per_step"] for e in kernels), 3), "other_configs": other, "before_the_path": before, "kernels": kernels,
         }
         print(json.dumps(line))

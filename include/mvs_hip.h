@@ -14,7 +14,9 @@
  *   - launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream); the
  *     device is the caller's current HIP device.  No global mutable state: re-entrant across streams,
  *     threads and devices.
- *   - arithmetic is IEEE fp32 (the reference forces fp32 for the cost volume, mvsformer_model.py:65-78).
+ *   - arithmetic is IEEE fp32 (the reference forces fp32 for the cost volume, mvsformer_model.py:65-78); the two entry
+ *     points that also offer a shortcut form (reciprocal instead of IEEE division, hardware exp2/log2) say so at their
+ *     `flags` argument - the Python layer asks for the IEEE form unless told otherwise.
  */
 #ifndef MVS_HIP_H
 #define MVS_HIP_H
@@ -79,10 +81,10 @@ int mvs_warp_fwd(const float* src, const float* rt, const float* depth, int dept
  *          sum_v w_v*corr_v / (sum_v w_v + 1e-6)  (mvsformer_model.py:101-105) and, if sim_depth != NULL, the
  *          eval-only similarity arg-max depth (mvsformer_model.py:81-85,151-158)
  *   weight  [B,V-1,H,W]   volume [B,G,D,H,W]   sim_depth [B,H,W] or NULL
- * flags bit 0 (both sweeps): 0 = sampling coordinates from one reciprocal + Newton step and hardware exp2/log2 in the
- * entropy (the default: ~1e-4 px / ~1e-6 entropy away from the reference's arithmetic, measured <= 1e-5 relative on the
- * cascade's depth), 1 = the reference's op order with IEEE divisions (warping.py:90-96) and libm exp/log - what the
- * training forward uses so that it matches mvs_cv_aggregate_bwd's recomputed geometry bit for bit.
+ * flags bit 0 (both sweeps): 1 = the reference's op order with IEEE divisions (warping.py:90-96) and libm exp/log - what
+ * mvsformer_amd passes by default, and what the training forward needs so that it matches mvs_cv_aggregate_bwd's recomputed
+ * geometry bit for bit; 0 = sampling coordinates from one reciprocal + Newton step and hardware exp2/log2 in the entropy
+ * (~1e-4 px / ~1e-6 entropy away from the reference's arithmetic; measured no faster on MI355X, kept for experiments).
  * Constraints: G == 8, C in {8,16,32,64} (C/G channels per group); sweep A needs (1024/C)*D*4 + 8192 bytes of
  * LDS per block (<= 64 KiB).
  * ------------------------------------------------------------------------------------------------------- */

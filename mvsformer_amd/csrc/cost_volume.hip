@@ -500,7 +500,7 @@ struct CorrCfg {
     static constexpr int RED_FLOATS = UNITS * 72;          // unit stride 72 floats: 64 used, padded so a 32-lane store group hits 32 banks
     static constexpr int STAGE_FLOATS = LPP * G * PPW;     // one chunk of group means (512 floats)
     static constexpr int SSTAGE_FLOATS = LPP * PPW;        // one chunk of similarities (64 floats)
-    static constexpr size_t lds_bytes(int D) { return (size_t)NW * (128 * 32 + (PPW * D + RED_FLOATS + STAGE_FLOATS + SSTAGE_FLOATS) * sizeof(float)); }
+    static constexpr size_t lds_bytes(int D) { return (size_t)NW * (64 * 32 + (PPW * D + RED_FLOATS + STAGE_FLOATS + SSTAGE_FLOATS) * sizeof(float)); }
 };
 
 template <int LPP, bool FAST>
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64 * NW) void cv_corr_kernel(const float* __restric
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     u32x4* taps_o = reinterpret_cast<u32x4*>(smem) + wave * 64;
     f32x4* taps_w = reinterpret_cast<f32x4*>(smem + NW * 64 * 16) + wave * 64;
-    float* fbase = reinterpret_cast<float*>(smem + NW * 128 * 16);
+    float* fbase = reinterpret_cast<float*>(smem + NW * 64 * 32);
     float* sims = fbase + (size_t)wave * PPW * D;                                            // [D][PPW]
     float* red = fbase + (size_t)NW * PPW * D + wave * Cfg::RED_FLOATS;
     float* stage = fbase + (size_t)NW * (PPW * D + Cfg::RED_FLOATS) + wave * Cfg::STAGE_FLOATS;   // [LPP][G][PPW]
@@ -559,18 +559,30 @@ __global__ __launch_bounds__(64 * NW) void cv_corr_kernel(const float* __restric
     for (int c0 = 0; c0 < D; c0 += LPP) {
         geometry_pass<PPW, FAST>(rt, depth_row, HW, c0, D, x0, y, H, W, half_w, half_h, lane, taps_o, taps_w);
         __builtin_amdgcn_wave_barrier();
+        // Software pipeline of depth 2 over the chunk's steps: step dd+1's four tap loads are issued before step dd's blend, reductions
+        // and LDS all-reduce (a chain of ~300 dependent cycles that would otherwise sit between two gathers of the same wavefront).
+        // Straight-line code on purpose: with wave-uniform branches around the steps hipcc's wait-count pass merges the two paths
+        // conservatively and waits for the prefetch it has just issued.  The slots of planes >= D hold clamped duplicates (valid
+        // addresses, geometry_pass), so every step runs; only the stores are predicated.  sched_barrier pins the issue order (left
+        // alone, the scheduler hoists all 16 steps' loads: 2.5x the registers).  Ping-pong register sets by the step's parity.
+        f32x4 tp[2][4], wp2[2];
+        wp2[0] = taps_w[pg];
+        load_taps4(src, pix_bytes, cq * 16u, taps_o[pg], tp[0]);
 #pragma unroll
         for (int dd = 0; dd < LPP; ++dd) {
-            // per-step uniform branch as in cv_aggregate_kernel: one step's loads in flight per wavefront, 4 wavefronts per SIMD
-            if (c0 + dd < D) {
-                const u32x4 o = taps_o[dd * PPW + pg];
-                const f32x4 w = taps_w[dd * PPW + pg];
-                const f32x4 g4 = gather4(src, pix_bytes, cq * 16u, o, w);
+            if (dd + 1 < LPP) {
+                wp2[(dd + 1) & 1] = taps_w[(dd + 1) * PPW + pg];
+                load_taps4(src, pix_bytes, cq * 16u, taps_o[(dd + 1) * PPW + pg], tp[(dd + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const bool valid = c0 + dd < D;
+                const f32x4 g4 = blend4(tp[dd & 1], wp2[dd & 1]);
                 const f32x4 p = {r[0] * g4[0], r[1] * g4[1], r[2] * g4[2], r[3] * g4[3]};
                 const float h = ((p[0] + p[1]) + p[2]) + p[3];
                 // sim_vol = sum over groups (cv_entropy_kernel's expression) and this lane's group mean (cv_aggregate_kernel's)
                 const float s = pixel_sum<LPP>(h) * (1.0f / CPG);
-                if (cq == 0) sims[(c0 + dd) * PPW + pg] = s;
+                if (valid && cq == 0) sims[(c0 + dd) * PPW + pg] = s;
                 if (CPG == 4) {
                     stage[(dd * G + cq) * PPW + pg] = h * 0.25f;
                 } else {
@@ -593,6 +605,7 @@ __global__ __launch_bounds__(64 * NW) void cv_corr_kernel(const float* __restric
                 term = pixel_sum<LPP>(term);
                 if (cq == 0) sstage[dd * PPW + pg] = term * (1.0f / CPG);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_wave_barrier();
         // this chunk's 2 KB of group means and 256 B of similarities: contiguous in the tile

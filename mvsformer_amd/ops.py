@@ -147,11 +147,12 @@ def warp(src: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, with_mask: bo
 
 # ----------------------------------------------------------------------------------------------- cost volume
 def _cv_flags(exact: Optional[bool]) -> int:
-    """bit 0 of the sweeps' ``flags``: reference op order + IEEE divisions (``exact``) vs reciprocal + hardware exp2/log2 (default;
-    MVS_CV_EXACT=1 flips the default)."""
+    """bit 0 of the sweeps' ``flags``: 1 = the reference's op order with IEEE divisions and libm exp/log (the default: measured no
+    slower than the shortcut form on MI355X, profiles/r03_bench_sweeps.txt), 0 = one reciprocal + Newton step and hardware
+    exp2/log2 (``exact=False``, or MVS_CV_FAST=1 to flip the default)."""
     import os
     if exact is None:
-        exact = os.environ.get("MVS_CV_EXACT", "0") == "1"
+        exact = os.environ.get("MVS_CV_FAST", "0") != "1"
     return 1 if exact else 0
 
 

@@ -31,8 +31,10 @@ from .module import ConvBnReLU, CostRegNet, CostRegNet3D, _versions, pack_vis_pa
 
 def _store_plan(feat_cl, D, G) -> bool:
     """True when the stage should keep its per-view correlation volumes (stored-correlation sweeps): built for C = 32 | 64 and only
-    worth it while the store stays Infinity-Cache sized (MVS_CV_STORE_MAX_MB, default 256; 0 disables the path)."""
-    limit = float(os.environ.get("MVS_CV_STORE_MAX_MB", "256"))
+    worth it while the store AND the feature maps stay inside the 256 MB Infinity Cache together (MVS_CV_STORE_MAX_MB, default 160;
+    0 disables the path).  Measured at config 2 (profiles/r03_bench_sweeps.txt): stage 1 (127 MB) 0.30 -> 0.20 ms for the pair,
+    stage 2 (254 MB: the round trip goes to HBM) 0.29 -> 0.32 ms - so stage 2 recomputes."""
+    limit = float(os.environ.get("MVS_CV_STORE_MAX_MB", "160"))
     nbytes = ops.cv_store_bytes(feat_cl, D, G)
     return 0 < nbytes <= limit * 2 ** 20
 
