@@ -130,6 +130,9 @@ def test_bn_act_bf16_fn(dev, relu, with_res):
         relclose(from_cl(rm.grad), rr.grad, 1e-2, "dres")
 
 
+STAGE_GRAD_L2 = 0.4          # measured, see the docstring; the per-layer guard is test_regularizer_bf16_layer_by_layer_attribution
+
+
 @pytest.mark.parametrize("kind,C,ndepth,H,W,V", [("costregnet", 32, 16, 32, 48, 3), ("costregnet3d", 8, 8, 40, 56, 4)])
 def test_stage_train_bf16_vs_fp32_oracle(dev, kind, C, ndepth, H, W, V):
     """StageNet.train() under ``torch.autocast(bfloat16)``: prob_volume_pre and every gradient against the fp32 CPU oracle."""
@@ -171,7 +174,7 @@ def test_stage_train_bf16_vs_fp32_oracle(dev, kind, C, ndepth, H, W, V):
             vis_b.append(b)
         else:
             rel = ((a - b).norm() / (b.norm() + 1e-30)).item()
-            assert rel < 0.4, (name, rel)                 # vs FP32: bf16 noise through ~22 rounded tensors and their ReLU gates
+            assert rel < STAGE_GRAD_L2, (name, rel)       # vs FP32: bf16 noise through ~22 rounded tensors and their ReLU gates
     a, b = torch.cat(vis_a), torch.cat(vis_b)
     cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
     assert cos > 0.9, ("vis.*", cos)
@@ -215,6 +218,81 @@ def test_regularizer_bf16_vs_cpu_autocast(dev, kind, D, H, W):
         worst[name] = ((a - b).norm() / (b.norm() + 1e-30)).item()
     bad = {k: v for k, v in worst.items() if v > 0.25}
     assert not bad, bad
+
+
+def _rel_l2(got, want):
+    got, want = torch.as_tensor(got).double().cpu().flatten(), torch.as_tensor(want).double().cpu().flatten()
+    return ((got - want).norm() / (want.norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("kind,D,H,W", [("costregnet", 16, 32, 48), ("costregnet3d", 8, 40, 56), ("costregnet", 32, 16, 24), ("costregnet3d", 8, 24, 40)])
+def test_regularizer_bf16_layer_by_layer_attribution(dev, kind, D, H, W):
+    """Per-layer attribution of the bf16 regularizer's error: every layer of the U-Net at its real place in the
+    network - conv / transposed conv on the bf16 matrix cores, batch-statistics BatchNorm, ReLU, skip - is TEACHER-FORCED: it gets the
+    reference chain's own (bf16-rounded) input activation and skip tensor and a bf16 upstream gradient, and its output, data gradient,
+    skip gradient, weight gradient and BatchNorm affine gradients are each bounded against fp32 autograd of the same layer on the same
+    bf16 operands.  What is left is one layer's own rounding (bf16 conv output, bf16 activation, bf16 gradients: 2^-9 relative per
+    element, a few 1e-3 in L2), so a broken layer cannot hide behind the stage-level bounds: 1e-2 on the output, 2e-2 on every gradient.
+    Covers the four layer geometries per net (stride 2 / (1,2,2) / 1, transposed) at all channel widths 8..64."""
+    import mvsformer_amd as m
+    from mvsformer_amd import module as mod
+    torch.manual_seed(D * 7 + H)
+    net = (m.CostRegNet(8, 8) if kind == "costregnet" else m.CostRegNet3D(8, 8)).train()
+    three_d = kind == "costregnet3d"
+    s_down = (1, 2, 2) if three_d else (2, 2, 2)
+    gen = torch.Generator().manual_seed(11)
+    x0 = bf(torch.randn(2, 8, D, H, W, generator=gen))
+
+    def parts(name):
+        l = getattr(net, name)
+        return (l[0], l[1]) if isinstance(l, torch.nn.Sequential) else (l.conv, l.bn)
+
+    def ref_layer(name, x, skip, transposed):
+        conv, bn = parts(name)
+        wb = bf(conv.weight.detach().cpu()).requires_grad_(True)
+        gam, bet = bn.weight.detach().cpu().clone().requires_grad_(True), bn.bias.detach().cpu().clone().requires_grad_(True)
+        xr = x.clone().requires_grad_(True)
+        sr = skip.clone().requires_grad_(True) if skip is not None else None
+        if transposed:
+            y = F.conv_transpose3d(xr, wb, None, stride=s_down, padding=1, output_padding=(0, 1, 1) if three_d else 1)
+        else:
+            y = F.conv3d(xr, wb, None, stride=conv.stride, padding=1)
+        y = y + (bf(y) - y).detach()                              # the kernel stores the convolution as bf16
+        z = F.relu(F.batch_norm(y, None, None, gam, bet, True, 0.1, bn.eps))
+        z = z + (bf(z) - z).detach()
+        out = z + sr if sr is not None else z
+        out = out + (bf(out) - out).detach()
+        return out, xr, sr, wb, gam, bet
+
+    chain = [("conv1", False, None), ("conv2", False, None), ("conv3", False, None), ("conv4", False, None), ("conv5", False, None),
+             ("conv6", False, None), ("conv7", True, "conv4"), ("conv9", True, "conv2"), ("conv11", True, "input")]
+    acts = {"input": x0}
+    x = x0
+    net_dev = net.to(dev)
+    worst = {}
+    for name, transposed, skip_name in chain:
+        skip = acts[skip_name] if skip_name else None
+        out, xr, sr, wb, gam, bet = ref_layer(name, x, skip, transposed)
+        R = bf(torch.randn(out.shape, generator=gen))
+        (out * R).sum().backward()
+        # the same layer on the HIP path: bf16 channel-last activations, fp32 master weights (rounded to bf16 by the packer)
+        layer = getattr(net_dev, name)
+        conv, bn = (layer[0], layer[1]) if isinstance(layer, torch.nn.Sequential) else (layer.conv, layer.bn)
+        for prm in (conv.weight, bn.weight, bn.bias):
+            prm.grad = None
+        xm = to_cl(x, dev).requires_grad_(True)
+        sm = to_cl(skip, dev).requires_grad_(True) if skip is not None else None
+        ym = mod._train_conv_bn_act(xm, conv, bn, True, sm, transposed_sd=(s_down[0] if transposed else None))
+        (ym.float() * R.permute(0, 2, 3, 4, 1).to(dev)).sum().backward()
+        errs = {"y": _rel_l2(from_cl(ym.detach()), out.detach()), "dx": _rel_l2(from_cl(xm.grad), xr.grad), "dw": _rel_l2(conv.weight.grad, wb.grad),
+                "dgamma": _rel_l2(bn.weight.grad, gam.grad), "dbeta": _rel_l2(bn.bias.grad, bet.grad)}
+        if skip is not None:
+            errs["dskip"] = _rel_l2(from_cl(sm.grad), sr.grad)
+        worst[name] = errs
+        assert errs["y"] < 1e-2, (name, errs)
+        assert all(v < 2e-2 for k, v in errs.items() if k != "y"), (name, errs)
+        acts[name] = out.detach()
+        x = out.detach()
 
 
 def test_bn_act_bf16_grouped_equals_per_group_calls(dev):
