@@ -60,13 +60,15 @@ def main():
             hyp = hyp_c if hname == "cascade" else hyp_s
             for exact in (False, True):
                 r = {"A": timeit(lambda: ops.cv_entropy(fcl, rt, hyp, 8, exact=exact)),
-                     "B": timeit(lambda: ops.cv_aggregate(fcl, rt, hyp, w, 8, True, exact=exact))}
+                     "B": timeit(lambda: ops.cv_aggregate(fcl, rt, hyp, w, 8, True, exact=exact)),
+                     "B(no sim_depth)": timeit(lambda: ops.cv_aggregate(fcl, rt, hyp, w, 8, False, exact=exact))}
                 if ops.cv_store_bytes(fcl, D, 8) > 0:
                     ent, store = ops.cv_corr(fcl, rt, hyp, 8, exact=exact)
                     r["A'"] = timeit(lambda: ops.cv_corr(fcl, rt, hyp, 8, exact=exact))
                     r["B'"] = timeit(lambda: ops.cv_merge(store, hyp, w, V, C, 8, True))
                 line = "stage%d %-7s %-5s transpose %.3f | " % (i, hname, "exact" if exact else "fast", t_tr) + "  ".join("%s %.3f" % kv for kv in r.items())
                 best = min(r["A"] + r["B"], r.get("A'", 9) + r.get("B'", 9))
+                r.pop("B(no sim_depth)") if False else None
                 line += "  | best pair %.3f ms" % best
                 tot[(hname, exact)] = tot.get((hname, exact), 0.0) + best + t_tr
                 print(line, flush=True)
