@@ -372,6 +372,23 @@ int mvs_conf_accumulate(const float* conf, int B, int H, int W, float* acc, int 
  *   level:  intra_prev [N,64,h,w], lateral [N,Ck,2h,2w], w_inner_p [32,Ck,2] (inner_k.weight [64,Ck] regrouped by output-channel PAIR:
  *           w_inner_p[q][j][e] = weight[2q+e][j], one scalar load per pair for the packed fp32 pipe) + b_inner [64], packed out_k weights ->
  *           intra_out [N,64,2h,2w] (NULL for the last level: it is only ever consumed inside this kernel) and out [N,2h,2w,Ck] */
+/* ---------------------------------------------------------------------------------------------------------
+ * Regularizer convolutions in THREE-TERM BF16 SPLIT form (conv3d_x3.hip): same contract as mvs_conv3d_fwd (fp32 NCDHW in and out,
+ * y = [relu](conv3d(x, w, padding 1) * scale[co] + shift[co]) [+ residual], models/module.py:83-123), but the contraction runs on the
+ * bf16 matrix cores with every fp32 operand written EXACTLY as h + m + l (three bf16) and the six products xh*wh, xh*wm, xm*wh, xh*wl,
+ * xl*wh, xm*wm accumulated in fp32: what is dropped is <= 2^-24 of a product, i.e. the result is as close to the exact convolution as an
+ * fp32 fma chain (tests/test_hip_x3.py) at 6/16 of the fp32 MFMA's matrix time.
+ *   supported:  1 if (Cin, Cout, depth stride sd, H/W stride shw) is built: sd = 1; shw = 1 with Cin, Cout in {16, 32, 64}; shw = 2 with
+ *               (Cin, Cout) = (8, 16) or Cin in {16, 32}, Cout in {16, 32, 64}  - the six Conv3d layers of CostRegNet3D
+ *   pack:       w [Cout,Cin,3,3,3] fp32 -> wpacked, mvs_conv3d_x3_packed_bytes(...) bytes (pre-split, per-lane fragments)
+ *   fwd:        x [B,Cin,D,H,W] -> y [B,Cout,D,(H-1)/shw+1,(W-1)/shw+1]; residual (optional) has y's shape
+ * ------------------------------------------------------------------------------------------------------- */
+int mvs_conv3d_x3_supported(int Cin, int Cout, int sd, int shw);
+int64_t mvs_conv3d_x3_packed_bytes(int Cin, int Cout, int sd, int shw);
+int mvs_conv3d_x3_pack_weights(const float* w, int Cin, int Cout, int sd, int shw, void* wpacked, mvs_stream_t stream);
+int mvs_conv3d_x3_fwd(const float* x, const void* wpacked, const float* scale, const float* shift, const float* residual, float* y,
+                      int B, int Cin, int Cout, int D, int H, int W, int sd, int shw, int relu, mvs_stream_t stream);
+
 /* FPNEncoder layers, models/module.py:40-73,208-240: y = leaky_relu(BatchNorm2d_eval(conv2d(x, w, stride, padding = K/2)), slope), NCHW.
  * Built for the encoder's eight layer shapes (Cin,Cout,K,stride) = (3,8,7,1) (8,8,5,1) (8,16,5,2) (16,16,3,1) (16,32,5,2) (32,32,3,1)
  * (32,64,3,2) (64,64,3,1); anything else returns MVS_EINVAL.  scale = gamma / sqrt(var + eps), shift = beta - mean * scale.

@@ -1,0 +1,373 @@
+// 3x3x3 convolutions of the eval regularizer (models/module.py:83-123 Conv3d = conv -> BatchNorm -> ReLU, used by CostRegNet /
+// CostRegNet3D, module.py:469-505,550-594) on the BF16 matrix cores in THREE-TERM SPLIT form - fp32 in, fp32 out, fp32-equivalent.
+//
+// Why.  v_mfma_f32_16x16x4_f32 runs at the fp32 VECTOR rate (32 MAC/clk/SIMD) and shares the issue pipe with every other vector
+// instruction (profiles/r03_ubench.txt: next to back-to-back fp32 MFMAs a second wavefront gets 2.4 vector instructions per 32
+// clocks), so the fp32 convolutions sit at 0.3-0.6 of a peak that is itself 16x below the bf16 matrix rate.  Every fp32 value is
+// EXACTLY h + m + l with h = bf16(v), m = bf16(v - h), l = bf16(v - h - m) (3 x 8 significand bits = fp32's 24), so
+//     x*w = xh*wh + (xh*wm + xm*wh) + (xh*wl + xl*wh + xm*wm)  + terms <= 2^-24 |x*w|
+// and six v_mfma_f32_16x16x32_bf16 (512 MAC/clk/SIMD, fp32 accumulation, every partial product exact) replace eight fp32 MFMAs of
+// the same K at 6/16 of their matrix time.  The dropped terms are at the level of ONE fp32 rounding of the product; measured
+// against fp64 the result is as close as (closer than) an fp32 fma chain (tests/test_hip_x3.py, tools/sim_x3.py).  This is not a
+// reduced-precision path: the 2-term form (error 2^-16) is NOT used anywhere.
+//
+// Structure (stride (1,1,1) and (1,2,2) layers: conv1 ... conv6 of CostRegNet3D, conv2 / conv4 / conv6 of CostRegNet):
+//   * a block owns a (4*NT) x 16 column of output pixels through ALL depth planes and 16*MTB output channels, and sweeps the INPUT planes:
+//     input plane p feeds output planes p+1, p, p-1 (kd = 0, 1, 2), whose accumulators live in registers (3 sets), so every input
+//     plane is staged ONCE (no depth halo) and the depth taps that only see padding are simply not issued;
+//   * staging: fp32 NCDHW -> (h, m, l) bf16 CHANNEL-LAST in LDS, the tile's input box (18 x 18 pixels at stride 1, (8NT+1) x 33 with the
+//     even columns first at stride 2) x CK = 8 | 16 channels per pass (27-54 KB): a thread loads 8
+//     channels of one pixel (8 coalesced dword loads), splits them (5.5 vector ops per value) and stores three 16-byte rows, so the
+//     MFMA B operand (8 consecutive channels of one tap of one pixel) is ONE ds_read_b128 per term;
+//   * K = (spatial tap, channel octet) in blocks of 8 channels, 4 blocks per MFMA: 9 taps x CK/8 octets = 18 (9) blocks = 5 (3) steps per
+//     depth tap (the last step is partly zero weights); A operands (weights, pre-split and pre-packed per lane) come straight from
+//     L1/L2, prefetched one step ahead into ping-pong registers, and are reused over the wavefront's NT pixel rows; M = 16 pixels of a
+//     row (so that a lane ends up with 4 consecutive pixels of one channel: 16-byte stores), N = 16 output channels;
+//   * volumes with few tiles are cut into depth segments (one halo plane re-staged per cut) so that every CU gets several blocks.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace {
+using namespace mvsconv;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Compile-time geometry of one kernel instance.  CK = input channels per staging pass (8 | 16), SHW = H/W stride (1 | 2), NT = pixel rows
+// per wavefront (the block's tile is 4*NT rows x 16 columns of OUTPUT pixels), MTB = 16-channel output tiles per block.
+template <int CK_, int SHW_, int NT_, int MTB_>
+struct X3Cfg {
+    static constexpr int CK = CK_, SHW = SHW_, NT = NT_, MTB = MTB_;
+    static constexpr int KQ = CK / 8;                          // channel octets per tap
+    static constexpr int NKB = 9 * KQ;                         // K blocks (tap, octet) per depth tap
+    static constexpr int STEPS = (NKB + 3) / 4;                // MFMAs of K = 32 per depth tap: 5 for CK = 16, 3 for CK = 8
+    static_assert(STEPS % 2 == 1, "the ping-pong parity bookkeeping of the kernel assumes an odd step count per depth tap");
+    static constexpr int TH = 4 * NT, TW = 16;
+    static constexpr int BH = SHW * TH + (3 - SHW), BWC = SHW * TW + (3 - SHW);   // staged box (halo 1): (TH+2) x 18 | (2TH+1) x 33
+    static constexpr int EV = (BWC + 1) / 2;                   // SHW = 2: even columns first (EV of them), then the odd ones
+    static constexpr int PB = CK * 2;                          // bytes per pixel per term
+    static constexpr int TERM_BYTES = BH * BWC * PB;
+    static constexpr int LDS_BYTES = 3 * TERM_BYTES;
+    static constexpr int FRAGS_PER_KD = STEPS * 3 * 64;        // bf16x8 units of one (cout tile, chunk, kd)
+    static constexpr int MIN_BLOCKS = (MTB == 1 && CK == 16) ? 3 : 2;   // blocks per CU the register budget is set for
+    __host__ __device__ static constexpr int col_index(int c) { return SHW == 1 ? c : (c & 1) * EV + (c >> 1); }
+};
+
+struct Split3 { bf16x8 h, m, l; };
+__device__ __forceinline__ Split3 split3(const float (&v)[8]) {
+    Split3 s;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)v[e];
+        const float r = v[e] - (float)h;      // exact
+        const __bf16 m = (__bf16)r;
+        const float r2 = r - (float)m;        // exact
+        s.h[e] = h;
+        s.m[e] = m;
+        s.l[e] = (__bf16)r2;
+    }
+    return s;
+}
+
+// packed[(((ct*NCH + chunk)*3 + kd)*STEPS + step)*3 + term][lane][8]:  A[m = ct*16 + (lane & 15)][K block q = 4*step + (lane >> 4)],
+// q -> (tap9 = q / KQ -> (kh, kw), octet = q % KQ), channel = chunk*CK + octet*8 + e; zero for q >= 9*KQ, for rows beyond Cout and for
+// the one extra unit at the end (the kernel prefetches one step ahead).  w = [Cout][Cin][27] fp32.
+__global__ void x3_pack_kernel(const float* __restrict__ w, int Cin, int Cout, int CK, bf16x8* __restrict__ out, int total) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int KQ = CK / 8, NKB = 9 * KQ, STEPS = (NKB + 3) / 4, NCH = Cin / CK;
+    const int lane = idx & 63, term = (idx >> 6) % 3, step = (idx / 192) % STEPS, kd = (idx / (192 * STEPS)) % 3;
+    const int chunk = (idx / (192 * STEPS * 3)) % NCH, ct = idx / (192 * STEPS * 3 * NCH);
+    const int m = ct * 16 + (lane & 15), q = 4 * step + (lane >> 4);
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float f = 0.0f;
+        if (q < NKB && m < Cout) {
+            const int tap9 = q / KQ, c = chunk * CK + (q % KQ) * 8 + e;
+            f = w[((size_t)m * Cin + c) * 27 + kd * 9 + tap9];
+        }
+        const __bf16 h = (__bf16)f;
+        const float r = f - (float)h;
+        const __bf16 mm = (__bf16)r;
+        const __bf16 l = (__bf16)(r - (float)mm);
+        v[e] = term == 0 ? h : (term == 1 ? mm : l);
+    }
+    out[idx] = v;
+}
+
+struct X3Args {
+    const float* x;
+    const bf16x8* wp;
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    float* y;
+    int Cin, Cout, D, H, W, Ho, Wo, relu, tiles_x;
+    int seg, seg_planes, nseg;      // depth segment of this block (seg is filled from blockIdx.z in the kernel)
+    int ablate;                     // diagnostics (MVS_X3_ABLATE): bit 0 skips the staging loads, bit 1 the split + LDS stores, bit 2 the MFMA phase
+};
+
+template <int V>
+using ic = std::integral_constant<int, V>;
+
+template <class Cfg>
+__global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(X3Args a) {
+    a.seg = blockIdx.z % a.nseg;
+    constexpr int CK = Cfg::CK, SHW = Cfg::SHW, NT = Cfg::NT, MTB = Cfg::MTB, KQ = Cfg::KQ, STEPS = Cfg::STEPS, BWC = Cfg::BWC, PB = Cfg::PB,
+                  TERM_BYTES = Cfg::TERM_BYTES, NPIX = Cfg::BH * Cfg::BWC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kb = lane >> 4;
+    const int tile = blockIdx.x, ctb = blockIdx.y, b = blockIdx.z / a.nseg;
+    const int x0 = (tile % a.tiles_x) * Cfg::TW, y0 = (tile / a.tiles_x) * Cfg::TH;       // output coordinates
+    const int Cin = a.Cin, Cout = a.Cout, D = a.D, H = a.H, W = a.W;
+    const int NCH = Cin / CK;
+    const size_t HW = (size_t)H * W, DHW = (size_t)D * HW, HWo = (size_t)a.Ho * a.Wo;
+    const float* xb = a.x + (size_t)b * Cin * DHW;
+
+    // B-operand byte offsets of this lane's K block in each step (without the row / term parts)
+    unsigned boff[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int q = min(4 * s + kb, Cfg::NKB - 1), tap9 = q / KQ, kh = tap9 / 3, kw = tap9 % 3;
+        boff[s] = (unsigned)((kh * BWC + Cfg::col_index(SHW * n + kw)) * PB + (q % KQ) * 16);
+    }
+
+    f32x4 acc[3][MTB][NT];                                 // [output plane p-1 | p | p+1][M tile][pixel row]
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MTB; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[s][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // D[m = pixel][n = output channel] (the activations are the MFMA's A operand): a lane holds 4 consecutive pixels (4*kb .. 4*kb+3) of
+    // output channel n of each (M tile, row) -> one 16-byte store, and one scale / shift pair per lane
+    const bool vec_ok = (a.Wo & 3) == 0;
+    auto store_plane = [&](int od, const f32x4 (&c)[MTB][NT]) {
+#pragma unroll
+        for (int mt = 0; mt < MTB; ++mt) {
+            const int co = (ctb * MTB + mt) * 16 + n;
+            if (co >= Cout) continue;
+            const float sc = a.scale ? a.scale[co] : 1.0f, sh = a.shift ? a.shift[co] : 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int gy = y0 + wave * NT + nt, gx = x0 + kb * 4;
+                if (gy >= a.Ho || gx >= a.Wo) continue;
+                const size_t o = ((size_t)(b * Cout + co) * D + od) * HWo + (size_t)gy * a.Wo + gx;
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = a.scale ? fmaf(c[mt][nt][r], sc, sh) : c[mt][nt][r] + sh;
+                    if (a.relu) v[r] = fmaxf(v[r], 0.0f);
+                }
+                if (vec_ok) {
+                    if (a.residual) {
+                        const f32x4 rs = *reinterpret_cast<const f32x4*>(a.residual + o);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] + rs[r];
+                    }
+                    *reinterpret_cast<f32x4*>(a.y + o) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (gx + r < a.Wo) a.y[o + r] = a.residual ? v[r] + a.residual[o + r] : v[r];
+                }
+            }
+        }
+    };
+
+    bf16x8 wbuf[2][MTB][3];                                // ping-pong weight fragments [buffer][M tile][h | m | l]
+    auto load_w = [&](const bf16x8* wk, bf16x8 (&aw)[MTB][3]) {
+#pragma unroll
+        for (int mt = 0; mt < MTB; ++mt)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) aw[mt][t] = wk[(size_t)mt * NCH * 3 * Cfg::FRAGS_PER_KD + t * 64];
+    };
+    // The STEPS steps of depth tap KD, starting with the weights of its first step already in wbuf[P]; every step prefetches the next
+    // step's weights (contiguous in memory, running on into the next depth tap) into the other buffer (measured: 10-20 % over loading
+    // each step's weights right before its MFMAs).  KD, P and s are compile-time, so every register index is static.
+    auto kd_steps = [&](auto kd_tag, auto p_tag, const bf16x8* wk) {
+        constexpr int KD = decltype(kd_tag)::value, P = decltype(p_tag)::value, SET = 2 - KD;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int cur = (P + s) & 1;
+            load_w(wk + (size_t)(s + 1) * 192, wbuf[cur ^ 1]);
+            // one step's operands (+ the prefetch) in flight at a time: left alone, the scheduler hoists every step's weight loads
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const unsigned char* bp = lds + (SHW * (wave * NT + nt)) * (BWC * PB) + boff[s];
+                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(bp);
+                const bf16x8 xm = *reinterpret_cast<const bf16x8*>(bp + TERM_BYTES);
+                const bf16x8 xl = *reinterpret_cast<const bf16x8*>(bp + 2 * TERM_BYTES);
+#pragma unroll
+                for (int mt = 0; mt < MTB; ++mt) {
+                    f32x4 c = acc[SET][mt][nt];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, wbuf[cur][mt][1], c, 0, 0, 0);     // smallest products first
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wbuf[cur][mt][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wbuf[cur][mt][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wbuf[cur][mt][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, wbuf[cur][mt][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wbuf[cur][mt][0], c, 0, 0, 0);
+                    acc[SET][mt][nt] = c;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // this block's depth segment: output planes [d_lo, d_hi); input planes d_lo-1 .. d_hi (clipped)
+    const int d_lo = a.seg * a.seg_planes, d_hi = min(D, d_lo + a.seg_planes);
+    const int p_first = max(0, d_lo - 1), p_last = min(D - 1, d_hi);
+    for (int p = p_first; p <= p_last; ++p) {
+        // depth taps of input plane p whose output plane od = p + 1 - kd lies in [d_lo, d_hi): a contiguous, block-uniform range
+        const int kd_lo = max(0, p + 2 - d_hi), kd_hi = min(2, p + 1 - d_lo);
+        for (int chunk = 0; chunk < NCH; ++chunk) {
+            const bf16x8* wk = a.wp + ((size_t)((ctb * MTB) * NCH + chunk) * 3 + kd_lo) * Cfg::FRAGS_PER_KD + lane;
+            load_w(wk, wbuf[0]);                           // the first step's weights travel while the plane is staged
+            // ---- stage plane p, channels [CK*chunk, CK*chunk + CK): fp32 -> (h, m, l) bf16 channel-last ----
+            // (issuing the NEXT pass's loads before this pass's MFMAs was measured and lost 10-25 %: the weight fragments are global
+            // loads too, vmcnt retires in order, so the first weight wait drains the whole prefetch)
+            // all of a thread's loads first (NI items x 8 channel planes in flight), then the split and the LDS stores
+            constexpr int NI = (KQ * NPIX + 255) / 256;
+            float pre[NI][8];
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const int i = tid + it * 256;
+                const int oct = min(i / NPIX, KQ - 1), v = i % NPIX;
+                const int gy = y0 * SHW - 1 + v / BWC, gx = x0 * SHW - 1 + v % BWC;
+                const bool in = i < KQ * NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const float* src = xb + ((size_t)(chunk * CK + oct * 8) * D + p) * HW + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pre[it][e] = (a.ablate & 1) ? 1.0f : src[(size_t)e * DHW];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pre[it][e] = in ? pre[it][e] : 0.0f;
+            }
+            __syncthreads();                               // the previous pass's fragment reads are done
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const int i = tid + it * 256;
+                if (i < KQ * NPIX && !(a.ablate & 2)) {
+                    const int oct = i / NPIX, v = i % NPIX;
+                    const Split3 sp = split3(pre[it]);
+                    unsigned char* dst = lds + ((v / BWC) * BWC + Cfg::col_index(v % BWC)) * PB + oct * 16;
+                    *reinterpret_cast<bf16x8*>(dst) = sp.h;
+                    *reinterpret_cast<bf16x8*>(dst + TERM_BYTES) = sp.m;
+                    *reinterpret_cast<bf16x8*>(dst + 2 * TERM_BYTES) = sp.l;
+                }
+            }
+            __syncthreads();
+            // ---- the depth taps of this plane; the buffer parity flips after each one (STEPS is odd) ----
+            int pos = 0;
+            if (a.ablate & 4) continue;
+            if (kd_lo == 0) {
+                kd_steps(ic<0>{}, ic<0>{}, wk);
+                wk += Cfg::FRAGS_PER_KD;
+                pos = 1;
+            }
+            if (kd_lo <= 1 && kd_hi >= 1) {
+                if (pos == 0) kd_steps(ic<1>{}, ic<0>{}, wk); else kd_steps(ic<1>{}, ic<1>{}, wk);
+                wk += Cfg::FRAGS_PER_KD;
+                pos ^= 1;
+            }
+            if (kd_hi >= 2) {
+                if (pos == 0) kd_steps(ic<2>{}, ic<0>{}, wk); else kd_steps(ic<2>{}, ic<1>{}, wk);
+            }
+        }
+        // output plane p-1 has seen its three input planes
+        if (p - 1 >= d_lo) store_plane(p - 1, acc[0]);
+#pragma unroll
+        for (int mt = 0; mt < MTB; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[0][mt][nt] = acc[1][mt][nt];
+                acc[1][mt][nt] = acc[2][mt][nt];
+                acc[2][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
+    if (p_last == D - 1 && d_hi == D) store_plane(D - 1, acc[0]);
+}
+
+// which instance serves a layer: CK, rows per wavefront, M tiles per block
+struct X3Plan { int ck, nt, mtb; };
+bool x3_plan(int Cin, int Cout, int sd, int shw, X3Plan* pl) {
+    if (sd != 1 || (shw != 1 && shw != 2)) return false;
+    if (Cout != 16 && Cout != 32 && Cout != 64) return false;
+    if (shw == 1) {
+        if (Cin != 16 && Cin != 32 && Cin != 64) return false;
+        *pl = Cout >= 32 ? X3Plan{16, 2, 2} : X3Plan{16, 4, 1};
+        return true;
+    }
+    if (Cin == 8) { *pl = X3Plan{8, 4, 1}; return Cout == 16; }
+    if (Cin != 16 && Cin != 32) return false;
+    *pl = X3Plan{16, 2, Cout >= 32 ? 2 : 1};
+    return true;
+}
+
+template <class Cfg>
+int launch_x3(X3Args a, int B, hipStream_t s) {
+    const int ty = mvs::ceil_div(a.Ho, Cfg::TH);
+    // depth segments: every segment re-stages one halo plane on each side, so split only while the grid is short of ~6 blocks per CU
+    const int64_t blocks = (int64_t)a.tiles_x * ty * mvs::ceil_div(a.Cout, 16 * Cfg::MTB) * B;
+    int nseg = 1;
+    while (nseg * 2 <= a.D / 2 && blocks * nseg < 1536) nseg *= 2;
+    a.nseg = nseg;
+    a.seg_planes = mvs::ceil_div(a.D, nseg);
+    a.seg = 0;
+    {
+        const char* e = getenv("MVS_X3_ABLATE");
+        a.ablate = e ? atoi(e) : 0;
+    }
+    static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_conv_kernel<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       Cfg::LDS_BYTES) == hipSuccess; }();
+    (void)once;
+    hipLaunchKernelGGL((x3_conv_kernel<Cfg>), dim3(a.tiles_x * ty, mvs::ceil_div(a.Cout, 16 * Cfg::MTB), B * nseg), dim3(256), Cfg::LDS_BYTES, s, a);
+    return mvs::finish_launch("mvs_conv3d_x3_fwd");
+}
+
+}  // namespace
+
+extern "C" int mvs_conv3d_x3_supported(int Cin, int Cout, int sd, int shw) {
+    X3Plan pl;
+    return x3_plan(Cin, Cout, sd, shw, &pl) ? 1 : 0;
+}
+
+extern "C" int64_t mvs_conv3d_x3_packed_bytes(int Cin, int Cout, int sd, int shw) {
+    X3Plan pl;
+    if (!x3_plan(Cin, Cout, sd, shw, &pl)) return 0;
+    const int steps = (9 * (pl.ck / 8) + 3) / 4;
+    return ((int64_t)(Cout / 16) * (Cin / pl.ck) * 3 + 1) * steps * 3 * 64 * 16;        // + one zero unit for the running prefetch
+}
+
+extern "C" int mvs_conv3d_x3_pack_weights(const float* w, int Cin, int Cout, int sd, int shw, void* wpacked, mvs_stream_t stream) {
+    MVS_REQUIRE(w && wpacked, "mvs_conv3d_x3_pack_weights: null pointer");
+    X3Plan pl;
+    MVS_REQUIRE(x3_plan(Cin, Cout, sd, shw, &pl), "mvs_conv3d_x3_pack_weights: Cin=%d Cout=%d stride (%d,%d,%d) is not built", Cin, Cout, sd, shw, shw);
+    const int total = (int)(mvs_conv3d_x3_packed_bytes(Cin, Cout, sd, shw) / 16);
+    hipLaunchKernelGGL(x3_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, MVS_STREAM(stream), w, Cin, Cout, pl.ck, static_cast<bf16x8*>(wpacked), total);
+    return mvs::finish_launch("mvs_conv3d_x3_pack_weights");
+}
+
+extern "C" int mvs_conv3d_x3_fwd(const float* x, const void* wpacked, const float* scale, const float* shift, const float* residual, float* y,
+                                 int B, int Cin, int Cout, int D, int H, int W, int sd, int shw, int relu, mvs_stream_t stream) {
+    MVS_REQUIRE(x && wpacked && y, "mvs_conv3d_x3_fwd: null pointer");
+    X3Plan pl;
+    MVS_REQUIRE(x3_plan(Cin, Cout, sd, shw, &pl), "mvs_conv3d_x3_fwd: Cin=%d Cout=%d stride (%d,%d,%d) is not built", Cin, Cout, sd, shw, shw);
+    MVS_REQUIRE(B >= 1 && B <= 65535 && D >= 1 && H >= 1 && W >= 1, "mvs_conv3d_x3_fwd: bad shape B=%d D=%d H=%d W=%d", B, D, H, W);
+    MVS_REQUIRE(!scale || shift, "mvs_conv3d_x3_fwd: scale without shift");
+    X3Args a;
+    a.x = x; a.wp = static_cast<const bf16x8*>(wpacked); a.scale = scale; a.shift = shift; a.residual = residual; a.y = y;
+    a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = relu;
+    a.Ho = (H - 1) / shw + 1;
+    a.Wo = (W - 1) / shw + 1;
+    a.tiles_x = mvs::ceil_div(a.Wo, 16);
+    hipStream_t s = MVS_STREAM(stream);
+    if (shw == 1) return pl.mtb == 2 ? launch_x3<X3Cfg<16, 1, 2, 2>>(a, B, s) : launch_x3<X3Cfg<16, 1, 4, 1>>(a, B, s);
+    if (pl.ck == 8) return launch_x3<X3Cfg<8, 2, 4, 1>>(a, B, s);
+    return pl.mtb == 2 ? launch_x3<X3Cfg<16, 2, 2, 2>>(a, B, s) : launch_x3<X3Cfg<16, 2, 2, 1>>(a, B, s);
+}

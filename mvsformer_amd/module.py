@@ -126,19 +126,29 @@ class Conv3d(nn.Module):
             if s == (1, 1, 1) and conv.in_channels % 4 == 0 and conv.out_channels % 16 == 0 and conv.out_channels <= 64 \
                     and os.environ.get("MVS_CONV_WINO", "1") != "0":
                 wino = ops.conv3d_wino_pack(_f32c(conv.weight))
+            # 3-term bf16 split form (csrc/conv3d_x3.hip: fp32-equivalent, bf16 matrix cores).  MVS_CONV_X3: "strided" (default) = the
+            # stride-(1,2,2) layers conv1 / conv3 / conv5 of CostRegNet3D, where it beats the fp32-MFMA kernel by 15-30 %; "all" = the
+            # stride-1 layers too (on a par with the Winograd fp32 kernel); "0" = off
+            x3 = None
+            x3_mode = os.environ.get("MVS_CONV_X3", "strided")
+            if x3_mode != "0" and ops.conv3d_x3_supported(conv.in_channels, conv.out_channels, (s[0], s[1])) \
+                    and (x3_mode == "all" or s[1] == 2):
+                x3 = ops.conv3d_x3_pack(_f32c(conv.weight), (s[0], s[1]))
             if self.bn is not None:
                 scale, shift = _bn_fold(self.bn)
             else:
                 scale = None
                 shift = _f32c(conv.bias) if conv.bias is not None else None
             _publish_cache()
-            self._cache = (key, packed, scale, shift, (s[0], s[1]), wino)
+            self._cache = (key, packed, scale, shift, (s[0], s[1]), wino, x3)
         return self._cache[1:]
 
     def forward(self, x, residual: Optional[torch.Tensor] = None):
         if self.training:
             return _train_conv_bn_act(x, self.conv, self.bn, self.relu, residual)
-        packed, scale, shift, stride, wino = self._prepared()
+        packed, scale, shift, stride, wino, x3 = self._prepared()
+        if x3 is not None:
+            return ops.conv3d_x3(x, x3, self.conv.in_channels, self.conv.out_channels, stride, scale, shift, residual, relu=self.relu)
         if wino is not None and ops.conv3d_wino_supported(self.conv.in_channels, self.conv.out_channels, *x.shape[2:]):
             return ops.conv3d_wino(x, wino, self.conv.in_channels, self.conv.out_channels, scale, shift, residual, relu=self.relu)
         return ops.conv3d(x, packed, self.conv.in_channels, self.conv.out_channels, stride, scale, shift, residual,

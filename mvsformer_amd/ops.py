@@ -386,6 +386,43 @@ def conv3d_wino(x, wpacked, cin, cout, scale=None, shift=None, residual=None, re
     return y
 
 
+def conv3d_x3_supported(cin: int, cout: int, stride) -> bool:
+    """True if the 3-term bf16 split form (csrc/conv3d_x3.hip) is built for this layer shape."""
+    return bool(_lib.load().mvs_conv3d_x3_supported(cin, cout, int(stride[0]), int(stride[1])))
+
+
+def conv3d_x3_pack(weight: torch.Tensor, stride=(1, 1)) -> torch.Tensor:
+    """Conv3d weight ``[Cout,Cin,3,3,3]`` -> pre-split (h, m, l) bf16 MFMA fragments for :func:`conv3d_x3` (uint8 storage)."""
+    _chk(weight, "conv weight")
+    cout, cin = weight.shape[0], weight.shape[1]
+    sd, shw = int(stride[0]), int(stride[1])
+    n = int(_lib.load().mvs_conv3d_x3_packed_bytes(cin, cout, sd, shw))
+    if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3) or n <= 0:
+        raise _lib.MvsHipError("conv3d_x3_pack: unsupported weight %s / stride %s" % (tuple(weight.shape), (sd, shw)))
+    packed = torch.empty(n, device=weight.device, dtype=torch.uint8)
+    _call("mvs_conv3d_x3_pack_weights", None, _ptr(weight), cin, cout, sd, shw, _ptr(packed), _stream())
+    return packed
+
+
+def conv3d_x3(x, wpacked, cin, cout, stride=(1, 1), scale=None, shift=None, residual=None, relu=True):
+    """``Conv3d`` layer (conv, stride (1,s,s) -> folded BatchNorm -> ReLU [+ residual]) on the bf16 matrix cores in 3-term split form:
+    fp32 in, fp32 out, fp32-equivalent (include/mvs_hip.h)."""
+    _chk(x, "x"), _chk(wpacked, "packed weights", torch.uint8), _opt(scale, "scale"), _opt(shift, "shift")
+    B, C, D, H, W = x.shape
+    assert C == cin
+    sd, shw = int(stride[0]), int(stride[1])
+    Ho, Wo = (H - 1) // shw + 1, (W - 1) // shw + 1
+    y = torch.empty(B, cout, D, Ho, Wo, device=x.device, dtype=torch.float32)
+    if residual is not None:
+        _chk(residual, "residual")
+        if residual.shape != y.shape:
+            raise _lib.MvsHipError("residual shape %s != output %s" % (tuple(residual.shape), tuple(y.shape)))
+    tag = ("x3_conv_kernel<%d,%d,s%d>" % (cin, cout, shw), "flops", 2.0 * 27 * cin * cout * B * D * Ho * Wo)
+    _call("mvs_conv3d_x3_fwd", tag, _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), B, cin, cout, D, H, W, sd, shw,
+          int(relu), _stream())
+    return y
+
+
 def deconv3d(x, wpacked, cin, cout, sd, scale=None, shift=None, residual=None, relu=True, tag=None):
     _chk(x, "x"), _chk(wpacked, "packed weights"), _opt(scale, "scale"), _opt(shift, "shift")
     B, C, Di, Hi, Wi = x.shape
