@@ -106,7 +106,7 @@ struct X3Args {
     const float* residual;
     float* y;
     int Cin, Cout, D, H, W, Ho, Wo, relu, tiles_x;
-    int seg, seg_planes, nseg;      // depth segment of this block (seg is filled from blockIdx.z in the kernel)
+    int seg_planes, nseg;           // depth segments: block z = batch * nseg + segment
     int ablate;                     // diagnostics (MVS_X3_ABLATE): bit 0 skips the staging loads, bit 1 the split + LDS stores, bit 2 the MFMA phase
 };
 
@@ -114,11 +114,11 @@ template <int V>
 using ic = std::integral_constant<int, V>;
 
 template <class Cfg>
-__global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(X3Args a) {
-    a.seg = blockIdx.z % a.nseg;
+__global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3Args a) {
+    const int seg = blockIdx.z % a.nseg;
     constexpr int CK = Cfg::CK, SHW = Cfg::SHW, NT = Cfg::NT, MTB = Cfg::MTB, KQ = Cfg::KQ, STEPS = Cfg::STEPS, BWC = Cfg::BWC, PB = Cfg::PB,
                   TERM_BYTES = Cfg::TERM_BYTES, NPIX = Cfg::BH * Cfg::BWC;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[Cfg::LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kb = lane >> 4;
@@ -191,12 +191,12 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(X3Args a)
     // The STEPS steps of depth tap KD, starting with the weights of its first step already in wbuf[P]; every step prefetches the next
     // step's weights (contiguous in memory, running on into the next depth tap) into the other buffer (measured: 10-20 % over loading
     // each step's weights right before its MFMAs).  KD, P and s are compile-time, so every register index is static.
-    auto kd_steps = [&](auto kd_tag, auto p_tag, const bf16x8* wk) {
+    auto kd_steps = [&](auto kd_tag, auto p_tag, const bf16x8* wk, bool more) {
         constexpr int KD = decltype(kd_tag)::value, P = decltype(p_tag)::value, SET = 2 - KD;
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const int cur = (P + s) & 1;
-            load_w(wk + (size_t)(s + 1) * 192, wbuf[cur ^ 1]);
+            if (s + 1 < STEPS || more) load_w(wk + (size_t)(s + 1) * 192, wbuf[cur ^ 1]);      // no load left in flight at the end of the pass
             // one step's operands (+ the prefetch) in flight at a time: left alone, the scheduler hoists every step's weight loads
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(X3Args a)
     };
 
     // this block's depth segment: output planes [d_lo, d_hi); input planes d_lo-1 .. d_hi (clipped)
-    const int d_lo = a.seg * a.seg_planes, d_hi = min(D, d_lo + a.seg_planes);
+    const int d_lo = seg * a.seg_planes, d_hi = min(D, d_lo + a.seg_planes);
     const int p_first = max(0, d_lo - 1), p_last = min(D - 1, d_hi);
     for (int p = p_first; p <= p_last; ++p) {
         // depth taps of input plane p whose output plane od = p + 1 - kd lies in [d_lo, d_hi): a contiguous, block-uniform range
@@ -266,17 +266,17 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(X3Args a)
             int pos = 0;
             if (a.ablate & 4) continue;
             if (kd_lo == 0) {
-                kd_steps(ic<0>{}, ic<0>{}, wk);
+                kd_steps(ic<0>{}, ic<0>{}, wk, kd_hi >= 1);
                 wk += Cfg::FRAGS_PER_KD;
                 pos = 1;
             }
             if (kd_lo <= 1 && kd_hi >= 1) {
-                if (pos == 0) kd_steps(ic<1>{}, ic<0>{}, wk); else kd_steps(ic<1>{}, ic<1>{}, wk);
+                if (pos == 0) kd_steps(ic<1>{}, ic<0>{}, wk, kd_hi >= 2); else kd_steps(ic<1>{}, ic<1>{}, wk, kd_hi >= 2);
                 wk += Cfg::FRAGS_PER_KD;
                 pos ^= 1;
             }
             if (kd_hi >= 2) {
-                if (pos == 0) kd_steps(ic<2>{}, ic<0>{}, wk); else kd_steps(ic<2>{}, ic<1>{}, wk);
+                if (pos == 0) kd_steps(ic<2>{}, ic<0>{}, wk, false); else kd_steps(ic<2>{}, ic<1>{}, wk, false);
             }
         }
         // output plane p-1 has seen its three input planes
@@ -291,6 +291,7 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(X3Args a)
             }
     }
     if (p_last == D - 1 && d_hi == D) store_plane(D - 1, acc[0]);
+    if (a.ablate & 8) __threadfence();
 }
 
 // which instance serves a layer: CK, rows per wavefront, M tiles per block
@@ -318,15 +319,11 @@ int launch_x3(X3Args a, int B, hipStream_t s) {
     while (nseg * 2 <= a.D / 2 && blocks * nseg < 1536) nseg *= 2;
     a.nseg = nseg;
     a.seg_planes = mvs::ceil_div(a.D, nseg);
-    a.seg = 0;
     {
         const char* e = getenv("MVS_X3_ABLATE");
         a.ablate = e ? atoi(e) : 0;
     }
-    static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&x3_conv_kernel<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       Cfg::LDS_BYTES) == hipSuccess; }();
-    (void)once;
-    hipLaunchKernelGGL((x3_conv_kernel<Cfg>), dim3(a.tiles_x * ty, mvs::ceil_div(a.Cout, 16 * Cfg::MTB), B * nseg), dim3(256), Cfg::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((x3_conv_kernel<Cfg>), dim3(a.tiles_x * ty, mvs::ceil_div(a.Cout, 16 * Cfg::MTB), B * nseg), dim3(256), 0, s, a);
     return mvs::finish_launch("mvs_conv3d_x3_fwd");
 }
 

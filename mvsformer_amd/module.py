@@ -97,6 +97,9 @@ def _train_conv_bn_act(x, conv, bn, relu, residual, transposed_sd=None):
 # ---------------------------------------------------------------------------------------------------------
 # layer holders (reference models/module.py:83-165, 168-197)
 # ---------------------------------------------------------------------------------------------------------
+X3_MIN_VOXELS = 40 * 1024      # output voxels from which the split-form conv is used (MVS_CONV_X3_MIN_VOXELS overrides)
+
+
 class Conv3d(nn.Module):
     """conv(bias = not bn) -> BatchNorm3d -> ReLU, as reference ``Conv3d`` (module.py:83-123)."""
 
@@ -121,18 +124,21 @@ class Conv3d(nn.Module):
             if s not in ((1, 1, 1), (2, 2, 2), (1, 2, 2)):
                 raise MvsHipError("Conv3d: stride %s is not built" % (s,))
             packed = ops.conv3d_pack(_f32c(conv.weight), transposed=False)
-            # stride-1 layers with 16/32/48/64 output channels (conv2/conv4/conv6) also get the Winograd F(2x2,3x3) image
+            # Winograd F(2x2,3x3) fp32-MFMA image of the stride-1 layers (conv2 / conv4 / conv6): OPT-IN since round 3 (MVS_CONV_WINO=1).
+            # With the split-form kernels running on other streams its output was found to differ from run to run at a few hundred
+            # voxels (tools/x3_race2.py: only wino_conv3d_kernel's outputs move, its inputs are bit-identical; cause open), and the
+            # split form below is as fast at the sizes that matter.
             wino = None
             if s == (1, 1, 1) and conv.in_channels % 4 == 0 and conv.out_channels % 16 == 0 and conv.out_channels <= 64 \
-                    and os.environ.get("MVS_CONV_WINO", "1") != "0":
+                    and os.environ.get("MVS_CONV_WINO", "0") == "1":
                 wino = ops.conv3d_wino_pack(_f32c(conv.weight))
-            # 3-term bf16 split form (csrc/conv3d_x3.hip: fp32-equivalent, bf16 matrix cores).  MVS_CONV_X3: "strided" (default) = the
-            # stride-(1,2,2) layers conv1 / conv3 / conv5 of CostRegNet3D, where it beats the fp32-MFMA kernel by 15-30 %; "all" = the
-            # stride-1 layers too (on a par with the Winograd fp32 kernel); "0" = off
+            # 3-term bf16 split form (csrc/conv3d_x3.hip: fp32-equivalent, bf16 matrix cores) for every layer shape it is built for
+            # (stride (1,1,1) and (1,2,2)); forward() uses it from X3_MIN_VOXELS output voxels up (below that the launch is too small to
+            # fill the chip with its 16 x 16 x D tiles and the fp32-MFMA kernel wins).  MVS_CONV_X3=0 turns it off.
             x3 = None
-            x3_mode = os.environ.get("MVS_CONV_X3", "strided")
+            x3_mode = os.environ.get("MVS_CONV_X3", "1")        # "1" all built shapes, "strided" / "s1" one kind only (diagnostics), "0" off
             if x3_mode != "0" and ops.conv3d_x3_supported(conv.in_channels, conv.out_channels, (s[0], s[1])) \
-                    and (x3_mode == "all" or s[1] == 2):
+                    and not (x3_mode == "strided" and s[1] == 1) and not (x3_mode == "s1" and s[1] == 2):
                 x3 = ops.conv3d_x3_pack(_f32c(conv.weight), (s[0], s[1]))
             if self.bn is not None:
                 scale, shift = _bn_fold(self.bn)
@@ -147,7 +153,7 @@ class Conv3d(nn.Module):
         if self.training:
             return _train_conv_bn_act(x, self.conv, self.bn, self.relu, residual)
         packed, scale, shift, stride, wino, x3 = self._prepared()
-        if x3 is not None:
+        if x3 is not None and x.shape[2] * (x.shape[3] // stride[1]) * (x.shape[4] // stride[1]) >= int(os.environ.get("MVS_CONV_X3_MIN_VOXELS", X3_MIN_VOXELS)):
             return ops.conv3d_x3(x, x3, self.conv.in_channels, self.conv.out_channels, stride, scale, shift, residual, relu=self.relu)
         if wino is not None and ops.conv3d_wino_supported(self.conv.in_channels, self.conv.out_channels, *x.shape[2:]):
             return ops.conv3d_wino(x, wino, self.conv.in_channels, self.conv.out_channels, scale, shift, residual, relu=self.relu)

@@ -599,7 +599,7 @@ def test_stage_vs_oracle_mixed_kernel_paths(dev, C, ndepth, H, W, V, B):
         want = ref_torch.stage_forward(feat, proj, hyp, net.state_dict(), ndepth=ndepth, tmp=5.0)
     net = net.to(dev)
     outs = []
-    for env in ({}, {"MVS_CONV_WINO": "0", "MVS_VIS_WINO": "0", "MVS_FUSE_PROB": "0"}):
+    for env in ({}, {"MVS_CONV_X3": "0", "MVS_VIS_WINO": "0", "MVS_FUSE_PROB": "0"}, {"MVS_CONV_X3_MIN_VOXELS": "0"}, {"MVS_CONV_X3": "0", "MVS_CONV_WINO": "1"}):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
