@@ -388,6 +388,14 @@ int64_t mvs_conv3d_x3_packed_bytes(int Cin, int Cout, int sd, int shw);
 int mvs_conv3d_x3_pack_weights(const float* w, int Cin, int Cout, int sd, int shw, void* wpacked, mvs_stream_t stream);
 int mvs_conv3d_x3_fwd(const float* x, const void* wpacked, const float* scale, const float* shift, const float* residual, float* y,
                       int B, int Cin, int Cout, int D, int H, int W, int sd, int shw, int relu, mvs_stream_t stream);
+/* Transposed twin (ConvTranspose3d k = 3, stride (1,2,2), padding 1, output_padding (0,1,1): conv7 / conv9 / conv11 of CostRegNet3D,
+ * models/module.py:562-575), same split form: w [Cin,Cout,3,3,3], x [B,Cin,D,H,W] -> y [B,Cout,D,2H,2W]; built for sd = 1, Cin in
+ * {16,32,64}, Cout in {8,16,32}; W even. */
+int mvs_deconv3d_x3_supported(int Cin, int Cout, int sd);
+int64_t mvs_deconv3d_x3_packed_bytes(int Cin, int Cout, int sd);
+int mvs_deconv3d_x3_pack_weights(const float* w, int Cin, int Cout, int sd, void* wpacked, mvs_stream_t stream);
+int mvs_deconv3d_x3_fwd(const float* x, const void* wpacked, const float* scale, const float* shift, const float* residual, float* y,
+                        int B, int Cin, int Cout, int D, int H, int W, int sd, int relu, mvs_stream_t stream);
 
 /* FPNEncoder layers, models/module.py:40-73,208-240: y = leaky_relu(BatchNorm2d_eval(conv2d(x, w, stride, padding = K/2)), slope), NCHW.
  * Built for the encoder's eight layer shapes (Cin,Cout,K,stride) = (3,8,7,1) (8,8,5,1) (8,16,5,2) (16,16,3,1) (16,32,5,2) (32,32,3,1)

@@ -42,6 +42,10 @@ SIGNATURES = {
     "mvs_conv3d_x3_packed_bytes": (L, [I, I, I, I]),
     "mvs_conv3d_x3_pack_weights": (I, [P, I, I, I, I, P, P]),
     "mvs_conv3d_x3_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "mvs_deconv3d_x3_supported": (I, [I, I, I]),
+    "mvs_deconv3d_x3_packed_bytes": (L, [I, I, I]),
+    "mvs_deconv3d_x3_pack_weights": (I, [P, I, I, I, P, P]),
+    "mvs_deconv3d_x3_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "mvs_cv_tiled_entropy_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, I, P, P]),
     "mvs_cv_tiled_aggregate_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, P, I, P, P]),
     "mvs_conv3d_packed_floats": (L, [I, I, I]),

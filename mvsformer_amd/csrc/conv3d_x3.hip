@@ -294,6 +294,223 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
     if (a.ablate & 8) __threadfence();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Transposed convolution, stride (1,2,2), kernel 3, padding 1, output_padding (0,1,1) (CostRegNet3D's conv7 / conv9 / conv11,
+// models/module.py:562-575), same split form.  out[od, oh, ow] gathers in[od + 1 - kd, (oh + 1 - kh) / 2, (ow + 1 - kw) / 2] where
+// divisible, so an output pixel of row parity ph and column parity pw sees only the taps kh in KH(ph), kw in KW(pw):
+//     parity 0: k = 1 (input offset 0);   parity 1: k = 0 (input offset +1), k = 2 (input offset 0)
+// i.e. 1, 2, 2 and 4 spatial taps for the four parity classes - 9 in total, no wasted work.  A block owns 8 x 16 INPUT pixels
+// (16 x 32 output pixels) through all depth planes and 16 output channels, sweeps the input planes like the convolution above
+// (input plane p feeds output planes p-1, p, p+1 for kd = 0, 1, 2), and a wavefront owns two input rows: for each class its N tiles
+// are (row, 16 output pixels of that class), so the weight fragments of a class step are reused over two tiles.  K blocks of a
+// class = (tap, channel octet): 2 / 4 / 4 / 8 blocks -> 1 / 1 / 1 / 2 steps per depth tap.
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace dcv {
+constexpr int TIH = 8, TIW = 16, BH = TIH + 1, BW = TIW + 1, NPIX = BH * BW, PB = 32, TERM_BYTES = NPIX * PB, LDS_BYTES = 3 * TERM_BYTES;
+constexpr int CSTEPS = 5;                                  // class steps per depth tap
+constexpr int FRAGS_PER_KD = CSTEPS * 3 * 64;
+// class step -> (row parity, column parity, step inside the class)
+__host__ __device__ constexpr int cs_ph(int cs) { return cs >= 2 ? 1 : 0; }
+__host__ __device__ constexpr int cs_pw(int cs) { return (cs == 1 || cs >= 3) ? 1 : 0; }
+__host__ __device__ constexpr int cs_step(int cs) { return cs == 4 ? 1 : 0; }
+__host__ __device__ constexpr int cs_class(int cs) { return cs_ph(cs) * 2 + cs_pw(cs); }
+// K block q of a class -> tap (kh, kw, input row offset, input column offset) and channel octet; false beyond the class's taps
+__host__ __device__ inline bool tap_of(int ph, int pw, int q, int* kh, int* kw, int* di, int* dj, int* oct) {
+    const int nkh = ph ? 2 : 1, nkw = pw ? 2 : 1, t = q >> 1;
+    *oct = q & 1;
+    if (t >= nkh * nkw) return false;
+    const int th = t / nkw, tw = t % nkw;
+    *kh = ph ? (th == 0 ? 0 : 2) : 1;
+    *di = ph ? (th == 0 ? 1 : 0) : 0;
+    *kw = pw ? (tw == 0 ? 0 : 2) : 1;
+    *dj = pw ? (tw == 0 ? 1 : 0) : 0;
+    return true;
+}
+}  // namespace dcv
+
+// packed[(((ct*NCH + chunk)*3 + kd)*CSTEPS + cs)*3 + term][lane][8]: B[n = ct*16 + (lane & 15)][K block q = 4*step(cs) + (lane >> 4)] of
+// class(cs); w = ConvTranspose3d weight [Cin][Cout][27]; one spare zero unit at the end (running prefetch)
+__global__ void x3_deconv_pack_kernel(const float* __restrict__ w, int Cin, int Cout, bf16x8* __restrict__ out, int total) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int NCH = Cin / 16;
+    const int lane = idx & 63, term = (idx >> 6) % 3, cs = (idx / 192) % dcv::CSTEPS, kd = (idx / (192 * dcv::CSTEPS)) % 3;
+    const int chunk = (idx / (192 * dcv::CSTEPS * 3)) % NCH, ct = idx / (192 * dcv::CSTEPS * 3 * NCH);
+    const int n = ct * 16 + (lane & 15), q = 4 * dcv::cs_step(cs) + (lane >> 4);
+    int kh, kw, di, dj, oct;
+    const bool ok = dcv::tap_of(dcv::cs_ph(cs), dcv::cs_pw(cs), q, &kh, &kw, &di, &dj, &oct) && n < Cout;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float f = 0.0f;
+        if (ok) f = w[((size_t)(chunk * 16 + oct * 8 + e) * Cout + n) * 27 + kd * 9 + kh * 3 + kw];
+        const __bf16 h = (__bf16)f;
+        const float r = f - (float)h;
+        const __bf16 mm = (__bf16)r;
+        const __bf16 l = (__bf16)(r - (float)mm);
+        v[e] = term == 0 ? h : (term == 1 ? mm : l);
+    }
+    out[idx] = v;
+}
+
+// H, W = INPUT size; output [B,Cout,D,2H,2W]
+__global__ __launch_bounds__(256, 2) void x3_deconv_kernel(const X3Args a) {
+    using namespace dcv;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kb = lane >> 4;               // as the A (activation) operand: pixel column j = n; as the accumulator: channel n
+    const int tile = blockIdx.x, ctb = blockIdx.y, b = blockIdx.z / a.nseg, seg = blockIdx.z % a.nseg;
+    const int x0 = (tile % a.tiles_x) * TIW, y0 = (tile / a.tiles_x) * TIH;              // input coordinates
+    const int Cin = a.Cin, Cout = a.Cout, D = a.D, H = a.H, W = a.W, Ho = 2 * H, Wo = 2 * W;
+    const int NCH = Cin / 16;
+    const size_t HW = (size_t)H * W, DHW = (size_t)D * HW, HWo = (size_t)Ho * Wo;
+    const float* xb = a.x + (size_t)b * Cin * DHW;
+
+    // activation-operand byte offsets of this lane's K block in each class step (row / term parts added later)
+    unsigned boff[CSTEPS];
+#pragma unroll
+    for (int cs = 0; cs < CSTEPS; ++cs) {
+        int kh, kw, di, dj, oct;
+        if (!tap_of(cs_ph(cs), cs_pw(cs), 4 * cs_step(cs) + kb, &kh, &kw, &di, &dj, &oct)) { di = 0; dj = 0; }      // zero weights: any valid address
+        boff[cs] = (unsigned)((di * BW + n + dj) * PB + oct * 16);
+    }
+
+    f32x4 acc[3][4][2];                                    // [output plane p-1 | p | p+1][parity class][input row of the wavefront]
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[s][c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // accumulator [pixel quad 4kb..4kb+3 of the class][channel n]: with both column classes of a row in one lane, the 8 output pixels
+    // 8kb .. 8kb+7 of the row are two 16-byte stores
+    const int co = ctb * 16 + n;
+    const float sc = (a.scale && co < Cout) ? a.scale[co] : 1.0f, sh = (a.shift && co < Cout) ? a.shift[co] : 0.0f;
+    auto store_plane = [&](int od, const f32x4 (&c)[4][2]) {
+        if (co >= Cout) return;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const int oy = 2 * (y0 + wave * 2 + r) + ph, ox = 2 * (x0 + kb * 4);
+                if (oy >= Ho || ox >= Wo) continue;
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[2 * q] = c[ph * 2 + 0][r][q];
+                    v[2 * q + 1] = c[ph * 2 + 1][r][q];
+                }
+                const size_t o = ((size_t)(b * Cout + co) * D + od) * HWo + (size_t)oy * Wo + ox;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    v[q] = a.scale ? fmaf(v[q], sc, sh) : v[q] + sh;
+                    if (a.relu) v[q] = fmaxf(v[q], 0.0f);
+                }
+                // Wo = 2W with W even: a multiple of 4, so each 16-byte half is either fully inside the row or fully outside
+                const bool second = ox + 4 < Wo;
+                if (a.residual) {
+                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.residual + o);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] += r0[q];
+                    if (second) {
+                        const f32x4 r1 = *reinterpret_cast<const f32x4*>(a.residual + o + 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[4 + q] += r1[q];
+                    }
+                }
+                *reinterpret_cast<f32x4*>(a.y + o) = f32x4{v[0], v[1], v[2], v[3]};
+                if (second) *reinterpret_cast<f32x4*>(a.y + o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+    };
+
+    bf16x8 wbuf[2][3];
+    auto load_w = [&](const bf16x8* wk, bf16x8 (&aw)[3]) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) aw[t] = wk[t * 64];
+    };
+    auto kd_steps = [&](auto kd_tag, auto p_tag, const bf16x8* wk, bool more) {
+        constexpr int KD = decltype(kd_tag)::value, P = decltype(p_tag)::value, SET = KD;      // od = p - 1 + kd
+#pragma unroll
+        for (int cs = 0; cs < CSTEPS; ++cs) {
+            const int cur = (P + cs) & 1;
+            if (cs + 1 < CSTEPS || more) load_w(wk + (size_t)(cs + 1) * 192, wbuf[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const unsigned char* bp = lds + (wave * 2 + r) * (BW * PB) + boff[cs];
+                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(bp);
+                const bf16x8 xm = *reinterpret_cast<const bf16x8*>(bp + TERM_BYTES);
+                const bf16x8 xl = *reinterpret_cast<const bf16x8*>(bp + 2 * TERM_BYTES);
+                f32x4 c = acc[SET][cs_class(cs)][r];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, wbuf[cur][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wbuf[cur][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wbuf[cur][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wbuf[cur][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, wbuf[cur][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wbuf[cur][0], c, 0, 0, 0);
+                acc[SET][cs_class(cs)][r] = c;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const int d_lo = seg * a.seg_planes, d_hi = min(D, d_lo + a.seg_planes);
+    const int p_first = max(0, d_lo - 1), p_last = min(D - 1, d_hi);
+    for (int p = p_first; p <= p_last; ++p) {
+        // depth taps whose output plane od = p - 1 + kd lies in [d_lo, d_hi)
+        const int kd_lo = max(0, d_lo + 1 - p), kd_hi = min(2, d_hi - p);
+        for (int chunk = 0; chunk < NCH; ++chunk) {
+            const bf16x8* wk = a.wp + ((size_t)(ctb * NCH + chunk) * 3 + kd_lo) * FRAGS_PER_KD + lane;
+            load_w(wk, wbuf[0]);
+            __syncthreads();
+            for (int i = tid; i < 2 * NPIX; i += 256) {
+                const int oct = i / NPIX, v = i % NPIX;
+                const int gy = y0 + v / BW, gx = x0 + v % BW;
+                const bool in = gy < H && gx < W;
+                const float* src = xb + ((size_t)(chunk * 16 + oct * 8) * D + p) * HW + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = src[(size_t)e * DHW];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = in ? f[e] : 0.0f;
+                const Split3 sp = split3(f);
+                unsigned char* dst = lds + v * PB + oct * 16;
+                *reinterpret_cast<bf16x8*>(dst) = sp.h;
+                *reinterpret_cast<bf16x8*>(dst + TERM_BYTES) = sp.m;
+                *reinterpret_cast<bf16x8*>(dst + 2 * TERM_BYTES) = sp.l;
+            }
+            __syncthreads();
+            int pos = 0;
+            if (kd_lo == 0 && kd_hi >= 0) {
+                kd_steps(ic<0>{}, ic<0>{}, wk, kd_hi >= 1);
+                wk += FRAGS_PER_KD;
+                pos = 1;
+            }
+            if (kd_lo <= 1 && kd_hi >= 1) {
+                if (pos == 0) kd_steps(ic<1>{}, ic<0>{}, wk, kd_hi >= 2); else kd_steps(ic<1>{}, ic<1>{}, wk, kd_hi >= 2);
+                wk += FRAGS_PER_KD;
+                pos ^= 1;
+            }
+            if (kd_lo <= 2 && kd_hi >= 2) {
+                if (pos == 0) kd_steps(ic<2>{}, ic<0>{}, wk, false); else kd_steps(ic<2>{}, ic<1>{}, wk, false);
+            }
+        }
+        // output plane p-1 has seen input planes p-2, p-1, p
+        if (p - 1 >= d_lo) store_plane(p - 1, acc[0]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                acc[0][c][r] = acc[1][c][r];
+                acc[1][c][r] = acc[2][c][r];
+                acc[2][c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
+    if (p_last == D - 1 && d_hi == D) store_plane(D - 1, acc[0]);
+}
+
 // which instance serves a layer: CK, rows per wavefront, M tiles per block
 struct X3Plan { int ck, nt, mtb; };
 bool x3_plan(int Cin, int Cout, int sd, int shw, X3Plan* pl) {
@@ -367,4 +584,47 @@ extern "C" int mvs_conv3d_x3_fwd(const float* x, const void* wpacked, const floa
     if (shw == 1) return pl.mtb == 2 ? launch_x3<X3Cfg<16, 1, 2, 2>>(a, B, s) : launch_x3<X3Cfg<16, 1, 4, 1>>(a, B, s);
     if (pl.ck == 8) return launch_x3<X3Cfg<8, 2, 4, 1>>(a, B, s);
     return pl.mtb == 2 ? launch_x3<X3Cfg<16, 2, 2, 2>>(a, B, s) : launch_x3<X3Cfg<16, 2, 2, 1>>(a, B, s);
+}
+
+extern "C" int mvs_deconv3d_x3_supported(int Cin, int Cout, int sd) {
+    return sd == 1 && (Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 8 || Cout == 16 || Cout == 32);
+}
+
+extern "C" int64_t mvs_deconv3d_x3_packed_bytes(int Cin, int Cout, int sd) {
+    if (!mvs_deconv3d_x3_supported(Cin, Cout, sd)) return 0;
+    return ((int64_t)((Cout + 15) / 16) * (Cin / 16) * 3 + 1) * dcv::FRAGS_PER_KD * 16;
+}
+
+extern "C" int mvs_deconv3d_x3_pack_weights(const float* w, int Cin, int Cout, int sd, void* wpacked, mvs_stream_t stream) {
+    MVS_REQUIRE(w && wpacked, "mvs_deconv3d_x3_pack_weights: null pointer");
+    MVS_REQUIRE(mvs_deconv3d_x3_supported(Cin, Cout, sd), "mvs_deconv3d_x3_pack_weights: Cin=%d Cout=%d sd=%d is not built", Cin, Cout, sd);
+    const int total = (int)(mvs_deconv3d_x3_packed_bytes(Cin, Cout, sd) / 16);
+    hipLaunchKernelGGL(x3_deconv_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, MVS_STREAM(stream), w, Cin, Cout, static_cast<bf16x8*>(wpacked), total);
+    return mvs::finish_launch("mvs_deconv3d_x3_pack_weights");
+}
+
+/* x [B,Cin,D,H,W] -> y [B,Cout,D,2H,2W] = [relu](conv_transpose3d(x, w, stride (1,2,2), padding 1, output_padding (0,1,1)) * scale + shift)
+ * [+ residual] */
+extern "C" int mvs_deconv3d_x3_fwd(const float* x, const void* wpacked, const float* scale, const float* shift, const float* residual, float* y,
+                                   int B, int Cin, int Cout, int D, int H, int W, int sd, int relu, mvs_stream_t stream) {
+    MVS_REQUIRE(x && wpacked && y, "mvs_deconv3d_x3_fwd: null pointer");
+    MVS_REQUIRE(mvs_deconv3d_x3_supported(Cin, Cout, sd), "mvs_deconv3d_x3_fwd: Cin=%d Cout=%d sd=%d is not built", Cin, Cout, sd);
+    MVS_REQUIRE(B >= 1 && B <= 65535 && D >= 1 && H >= 1 && W >= 1 && (W % 2) == 0, "mvs_deconv3d_x3_fwd: bad shape B=%d D=%d H=%d W=%d (W even)", B, D, H, W);
+    MVS_REQUIRE(!scale || shift, "mvs_deconv3d_x3_fwd: scale without shift");
+    X3Args a;
+    a.x = x; a.wp = static_cast<const bf16x8*>(wpacked); a.scale = scale; a.shift = shift; a.residual = residual; a.y = y;
+    a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = relu; a.Ho = 2 * H; a.Wo = 2 * W;
+    a.tiles_x = mvs::ceil_div(W, dcv::TIW);
+    const int ty = mvs::ceil_div(H, dcv::TIH), cts = (Cout + 15) / 16;
+    const int64_t blocks = (int64_t)a.tiles_x * ty * cts * B;
+    int nseg = 1;
+    while (nseg * 2 <= D / 2 && blocks * nseg < 1536) nseg *= 2;
+    a.nseg = nseg;
+    a.seg_planes = mvs::ceil_div(D, nseg);
+    {
+        const char* e = getenv("MVS_X3_ABLATE");
+        a.ablate = e ? atoi(e) : 0;
+    }
+    hipLaunchKernelGGL(x3_deconv_kernel, dim3(a.tiles_x * ty, cts, B * nseg), dim3(256), 0, MVS_STREAM(stream), a);
+    return mvs::finish_launch("mvs_deconv3d_x3_fwd");
 }

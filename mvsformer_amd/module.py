@@ -340,8 +340,18 @@ class CostRegNet3D(nn.Module):
             _publish_cache()
             self._dcache[name] = c
         _, packed, scale, shift, sd = c
-        return ops.deconv3d(x, packed, seq[0].in_channels, seq[0].out_channels, sd, scale, shift, residual, relu=True,
-                            tag="deconv3d_%dto%d_s%d" % (seq[0].in_channels, seq[0].out_channels, sd))
+        cin, cout = seq[0].in_channels, seq[0].out_channels
+        # split-form transposed conv (csrc/conv3d_x3.hip) where it beats the fp32-MFMA kernel: conv7 / conv9 at real sizes; conv11
+        # (8 output channels fill half a matrix tile, and its fp32 kernel fuses the 1x1x1 prob) stays
+        if cout >= 16 and os.environ.get("MVS_CONV_X3", "1") != "0" and ops.deconv3d_x3_supported(cin, cout, sd) and x.shape[4] % 2 == 0 \
+                and 4 * x.shape[2] * x.shape[3] * x.shape[4] >= int(os.environ.get("MVS_CONV_X3_MIN_VOXELS", X3_MIN_VOXELS)):
+            px = self._dcache.get(name + ".x3")
+            if px is None or px[0] != key:
+                px = (key, ops.deconv3d_x3_pack(_f32c(seq[0].weight), sd))
+                _publish_cache()
+                self._dcache[name + ".x3"] = px
+            return ops.deconv3d_x3(x, px[1], cin, cout, sd, scale, shift, residual, relu=True)
+        return ops.deconv3d(x, packed, cin, cout, sd, scale, shift, residual, relu=True, tag="deconv3d_%dto%d_s%d" % (cin, cout, sd))
 
     def logits(self, x: torch.Tensor) -> torch.Tensor:
         """Eval-mode ``forward`` without the channel axis, ``[B,D,H,W]``: conv11 and the 1x1x1 ``prob`` run as ONE launch

@@ -435,6 +435,38 @@ def conv3d_x3(x, wpacked, cin, cout, stride=(1, 1), scale=None, shift=None, resi
     return y
 
 
+def deconv3d_x3_supported(cin: int, cout: int, sd: int) -> bool:
+    return bool(_lib.load().mvs_deconv3d_x3_supported(cin, cout, int(sd)))
+
+
+def deconv3d_x3_pack(weight: torch.Tensor, sd: int = 1) -> torch.Tensor:
+    """ConvTranspose3d weight ``[Cin,Cout,3,3,3]`` -> pre-split bf16 MFMA fragments for :func:`deconv3d_x3` (uint8 storage)."""
+    _chk(weight, "deconv weight")
+    cin, cout = weight.shape[0], weight.shape[1]
+    n = int(_lib.load().mvs_deconv3d_x3_packed_bytes(cin, cout, int(sd)))
+    if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3) or n <= 0:
+        raise _lib.MvsHipError("deconv3d_x3_pack: unsupported weight %s / sd %d" % (tuple(weight.shape), sd))
+    packed = torch.empty(n, device=weight.device, dtype=torch.uint8)
+    _call("mvs_deconv3d_x3_pack_weights", None, _ptr(weight), cin, cout, int(sd), _ptr(packed), _stream())
+    return packed
+
+
+def deconv3d_x3(x, wpacked, cin, cout, sd=1, scale=None, shift=None, residual=None, relu=True):
+    """Transposed-conv layer (stride (1,2,2)) -> folded BatchNorm -> ReLU [+ residual] in 3-term bf16 split form (include/mvs_hip.h)."""
+    _chk(x, "x"), _chk(wpacked, "packed weights", torch.uint8), _opt(scale, "scale"), _opt(shift, "shift")
+    B, C, D, H, W = x.shape
+    assert C == cin
+    y = torch.empty(B, cout, D, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+    if residual is not None:
+        _chk(residual, "residual")
+        if residual.shape != y.shape:
+            raise _lib.MvsHipError("residual shape %s != output %s" % (tuple(residual.shape), tuple(y.shape)))
+    tag = ("x3_deconv_kernel<%d,%d>" % (cin, cout), "flops", 2.0 * 27 * cin * cout * B * D * H * W)
+    _call("mvs_deconv3d_x3_fwd", tag, _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), B, cin, cout, D, H, W, int(sd),
+          int(relu), _stream())
+    return y
+
+
 def deconv3d(x, wpacked, cin, cout, sd, scale=None, shift=None, residual=None, relu=True, tag=None):
     _chk(x, "x"), _chk(wpacked, "packed weights"), _opt(scale, "scale"), _opt(shift, "shift")
     B, C, Di, Hi, Wi = x.shape

@@ -69,5 +69,23 @@ for st in [int(s) for s in args.stages.split(",")]:
             st, name, cin, cout, d, h, w, stride, gf, t0, t1, t2, gf / t2, err) + abl
         print(line, flush=True)
         lines.append(line)
+    if sd == 1:
+        for name, cin, cout, lvl in (("conv7", 64, 32, 3), ("conv9", 32, 16, 2), ("conv11", 16, 8, 1)):
+            d, h, w = dims[lvl]
+            x = torch.randn(1, cin, d, h, w, device=dev)
+            wt = torch.randn(cin, cout, 3, 3, 3, device=dev) * 0.05
+            scale, shift = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev)
+            res = torch.randn(1, cout, d, 2 * h, 2 * w, device=dev)
+            pk, px = ops.conv3d_pack(wt, True, 1), ops.deconv3d_x3_pack(wt, 1)
+            y0 = ops.deconv3d(x, pk, cin, cout, 1, scale, shift, res, True)
+            y2 = ops.deconv3d_x3(x, px, cin, cout, 1, scale, shift, res, True)
+            err = (y2 - y0).abs().max().item() / y0.abs().max().item()
+            t0 = timeit(lambda: ops.deconv3d(x, pk, cin, cout, 1, scale, shift, res, True))
+            t2 = timeit(lambda: ops.deconv3d_x3(x, px, cin, cout, 1, scale, shift, res, True))
+            gf = 2.0 * 27 * cin * cout * d * h * w / 1e9
+            line = "stage%d %-6s %2d->%2d %3dx%4dx%4d deconv %5.1f GF | direct %.4f ms  x3 %.4f ms (%.1f TFLOP/s direct-form) | max diff %.1e of scale" % (
+                st, name, cin, cout, d, h, w, gf, t0, t2, gf / t2, err)
+            print(line, flush=True)
+            lines.append(line)
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
 open(os.path.join(REPO, "gpurun_out", "bench_x3.txt"), "w").write("\n".join(lines) + "\n")
