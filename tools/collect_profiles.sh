@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round-end evidence on the GPU box (run from the repo root through gpurun): gather ceiling, per-stage breakdown, kernel trace of the bench,
+# HBM traffic counters (separate --pmc passes), final bench line.  Everything lands in gpurun_out/, copy what is judged into profiles/.
+set -x
+mkdir -p gpurun_out
+REPO=$(pwd)
+python tools/gather_bound.py > gpurun_out/gather_bound.log 2>&1
+python tools/stage_breakdown.py > /dev/null 2>&1
+python tools/bench_sweeps.py --hyps cascade > /dev/null 2>&1
+python tools/bench_x3.py --stages 3,4 > /dev/null 2>&1
+cd /tmp && export TMPDIR=/tmp
+rm -rf $REPO/gpurun_out/prof_r03 $REPO/gpurun_out/pmc_r03
+rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_r03 -o r03 -- python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs --streams 1 > $REPO/gpurun_out/bench_under_rocprof.json 2> $REPO/gpurun_out/rocprof_trace.log
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $REPO/gpurun_out/pmc_r03/fetch -- python $REPO/tools/prof_traffic.py > $REPO/gpurun_out/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $REPO/gpurun_out/pmc_r03/write -- python $REPO/tools/prof_traffic.py > $REPO/gpurun_out/pmc_write.log 2>&1
+cd $REPO
+DB=$(find gpurun_out/prof_r03 -name "*.db" | head -1)
+python tools/rocpd_stats.py $DB > gpurun_out/r03_kernel_stats.csv 2> gpurun_out/rocpd_stats.err
+python tools/pmc_traffic.py gpurun_out/pmc_r03/fetch gpurun_out/pmc_r03/write gpurun_out/traffic_by_kernel.json > gpurun_out/pmc_traffic.log 2>&1
+rm -rf gpurun_out/pmc_r03 gpurun_out/prof_r03
+python bench.py --steps 200 --warmup 10 > gpurun_out/r03_final_bench.json 2> gpurun_out/r03_final_bench.err
+tail -c 400 gpurun_out/r03_final_bench.err
+ls -la gpurun_out | tail -20

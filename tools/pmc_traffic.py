@@ -31,6 +31,9 @@ def tagname(k):
     m = re.match(r"cv_aggregate_kernel<(\d+),(true|false),(true|false)>", k)
     if m:
         return "cv_aggregate_kernel<%s,%s>" % (m.group(1), m.group(2))
+    m = re.match(r"cv_corr_kernel<(\d+),(true|false)>", k)
+    if m:
+        return "cv_corr_kernel<%s>" % m.group(1)
     m = re.match(r"nchw_to_nhwc_kernel<(\d+),", k)
     if m:
         return "nchw_to_nhwc_kernel<%s>" % m.group(1)
@@ -58,13 +61,20 @@ def main():
     cal_bytes = 4.0 * 5 * 8 * 1152 * 1536
     ffac = cal_bytes / fetch[calk] if fetch.get(calk) else 2.0
     wfac = cal_bytes / write[calk] if write.get(calk) else 1.0
-    out = {"_units": "bytes per launch (mean over launches)", "_calibration": {"kernel": calk, "known_bytes_each_way": cal_bytes,
+    import glob as _g
+    import hashlib
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in sorted(_g.glob(os.path.join(repo, "mvsformer_amd", "csrc", "*.hip")) + _g.glob(os.path.join(repo, "mvsformer_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    out = {"csrc_digest": h.hexdigest()[:16], "_units": "bytes per launch (mean over launches)", "_calibration": {"kernel": calk, "known_bytes_each_way": cal_bytes,
            "fetch_raw": fetch.get(calk), "write_raw": write.get(calk), "fetch_factor": ffac, "write_factor": wfac},
            "_note": "hbm_bytes_per_launch = FETCH_SIZE*1024*fetch_factor + WRITE_SIZE*1024*write_factor; factors from the float4 copy "
                     "of the same run (exact for 16 B/lane streams; 'narrow' kernels load dwords and are only indicative)", "kernels": {}}
-    wide = ("cv_entropy_kernel", "cv_aggregate_kernel", "nchw_to_nhwc", "cv_tiled")
+    wide = ("cv_entropy_kernel", "cv_aggregate_kernel", "cv_corr_kernel", "cv_merge_kernel", "nchw_to_nhwc", "cv_tiled")
     for k in sorted(set(fetch) | set(write)):
-        if not re.search(r"cv_|vis_|conv3d|deconv|head|prob3|nchw|schedule|init_inv|wino", k):
+        if not re.search(r"cv_|vis_|conv3d|deconv|head|prob3|nchw|schedule|init_inv|wino|x3_", k):
             continue
         fr, wr = fetch.get(k, 0.0), write.get(k, 0.0)
         out["kernels"][k] = {"fetch_raw": fr, "write_raw": wr, "hbm_bytes_per_launch": fr * ffac + wr * wfac, "narrow": not k.startswith(wide)}
