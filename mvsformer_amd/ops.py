@@ -386,9 +386,6 @@ def conv3d_wino(x, wpacked, cin, cout, scale=None, shift=None, residual=None, re
     return y
 
 
-_X3_KEEP = []
-
-
 def conv3d_x3_supported(cin: int, cout: int, stride) -> bool:
     """True if the 3-term bf16 split form (csrc/conv3d_x3.hip) is built for this layer shape."""
     return bool(_lib.load().mvs_conv3d_x3_supported(cin, cout, int(stride[0]), int(stride[1])))
@@ -421,17 +418,8 @@ def conv3d_x3(x, wpacked, cin, cout, stride=(1, 1), scale=None, shift=None, resi
         if residual.shape != y.shape:
             raise _lib.MvsHipError("residual shape %s != output %s" % (tuple(residual.shape), tuple(y.shape)))
     tag = ("x3_conv_kernel<%d,%d,s%d>" % (cin, cout, shw), "flops", 2.0 * 27 * cin * cout * B * D * Ho * Wo)
-    dbg = os.environ.get("MVS_X3_DEBUG_SYNC", "")
-    if "before" in dbg:
-        torch.cuda.current_stream().synchronize()
     _call("mvs_conv3d_x3_fwd", tag, _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), B, cin, cout, D, H, W, sd, shw,
           int(relu), _stream())
-    if "after" in dbg:
-        torch.cuda.current_stream().synchronize()
-    if "keepin" in dbg:
-        _X3_KEEP.append(x)
-    if "keepout" in dbg:
-        _X3_KEEP.append(y)
     return y
 
 
