@@ -29,7 +29,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 7
+#define MVS_ABI_VERSION 8
 
 typedef void* mvs_stream_t;
 
@@ -99,6 +99,14 @@ int mvs_cv_entropy_fwd(const float* feat, const float* rt, const float* depth,
 int mvs_vis_wino_prepare(const float* params, float* prepared, mvs_stream_t stream);
 int mvs_vis_wino_fwd(const float* entropy, const float* params, const float* prepared, int N, int H, int W, float* weight,
                      mvs_stream_t stream);
+/* Split-form bf16-MFMA version of the same CNN (vis_net_x3.hip; the eval default since round 3): `prepared` = MVS_VIS_X3_BYTES bytes
+ * written once per parameter set by mvs_vis_x3_prepare (the two 3x3 layers' weights as three-term bf16 splits, laid out per MFMA
+ * lane); fp32 in, fp32 out, fp32-equivalent arithmetic (every fp32 operand = h + m + l exactly, six bf16 MFMAs with fp32 accumulation
+ * per K = 32 step) - mvs_vis_x3_fwd computes what mvs_vis_fwd computes, to fp32 rounding. */
+#define MVS_VIS_X3_BYTES 33792
+int mvs_vis_x3_prepare(const float* params, void* prepared, mvs_stream_t stream);
+int mvs_vis_x3_fwd(const float* entropy, const float* params, const void* prepared, int N, int H, int W, float* weight,
+                   mvs_stream_t stream);
 int mvs_vis_fwd(const float* entropy, const float* params, int N, int H, int W, float* weight, mvs_stream_t stream);
 int mvs_cv_aggregate_fwd(const float* feat, const float* rt, const float* depth, const float* weight,
                          int B, int V, int C, int G, int D, int H, int W,

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (load order, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 from ctypes import c_double  # noqa: E402
 
@@ -103,6 +103,8 @@ SIGNATURES = {
     "mvs_conv3d_wino_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "mvs_vis_wino_prepare": (I, [P, P, P]),
     "mvs_vis_wino_fwd": (I, [P, P, P, I, I, I, P, P]),
+    "mvs_vis_x3_prepare": (I, [P, P, P]),
+    "mvs_vis_x3_fwd": (I, [P, P, P, I, I, I, P, P]),
     "mvs_deconv3d_prob1_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "mvs_prob_filter": (I, [P, I, I, L, P, P, P, P]),
     "mvs_init_inverse_range": (I, [P, I, I, I, I, I, P, P]),

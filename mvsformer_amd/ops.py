@@ -224,6 +224,33 @@ def vis_wino(entropy: torch.Tensor, params: torch.Tensor, prepared: torch.Tensor
     return out
 
 
+VIS_X3_BYTES = 33792
+
+
+def vis_x3_prepare(params: torch.Tensor) -> torch.Tensor:
+    """The two 3x3 layers' weights as three-term bf16 splits, laid out per MFMA lane, for :func:`vis_x3` (uint8 storage)."""
+    _chk(params, "vis params")
+    if params.numel() != VIS_PARAM_FLOATS:
+        raise _lib.MvsHipError("vis params must hold %d floats" % VIS_PARAM_FLOATS)
+    prepared = torch.empty(VIS_X3_BYTES, device=params.device, dtype=torch.uint8)
+    _call("mvs_vis_x3_prepare", None, _ptr(params), _ptr(prepared), _stream())
+    return prepared
+
+
+def vis_x3(entropy: torch.Tensor, params: torch.Tensor, prepared: torch.Tensor) -> torch.Tensor:
+    """Same function as :func:`vis`; layers 2-3 as direct convolutions on the bf16 matrix cores in three-term split form
+    (fp32 in / out, fp32-equivalent; csrc/vis_net_x3.hip)."""
+    _chk(entropy, "entropy"), _chk(params, "vis params")
+    if params.numel() != VIS_PARAM_FLOATS or prepared.dtype != torch.uint8 or prepared.numel() != VIS_X3_BYTES or not prepared.is_cuda:
+        raise _lib.MvsHipError("vis params / prepared block have the wrong size or type")
+    H, W = entropy.shape[-2:]
+    N = entropy.numel() // (H * W)
+    out = torch.empty_like(entropy)
+    tag = ("vis_x3_kernel", "flops", 2.0 * 3608 * N * H * W)
+    _call("mvs_vis_x3_fwd", tag, _ptr(entropy), _ptr(params), _ptr(prepared), N, H, W, _ptr(out), _stream())
+    return out
+
+
 def cv_aggregate(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, weight: torch.Tensor, G: int,
                  want_sim_depth: bool, exact: Optional[bool] = None):
     _chk(feat, "features"), _chk(rt, "rt"), _chk(depth, "depth_values"), _chk(weight, "vis_weight")

@@ -59,11 +59,15 @@ class StageNet(nn.Module):
         self._vis_cache = None
 
     def _vis_params(self):
-        """-> (parameter block, transform-domain weights of the 3x3 layers or None when MVS_VIS_WINO=0)."""
+        """-> (parameter block, the 3x3 layers' weights prepared for the selected kernel or None for the all-VALU form)."""
         key = _versions(self.vis)
         if self._vis_cache is None or self._vis_cache[0] != key:
             params = pack_vis_params(self.vis)
-            prepared = ops.vis_wino_prepare(params) if os.environ.get("MVS_VIS_WINO", "1") != "0" else None
+            # MVS_VIS = x3 (default: split-form bf16 MFMA) | wino (Winograd fp32 MFMA) | valu (the all-VALU reference form)
+            mode = os.environ.get("MVS_VIS", "x3" if os.environ.get("MVS_VIS_WINO", "1") != "0" else "valu")
+            if mode not in ("x3", "wino", "valu"):
+                raise ValueError("MVS_VIS must be x3, wino or valu, not %r" % mode)
+            prepared = ops.vis_x3_prepare(params) if mode == "x3" else ops.vis_wino_prepare(params) if mode == "wino" else None
             from .module import _publish_cache
             _publish_cache()                                    # cached tensors are read from any stream afterwards
             self._vis_cache = (key, params, prepared)
@@ -71,7 +75,11 @@ class StageNet(nn.Module):
 
     @staticmethod
     def _vis_weight(entropy, vis_params, vis_prepared):
-        return ops.vis_wino(entropy, vis_params, vis_prepared) if vis_prepared is not None else ops.vis(entropy, vis_params)
+        if vis_prepared is None:
+            return ops.vis(entropy, vis_params)
+        if vis_prepared.dtype == torch.uint8:
+            return ops.vis_x3(entropy, vis_params, vis_prepared)
+        return ops.vis_wino(entropy, vis_params, vis_prepared)
 
     def forward(self, features, proj_matrices, depth_values, tmp=2.0):
         """``features [B,V,C,H,W]`` (view 0 = reference), ``proj_matrices [B,V,2,4,4]``, ``depth_values [B,D,H,W]``."""

@@ -289,7 +289,7 @@ def test_config2_full_size_cascade_properties(dev):
         assert torch.equal(o["photometric_confidence"], a["photometric_confidence"])
         assert torch.equal(o["stage2"]["sim_depth"], a["stage2"]["sim_depth"])
     # (a)
-    old = _set_env({"MVS_CONV_WINO": "0", "MVS_CONV_X3": "0", "MVS_VIS_WINO": "0", "MVS_FUSE_PROB": "0", "MVS_CV_TILED": "0"})
+    old = _set_env({"MVS_CONV_WINO": "0", "MVS_CONV_X3": "0", "MVS_VIS": "valu", "MVS_FUSE_PROB": "0", "MVS_CV_TILED": "0"})
     try:
         _reset_caches(net)
         b = net(feats, proj, dv, tmp=tmp)

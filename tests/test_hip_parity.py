@@ -136,8 +136,11 @@ def test_cost_volume_taps(dev, kind, impl, exact, tol):
     # vis CNN alone on the reference's own entropy (decouples the two kernels): VALU kernel and Winograd/MFMA kernel
     w2 = ops.vis(g2d(g["tap_entropy"], dev), vis_params)
     robust_close(w2, g["tap_vis_weight"], atol=1e-5, frac=0)
-    w3 = ops.vis_wino(g2d(g["tap_entropy"], dev), vis_params, vis_prepared)
+    w3 = ops.vis_wino(g2d(g["tap_entropy"], dev), vis_params, ops.vis_wino_prepare(vis_params))
     robust_close(w3, g["tap_vis_weight"], atol=1e-5, frac=0)
+    assert vis_prepared.dtype == torch.uint8            # the default: the split-form bf16-MFMA kernel
+    w4 = ops.vis_x3(g2d(g["tap_entropy"], dev), vis_params, vis_prepared)
+    robust_close(w4, g["tap_vis_weight"], atol=1e-5, frac=0)
     vol, sim = sweep_b(feat, rt, hyp, g2d(g["tap_vis_weight"], dev), True)
     robust_close(vol, g["tap_volume_mean"], atol=tol, frac=0, hard=tol)
     assert (sim.cpu().numpy() != g["eval_sim_depth"]).mean() < 0.02
@@ -555,6 +558,30 @@ def test_vis_wino_matches_valu_kernel(dev, shape):
     assert (a - b).abs().max().item() < 5e-6, (a - b).abs().max().item()
 
 
+@pytest.mark.parametrize("shape", [(3, 37, 53), (2, 14, 30), (1, 144, 192), (5, 9, 7), (2, 16, 16), (1, 33, 17), (4, 288, 384)])
+def test_vis_x3_matches_valu_kernel(dev, shape):
+    """Split-form bf16-MFMA visibility CNN == the all-VALU kernel (itself pinned to the reference goldens) to fp32 rounding: sizes that
+    are not multiples of the 16 x 16 block tile, smaller than one tile, exactly one tile, real stage-1 / stage-2 maps; the outputs of the
+    three intermediate layers are bounded through the final sigmoid only (no intermediate leaves the kernel)."""
+    from mvsformer_amd import ops
+    torch.manual_seed(sum(shape))
+    prm = torch.randn(ops.VIS_PARAM_FLOATS, device=dev) * 0.2
+    prm[144:160] = prm[144:160].abs() + 0.5            # BN scales
+    prm[2480:2496] = prm[2480:2496].abs() + 0.5
+    prm[3664:3672] = prm[3664:3672].abs() + 0.5
+    ent = torch.rand(*shape, device=dev) * 3.0
+    a = ops.vis(ent, prm)
+    prep = ops.vis_x3_prepare(prm)
+    b = ops.vis_x3(ent, prm, prep)
+    assert (a - b).abs().max().item() < 5e-6, (a - b).abs().max().item()
+    assert torch.equal(b, ops.vis_x3(ent, prm, prep))   # run-to-run identical
+    # a pre-sigmoid check: with the last layer's bias pushed far out the sigmoid saturates differently per pixel only if the logits differ
+    prm2 = prm.clone()
+    prm2[3680:3688] *= 30.0
+    a2, b2 = ops.vis(ent, prm2), ops.vis_x3(ent, prm2, ops.vis_x3_prepare(prm2))
+    assert (a2 - b2).abs().max().item() < 2e-4, (a2 - b2).abs().max().item()
+
+
 @pytest.mark.parametrize("shape", [(1, 16, 2, 4, 12), (2, 16, 3, 5, 72), (1, 8, 1, 2, 4)])
 def test_fused_conv11_prob_matches_two_launches(dev, shape):
     """mvs_deconv3d_prob1_fwd == mvs_deconv3d_fwd followed by the 1x1x1 conv, with and without skip tensor / bias."""
@@ -599,7 +626,7 @@ def test_stage_vs_oracle_mixed_kernel_paths(dev, C, ndepth, H, W, V, B):
         want = ref_torch.stage_forward(feat, proj, hyp, net.state_dict(), ndepth=ndepth, tmp=5.0)
     net = net.to(dev)
     outs = []
-    for env in ({}, {"MVS_CONV_X3": "0", "MVS_VIS_WINO": "0", "MVS_FUSE_PROB": "0"}, {"MVS_CONV_X3_MIN_VOXELS": "0"}, {"MVS_CONV_X3": "0", "MVS_CONV_WINO": "1"}):
+    for env in ({}, {"MVS_CONV_X3": "0", "MVS_VIS": "valu", "MVS_FUSE_PROB": "0"}, {"MVS_CONV_X3_MIN_VOXELS": "0"}, {"MVS_CONV_X3": "0", "MVS_CONV_WINO": "1"}):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
