@@ -33,6 +33,10 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_16x16x4_f32)
+BF16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_16x16x32_bf16)
+# kernels that do fp32-equivalent work on the bf16 matrix cores in three-term split form execute SIX bf16 MFMAs per fp32-equivalent
+# K = 32 step: their roofline is the bf16 peak / 6 in direct-form fp32 FLOPs, not the fp32 matrix peak
+SPLIT_FORM_PREFIXES = ("x3_", "vis_x3")
 TRAFFIC_FILE = os.path.join(REPO, "profiles", "traffic_by_kernel.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
 
 
@@ -265,8 +269,13 @@ def main(args):
                          algorithmic_per_launch=per_launch)
             else:
                 ach = per_launch / (s["avg_ms"] * 1e-3) / 1e12
-                e.update(bound="mfma", achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s",
-                         frac=round(ach / FP32_MFMA_PEAK_TF, 4), algorithmic_per_launch=per_launch)
+                split = name.startswith(SPLIT_FORM_PREFIXES)
+                peak = round(BF16_MFMA_PEAK_TF / 6.0, 1) if split else FP32_MFMA_PEAK_TF
+                e.update(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), algorithmic_per_launch=per_launch,
+                         peak_basis=("dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 MFMAs per fp32-equivalent product (three-term split form)" if split
+                                     else "dense fp32 MFMA peak"))
+                if split:
+                    e["frac_of_fp32_mfma_peak"] = round(ach / FP32_MFMA_PEAK_TF, 4)
             tr = traffic_db.get(name)
             e["traffic"] = tr["hbm_bytes_per_launch"] if tr else None
         kernels.append(e)
@@ -275,6 +284,8 @@ def main(args):
     roofline = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
                 "frac": dom["frac"], "traffic": dom.get("traffic"), "avg_launch_ms": dom["avg_ms"],
                 "algorithmic_per_launch": dom["algorithmic_per_launch"]}
+    if "peak_basis" in dom:
+        roofline["peak_basis"] = dom["peak_basis"]
 
     # ---- the north-star number: the fused cost-volume build of the whole cascade against the HBM roofline ----
     cv = [e for e in kernels if e["kernel"].startswith(("cv_", "nchw_to_nhwc"))]
