@@ -53,7 +53,7 @@ alg = 4.0 * H * W * (V * C + D + 8 * D)
 timeit("nchw_to_nhwc", lambda: ops.to_channels_last(feat), 8.0 * feat.numel(), "GB/s")
 timeit("cv_entropy", lambda: ops.cv_entropy(fcl, rt, hyp, 8), 4.0 * H * W * (V * C + D), "GB/s")
 timeit("vis", lambda: ops.vis(ent, net._vis_params()[0]), 2.0 * 3608 * 4 * H * W, "TFLOP/s")
-timeit("vis_wino", lambda: ops.vis_wino(ent, *net._vis_params()), 2.0 * 3608 * 4 * H * W, "TFLOP/s")
+timeit("vis (default kernel)", lambda: net._vis_weight(ent, *net._vis_params()), 2.0 * 3608 * 4 * H * W, "TFLOP/s")
 timeit("cv_aggregate(sim)", lambda: ops.cv_aggregate(fcl, rt, hyp, w, 8, True), alg, "GB/s")
 timeit("cv_aggregate(nosim)", lambda: ops.cv_aggregate(fcl, rt, hyp, w, 8, False), alg, "GB/s")
 if D <= 8:

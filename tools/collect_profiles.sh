@@ -24,6 +24,7 @@ python tools/pmc_table.py gpurun_out/pmc_r03/sq_SQ_WAVES gpurun_out/pmc_r03/sq_S
 DB=$(find gpurun_out/prof_r03 -name "*.db" | head -1)
 python tools/rocpd_stats.py $DB > gpurun_out/r03_kernel_stats.csv 2> gpurun_out/rocpd_stats.err
 python tools/pmc_traffic.py gpurun_out/pmc_r03/fetch gpurun_out/pmc_r03/write gpurun_out/traffic_by_kernel.json > gpurun_out/pmc_traffic.log 2>&1
+cp gpurun_out/traffic_by_kernel.json profiles/traffic_by_kernel.json; cp gpurun_out/gather_bound.json profiles/r03_gather_bound.json   # the final bench line below reads them
 rm -rf gpurun_out/pmc_r03 gpurun_out/prof_r03
 python bench.py --steps 200 --warmup 10 > gpurun_out/r03_final_bench.json 2> gpurun_out/r03_final_bench.err
 tail -c 400 gpurun_out/r03_final_bench.err

@@ -39,7 +39,7 @@ for _ in range(args.iters):
         ent = torch.rand(1, 4, H, W, device=dev)
     if "vis" in args.what:
         vp, vprep = net._vis_params()
-        w = ops.vis_wino(ent, vp, vprep) if vprep is not None else ops.vis(ent, vp)
+        w = net._vis_weight(ent, vp, vprep)
     else:
         w = torch.rand(1, 4, H, W, device=dev)
     if "cv" in args.what:
