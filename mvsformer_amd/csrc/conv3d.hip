@@ -262,40 +262,82 @@ __global__ __launch_bounds__(256) void prob3_kernel(const float* __restrict__ x,
     out[((size_t)(b * D + d) * H + yh) * W + xw] = acc;
 }
 
-// Register-blocked form for W % 4 == 0: a lane owns 4 consecutive voxels along W on 4 consecutive depth planes.  Each
-// input row segment (1 float4 + its two neighbours) is loaded once and feeds up to 3 planes x 4 voxels x 3 taps = 36 FMAs,
-// 8x fewer vector-memory lane requests per output than the kernel above (which is bound by exactly that rate).  Same
-// accumulation order per output (c, kd, kh, kw ascending), so results are bit-identical.
+// Register-blocked form for W % 4 == 0: a lane owns 4 consecutive voxels along W on PD consecutive depth planes.  Each input row segment
+// (1 float4 + its two neighbours) is loaded once and feeds up to min(3, PD) planes x 4 voxels x 3 taps FMAs, 8x fewer vector-memory lane
+// requests per output than the kernel above at PD = 4.  All of a channel's loads are issued before its FMAs (the first form waited on every
+// row segment: 18 memory latencies per channel with 2 wavefronts per SIMD - 67 us for a 57 MB volume).  PD is chosen by the host so that
+// the volume yields several wavefronts per SIMD: one wavefront issues at most one vector instruction per ~4.5 clocks, and the 216 FMAs
+// per output are what this kernel consists of.  Same accumulation order per output (c, kd, kh, kw ascending) for every PD and for
+// prob3_kernel: bit-identical results.
+template <int PD>
 __global__ __launch_bounds__(256) void prob3_blocked_kernel(const float* __restrict__ x, const float* __restrict__ w, int C, int D, int H,
                                                             int W, float* __restrict__ out) {
     const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int yh = blockIdx.y * blockDim.y + threadIdx.y;
-    const int ndb = (D + 3) / 4;
-    const int b = blockIdx.z / ndb, d0 = (blockIdx.z % ndb) * 4;
+    const int ndb = (D + PD - 1) / PD;
+    const int b = blockIdx.z / ndb, d0 = (blockIdx.z % ndb) * PD;
     if (x4 >= W || yh >= H) return;
     const size_t plane = (size_t)H * W;
     const mvsconv::rsrc_t r = mvsconv::make_rsrc(x + (size_t)b * C * D * plane, (unsigned)((size_t)C * D * plane * 4));
-    float acc[4][4];
+    float acc[PD][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < PD; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+    // per-lane byte offsets of the row segments of a channel (depth planes d0-1 .. d0+PD x rows yh-1 .. yh+1), OOB where padded
+    unsigned roff[PD + 2][3];
+#pragma unroll
+    for (int pz = 0; pz < PD + 2; ++pz)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int zd = d0 - 1 + pz, zh = yh + kh - 1;
+            const bool ok = zd >= 0 && zd < D && zh >= 0 && zh < H;
+            roff[pz][kh] = ok ? (unsigned)((((size_t)zd) * plane + (size_t)zh * W + x4) * 4) : mvsconv::OOB;
+        }
+    const bool has_l = x4 > 0, has_r = x4 + 4 < W;
+    const int lane = threadIdx.x;
+    const unsigned cstride = (unsigned)((size_t)D * plane * 4);
     for (int c = 0; c < C; ++c) {
         const float* wc = w + c * 27;
+        mvsconv::f32x4 q[PD + 2][3];
+        float lft[PD + 2][3], rgt[PD + 2][3];
+        const unsigned cbase = (unsigned)c * cstride;
 #pragma unroll
-        for (int pz = 0; pz < 6; ++pz) {
-            const int zd = d0 - 1 + pz;
+        for (int pz = 0; pz < PD + 2; ++pz)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)      // (a padded segment's offset stays beyond the descriptor's range after the channel offset is added)
+                q[pz][kh] = __builtin_bit_cast(mvsconv::f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, roff[pz][kh] + cbase, 0, 0));
+        // The two halo values of a segment come from the neighbouring lanes' segments; only the wavefront's first / last lane load theirs
+        // (a 64-lane dword load costs the address path as much as the 16-byte one: with three loads per segment the kernel was bound by
+        // exactly that), in one two-lane load per segment.
+        float edge[PD + 2][3];
+#pragma unroll
+        for (int pz = 0; pz < PD + 2; ++pz)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) edge[pz][kh] = 0.0f;
+        if ((lane == 0 && has_l) || (lane == 63 && has_r)) {
+            const unsigned eo = cbase + (lane == 0 ? 0u - 4u : 16u);
+#pragma unroll
+            for (int pz = 0; pz < PD + 2; ++pz)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) edge[pz][kh] = mvsconv::buf_load(r, roff[pz][kh] + eo, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pz = 0; pz < PD + 2; ++pz)
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-                const int zh = yh + kh - 1;
-                const bool ok = zd >= 0 && zd < D && zh >= 0 && zh < H;
-                const unsigned off = (unsigned)((((size_t)c * D + zd) * plane + (size_t)zh * W + x4) * 4);
-                const mvsconv::f32x4 q = __builtin_bit_cast(mvsconv::f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, ok ? off : mvsconv::OOB, 0, 0));
-                const float lft = mvsconv::buf_load(r, (ok && x4 > 0) ? off - 4 : mvsconv::OOB, 0);
-                const float rgt = mvsconv::buf_load(r, (ok && x4 + 4 < W) ? off + 16 : mvsconv::OOB, 0);
-                const float v[6] = {lft, q[0], q[1], q[2], q[3], rgt};
+                const float up = __shfl_up(q[pz][kh][3], 1, 64), dn = __shfl_down(q[pz][kh][0], 1, 64);
+                lft[pz][kh] = lane == 0 ? edge[pz][kh] : up;                              // (x4 == 0: zero padding)
+                rgt[pz][kh] = !has_r ? 0.0f : (lane == 63 ? edge[pz][kh] : dn);          // (the lane behind the row's last one has exited)
+            }
 #pragma unroll
-                for (int od = 0; od < 4; ++od) {
+        for (int pz = 0; pz < PD + 2; ++pz) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const float v[6] = {lft[pz][kh], q[pz][kh][0], q[pz][kh][1], q[pz][kh][2], q[pz][kh][3], rgt[pz][kh]};
+#pragma unroll
+                for (int od = 0; od < PD; ++od) {
                     const int kd = pz - od;
                     if (kd < 0 || kd > 2) continue;
 #pragma unroll
@@ -305,9 +347,10 @@ __global__ __launch_bounds__(256) void prob3_blocked_kernel(const float* __restr
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int od = 0; od < 4; ++od)
+    for (int od = 0; od < PD; ++od)
         if (d0 + od < D) {
             mvsconv::f32x4 o = {acc[od][0], acc[od][1], acc[od][2], acc[od][3]};
             *reinterpret_cast<mvsconv::f32x4*>(out + ((size_t)(b * D + d0 + od) * H + yh) * W + x4) = o;
@@ -394,9 +437,19 @@ extern "C" int mvs_prob3_fwd(const float* x, const float* w, int B, int C, int D
     MVS_REQUIRE(x && w && logits, "mvs_prob3_fwd: null pointer");
     MVS_REQUIRE(B >= 1 && C >= 1 && D >= 1 && H >= 1 && W >= 1 && (int64_t)B * D <= 65535, "mvs_prob3_fwd: bad shape");
     if (W % 4 == 0 && (int64_t)C * D * H * W * 4 < ((int64_t)1 << 31)) {
-        // one wavefront per block: the stage-1/2 volumes are small (a few hundred wavefronts), spread them over all CUs
-        dim3 grid(mvs::ceil_div(W / 4, 64), H, B * ((D + 3) / 4)), block(64, 1);
-        hipLaunchKernelGGL(prob3_blocked_kernel, grid, block, 0, MVS_STREAM(stream), x, w, C, D, H, W, logits);
+        // one wavefront per block, and as many depth planes per lane as still leave ~2 wavefronts per SIMD (1024 SIMDs)
+        const int64_t waves1 = (int64_t)mvs::ceil_div(W / 4, 64) * H * B * D;
+        const int pd = waves1 >= 4 * 2048 ? 4 : (waves1 >= 2 * 2048 ? 2 : 1);
+        // four consecutive rows per block: their wavefronts share 2 of every 3 input rows through the CU's L1 (one row per block sent
+        // every row to the L2 three times - the kernel ran at the L2's rate: 43 us for a 57 MB volume); MVS_PROB3_ROWS overrides
+        const char* e = getenv("MVS_PROB3_ROWS");
+        const int rows = e ? atoi(e) : 4;
+        MVS_REQUIRE(rows == 1 || rows == 2 || rows == 4, "MVS_PROB3_ROWS must be 1, 2 or 4");
+        dim3 grid(mvs::ceil_div(W / 4, 64), mvs::ceil_div(H, rows), B * mvs::ceil_div(D, pd)), block(64, rows);
+        MVS_REQUIRE((int64_t)B * mvs::ceil_div(D, pd) <= 65535, "mvs_prob3_fwd: bad shape");
+        if (pd == 4) hipLaunchKernelGGL(prob3_blocked_kernel<4>, grid, block, 0, MVS_STREAM(stream), x, w, C, D, H, W, logits);
+        else if (pd == 2) hipLaunchKernelGGL(prob3_blocked_kernel<2>, grid, block, 0, MVS_STREAM(stream), x, w, C, D, H, W, logits);
+        else hipLaunchKernelGGL(prob3_blocked_kernel<1>, grid, block, 0, MVS_STREAM(stream), x, w, C, D, H, W, logits);
         return mvs::finish_launch("mvs_prob3_fwd");
     }
     dim3 grid(mvs::ceil_div(W, 64), mvs::ceil_div(H, 4), B * D), block(64, 4);

@@ -60,6 +60,53 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ log
     conf[(size_t)b * plane + pix] = pmax;
 }
 
+// The same head for the depth counts the cascade uses (D = 4 | 8 | 16 | 32) with the logits in memory: ALL of a pixel's logits and
+// hypotheses are requested before the first is consumed, then the three sweeps run from registers.  The generic kernel above walks the
+// depth axis three times with one dependent load per step - at stage 1 (27 648 pixels = 432 wavefronts, D = 32) that is 96 memory
+// latencies in a row: 34 us for 3.5 MB.  Same operations in the same order on the same values: bit-identical outputs.
+template <int DT>
+__global__ __launch_bounds__(256) void head_reg_kernel(const float* __restrict__ logits, const float* __restrict__ depth_values, float tmp, int training,
+                                                       int H, int W, float* __restrict__ prob, float* __restrict__ depth, float* __restrict__ conf) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y, b = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const size_t plane = (size_t)H * W, pix = (size_t)y * W + x;
+    const size_t base = (size_t)b * DT * plane + pix;
+    float l[DT], dv[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) l[d] = logits[base + (size_t)d * plane];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) dv[d] = depth_values[base + (size_t)d * plane];
+    float m = -INFINITY, mt = -INFINITY;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+        m = fmaxf(m, l[d]);
+        mt = fmaxf(mt, l[d] * tmp);
+    }
+    float e[DT], et[DT];
+    float s = 0.0f, st = 0.0f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+        e[d] = expf(l[d] - m);
+        et[d] = expf(l[d] * tmp - mt);
+        s += e[d];
+        st += et[d];
+    }
+    float pmax = -INFINITY, reg = 0.0f;
+    int arg = 0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+        const float p = e[d] / s;
+        prob[base + (size_t)d * plane] = p;
+        if (p > pmax) { pmax = p; arg = d; }
+        if (!training) reg = reg + (et[d] / st) * dv[d];
+    }
+    float darg = dv[0];
+#pragma unroll
+    for (int d = 1; d < DT; ++d) darg = arg == d ? dv[d] : darg;
+    depth[(size_t)b * plane + pix] = training ? darg : reg;
+    conf[(size_t)b * plane + pix] = pmax;
+}
+
 __global__ void init_inverse_kernel(const float* __restrict__ range, int N, int D, int H, int W, float* __restrict__ hyp) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     const int b = blockIdx.z / D, d = blockIdx.z % D;
@@ -242,6 +289,13 @@ extern "C" int mvs_head_fwd(const float* logits, const float* x8, const float* w
         MVS_REQUIRE(w1 && b1 && prob_volume_pre && x8_channels >= 1, "mvs_head_fwd: fused 1x1x1 conv needs w1, b1, prob_volume_pre");
         hipLaunchKernelGGL(head_kernel<true>, grid, block, 0, s, logits, x8, w1, b1, x8_channels, depth_values, tmp, training, D, H, W,
                            prob_volume_pre, prob_volume, depth, conf);
+    } else if (D == 4 || D == 8 || D == 16 || D == 32) {
+        // small maps: one wavefront per block so that a few hundred wavefronts spread over all CUs
+        const bool small = (int64_t)H * W * B < 256 * 1024;
+        dim3 g(mvs::ceil_div(W, 64), small ? H : mvs::ceil_div(H, 4), B), bl(64, small ? 1 : 4);
+#define MVS_HEAD_REG(DT) hipLaunchKernelGGL(head_reg_kernel<DT>, g, bl, 0, s, logits, depth_values, tmp, training, H, W, prob_volume, depth, conf)
+        if (D == 4) MVS_HEAD_REG(4); else if (D == 8) MVS_HEAD_REG(8); else if (D == 16) MVS_HEAD_REG(16); else MVS_HEAD_REG(32);
+#undef MVS_HEAD_REG
     } else {
         hipLaunchKernelGGL(head_kernel<false>, grid, block, 0, s, logits, x8, w1, b1, x8_channels, depth_values, tmp, training, D, H, W,
                            prob_volume_pre, prob_volume, depth, conf);
