@@ -233,49 +233,32 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
             // ---- stage plane p, channels [CK*chunk, CK*chunk + CK): fp32 -> (h, m, l) bf16 channel-last ----
             // (issuing the NEXT pass's loads before this pass's MFMAs was measured and lost 10-25 %: the weight fragments are global
             // loads too, vmcnt retires in order, so the first weight wait drains the whole prefetch)
-            // A thread stages FOUR consecutive pixels of a box row x 8 channels: eight 16-byte loads (one per channel plane), all in
-            // flight before the split.  (The first version loaded one pixel per thread = eight DWORD loads: four times the load
-            // instructions for the same bytes, and a 64-lane dword load occupies the address path exactly as long as a 16-byte one -
-            // a quarter of the staging phase was that.)  Groups that touch the image border take the guarded element-wise path.
-            constexpr int G4 = (BWC + 3) / 4, NGRP = KQ * Cfg::BH * G4, NI = (NGRP + 255) / 256;
-            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-            f32x4 pre[NI][8];
+            // all of a thread's loads first (NI items x 8 channel planes in flight), then the split and the LDS stores
+            constexpr int NI = (KQ * NPIX + 255) / 256;
+            float pre[NI][8];
 #pragma unroll
             for (int it = 0; it < NI; ++it) {
-                const int i = min(tid + it * 256, NGRP - 1);
-                const int oct = i / (Cfg::BH * G4), v = i % (Cfg::BH * G4), row = v / G4, g = v % G4;
-                const int gy = y0 * SHW - 1 + row, gx = x0 * SHW - 1 + 4 * g;
-                const bool rowin = gy >= 0 && gy < H;
-                const float* src = xb + ((size_t)(chunk * CK + oct * 8) * D + p) * HW + (size_t)(rowin ? gy : 0) * W;
-                if (rowin && gx >= 0 && gx + 3 < W && !(a.ablate & 1)) {
+                const int i = tid + it * 256;
+                const int oct = min(i / NPIX, KQ - 1), v = i % NPIX;
+                const int gy = y0 * SHW - 1 + v / BWC, gx = x0 * SHW - 1 + v % BWC;
+                const bool in = i < KQ * NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const float* src = xb + ((size_t)(chunk * CK + oct * 8) * D + p) * HW + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) pre[it][e] = *reinterpret_cast<const f32x4u*>(src + (size_t)e * DHW + gx);
-                } else {
+                for (int e = 0; e < 8; ++e) pre[it][e] = (a.ablate & 1) ? 1.0f : src[(size_t)e * DHW];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            pre[it][e][k] = (rowin && gx + k >= 0 && gx + k < W && !(a.ablate & 1)) ? src[(size_t)e * DHW + gx + k] : 0.0f;
-                }
+                for (int e = 0; e < 8; ++e) pre[it][e] = in ? pre[it][e] : 0.0f;
             }
             __syncthreads();                               // the previous pass's fragment reads are done
 #pragma unroll
             for (int it = 0; it < NI; ++it) {
                 const int i = tid + it * 256;
-                if (i < NGRP && !(a.ablate & 2)) {
-                    const int oct = i / (Cfg::BH * G4), v = i % (Cfg::BH * G4), row = v / G4, g = v % G4;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int col = 4 * g + k;
-                        if (col < BWC) {
-                            const float px[8] = {pre[it][0][k], pre[it][1][k], pre[it][2][k], pre[it][3][k], pre[it][4][k], pre[it][5][k], pre[it][6][k], pre[it][7][k]};
-                            const Split3 sp = split3(px);
-                            unsigned char* dst = lds + (row * BWC + Cfg::col_index(col)) * PB + oct * 16;
-                            *reinterpret_cast<bf16x8*>(dst) = sp.h;
-                            *reinterpret_cast<bf16x8*>(dst + TERM_BYTES) = sp.m;
-                            *reinterpret_cast<bf16x8*>(dst + 2 * TERM_BYTES) = sp.l;
-                        }
-                    }
+                if (i < KQ * NPIX && !(a.ablate & 2)) {
+                    const int oct = i / NPIX, v = i % NPIX;
+                    const Split3 sp = split3(pre[it]);
+                    unsigned char* dst = lds + ((v / BWC) * BWC + Cfg::col_index(v % BWC)) * PB + oct * 16;
+                    *reinterpret_cast<bf16x8*>(dst) = sp.h;
+                    *reinterpret_cast<bf16x8*>(dst + TERM_BYTES) = sp.m;
+                    *reinterpret_cast<bf16x8*>(dst + 2 * TERM_BYTES) = sp.l;
                 }
             }
             __syncthreads();
