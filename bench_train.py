@@ -108,11 +108,50 @@ def main(args):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    own_dt = time.perf_counter() - t0
+    dt = torch.tensor([own_dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    # ---- who ran: one record per rank (device, its own wall time), so that a scaling run shows N distinct GPUs ----
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "local_rank": local, "device": props.name, "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
+            "ms_per_step": round(own_dt / args.steps * 1e3, 3)}
+    ranks = [mine]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+    # ---- per-kernel durations of ONE eager step (HIP events around every C-ABI launch, on the launch stream) and the roofline of the
+    #      dominant kernel that has an algorithmic work figure; rank 0 only, after the timed region ----
+    kernels, roofline = [], None
+    if rank == 0 and not ddp:
+        from mvsformer_amd import ops
+        eager_step()
+        torch.cuda.synchronize()
+        with ops.kernel_timer() as kt:
+            eager_step()
+        work = kt.work
+        for name, st in kt.summary().items():
+            e = {"kernel": name, "calls_per_step": st["calls"], "ms_per_step": round(st["total_ms"], 4)}
+            w = work.get(name)
+            if w:
+                per_s = w["amount"] / (st["total_ms"] * 1e-3)
+                if w["kind"] == "bytes":
+                    e.update(bound="hbm", achieved=round(per_s / 1e9, 1), peak=8000.0, unit="GB/s", frac=round(per_s / 1e9 / 8000.0, 4))
+                else:
+                    peak = 2500.0 if name.startswith("bf16_") else 157.3         # dense bf16 / fp32 MFMA peaks (MI355X_MICROARCH.md)
+                    e.update(bound="mfma", achieved=round(per_s / 1e12, 2), peak=peak, unit="TFLOP/s", frac=round(per_s / 1e12 / peak, 4))
+                e["algorithmic_per_step"] = w["amount"]
+            kernels.append(e)
+        kernels.sort(key=lambda e: -e["ms_per_step"])
+        dom = next((e for e in kernels if "bound" in e), None)
+        if dom:
+            roofline = {k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")}
+            roofline.update(ms_per_step=dom["ms_per_step"], calls_per_step=dom["calls_per_step"], algorithmic_per_step=dom["algorithmic_per_step"],
+                            traffic=None, note="largest kernel of the step with an algorithmic work figure; summed over its launches of one eager step")
     if rank == 0:
-        print(json.dumps({"metric": "training samples/s (fwd+bwd+AdamW), 640x512, 5 views, cascade 32/16/8/8", "value": round(world * args.steps / dt.item(), 3),
+        print(json.dumps({"roofline": roofline, "kernel_ms_sum": round(sum(e["ms_per_step"] for e in kernels), 3), "kernels": kernels[:12],
+                          "ranks_seen": dist.get_world_size() if world > 1 else 1, "ranks": ranks,
+                          "metric": "training samples/s (fwd+bwd+AdamW), 640x512, 5 views, cascade 32/16/8/8", "value": round(world * args.steps / dt.item(), 3),
                           "unit": "samples/s", "n_gpus": world, "steps": args.steps, "ms_per_step": round(dt.item() / args.steps * 1e3, 2),
                           "host_enqueue_ms_per_step": round(t_enqueue * 1e3, 2), "hip_graph": use_graph, "graph_note": graph_note, "dtype": args.dtype, "data": "synthetic", "scaling": "weak", "final_loss": round(float(loss.detach()), 4),
                           "parallelism": "DDP + SyncBatchNorm over RCCL" if ddp else "single GPU"}))

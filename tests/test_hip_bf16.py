@@ -378,3 +378,69 @@ def test_conv_bf16_epilogue_statistics(dev, cin, cout, gather, stride, N, D, H, 
     yf = y0.float().reshape(N // groups, groups, -1, cout)
     relclose(sums[:groups * cout].view(groups, cout), yf.sum(dim=(0, 2)), 1e-4, "sum vs torch")
     relclose(sums[groups * cout:].view(groups, cout), (yf * yf).sum(dim=(0, 2)), 1e-4, "sumsq vs torch")
+
+
+CASCADE_BF16 = {"logits_l2": 3e-2, "logits_max": 4e-2, "depth_agree": 0.95, "loss_fp32": 5e-3, "loss_autocast": 1e-2}      # measured values in the docstring below
+
+
+def test_cascade_bf16_vs_cpu_autocast_all_stage_geometries(dev):
+    """The whole 32/16/8/8 training cascade of BASELINE configs[2] under autocast(bfloat16) on 128x192 x 3 views - all four stage
+    geometries (C = 64/32/16/8, CostRegNet at stages 1-2, CostRegNet3D at 3-4) - against the oracle cascade.  Training-mode depth is an
+    arg-max over hypotheses, so one flipped arg-max at a coarse stage moves that pixel's hypotheses at every later stage: the stages are
+    therefore compared ON THE ORACLE'S HYPOTHESES (each HIP stage is fed the hypotheses the oracle cascade used at that stage), and the
+    free-running HIP cascade is compared through its loss.  Two oracles:
+      * the fp32 oracle (what the bf16 path approximates): per-stage logits within 3e-2 relative L2 and 4e-2 of scale in max norm (measured
+        on MI355X: 0.5e-2 ... 1.3e-2 and 0.8e-2 ... 1.5e-2), arg-max depth equal at >= 95 % of the pixels of every stage (measured 98 %),
+        four-stage cross-entropy loss of the free-running cascade within 5e-3 relative (measured 6e-4);
+      * the oracle under ``torch.autocast('cpu', bfloat16)`` (the reference trainer's semantics, trainer/mvsformer_trainer.py:104-106):
+        bounded through the loss only (1e-2 relative; measured 1.4e-3).  CPU autocast also runs the 4x4 projection products and the
+        warping arithmetic in bf16, which the HIP path keeps in fp32, so voxel-wise differences against it (measured: logits 5e-2 ... 3e-1
+        relative L2, arg-max agreement 91 % ... 65 % from stage 1 to 4 - it is the autocast oracle that moves away from the fp32 one, by
+        5-30x more than the HIP path does) measure that, not the regularizer; they are printed, not asserted.
+    """
+    import mvsformer_amd as m
+    from mvsformer_amd import synth
+    from mvsformer_amd.losses import ce_loss_stage4
+    from oracle import ref_torch, ref_losses
+    torch.manual_seed(3)
+    ndepths, tmp = [32, 16, 8, 8], [5.0, 5.0, 5.0, 1.0]
+    net = m.CascadeMVS(dict(ndepths=ndepths)).train()
+    ratios = list(net.depth_interals_ratio)
+    m.randomize_bn_(net, 5)
+    feats, proj, dv, scene = synth.make_inputs(3, 128, 192, seed=2)      # stage 1 = 16 x 24: three halvings of the D-strided regularizer
+    sds = [{k: v.detach().clone() for k, v in net.fusions[i].state_dict().items()} for i in range(4)]
+    with torch.no_grad():
+        want32 = ref_torch.cascade_forward(feats, proj, dv, sds, ndepths=ndepths, depth_interals_ratio=ratios, tmp=tmp, training=True)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            want16 = ref_torch.cascade_forward(feats, proj, dv, sds, ndepths=ndepths, depth_interals_ratio=ratios, tmp=tmp, training=True)
+    gts = {"stage%d" % (i + 1): synth.plane_depth(scene, s)[None] for i, s in enumerate(synth.STAGE_SCALES)}
+    masks = {k: torch.ones_like(v) for k, v in gts.items()}
+
+    def ref_loss(w):
+        wf = {k: ({kk: (vv.float() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in w.items()}
+        return sum(float(v) for v in ref_losses.ce_loss_stage4(wf, gts, masks, dlossw=[1, 1, 1, 1], inverse_depth=True).values())
+
+    net = net.to(dev)
+    fd = {k: v.to(dev) for k, v in feats.items()}
+    pd = {k: v.to(dev) for k, v in proj.items()}
+    report = {}
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        for name, want in (("fp32", want32), ("autocast", want16)):
+            for i in range(4):
+                k = "stage%d" % (i + 1)
+                hyp = want[k]["depth_values"].float().to(dev).contiguous()
+                got = net.fusions[i](fd[k], pd[k], hyp, tmp=tmp[i])
+                w = want[k]["prob_volume_pre"].float()
+                g = got["prob_volume_pre"].float().cpu()
+                report[name + "/" + k] = (round(_rel_l2(g, w), 4), round((g - w).abs().max().item() / w.abs().max().item(), 4),
+                                          round((got["depth"].float().cpu() == want[k]["depth"].float()).float().mean().item(), 4))
+        free = net(fd, pd, dv.to(dev), tmp=tmp)
+    loss_hip = sum(v.item() for v in ce_loss_stage4(free, {k: v.to(dev) for k, v in gts.items()}, {k: v.to(dev) for k, v in masks.items()},
+                                                    dlossw=[1, 1, 1, 1], inverse_depth=True).values())
+    l32, l16 = ref_loss(want32), ref_loss(want16)
+    report["loss"] = {"hip": round(loss_hip, 4), "fp32": round(l32, 4), "autocast": round(l16, 4)}
+    print("cascade bf16 report (rel-L2, max err / scale, arg-max agreement):", report)
+    for i in range(4):
+        l2, mx, agree = report["fp32/stage%d" % (i + 1)]
+        assert l2 < CASCADE_BF16["logits_l2"] and mx < CASCADE_BF16["logits_max"] and agree >= CASCADE_BF16["depth_agree"], report
+    assert abs(loss_hip - l32) / l32 < CASCADE_BF16["loss_fp32"] and abs(loss_hip - l16) / l16 < CASCADE_BF16["loss_autocast"], report
