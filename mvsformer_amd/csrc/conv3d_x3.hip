@@ -191,6 +191,37 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
     // The STEPS steps of depth tap KD, starting with the weights of its first step already in wbuf[P]; every step prefetches the next
     // step's weights (contiguous in memory, running on into the next depth tap) into the other buffer (measured: 10-20 % over loading
     // each step's weights right before its MFMAs).  KD, P and s are compile-time, so every register index is static.
+    // staging: item i = tid + it * 256 -> (channel octet, box pixel); the 8 channel planes of the pixel are 8 coalesced dword loads
+    constexpr int NI = (KQ * NPIX + 255) / 256;
+    float pre[NI][8];
+    auto issue = [&](int it, int pp, int cc) {
+        const int i = tid + it * 256;
+        const int oct = min(i / NPIX, KQ - 1), v = i % NPIX;
+        const int gy = y0 * SHW - 1 + v / BWC, gx = x0 * SHW - 1 + v % BWC;
+        const bool in = i < KQ * NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const float* src = xb + ((size_t)(cc * CK + oct * 8) * D + pp) * HW + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pre[it][e] = (a.ablate & 1) ? 1.0f : src[(size_t)e * DHW];
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int i = tid + it * 256;
+            if (i < KQ * NPIX && !(a.ablate & 2)) {
+                const int oct = i / NPIX, v = i % NPIX;
+                const int gy = y0 * SHW - 1 + v / BWC, gx = x0 * SHW - 1 + v % BWC;
+                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                float px[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) px[e] = in ? pre[it][e] : 0.0f;
+                const Split3 sp = split3(px);
+                unsigned char* dst = lds + ((v / BWC) * BWC + Cfg::col_index(v % BWC)) * PB + oct * 16;
+                *reinterpret_cast<bf16x8*>(dst) = sp.h;
+                *reinterpret_cast<bf16x8*>(dst + TERM_BYTES) = sp.m;
+                *reinterpret_cast<bf16x8*>(dst + 2 * TERM_BYTES) = sp.l;
+            }
+        }
+    };
     auto kd_steps = [&](auto kd_tag, auto p_tag, const bf16x8* wk, bool more) {
         constexpr int KD = decltype(kd_tag)::value, P = decltype(p_tag)::value, SET = 2 - KD;
 #pragma unroll
@@ -224,47 +255,27 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
     // this block's depth segment: output planes [d_lo, d_hi); input planes d_lo-1 .. d_hi (clipped)
     const int d_lo = seg * a.seg_planes, d_hi = min(D, d_lo + a.seg_planes);
     const int p_first = max(0, d_lo - 1), p_last = min(D - 1, d_hi);
-    for (int p = p_first; p <= p_last; ++p) {
+    const int NP = (p_last - p_first + 1) * NCH;           // passes: (input plane, channel chunk)
+    for (int pass = 0; pass < NP; ++pass) {
+        const int p = p_first + pass / NCH, chunk = pass % NCH;
         // depth taps of input plane p whose output plane od = p + 1 - kd lies in [d_lo, d_hi): a contiguous, block-uniform range
         const int kd_lo = max(0, p + 2 - d_hi), kd_hi = min(2, p + 1 - d_lo);
-        for (int chunk = 0; chunk < NCH; ++chunk) {
-            const bf16x8* wk = a.wp + ((size_t)((ctb * MTB) * NCH + chunk) * 3 + kd_lo) * Cfg::FRAGS_PER_KD + lane;
-            load_w(wk, wbuf[0]);                           // the first step's weights travel while the plane is staged
-            // ---- stage plane p, channels [CK*chunk, CK*chunk + CK): fp32 -> (h, m, l) bf16 channel-last ----
-            // (issuing the NEXT pass's loads before this pass's MFMAs was measured and lost 10-25 %: the weight fragments are global
-            // loads too, vmcnt retires in order, so the first weight wait drains the whole prefetch)
-            // all of a thread's loads first (NI items x 8 channel planes in flight), then the split and the LDS stores
-            constexpr int NI = (KQ * NPIX + 255) / 256;
-            float pre[NI][8];
+        const bf16x8* wk = a.wp + ((size_t)((ctb * MTB) * NCH + chunk) * 3 + kd_lo) * Cfg::FRAGS_PER_KD + lane;
+        load_w(wk, wbuf[0]);                               // the first step's weights travel while the plane is staged
+        // ---- stage plane p, channels [CK*chunk, CK*chunk + CK): fp32 -> (h, m, l) bf16 channel-last: all of a thread's loads first (NI
+        //      items x 8 channel planes in flight), then the split and the LDS stores.  Measured and dropped: the NEXT pass's loads in
+        //      FRONT of this pass's MFMA phase (-10...25 %: the weight fragments are global loads too, vmcnt retires in order, so the
+        //      first weight wait drains the whole prefetch), and INSIDE it, a few per step behind each step's weight prefetch, held in
+        //      registers until the pass ends (+2 % for the 32/64-channel stride-1 layers, -12...-40 % elsewhere: 24-40 more live
+        //      registers through the MFMA phase) ----
 #pragma unroll
-            for (int it = 0; it < NI; ++it) {
-                const int i = tid + it * 256;
-                const int oct = min(i / NPIX, KQ - 1), v = i % NPIX;
-                const int gy = y0 * SHW - 1 + v / BWC, gx = x0 * SHW - 1 + v % BWC;
-                const bool in = i < KQ * NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
-                const float* src = xb + ((size_t)(chunk * CK + oct * 8) * D + p) * HW + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pre[it][e] = (a.ablate & 1) ? 1.0f : src[(size_t)e * DHW];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pre[it][e] = in ? pre[it][e] : 0.0f;
-            }
-            __syncthreads();                               // the previous pass's fragment reads are done
-#pragma unroll
-            for (int it = 0; it < NI; ++it) {
-                const int i = tid + it * 256;
-                if (i < KQ * NPIX && !(a.ablate & 2)) {
-                    const int oct = i / NPIX, v = i % NPIX;
-                    const Split3 sp = split3(pre[it]);
-                    unsigned char* dst = lds + ((v / BWC) * BWC + Cfg::col_index(v % BWC)) * PB + oct * 16;
-                    *reinterpret_cast<bf16x8*>(dst) = sp.h;
-                    *reinterpret_cast<bf16x8*>(dst + TERM_BYTES) = sp.m;
-                    *reinterpret_cast<bf16x8*>(dst + 2 * TERM_BYTES) = sp.l;
-                }
-            }
-            __syncthreads();
-            // ---- the depth taps of this plane; the buffer parity flips after each one (STEPS is odd) ----
-            int pos = 0;
-            if (a.ablate & 4) continue;
+        for (int it = 0; it < NI; ++it) issue(it, p, chunk);
+        __syncthreads();                                   // the previous pass's fragment reads are done
+        commit();
+        __syncthreads();
+        // ---- the depth taps of this plane; the buffer parity flips after each one (STEPS is odd) ----
+        int pos = 0;
+        if (!(a.ablate & 4)) {
             if (kd_lo == 0) {
                 kd_steps(ic<0>{}, ic<0>{}, wk, kd_hi >= 1);
                 wk += Cfg::FRAGS_PER_KD;
@@ -279,16 +290,18 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
                 if (pos == 0) kd_steps(ic<2>{}, ic<0>{}, wk, false); else kd_steps(ic<2>{}, ic<1>{}, wk, false);
             }
         }
-        // output plane p-1 has seen its three input planes
-        if (p - 1 >= d_lo) store_plane(p - 1, acc[0]);
+        if (chunk == NCH - 1) {
+            // output plane p-1 has seen its three input planes
+            if (p - 1 >= d_lo) store_plane(p - 1, acc[0]);
 #pragma unroll
-        for (int mt = 0; mt < MTB; ++mt)
+            for (int mt = 0; mt < MTB; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[0][mt][nt] = acc[1][mt][nt];
-                acc[1][mt][nt] = acc[2][mt][nt];
-                acc[2][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[0][mt][nt] = acc[1][mt][nt];
+                    acc[1][mt][nt] = acc[2][mt][nt];
+                    acc[2][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
     }
     if (p_last == D - 1 && d_hi == D) store_plane(D - 1, acc[0]);
     if (a.ablate & 8) __threadfence();
@@ -464,22 +477,36 @@ __global__ __launch_bounds__(256, 2) void x3_deconv_kernel(const X3Args a) {
         for (int chunk = 0; chunk < NCH; ++chunk) {
             const bf16x8* wk = a.wp + ((size_t)(ctb * NCH + chunk) * 3 + kd_lo) * FRAGS_PER_KD + lane;
             load_w(wk, wbuf[0]);
-            __syncthreads();
-            for (int i = tid; i < 2 * NPIX; i += 256) {
+            // both of a thread's items' loads first (16 in flight), then the barrier, the split and the LDS stores
+            constexpr int NI = (2 * NPIX + 255) / 256;
+            float pre[NI][8];
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const int i = min(tid + it * 256, 2 * NPIX - 1);
                 const int oct = i / NPIX, v = i % NPIX;
                 const int gy = y0 + v / BW, gx = x0 + v % BW;
                 const bool in = gy < H && gx < W;
                 const float* src = xb + ((size_t)(chunk * 16 + oct * 8) * D + p) * HW + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
-                float f[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = src[(size_t)e * DHW];
+                for (int e = 0; e < 8; ++e) pre[it][e] = src[(size_t)e * DHW];
+            }
+            __syncthreads();
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = in ? f[e] : 0.0f;
-                const Split3 sp = split3(f);
-                unsigned char* dst = lds + v * PB + oct * 16;
-                *reinterpret_cast<bf16x8*>(dst) = sp.h;
-                *reinterpret_cast<bf16x8*>(dst + TERM_BYTES) = sp.m;
-                *reinterpret_cast<bf16x8*>(dst + 2 * TERM_BYTES) = sp.l;
+            for (int it = 0; it < NI; ++it) {
+                const int i = tid + it * 256;
+                if (i < 2 * NPIX) {
+                    const int oct = i / NPIX, v = i % NPIX;
+                    const int gy = y0 + v / BW, gx = x0 + v % BW;
+                    const bool in = gy < H && gx < W;
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = in ? pre[it][e] : 0.0f;
+                    const Split3 sp = split3(f);
+                    unsigned char* dst = lds + v * PB + oct * 16;
+                    *reinterpret_cast<bf16x8*>(dst) = sp.h;
+                    *reinterpret_cast<bf16x8*>(dst + TERM_BYTES) = sp.m;
+                    *reinterpret_cast<bf16x8*>(dst + 2 * TERM_BYTES) = sp.l;
+                }
             }
             __syncthreads();
             int pos = 0;
