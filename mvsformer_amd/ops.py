@@ -64,7 +64,7 @@ class KernelTimer:
         out = {}
         for k, evs in self.events.items():
             ms = [a.elapsed_time(b) for a, b in evs]
-            out[k] = {"calls": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / max(1, len(ms))}
+            out[k] = {"calls": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / max(1, len(ms)), "all_ms": ms}
         return out
 
 
