@@ -558,10 +558,11 @@ def test_vis_wino_matches_valu_kernel(dev, shape):
     assert (a - b).abs().max().item() < 5e-6, (a - b).abs().max().item()
 
 
-@pytest.mark.parametrize("shape", [(3, 37, 53), (2, 14, 30), (1, 144, 192), (5, 9, 7), (2, 16, 16), (1, 33, 17), (4, 288, 384)])
+@pytest.mark.parametrize("shape", [(3, 37, 53), (2, 14, 30), (1, 144, 192), (5, 9, 7), (2, 16, 16), (1, 33, 17), (4, 288, 384), (4, 1152, 1536)])
 def test_vis_x3_matches_valu_kernel(dev, shape):
     """Split-form bf16-MFMA visibility CNN == the all-VALU kernel (itself pinned to the reference goldens) to fp32 rounding: sizes that
-    are not multiples of the 16 x 16 block tile, smaller than one tile, exactly one tile, real stage-1 / stage-2 maps; the outputs of the
+    are not multiples of the 16 x 16 block tile, smaller than one tile, exactly one tile, real stage-1 / stage-2 / stage-4 maps (the last one
+    is the persistent kernel's full grid: 27 648 tiles over 512 blocks); the outputs of the
     three intermediate layers are bounded through the final sigmoid only (no intermediate leaves the kernel)."""
     from mvsformer_amd import ops
     torch.manual_seed(sum(shape))
