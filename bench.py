@@ -262,10 +262,9 @@ def main(args):
         # The j-th launch of a kernel name within a step has the same shape in every profile step: its duration = the MEDIAN over the
         # steps (an event pair also brackets whatever the host does between recording the start event and enqueueing the kernel, and
         # one pre-empted launch out of five must not move the figure); a step's total for the name = the sum of those medians.
-        cps = s["calls"] // args.profile_steps
-        if cps >= 1 and s["calls"] == cps * args.profile_steps and args.profile_steps >= 3:
-            med = [sorted(s["all_ms"][j::cps])[args.profile_steps // 2] for j in range(cps)]
-            s = dict(s, avg_ms=sum(med) / cps, total_ms=sum(med) * args.profile_steps)
+        med = timer.per_step_medians(s["all_ms"], args.profile_steps)
+        if med:
+            s = dict(s, avg_ms=sum(med) / len(med), total_ms=sum(med) * args.profile_steps)
         e = {"kernel": name, "calls_per_step": s["calls"] // args.profile_steps, "avg_ms": round(s["avg_ms"], 5),
              "ms_per_step": round(s["total_ms"] / args.profile_steps, 4)}
         if w:

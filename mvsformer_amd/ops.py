@@ -59,6 +59,18 @@ class KernelTimer:
         w = self.work.setdefault(tag, {"kind": kind, "amount": 0.0})
         w["amount"] += amount
 
+    @staticmethod
+    def per_step_medians(all_ms, steps: int):
+        """Durations of one kernel name over ``steps`` identical steps (launch order preserved) -> the median over the steps for each
+        of the name's launches within a step, or None if the launches do not divide into ``steps`` equal steps.  The j-th launch of a
+        name has the same shape in every step, and an event pair also brackets whatever the host does between recording the start
+        event and enqueueing the kernel: one pre-empted launch out of five must not move a per-kernel figure."""
+        n = len(all_ms)
+        if steps < 3 or n == 0 or n % steps:
+            return None
+        cps = n // steps
+        return [sorted(all_ms[j::cps])[steps // 2] for j in range(cps)]
+
     def summary(self) -> Dict[str, Dict[str, float]]:
         torch.cuda.synchronize()
         out = {}

@@ -123,3 +123,20 @@ print("OK", sorted(done))
 ''' % REPO
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_kernel_timer_per_step_medians():
+    """bench.py's per-kernel figures: the j-th launch of a kernel name within a step is the median over the profile steps (a launch whose
+    event pair also caught a pre-empted host thread must not move the figure), launches of different shapes under one name stay apart."""
+    from mvsformer_amd.ops import KernelTimer
+    # 5 steps x 3 launches of one name (three shapes: 0.03, 0.09, 0.14 ms); step 2's first launch waited 12 ms for the host
+    ms = []
+    for step in range(5):
+        ms += [0.03 + 0.001 * step, 0.09, 0.14 - 0.001 * step]
+    ms[2 * 3] = 12.0
+    med = KernelTimer.per_step_medians(ms, 5)
+    assert med is not None and len(med) == 3
+    assert abs(med[0] - 0.033) < 1e-9 and med[1] == 0.09 and abs(med[2] - 0.138) < 1e-9
+    assert abs(sum(ms) / 5 - sum(med)) > 2.0                      # the mean over the steps would have reported 2.65 ms for 0.26 ms of work
+    assert KernelTimer.per_step_medians(ms[:-1], 5) is None        # launches do not divide into equal steps: caller keeps the plain mean
+    assert KernelTimer.per_step_medians(ms[:6], 2) is None         # fewer than three steps: no median
