@@ -52,6 +52,9 @@ struct X3Cfg {
     static constexpr int LDS_BYTES = 3 * TERM_BYTES;
     static constexpr int FRAGS_PER_KD = STEPS * 3 * 64;        // bf16x8 units of one (cout tile, chunk, kd)
     static constexpr int MIN_BLOCKS = (MTB == 1 && CK == 16) ? 3 : 2;   // blocks per CU the register budget is set for
+    // B fragments of the next (step, row) item read under the current item's MFMAs (+2...6 % measured); not where the 168-register budget
+    // of three blocks per CU has no room for the second fragment set (<16,1,4,1>: 16 spills, -5 %)
+    static constexpr bool BPIPE = !(MTB == 1 && CK == 16 && NT == 4);
     __host__ __device__ static constexpr int col_index(int c) { return SHW == 1 ? c : (c & 1) * EV + (c >> 1); }
 };
 
@@ -222,20 +225,31 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
             }
         }
     };
+    auto load_b = [&](int s, int nt, bf16x8 (&bf)[3]) {
+        const unsigned char* bp = lds + (SHW * (wave * NT + nt)) * (BWC * PB) + boff[s];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bf[t] = *reinterpret_cast<const bf16x8*>(bp + t * TERM_BYTES);
+    };
     auto kd_steps = [&](auto kd_tag, auto p_tag, const bf16x8* wk, bool more) {
         constexpr int KD = decltype(kd_tag)::value, P = decltype(p_tag)::value, SET = 2 - KD;
+        bf16x8 bf[2][3];                                   // B fragments of (step, row) item j and j + 1: the next item's reads run under this item's MFMAs
+        if (Cfg::BPIPE) load_b(0, 0, bf[0]);
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const int cur = (P + s) & 1;
             if (s + 1 < STEPS || more) load_w(wk + (size_t)(s + 1) * 192, wbuf[cur ^ 1]);      // no load left in flight at the end of the pass
-            // one step's operands (+ the prefetch) in flight at a time: left alone, the scheduler hoists every step's weight loads
-            __builtin_amdgcn_sched_barrier(0);
+            // one step's (BPIPE: one item's) operands + the prefetches in flight at a time: left alone, the scheduler hoists every step's loads
+            if (!Cfg::BPIPE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const unsigned char* bp = lds + (SHW * (wave * NT + nt)) * (BWC * PB) + boff[s];
-                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(bp);
-                const bf16x8 xm = *reinterpret_cast<const bf16x8*>(bp + TERM_BYTES);
-                const bf16x8 xl = *reinterpret_cast<const bf16x8*>(bp + 2 * TERM_BYTES);
+                const int j = s * NT + nt;
+                if (Cfg::BPIPE) {
+                    if (j + 1 < STEPS * NT) load_b((j + 1) / NT, (j + 1) % NT, bf[(j + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    load_b(s, nt, bf[0]);
+                }
+                const bf16x8 xh = bf[Cfg::BPIPE ? (j & 1) : 0][0], xm = bf[Cfg::BPIPE ? (j & 1) : 0][1], xl = bf[Cfg::BPIPE ? (j & 1) : 0][2];
 #pragma unroll
                 for (int mt = 0; mt < MTB; ++mt) {
                     f32x4 c = acc[SET][mt][nt];
@@ -247,8 +261,9 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wbuf[cur][mt][0], c, 0, 0, 0);
                     acc[SET][mt][nt] = c;
                 }
+                if (Cfg::BPIPE) __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (!Cfg::BPIPE) __builtin_amdgcn_sched_barrier(0);
         }
     };
 
