@@ -140,3 +140,26 @@ def test_kernel_timer_per_step_medians():
     assert abs(sum(ms) / 5 - sum(med)) > 2.0                      # the mean over the steps would have reported 2.65 ms for 0.26 ms of work
     assert KernelTimer.per_step_medians(ms[:-1], 5) is None        # launches do not divide into equal steps: caller keeps the plain mean
     assert KernelTimer.per_step_medians(ms[:6], 2) is None         # fewer than three steps: no median
+
+
+def test_store_plan_and_vis_mode_host_logic(monkeypatch):
+    """Host-side decisions of StageNet that need no GPU: which stages keep their per-view correlation volumes (config-2 stage 1: 127 MB,
+    stored; stage 2: 254 MB, recomputed; the MVS_CV_STORE_MAX_MB override), and the MVS_VIS switch rejecting unknown values."""
+    import pytest
+    import mvsformer_amd as m
+    from mvsformer_amd import stagenet
+    monkeypatch.delenv("MVS_CV_STORE_MAX_MB", raising=False)
+    f1 = torch.empty(1, 5, 144, 192, 64)                  # [B,V,H,W,C] channel-last, stage 1 of config 2
+    f2 = torch.empty(1, 5, 288, 384, 32)
+    f3 = torch.empty(1, 5, 576, 768, 16)
+    assert stagenet._store_plan(f1, 32, 8) is True
+    assert stagenet._store_plan(f2, 16, 8) is False
+    assert stagenet._store_plan(f3, 8, 8) is False          # C = 16: not built (zero bytes)
+    monkeypatch.setenv("MVS_CV_STORE_MAX_MB", "400")
+    assert stagenet._store_plan(f2, 16, 8) is True
+    monkeypatch.setenv("MVS_CV_STORE_MAX_MB", "0")
+    assert stagenet._store_plan(f1, 32, 8) is False
+    net = m.StageNet(dict(base_ch=8, fusion_type="cnn", depth_type="ce"), 8, 0).eval()
+    monkeypatch.setenv("MVS_VIS", "winograd")
+    with pytest.raises(ValueError):
+        net._vis_params()
