@@ -12,11 +12,23 @@
  *   - every pointer is a DEVICE pointer owned by the caller (fp32 unless stated, dense, row-major, the
  *     layout given in brackets).  Nothing is allocated or freed; scratch comes in as a caller workspace.
  *   - launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream); the
- *     device is the caller's current HIP device.  No global mutable state: re-entrant across streams,
- *     threads and devices.
- *   - arithmetic is IEEE fp32 (the reference forces fp32 for the cost volume, mvsformer_model.py:65-78); the two entry
- *     points that also offer a shortcut form (reciprocal instead of IEEE division, hardware exp2/log2) say so at their
- *     `flags` argument - the Python layer asks for the IEEE form unless told otherwise.
+ *     device is the caller's current HIP device.  No global mutable state beyond two per-device caches (the CU count, "dynamic LDS
+ *     limit already raised for this kernel"): re-entrant across streams, threads and devices.
+ *   - Arithmetic.  Data is fp32 in, fp32 out (the reference forces fp32 for the cost volume, mvsformer_model.py:65-78).  Sweeps,
+ *     heads, schedulers, filters and the `mvs_conv3d_fwd` / `mvs_deconv3d_fwd` family compute in IEEE fp32 (VALU / fp32 MFMA); the two
+ *     entry points that also offer a shortcut form (reciprocal instead of IEEE division, hardware exp2/log2) say so at their `flags`
+ *     argument - the Python layer asks for the IEEE form unless told otherwise.  The entry points with `x3` in their name
+ *     (`mvs_conv3d_x3_*`, `mvs_deconv3d_x3_*`, `mvs_tail_x3_*`, `mvs_vis_x3_*`: the DEFAULT regularizer / visibility-CNN path of the
+ *     Python layer) are fp32-EQUIVALENT, not IEEE fp32 op for op: every operand is split exactly into three bf16 terms
+ *     (v = h + m + l) and a product is the six bf16 matrix-core products xh*wh + xh*wm + xm*wh + xh*wl + xl*wh + xm*wm with fp32
+ *     accumulation (dropped terms <= 2^-24 |x*w|).  Their contract, tested in tests/test_hip_x3.py against fp64:
+ *       * error against the exact result <= 3x the fp32-MFMA kernel's own error on the same operands (+ 2e-7 of the output scale);
+ *       * any finite fp32 input is accepted, including |v| above the largest finite bf16 (3.3895e38; h is clamped, m and l carry
+ *         the remainder exactly) and inputs scaled by 2^+-100, as long as the exact products and sums stay inside the fp32 range;
+ *       * subnormal operands may be flushed to zero by the matrix cores: absolute error <= K * 2^-126 * max|other operand|;
+ *       * a non-finite input (+-Inf, NaN) makes exactly the outputs whose receptive field contains it non-finite; the value is NaN
+ *         where IEEE fp32 arithmetic would give +-Inf (Inf - Inf in the remainder terms).
+ *     The x3 kernels need gfx950: v_mfma_f32_16x16x32_bf16 and up to 72 KB of LDS per block (`mvs_vis_x3_fwd`, raised per device).
  */
 #ifndef MVS_HIP_H
 #define MVS_HIP_H
@@ -29,7 +41,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 8
+#define MVS_ABI_VERSION 9
 
 typedef void* mvs_stream_t;
 
@@ -404,6 +416,18 @@ int64_t mvs_deconv3d_x3_packed_bytes(int Cin, int Cout, int sd);
 int mvs_deconv3d_x3_pack_weights(const float* w, int Cin, int Cout, int sd, void* wpacked, mvs_stream_t stream);
 int mvs_deconv3d_x3_fwd(const float* x, const void* wpacked, const float* scale, const float* shift, const float* residual, float* y,
                         int B, int Cin, int Cout, int D, int H, int W, int sd, int relu, mvs_stream_t stream);
+
+/* CostRegNet3D's tail in one launch, split form (csrc/tail_x3.hip): logits = prob(residual + relu(bn(conv11(x)))) with conv11 =
+ * ConvTranspose3d(16, 8, 3, stride (1,2,2), padding 1, output_padding (0,1,1), bias=False) and prob = Conv3d(8, 1, 1) - models/module.py:
+ * 575-576 (conv11), 582 (prob), 590-592 (`x = x + self.conv11(x)` / `self.prob(x)`).  Same contract as mvs_deconv3d_prob1_fwd (which
+ * computes it on the fp32 matrix cores) for Cin = 16; the 8-channel feature volume is never written.
+ *   pack: w [16,8,3,3,3] -> wpacked, mvs_tail_x3_packed_bytes() bytes
+ *   x [B,16,D,H,W] (conv9's output), scale/shift [8] or NULL, residual [B,8,D,2H,2W] or NULL, prob_w [8], prob_b [1] or NULL
+ *   -> logits [B,D,2H,2W] */
+int64_t mvs_tail_x3_packed_bytes(void);
+int mvs_tail_x3_pack_weights(const float* w, void* wpacked, mvs_stream_t stream);
+int mvs_tail_x3_fwd(const float* x, const void* wpacked, const float* scale, const float* shift, const float* residual, const float* prob_w,
+                    const float* prob_b, float* logits, int B, int D, int H, int W, int relu, mvs_stream_t stream);
 
 /* FPNEncoder layers, models/module.py:40-73,208-240: y = leaky_relu(BatchNorm2d_eval(conv2d(x, w, stride, padding = K/2)), slope), NCHW.
  * Built for the encoder's eight layer shapes (Cin,Cout,K,stride) = (3,8,7,1) (8,8,5,1) (8,16,5,2) (16,16,3,1) (16,32,5,2) (32,32,3,1)

@@ -28,6 +28,12 @@ void launch_partials_reduce(const float* part, int nparts, int n, float* out, hi
 // out[g*C + c] / out[groups*C + g*C + c] = sums over the samples n = g (mod groups) and their bps blocks, fixed order.
 void launch_partials_reduce_grouped(const float* part, int bps, int nsamples, int groups, int C, float* out, hipStream_t stream);
 
+// Per-device facts.  The library keeps no other mutable global state (header contract: re-entrant across threads and devices), and these
+// two are caches keyed by the CURRENT device id (hipGetDevice), so a single process driving several GPUs gets each device's own answer.
+int device_cus();                                              // compute units of the current device (256 on MI355X)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) for `func`, once per (function, device); MVS_OK or a negative error with set_error()
+int ensure_dynamic_lds(const void* func, int bytes, const char* who);
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline long long ceil_div(long long a, long long b) { return (a + b - 1) / b; }
 

@@ -1,6 +1,10 @@
 // Error channel + ABI version of libmvs_hip.so.
 #include "common.h"
 
+#include <atomic>
+#include <mutex>
+#include <vector>
+
 namespace mvs {
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
@@ -8,6 +12,41 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::atomic<int> g_cus[MAX_DEVICES];                            // 0 = not asked yet
+struct LdsKey { const void* func; int dev; int bytes; };
+std::mutex g_lds_mutex;
+std::vector<LdsKey> g_lds_done;
+}  // namespace
+
+int device_cus() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return 256;
+    int n = g_cus[dev].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_cus[dev].store(n, std::memory_order_relaxed);       // idempotent: a race only repeats the query
+    }
+    return n;
+}
+
+int ensure_dynamic_lds(const void* func, int bytes, const char* who) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lock(g_lds_mutex);
+    for (const LdsKey& k : g_lds_done)
+        if (k.func == func && k.dev == dev && k.bytes >= bytes) return MVS_OK;
+    const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("%s: cannot reserve %d bytes of dynamic LDS (this library needs gfx950's 160 KB per CU): %s", who, bytes, hipGetErrorString(e));
+        return -(1000 + (int)e);
+    }
+    g_lds_done.push_back(LdsKey{func, dev, bytes});
+    return MVS_OK;
 }
 
 static __global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ out) {

@@ -367,14 +367,9 @@ template <int NT, int SD>
 int launch_deconv(const float* x, const float* wp, const float* scale, const float* shift, const float* res, float* y, int B,
                   int Cin, int Cout, int Di, int Hi, int Wi, int relu, hipStream_t s) {
     const size_t lds = deconv_lds_bytes<NT, SD>();
-    static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(deconv3d_kernel<NT, SD>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            mvs::set_error("mvs_deconv3d_fwd: cannot raise dynamic LDS to %zu bytes", lds);
-            return -(1000 + (int)hipGetLastError());
-        }
-        attr_done = true;
+    if (lds > 48 * 1024) {
+        const int rc = mvs::ensure_dynamic_lds(reinterpret_cast<const void*>(deconv3d_kernel<NT, SD>), (int)lds, "mvs_deconv3d_fwd");
+        if (rc != MVS_OK) return rc;
     }
     dim3 grid(mvs::ceil_div(Wi, 32), mvs::ceil_div(Hi, 2), B * ((SD == 1) ? mvs::ceil_div(Di, 2) : Di));
     hipLaunchKernelGGL((deconv3d_kernel<NT, SD>), grid, dim3(256), lds, s, x, wp, scale, shift, res, y, Cin, Cout, Di, Hi, Wi, relu);

@@ -202,14 +202,9 @@ template <int NT, int NP, int SD, int SHW, int TD, int TH, int MT>
 int launch(const ConvArgs& a) {
     constexpr size_t lds = lds_bytes(NP, SD, SHW, TD, TH, MT);
     static_assert(lds <= 160 * 1024, "tile does not fit in LDS");
-    static bool attr_done = false;                           // idempotent; a race only repeats the call
-    if (!attr_done && lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_kernel<NT, NP, SD, SHW, TD, TH, MT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            mvs::set_error("mvs_conv3d_fwd: cannot raise dynamic LDS to %zu bytes", lds);
-            return -(1000 + (int)hipGetLastError());
-        }
-        attr_done = true;
+    if (lds > 48 * 1024) {
+        const int rc = mvs::ensure_dynamic_lds(reinterpret_cast<const void*>(conv3d_kernel<NT, NP, SD, SHW, TD, TH, MT>), (int)lds, "mvs_conv3d_fwd");
+        if (rc != MVS_OK) return rc;
     }
     const int nsplit = mvs::ceil_div(nt_of(a.Cout), NT);
     dim3 grid(mvs::ceil_div(a.Wo, 16 * MT) * nsplit, mvs::ceil_div(a.Ho, TH), a.B * mvs::ceil_div(a.Do, TD));

@@ -29,11 +29,13 @@
 #include <type_traits>
 
 #include "conv_common.h"
+#include "split3.h"
 
 namespace {
 using namespace mvsconv;
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+using mvsx3::bf16x8;
+using mvsx3::Split3;
+using mvsx3::split3;
 
 // Compile-time geometry of one kernel instance.  CK = input channels per staging pass (8 | 16), SHW = H/W stride (1 | 2), NT = pixel rows
 // per wavefront (the block's tile is 4*NT rows x 16 columns of OUTPUT pixels), MTB = 16-channel output tiles per block.
@@ -58,22 +60,6 @@ struct X3Cfg {
     __host__ __device__ static constexpr int col_index(int c) { return SHW == 1 ? c : (c & 1) * EV + (c >> 1); }
 };
 
-struct Split3 { bf16x8 h, m, l; };
-__device__ __forceinline__ Split3 split3(const float (&v)[8]) {
-    Split3 s;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const __bf16 h = (__bf16)v[e];
-        const float r = v[e] - (float)h;      // exact
-        const __bf16 m = (__bf16)r;
-        const float r2 = r - (float)m;        // exact
-        s.h[e] = h;
-        s.m[e] = m;
-        s.l[e] = (__bf16)r2;
-    }
-    return s;
-}
-
 // packed[(((ct*NCH + chunk)*3 + kd)*STEPS + step)*3 + term][lane][8]:  A[m = ct*16 + (lane & 15)][K block q = 4*step + (lane >> 4)],
 // q -> (tap9 = q / KQ -> (kh, kw), octet = q % KQ), channel = chunk*CK + octet*8 + e; zero for q >= 9*KQ, for rows beyond Cout and for
 // the one extra unit at the end (the kernel prefetches one step ahead).  w = [Cout][Cin][27] fp32.
@@ -92,11 +78,7 @@ __global__ void x3_pack_kernel(const float* __restrict__ w, int Cin, int Cout, i
             const int tap9 = q / KQ, c = chunk * CK + (q % KQ) * 8 + e;
             f = w[((size_t)m * Cin + c) * 27 + kd * 9 + tap9];
         }
-        const __bf16 h = (__bf16)f;
-        const float r = f - (float)h;
-        const __bf16 mm = (__bf16)r;
-        const __bf16 l = (__bf16)(r - (float)mm);
-        v[e] = term == 0 ? h : (term == 1 ? mm : l);
+        v[e] = mvsx3::split3_term(f, term);
     }
     out[idx] = v;
 }
@@ -269,6 +251,7 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
 
     // this block's depth segment: output planes [d_lo, d_hi); input planes d_lo-1 .. d_hi (clipped)
     const int d_lo = seg * a.seg_planes, d_hi = min(D, d_lo + a.seg_planes);
+    if (d_lo >= D) return;                                 // an empty segment owns no output plane (block-uniform; the launchers never create one)
     const int p_first = max(0, d_lo - 1), p_last = min(D - 1, d_hi);
     const int NP = (p_last - p_first + 1) * NCH;           // passes: (input plane, channel chunk)
     for (int pass = 0; pass < NP; ++pass) {
@@ -323,6 +306,242 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same convolution with the NEXT pass's staging running UNDER the current pass's MFMAs.
+// In x3_conv_kernel a pass is [all loads] [wait] [barrier] [split + LDS stores] [barrier] [MFMA phase] and the parts ADD (measured: conv2
+// at stage 4 = 0.068 MFMA + 0.057 staging + 0.041 skeleton/epilogue -> 0.147 ms): two or three co-resident blocks run the same part at the
+// same time.  Here the activations have TWO LDS buffers and one pass is
+//     first depth-tap group, step 0 : the next pass's loads are issued right AFTER that step's weight prefetch (vmcnt retires in order: a
+//                                     wait for weights only has to leave the younger staging loads in flight - the compiler counts that)
+//     ... every step's MFMAs ...
+//     last depth-tap group, last step: split + store into the OTHER buffer (the loads have had the whole MFMA phase to arrive)
+//     one barrier
+// so a wavefront never sits in a staging phase.  The first weights of the next pass are prefetched into a third fragment set during the
+// last step (a pass always starts at buffer parity 0), the staging loads are BUFFER loads (one 32-bit lane offset per item for the whole
+// kernel, channel / depth plane in the scalar offset, out-of-volume pixels read 0 through the descriptor's range check: no 64-bit address
+// arithmetic, no select).  Two buffers of 31 KB mean two blocks per CU for the NT = 4 instance instead of three - with 256 registers each.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <class Cfg>
+__global__ __launch_bounds__(256, 2) void x3_conv_db_kernel(const X3Args a) {
+    const int seg = blockIdx.z % a.nseg;
+    constexpr int CK = Cfg::CK, SHW = Cfg::SHW, NT = Cfg::NT, MTB = Cfg::MTB, KQ = Cfg::KQ, STEPS = Cfg::STEPS, BWC = Cfg::BWC, PB = Cfg::PB,
+                  TERM_BYTES = Cfg::TERM_BYTES, NPIX = Cfg::BH * Cfg::BWC, BUF = Cfg::LDS_BYTES;
+    static_assert(2 * BUF <= 64 * 1024, "two activation buffers must fit the static LDS limit");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kb = lane >> 4;
+    const int tile = blockIdx.x, ctb = blockIdx.y, b = blockIdx.z / a.nseg;
+    const int x0 = (tile % a.tiles_x) * Cfg::TW, y0 = (tile / a.tiles_x) * Cfg::TH;       // output coordinates
+    const int Cin = a.Cin, Cout = a.Cout, D = a.D, H = a.H, W = a.W;
+    const int NCH = Cin / CK;
+    const size_t HW = (size_t)H * W, DHW = (size_t)D * HW, HWo = (size_t)a.Ho * a.Wo;
+
+    const int d_lo = seg * a.seg_planes, d_hi = min(D, d_lo + a.seg_planes);
+    if (d_lo >= D) return;
+    const int p_first = max(0, d_lo - 1), p_last = min(D - 1, d_hi);
+    const int NP = (p_last - p_first + 1) * NCH;           // passes: (input plane, channel chunk)
+
+    unsigned boff[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int q = min(4 * s + kb, Cfg::NKB - 1), tap9 = q / KQ, kh = tap9 / 3, kw = tap9 % 3;
+        boff[s] = (unsigned)((kh * BWC + Cfg::col_index(SHW * n + kw)) * PB + (q % KQ) * 16);
+    }
+
+    f32x4 acc[3][MTB][NT];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MTB; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[s][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bool vec_ok = (a.Wo & 3) == 0;
+    auto store_plane = [&](int od, const f32x4 (&c)[MTB][NT]) {
+#pragma unroll
+        for (int mt = 0; mt < MTB; ++mt) {
+            const int co = (ctb * MTB + mt) * 16 + n;
+            if (co >= Cout) continue;
+            const float sc = a.scale ? a.scale[co] : 1.0f, sh = a.shift ? a.shift[co] : 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int gy = y0 + wave * NT + nt, gx = x0 + kb * 4;
+                if (gy >= a.Ho || gx >= a.Wo) continue;
+                const size_t o = ((size_t)(b * Cout + co) * D + od) * HWo + (size_t)gy * a.Wo + gx;
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = a.scale ? fmaf(c[mt][nt][r], sc, sh) : c[mt][nt][r] + sh;
+                    if (a.relu) v[r] = fmaxf(v[r], 0.0f);
+                }
+                if (vec_ok) {
+                    if (a.residual) {
+                        const f32x4 rs = *reinterpret_cast<const f32x4*>(a.residual + o);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] + rs[r];
+                    }
+                    *reinterpret_cast<f32x4*>(a.y + o) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (gx + r < a.Wo) a.y[o + r] = a.residual ? v[r] + a.residual[o + r] : v[r];
+                }
+            }
+        }
+    };
+
+    // ---- staging through buffer loads: item i = tid + it * 256 -> (channel octet, box pixel); voff = the item's byte offset inside
+    //      (8 channels of the chunk's first octet ...) for depth plane 0 of chunk 0; plane and chunk go into the scalar offset ----
+    constexpr int NI = (KQ * NPIX + 255) / 256;
+    const rsrc_t xin = make_rsrc(a.x + (size_t)b * Cin * DHW, (unsigned)((size_t)Cin * DHW * 4));
+    unsigned voff[NI];
+    int ldst[NI];                                          // LDS byte offset of the item's h row (-1: no item)
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int i = tid + it * 256;
+        const int oct = i / NPIX, v = i % NPIX;
+        const int gy = y0 * SHW - 1 + v / BWC, gx = x0 * SHW - 1 + v % BWC;
+        const bool item = i < KQ * NPIX;
+        voff[it] = (item && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (unsigned)(((size_t)(oct * 8) * DHW + (size_t)gy * W + gx) * 4) : OOB;
+        ldst[it] = item ? ((v / BWC) * BWC + Cfg::col_index(v % BWC)) * PB + oct * 16 : -1;
+    }
+    float pre[NI][8];
+    auto issue_all = [&](int pp, int cc) {
+        const size_t base = (size_t)(cc * CK) * DHW + (size_t)pp * HW;
+#pragma unroll
+        for (int it = 0; it < NI; ++it)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pre[it][e] = (a.ablate & 1) ? 1.0f : buf_load(xin, voff[it], (unsigned)((base + (size_t)e * DHW) * 4));
+    };
+    auto commit_all = [&](unsigned char* buf) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it)
+            if (ldst[it] >= 0 && !(a.ablate & 2)) {
+                const Split3 sp = split3(pre[it]);
+                unsigned char* dst = buf + ldst[it];
+                *reinterpret_cast<bf16x8*>(dst) = sp.h;
+                *reinterpret_cast<bf16x8*>(dst + TERM_BYTES) = sp.m;
+                *reinterpret_cast<bf16x8*>(dst + 2 * TERM_BYTES) = sp.l;
+            }
+    };
+
+    bf16x8 wbuf[2][MTB][3];                                // ping-pong weight fragments; the parity runs on ACROSS passes (see kd_steps)
+    auto load_w = [&](const bf16x8* wk, bf16x8 (&aw)[MTB][3]) {
+#pragma unroll
+        for (int mt = 0; mt < MTB; ++mt)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) aw[mt][t] = wk[(size_t)mt * NCH * 3 * Cfg::FRAGS_PER_KD + t * 64];
+    };
+    // weights of (chunk, first valid depth tap) of the pass that stages plane p
+    auto first_weights = [&](int p, int chunk) {
+        const int kd_lo = max(0, p + 2 - d_hi);
+        return a.wp + ((size_t)((ctb * MTB) * NCH + chunk) * 3 + kd_lo) * Cfg::FRAGS_PER_KD + lane;
+    };
+
+    const unsigned char* cur_buf = lds;                    // block-uniform, set per pass
+    unsigned char* nxt_buf = lds + BUF;
+    int np = 0, nchunk = 0;                                // the next pass's (plane, chunk); has_next says whether there is one
+    bool has_next = false;
+    const bf16x8* wk_next = a.wp;
+
+    auto load_b = [&](int s, int nt, bf16x8 (&bf)[3]) {
+        const unsigned char* bp = cur_buf + (SHW * (wave * NT + nt)) * (BWC * PB) + boff[s];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) bf[t] = *reinterpret_cast<const bf16x8*>(bp + t * TERM_BYTES);
+    };
+    // one depth tap (STEPS steps).  do_issue: this is the pass's FIRST group - the next pass's loads go out behind step 0's weight prefetch;
+    // do_commit: this is its LAST group - after the last step's MFMAs the loads are split and stored into the other buffer.
+    auto kd_steps = [&](auto kd_tag, auto p_tag, const bf16x8* wk, bool more, bool do_issue, bool do_commit) {
+        constexpr int KD = decltype(kd_tag)::value, P = decltype(p_tag)::value, SET = 2 - KD;
+        bf16x8 bf[2][3];
+        load_b(0, 0, bf[0]);
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int cur = (P + s) & 1;
+            // the next step's weights; at a pass's very last step the buffer is free for the NEXT pass's first step, which therefore
+            // starts at the flipped parity (STEPS is odd: every group flips it once)
+            if (s + 1 < STEPS || more) load_w(wk + (size_t)(s + 1) * 192, wbuf[cur ^ 1]);
+            else if (has_next) load_w(wk_next, wbuf[cur ^ 1]);
+            if (s == 0 && do_issue && has_next) issue_all(np, nchunk);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int j = s * NT + nt;
+                if (j + 1 < STEPS * NT) load_b((j + 1) / NT, (j + 1) % NT, bf[(j + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 xh = bf[j & 1][0], xm = bf[j & 1][1], xl = bf[j & 1][2];
+#pragma unroll
+                for (int mt = 0; mt < MTB; ++mt) {
+                    f32x4 c = acc[SET][mt][nt];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, wbuf[cur][mt][1], c, 0, 0, 0);     // smallest products first
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wbuf[cur][mt][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wbuf[cur][mt][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wbuf[cur][mt][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, wbuf[cur][mt][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wbuf[cur][mt][0], c, 0, 0, 0);
+                    acc[SET][mt][nt] = c;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (do_commit && has_next) commit_all(nxt_buf);
+    };
+
+    // ---- prologue: the first pass's plane is staged the plain way; its first weights travel meanwhile ----
+    load_w(first_weights(p_first, 0), wbuf[0]);
+    issue_all(p_first, 0);
+    commit_all(lds);
+    __syncthreads();
+
+    int par = 0;                                           // buffer parity of the next depth-tap group's first step
+    for (int pass = 0; pass < NP; ++pass) {
+        const int p = p_first + pass / NCH, chunk = pass % NCH;
+        cur_buf = lds + (pass & 1) * BUF;
+        nxt_buf = lds + ((pass & 1) ^ 1) * BUF;
+        has_next = pass + 1 < NP;
+        np = p_first + (pass + 1) / NCH;
+        nchunk = (pass + 1) % NCH;
+        wk_next = first_weights(np, nchunk);
+        // depth taps of input plane p whose output plane od = p + 1 - kd lies in [d_lo, d_hi): a contiguous, block-uniform range
+        const int kd_lo = max(0, p + 2 - d_hi), kd_hi = min(2, p + 1 - d_lo);
+        const bf16x8* wk = a.wp + ((size_t)((ctb * MTB) * NCH + chunk) * 3 + kd_lo) * Cfg::FRAGS_PER_KD + lane;
+        if (!(a.ablate & 4)) {
+            if (kd_lo == 0) {
+                if (par == 0) kd_steps(ic<0>{}, ic<0>{}, wk, kd_hi >= 1, true, kd_hi == 0); else kd_steps(ic<0>{}, ic<1>{}, wk, kd_hi >= 1, true, kd_hi == 0);
+                wk += Cfg::FRAGS_PER_KD;
+                par ^= 1;
+            }
+            if (kd_lo <= 1 && kd_hi >= 1) {
+                const bool first = kd_lo == 1;
+                if (par == 0) kd_steps(ic<1>{}, ic<0>{}, wk, kd_hi >= 2, first, kd_hi == 1); else kd_steps(ic<1>{}, ic<1>{}, wk, kd_hi >= 2, first, kd_hi == 1);
+                wk += Cfg::FRAGS_PER_KD;
+                par ^= 1;
+            }
+            if (kd_hi >= 2) {
+                const bool first = kd_lo == 2;
+                if (par == 0) kd_steps(ic<2>{}, ic<0>{}, wk, false, first, true); else kd_steps(ic<2>{}, ic<1>{}, wk, false, first, true);
+                par ^= 1;
+            }
+        } else if (has_next) {                             // diagnostics: staging without the MFMA phase
+            issue_all(np, nchunk);
+            commit_all(nxt_buf);
+        }
+        if (chunk == NCH - 1) {
+            if (p - 1 >= d_lo) store_plane(p - 1, acc[0]);
+#pragma unroll
+            for (int mt = 0; mt < MTB; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[0][mt][nt] = acc[1][mt][nt];
+                    acc[1][mt][nt] = acc[2][mt][nt];
+                    acc[2][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+        if (has_next) __syncthreads();                     // this pass's fragment reads are done, the next pass's plane is visible
+    }
+    if (p_last == D - 1 && d_hi == D) store_plane(D - 1, acc[0]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // Transposed convolution, stride (1,2,2), kernel 3, padding 1, output_padding (0,1,1) (CostRegNet3D's conv7 / conv9 / conv11,
 // models/module.py:562-575), same split form.  out[od, oh, ow] gathers in[od + 1 - kd, (oh + 1 - kh) / 2, (ow + 1 - kw) / 2] where
 // divisible, so an output pixel of row parity ph and column parity pw sees only the taps kh in KH(ph), kw in KW(pw):
@@ -372,11 +591,7 @@ __global__ void x3_deconv_pack_kernel(const float* __restrict__ w, int Cin, int 
     for (int e = 0; e < 8; ++e) {
         float f = 0.0f;
         if (ok) f = w[((size_t)(chunk * 16 + oct * 8 + e) * Cout + n) * 27 + kd * 9 + kh * 3 + kw];
-        const __bf16 h = (__bf16)f;
-        const float r = f - (float)h;
-        const __bf16 mm = (__bf16)r;
-        const __bf16 l = (__bf16)(r - (float)mm);
-        v[e] = term == 0 ? h : (term == 1 ? mm : l);
+        v[e] = mvsx3::split3_term(f, term);
     }
     out[idx] = v;
 }
@@ -485,6 +700,7 @@ __global__ __launch_bounds__(256, 2) void x3_deconv_kernel(const X3Args a) {
     };
 
     const int d_lo = seg * a.seg_planes, d_hi = min(D, d_lo + a.seg_planes);
+    if (d_lo >= D) return;                                 // empty segment (block-uniform)
     const int p_first = max(0, d_lo - 1), p_last = min(D - 1, d_hi);
     for (int p = p_first; p <= p_last; ++p) {
         // depth taps whose output plane od = p - 1 + kd lies in [d_lo, d_hi)
@@ -576,13 +792,23 @@ int launch_x3(X3Args a, int B, hipStream_t s) {
     const int64_t blocks = (int64_t)a.tiles_x * ty * mvs::ceil_div(a.Cout, 16 * Cfg::MTB) * B;
     int nseg = 1;
     while (nseg * 2 <= a.D / 2 && blocks * nseg < 1536) nseg *= 2;
-    a.nseg = nseg;
     a.seg_planes = mvs::ceil_div(a.D, nseg);
+    nseg = mvs::ceil_div(a.D, a.seg_planes);               // no empty segments (D = 9: 4 x 3 planes would leave segment 3 = [9, 9) writing plane D-1)
+    a.nseg = nseg;
     {
         const char* e = getenv("MVS_X3_ABLATE");
         a.ablate = e ? atoi(e) : 0;
     }
-    hipLaunchKernelGGL((x3_conv_kernel<Cfg>), dim3(a.tiles_x * ty, mvs::ceil_div(a.Cout, 16 * Cfg::MTB), B * nseg), dim3(256), 0, s, a);
+    const dim3 grid(a.tiles_x * ty, mvs::ceil_div(a.Cout, 16 * Cfg::MTB), B * nseg);
+    if constexpr (2 * Cfg::LDS_BYTES <= 64 * 1024) {
+        // the double-buffered form (staging under the MFMAs) wherever two activation buffers fit; MVS_X3_DB=0: the round-3 kernel (diagnostics)
+        const char* e = getenv("MVS_X3_DB");
+        if (!e || atoi(e) != 0) {
+            hipLaunchKernelGGL((x3_conv_db_kernel<Cfg>), grid, dim3(256), 0, s, a);
+            return mvs::finish_launch("mvs_conv3d_x3_fwd");
+        }
+    }
+    hipLaunchKernelGGL((x3_conv_kernel<Cfg>), grid, dim3(256), 0, s, a);
     return mvs::finish_launch("mvs_conv3d_x3_fwd");
 }
 
@@ -616,6 +842,7 @@ extern "C" int mvs_conv3d_x3_fwd(const float* x, const void* wpacked, const floa
     MVS_REQUIRE(x3_plan(Cin, Cout, sd, shw, &pl), "mvs_conv3d_x3_fwd: Cin=%d Cout=%d stride (%d,%d,%d) is not built", Cin, Cout, sd, shw, shw);
     MVS_REQUIRE(B >= 1 && B <= 65535 && D >= 1 && H >= 1 && W >= 1, "mvs_conv3d_x3_fwd: bad shape B=%d D=%d H=%d W=%d", B, D, H, W);
     MVS_REQUIRE(!scale || shift, "mvs_conv3d_x3_fwd: scale without shift");
+    MVS_REQUIRE((int64_t)Cin * D * H * W * 4 < ((int64_t)1 << 31), "mvs_conv3d_x3_fwd: one sample's input exceeds the 2 GiB buffer window");
     X3Args a;
     a.x = x; a.wp = static_cast<const bf16x8*>(wpacked); a.scale = scale; a.shift = shift; a.residual = residual; a.y = y;
     a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = relu;
@@ -661,8 +888,9 @@ extern "C" int mvs_deconv3d_x3_fwd(const float* x, const void* wpacked, const fl
     const int64_t blocks = (int64_t)a.tiles_x * ty * cts * B;
     int nseg = 1;
     while (nseg * 2 <= D / 2 && blocks * nseg < 1536) nseg *= 2;
-    a.nseg = nseg;
     a.seg_planes = mvs::ceil_div(D, nseg);
+    nseg = mvs::ceil_div(D, a.seg_planes);                 // no empty segments
+    a.nseg = nseg;
     {
         const char* e = getenv("MVS_X3_ABLATE");
         a.ablate = e ? atoi(e) : 0;

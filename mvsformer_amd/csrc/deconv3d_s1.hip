@@ -287,14 +287,9 @@ int launch_s1(const float* x, const float* wp, const float* scale, const float* 
               int Di, int Hi, int Wi, int relu, hipStream_t s, const float* prob_w = nullptr, const float* prob_b = nullptr) {
     constexpr int CC = 8;
     constexpr size_t lds = (size_t)(CC * pad_cs(4 * 3 * 65, 1) + (CC / 4) * 3 * 4 * npd_of(NC)) * 4;
-    static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(deconv3d_s1_kernel<NC, PROB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
-            mvs::set_error("mvs_deconv3d_fwd: cannot raise dynamic LDS to %zu bytes", lds);
-            return -(1000 + (int)hipGetLastError());
-        }
-        attr_done = true;
+    if (lds > 48 * 1024) {
+        const int rc = mvs::ensure_dynamic_lds(reinterpret_cast<const void*>(deconv3d_s1_kernel<NC, PROB>), (int)lds, "mvs_deconv3d_fwd");
+        if (rc != MVS_OK) return rc;
     }
     dim3 grid(mvs::ceil_div(Wi, 64), mvs::ceil_div(Hi, 2), B * mvs::ceil_div(Di, 2));
     hipLaunchKernelGGL((deconv3d_s1_kernel<NC, PROB>), grid, dim3(256), lds, s, x, wp, scale, shift, res, y, Cin, Di, Hi, Wi, relu, prob_w,

@@ -1,0 +1,59 @@
+// The three-term bf16 split every "x3" kernel is built on (conv3d_x3.hip, vis_net_x3.hip, tail_x3.hip): an fp32 value v is EXACTLY
+// h + m + l with h = bf16(v), m = bf16(v - h), l = bf16(v - h - m) - three 8-bit significands cover fp32's 24 bits, every difference is
+// exact - so a product x*w = xh*wh + (xh*wm + xm*wh) + (xh*wl + xl*wh + xm*wm) + terms <= 2^-24 |x*w| is six v_mfma_f32_16x16x32_bf16
+// with fp32 accumulation.  Edges (include/mvs_hip.h "Arithmetic", tests/test_hip_x3.py):
+//   * |v| above the largest finite bf16 (0x7F7F0000 = 3.3895e38) would round to +-Inf: h is clamped to that value (one v_med3_f32), the
+//     remainder (< 2^120) fits m and l exactly, so finite inputs up to FLT_MAX keep the exact three-term form;
+//   * +-Inf / NaN: the remainder v - h is Inf / NaN, so at least one term is non-finite and every output the value reaches is non-finite;
+//   * subnormal v: h, m, l are subnormal bf16 values; the matrix cores may flush them (absolute error <= 2^-126 per operand).
+#pragma once
+
+namespace mvsx3 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr float BF16_MAX = 3.3895313892515355e38f;         // 0x7F7F0000
+
+__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)__builtin_amdgcn_fmed3f(v, -BF16_MAX, BF16_MAX);
+    const float r = v - (float)h;                          // exact
+    m = (__bf16)r;
+    l = (__bf16)(r - (float)m);                            // exact difference, exact conversion (8 bits left)
+}
+
+struct Split3 { bf16x8 h, m, l; };
+__device__ __forceinline__ Split3 split3(const float (&v)[8]) {
+    Split3 s;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        __bf16 h, m, l;
+        split3(v[e], h, m, l);
+        s.h[e] = h;
+        s.m[e] = m;
+        s.l[e] = l;
+    }
+    return s;
+}
+
+// one term (0 = h, 1 = m, 2 = l) of the split of f: the weight-packing kernels
+__device__ __forceinline__ __bf16 split3_term(float f, int term) {
+    __bf16 h, m, l;
+    split3(f, h, m, l);
+    return term == 0 ? h : (term == 1 ? m : l);
+}
+
+// six MFMAs of one fp32-equivalent K = 32 step, smallest products first; a = first MFMA operand's terms, b = second's
+__device__ __forceinline__ __attribute__((ext_vector_type(4))) float mfma6(const bf16x8& ah, const bf16x8& am, const bf16x8& al, const bf16x8& bh,
+                                                                          const bf16x8& bm, const bf16x8& bl,
+                                                                          __attribute__((ext_vector_type(4))) float c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+    return c;
+}
+
+}  // namespace mvsx3

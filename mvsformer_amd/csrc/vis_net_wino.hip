@@ -339,23 +339,13 @@ extern "C" int mvs_vis_wino_fwd(const float* entropy, const float* params, const
     MVS_REQUIRE(N >= 1 && H >= 1 && W >= 1, "mvs_vis_wino_fwd: bad shape N=%d H=%d W=%d", N, H, W);
     const int ntx = mvs::ceil_div(W, TW), nty = mvs::ceil_div(H, TH);
     MVS_REQUIRE((int64_t)N * ntx * nty < ((int64_t)1 << 31), "mvs_vis_wino_fwd: too many tiles");
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
-            ncu = 256;
-    }
+    const int ncu = mvs::device_cus();
     const int ntiles = N * ntx * nty;
     const int blocks = ntiles < 2 * ncu ? ntiles : 2 * ncu;       // persistent: two resident blocks per CU
     constexpr size_t lds = (size_t)(16 * (A1PL + A2PL) + INH * INW) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(vis_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess) {
-            mvs::set_error("mvs_vis_wino_fwd: cannot raise dynamic LDS to %zu bytes", lds);
-            return MVS_EINVAL;
-        }
-        attr_done = true;
+    {
+        const int rc = mvs::ensure_dynamic_lds(reinterpret_cast<const void*>(vis_wino_kernel), (int)lds, "mvs_vis_wino_fwd");
+        if (rc != MVS_OK) return rc;
     }
     hipLaunchKernelGGL(vis_wino_kernel, dim3(blocks), dim3(256), lds, MVS_STREAM(stream), entropy, params, prepared, N, H, W, ntx, nty,
                        weight);

@@ -23,12 +23,13 @@
 #include <stdlib.h>
 
 #include "conv_common.h"
+#include "split3.h"
 
 namespace {
 using namespace mvsconv;
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+using mvsx3::bf16x4;
+using mvsx3::bf16x8;
+using mvsx3::split3;
 
 constexpr int T = 16;                                      // output tile edge
 constexpr int INW = T + 6, A1W = T + 4, A2W = T + 2;       // entropy (halo 3), layer-1 output (halo 2), layer-2 output (halo 1)
@@ -43,13 +44,6 @@ static_assert(A1N % 16 == 0, "layer 1 tiles are full");
 // offsets inside the MVS_VIS_PARAM_FLOATS block (vis_net.hip)
 constexpr int OFF_W0 = 0, OFF_S0 = 144, OFF_B0 = 160, OFF_W1 = 176, OFF_S1 = 2480, OFF_B1 = 2496, OFF_W2 = 2512, OFF_S2 = 3664,
               OFF_B2 = 3672, OFF_W3 = 3680, OFF_B3 = 3688;
-
-__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)v;
-    const float r = v - (float)h;                          // exact
-    m = (__bf16)r;
-    l = (__bf16)(r - (float)m);                            // exact difference, exact conversion (8 bits left)
-}
 
 // prepared[(layer 2: step 0..4 | layer 3: step 5..10)][term][lane][8]:  the MFMA A operand, lane = kb * 16 + m.
 //   layer 2: m = output channel, K block 2*step + (kb >> 1) = tap (9 = zero), channels (kb & 1) * 8 + e
@@ -330,16 +324,13 @@ extern "C" int mvs_vis_x3_fwd(const float* entropy, const float* params, const v
     MVS_REQUIRE(N >= 1 && H >= 1 && W >= 1, "mvs_vis_x3_fwd: bad shape N=%d H=%d W=%d", N, H, W);
     const int ntx = mvs::ceil_div(W, T), nty = mvs::ceil_div(H, T);
     MVS_REQUIRE((int64_t)N * ntx * nty < ((int64_t)1 << 31), "mvs_vis_x3_fwd: too many tiles");
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
-            ncu = 256;
-    }
+    const int ncu = mvs::device_cus();                         // of the CURRENT device (cached per device id)
     const int ntiles = N * ntx * nty;
     const int blocks = ntiles < 2 * ncu ? ntiles : 2 * ncu;       // persistent: two resident blocks per CU
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&vis_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    MVS_REQUIRE(attr == hipSuccess, "mvs_vis_x3_fwd: cannot reserve %d bytes of LDS: %s", LDS_BYTES, hipGetErrorString(attr));
+    {   // 71.5 KB of dynamic LDS per block: more than the 64 KB of earlier CDNA parts - gfx950 only, asked for once per device
+        const int rc = mvs::ensure_dynamic_lds(reinterpret_cast<const void*>(&vis_x3_kernel), LDS_BYTES, "mvs_vis_x3_fwd");
+        if (rc != MVS_OK) return rc;
+    }
     hipLaunchKernelGGL(vis_x3_kernel, dim3(blocks), dim3(256), LDS_BYTES, MVS_STREAM(stream), entropy, params, static_cast<const bf16x8*>(prepared), N,
                        H, W, ntx, nty, weight, getenv("MVS_VIS_ABLATE") ? atoi(getenv("MVS_VIS_ABLATE")) : 0);
     return mvs::finish_launch("mvs_vis_x3_fwd");

@@ -280,14 +280,9 @@ int launch_wgrad_tiled(const float* A, const float* Bt, float* dW, int nbatch, i
     if (gy > ntiles) gy = ntiles;
     if (gy < 1) gy = 1;
     constexpr size_t lds = (size_t)(T::NA + T::NBF) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tiled_kernel<MT, SHW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
-            mvs::set_error("mvs_conv3d_wgrad: cannot raise dynamic LDS to %zu bytes", lds);
-            return MVS_EINVAL;
-        }
-        attr_done = true;
+    if (lds > 48 * 1024) {
+        const int rc = mvs::ensure_dynamic_lds(reinterpret_cast<const void*>(wgrad_tiled_kernel<MT, SHW>), (int)lds, "mvs_conv3d_wgrad");
+        if (rc != MVS_OK) return rc;
     }
     hipLaunchKernelGGL((wgrad_tiled_kernel<MT, SHW>), dim3(nchunk, (unsigned)gy), dim3(256), lds, s, A, Bt, dW, CA, CB, Dp, Hp, Wp, Db, Hb,
                        Wb, sd, nbatch);

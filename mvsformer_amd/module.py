@@ -368,6 +368,15 @@ class CostRegNet3D(nn.Module):
                 _publish_cache()
                 self._dcache["conv11"] = c
             _, packed, scale, shift, _sd = c
+            # split form (csrc/tail_x3.hip) for the shape it is built for (16 -> 8) from X3_MIN_VOXELS up; MVS_TAIL=fp32 keeps the fp32-MFMA tail
+            if seq[0].in_channels == 16 and os.environ.get("MVS_CONV_X3", "1") != "0" and os.environ.get("MVS_TAIL", "x3") == "x3" \
+                    and 4 * y.shape[2] * y.shape[3] * y.shape[4] >= int(os.environ.get("MVS_CONV_X3_MIN_VOXELS", X3_MIN_VOXELS)):
+                px = self._dcache.get("conv11.x3")
+                if px is None or px[0] != key:
+                    px = (key, ops.tail_x3_pack(_f32c(seq[0].weight)))
+                    _publish_cache()
+                    self._dcache["conv11.x3"] = px
+                return ops.tail_x3(y, px[1], scale, shift, skip, w, b, relu=True)
             return ops.deconv3d_prob1(y, packed, seq[0].in_channels, scale, shift, skip, w, b, relu=True)
         return ops.prob1(self._up("conv11", y, skip), w, b).squeeze(1)
 

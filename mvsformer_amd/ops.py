@@ -528,6 +528,34 @@ def deconv3d_prob1(x, wpacked, cin, scale, shift, residual, prob_w, prob_b, relu
     return logits
 
 
+def tail_x3_pack(weight: torch.Tensor) -> torch.Tensor:
+    """conv11's ConvTranspose3d weight ``[16,8,3,3,3]`` -> pre-split bf16 MFMA fragments for :func:`tail_x3` (uint8 storage)."""
+    _chk(weight, "conv11 weight")
+    if tuple(weight.shape) != (16, 8, 3, 3, 3):
+        raise _lib.MvsHipError("tail_x3_pack: weight %s is not [16,8,3,3,3]" % (tuple(weight.shape),))
+    packed = torch.empty(int(_lib.load().mvs_tail_x3_packed_bytes()), device=weight.device, dtype=torch.uint8)
+    _call("mvs_tail_x3_pack_weights", None, _ptr(weight), _ptr(packed), _stream())
+    return packed
+
+
+def tail_x3(x, wpacked, scale, shift, residual, prob_w, prob_b, relu=True):
+    """CostRegNet3D tail in split form: ``prob(residual + relu(bn(conv11(x))))`` -> logits ``[B,D,2H,2W]`` (include/mvs_hip.h)."""
+    _chk(x, "x"), _chk(wpacked, "packed weights", torch.uint8), _chk(prob_w, "prob.weight"), _opt(prob_b, "prob.bias")
+    _opt(scale, "scale"), _opt(shift, "shift")
+    B, C, D, H, W = x.shape
+    if C != 16:
+        raise _lib.MvsHipError("tail_x3: %d input channels (built for 16)" % C)
+    if residual is not None:
+        _chk(residual, "residual")
+        if tuple(residual.shape) != (B, 8, D, 2 * H, 2 * W):
+            raise _lib.MvsHipError("residual shape %s != %s" % (tuple(residual.shape), (B, 8, D, 2 * H, 2 * W)))
+    logits = torch.empty(B, D, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+    tag = ("x3_tail_kernel<16,8,prob>", "flops", 2.0 * 27 * 16 * 8 * B * D * H * W)
+    _call("mvs_tail_x3_fwd", tag, _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(prob_w), _ptr(prob_b),
+          _ptr(logits), B, D, H, W, int(relu), _stream())
+    return logits
+
+
 def prob3(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     _chk(x, "x"), _chk(w, "prob weight")
     B, C, D, H, W = x.shape

@@ -583,6 +583,34 @@ def test_vis_x3_matches_valu_kernel(dev, shape):
     assert (a2 - b2).abs().max().item() < 2e-4, (a2 - b2).abs().max().item()
 
 
+@pytest.mark.parametrize("shape", [(2, 96, 128), (1, 67, 83), (3, 160, 64)])
+def test_vis_x3_vs_oracle(dev, shape):
+    """The split-form visibility CNN against the CPU restatement of the reference's ``vis`` Sequential (oracle.ref_torch.vis_net, itself
+    pinned to the real reference by tests/golden) - not against another kernel of this library: a StageNet with fresh weights and
+    randomized BatchNorm statistics, entropies over the range the sweep produces (0 .. log D), maps of several tiles with ragged edges."""
+    import mvsformer_amd as m
+    from mvsformer_amd import ops
+    from oracle import ref_torch
+    torch.manual_seed(sum(shape))
+    net = m.StageNet(dict(base_ch=8, fusion_type="cnn", depth_type="ce"), 8, 0).eval()
+    m.randomize_bn_(net, 11)
+    N, H, W = shape
+    ent = torch.rand(N, H, W) * 2.0
+    ent[:, : H // 3] *= 0.05                                   # a confident region (entropy near 0) next to an ambiguous one
+    with torch.no_grad():
+        want = ref_torch.vis_net(ent.unsqueeze(1), net.state_dict(), prefix="vis").squeeze(1)
+    net = net.to(dev)
+    prm, prep = net._vis_params()
+    assert prep is not None and prep.dtype == torch.uint8      # the default path is the x3 kernel
+    got = ops.vis_x3(ent.to(dev), prm, prep).cpu()
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() < 2e-5, (got - want).abs().max().item()
+    # the logit itself (before the sigmoid flattens differences): recover it from both sides where the sigmoid is not saturated
+    mask = (want > 1e-3) & (want < 1 - 1e-3)
+    lg, lw = torch.logit(got[mask].double()), torch.logit(want[mask].double())
+    assert (lg - lw).abs().max().item() < 2e-4
+
+
 @pytest.mark.parametrize("shape", [(1, 16, 2, 4, 12), (2, 16, 3, 5, 72), (1, 8, 1, 2, 4)])
 def test_fused_conv11_prob_matches_two_launches(dev, shape):
     """mvs_deconv3d_prob1_fwd == mvs_deconv3d_fwd followed by the 1x1x1 conv, with and without skip tensor / bias."""
