@@ -353,6 +353,53 @@ def main(args):
         roofline_cv["gather_bound_source"] = ("profiles/r03_gather_bound.json (tools/gather_bound.py: the same tap addresses, no arithmetic, one launch per "
                                               "gathering sweep); measured on another box of the pool, not in this run")
 
+    # ---- extra key: the same cost-volume build on SMOOTH hypotheses (a band around the true surface - what a trained checkpoint predicts,
+    #      not the noisy ones of a random-weight cascade): per stage the direct gather pair and the LDS-tiled pair (whose reuse only pays
+    #      when neighbouring pixels sample neighbouring texels) are both timed and the faster one is taken.  `value` is NOT affected. ----
+    roofline_cv_smooth = None
+    if rank == 0 and world == 1 and not args.no_other_configs and (args.height, args.width, args.batch) == (1152, 1536, 1):
+        scene = synth.make_scene(args.views, args.height, args.width, seed=0)
+        per_stage, total_ms = {}, 0.0
+
+        def t_ms(fn, n=10):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n
+        for i in range(1, 5):
+            k = "stage%d" % i
+            f = feats[k].contiguous()
+            Bf, Vf, Cf, Hf, Wf = f.shape
+            hyp_c = out[k]["depth_values"].contiguous()
+            Df = hyp_c.shape[1]
+            z = synth.plane_depth(scene, synth.STAGE_SCALES[i - 1], device=dev)
+            half = ((1.0 / hyp_c.min(1)[0] - 1.0 / hyp_c.max(1)[0]) * 0.5).mean()
+            hyp_s = (1.0 / (1.0 / z[None, None] + torch.linspace(-1, 1, Df, device=dev).view(1, Df, 1, 1) * half)).contiguous()
+            rt = ops.proj_prepare(proj[k])
+            wgt = torch.rand(Bf, Vf - 1, Hf, Wf, device=dev)
+            fcl = ops.to_channels_last(f)
+            t_tr = t_ms(lambda: ops.to_channels_last(f))
+            direct = t_tr + t_ms(lambda: ops.cv_entropy(fcl, rt, hyp_s, 8)) + t_ms(lambda: ops.cv_aggregate(fcl, rt, hyp_s, wgt, 8, True))
+            tiled = None
+            if ops.cv_tiled_supported(f):
+                tiled = t_ms(lambda: ops.cv_tiled_entropy(f, rt, hyp_s, 8)) + t_ms(lambda: ops.cv_tiled_aggregate(f, rt, hyp_s, wgt, 8, True))
+            best = min(direct, tiled) if tiled is not None else direct
+            per_stage[k] = {"direct_incl_transpose_ms": round(direct, 4), "tiled_ms": round(tiled, 4) if tiled is not None else None,
+                            "chosen": "tiled" if tiled is not None and tiled < direct else "direct"}
+            total_ms += best
+            del fcl, wgt, hyp_s
+        roofline_cv_smooth = {"bound": "hbm", "algorithmic_bytes_per_depth_map": cv_bytes, "ms_per_depth_map": round(total_ms, 4),
+                              "achieved": round(cv_bytes / (total_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(cv_bytes / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "stages": per_stage,
+                              "note": "hypotheses = a smooth band around the true surface (same band width as the cascade's own); the pair "
+                                      "of sweeps is chosen per stage by timing both; standalone launches, not part of `value`"}
+
     # ---- BASELINE configs[3] / configs[4] shapes through the same cascade (short runs, extra keys; not the judged metric) ----
     other = None
     if rank == 0 and world == 1 and not args.no_other_configs:
@@ -450,6 +497,7 @@ def main(args):
             "ranks_seen": dist.get_world_size() if world > 1 else 1,
             "kernel_ms_sum": round(sum(e["ms_per_step"] for e in kernels), 3),
             "latency_ms_single_stream": latency["median"] if latency else None, "latency": latency,
+            "roofline_cost_volume_smooth": roofline_cv_smooth,
             "cpu_baseline": cpu, "roofline_cost_volume": roofline_cv, "roofline": roofline,
             "max_rel_depth_err": parity["max_rel_depth_err"] if parity else None,
         }

@@ -129,7 +129,8 @@ int mvs_cv_aggregate_fwd(const float* feat, const float* rt, const float* depth,
  * (models/mvsformer_model.py:73-105,151-158).  There the V-1 per-view correlation volumes [G,D,H,W] fit the 256 MB
  * Infinity Cache (113 / 226 MB at stages 1 / 2 of BASELINE configs[1]), so sweep A' keeps them - and the per-view eval
  * similarity - in `store`, and sweep B' is a pure stream over the store: no second gather sweep.
- *   mvs_cv_corr_store_bytes  size of `store` for a shape (-1 if the shape is not built: C must be 32 or 64, G 8)
+ *   mvs_cv_corr_store_bytes  size of `store` for a shape (-1 if the shape is not built: C must be 32 or 64, G 8, and D small enough for
+ *                     mvs_cv_corr_fwd's per-pixel LDS rows - about D <= 300 at C = 32; the caller then uses the recomputing sweeps)
  *   mvs_cv_corr_fwd   feat [B,V,H,W,C], rt, depth as in mvs_cv_entropy_fwd -> entropy [B,V-1,H,W] (bit-identical to
  *                     mvs_cv_entropy_fwd's) + store; flags as above
  *   mvs_cv_merge_fwd  store + weight [B,V-1,H,W] + depth -> volume [B,G,D,H,W] (bit-identical to mvs_cv_aggregate_fwd's on the

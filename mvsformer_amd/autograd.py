@@ -74,7 +74,10 @@ def _momentum(bn) -> float:
 
 
 def _wino_ok(stride, cin, cout, x) -> bool:
-    """Stride-1 layers with 16/32/48/64 output channels take the Winograd F(2x2,3x3) kernel (MVS_CONV_WINO=0 disables)."""
+    """TRAINING forward: stride-1 layers with 16/32/48/64 output channels take the Winograd F(2x2,3x3) fp32 kernel (MVS_CONV_WINO=0
+    disables).  The eval path prefers the split-form bf16 kernels instead (module.Conv3d: Winograd there is opt-in, MVS_CONV_WINO=1);
+    training keeps fp32 MFMA arithmetic end to end, and the Winograd kernel is bit-reproducible in the shipped build (no packed fp32
+    instructions: DESIGN.md 4.7c)."""
     return tuple(stride) == (1, 1) and os.environ.get("MVS_CONV_WINO", "1") != "0" and \
         ops.conv3d_wino_supported(cin, cout, *x.shape[2:])
 

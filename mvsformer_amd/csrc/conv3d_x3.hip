@@ -53,10 +53,16 @@ struct X3Cfg {
     static constexpr int TERM_BYTES = BH * BWC * PB;
     static constexpr int LDS_BYTES = 3 * TERM_BYTES;
     static constexpr int FRAGS_PER_KD = STEPS * 3 * 64;        // bf16x8 units of one (cout tile, chunk, kd)
-    static constexpr int MIN_BLOCKS = (MTB == 1 && CK == 16) ? 3 : 2;   // blocks per CU the register budget is set for
+#ifndef X3_MB_MTB2
+#define X3_MB_MTB2 2
+#endif
+#ifndef X3_MB_CK8
+#define X3_MB_CK8 3      // conv1's instance (8 -> 16, stride 2) is HBM-bound (340 MB at stage 4): a third block per CU (164 registers, 3 x 52 KB of
+#endif                   // LDS) keeps 50 % more loads in flight - measured 0.140 -> 0.130 ms at stage 4, 0.088 -> 0.076 at stage 3 (round 4)
+    static constexpr int MIN_BLOCKS = (MTB == 1 && CK == 16) ? 3 : ((SHW == 1 && MTB == 2) ? X3_MB_MTB2 : (CK == 8 ? X3_MB_CK8 : 2));   // blocks per CU the register budget is set for
     // B fragments of the next (step, row) item read under the current item's MFMAs (+2...6 % measured); not where the 168-register budget
     // of three blocks per CU has no room for the second fragment set (<16,1,4,1>: 16 spills, -5 %)
-    static constexpr bool BPIPE = !(MTB == 1 && CK == 16 && NT == 4);
+    static constexpr bool BPIPE = MIN_BLOCKS < 3;
     __host__ __device__ static constexpr int col_index(int c) { return SHW == 1 ? c : (c & 1) * EV + (c >> 1); }
 };
 
@@ -92,7 +98,6 @@ struct X3Args {
     float* y;
     int Cin, Cout, D, H, W, Ho, Wo, relu, tiles_x;
     int seg_planes, nseg;           // depth segments: block z = batch * nseg + segment
-    int ablate;                     // diagnostics (MVS_X3_ABLATE): bit 0 skips the staging loads, bit 1 the split + LDS stores, bit 2 the MFMA phase
 };
 
 template <int V>
@@ -177,35 +182,37 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
     // step's weights (contiguous in memory, running on into the next depth tap) into the other buffer (measured: 10-20 % over loading
     // each step's weights right before its MFMAs).  KD, P and s are compile-time, so every register index is static.
     // staging: item i = tid + it * 256 -> (channel octet, box pixel); the 8 channel planes of the pixel are 8 coalesced dword loads
+    // staging through BUFFER loads (round 4): one 32-bit lane offset per item for the whole kernel, channel chunk / depth plane in the
+    // scalar offset, out-of-volume pixels read 0 through the descriptor's range check - no 64-bit address arithmetic, no select
     constexpr int NI = (KQ * NPIX + 255) / 256;
+    const rsrc_t xin = make_rsrc(xb, (unsigned)((size_t)Cin * DHW * 4));
+    unsigned voff[NI];
+    int ldst[NI];                                          // LDS byte offset of the item's h row (-1: no item)
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int i = tid + it * 256;
+        const int oct = i / NPIX, v = i % NPIX;
+        const int gy = y0 * SHW - 1 + v / BWC, gx = x0 * SHW - 1 + v % BWC;
+        const bool item = i < KQ * NPIX;
+        voff[it] = (item && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (unsigned)(((size_t)(oct * 8) * DHW + (size_t)gy * W + gx) * 4) : OOB;
+        ldst[it] = item ? ((v / BWC) * BWC + Cfg::col_index(v % BWC)) * PB + oct * 16 : -1;
+    }
     float pre[NI][8];
     auto issue = [&](int it, int pp, int cc) {
-        const int i = tid + it * 256;
-        const int oct = min(i / NPIX, KQ - 1), v = i % NPIX;
-        const int gy = y0 * SHW - 1 + v / BWC, gx = x0 * SHW - 1 + v % BWC;
-        const bool in = i < KQ * NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const float* src = xb + ((size_t)(cc * CK + oct * 8) * D + pp) * HW + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+        const size_t base = (size_t)(cc * CK) * DHW + (size_t)pp * HW;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pre[it][e] = (a.ablate & 1) ? 1.0f : src[(size_t)e * DHW];
+        for (int e = 0; e < 8; ++e) pre[it][e] = buf_load(xin, voff[it], (unsigned)((base + (size_t)e * DHW) * 4));
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int it = 0; it < NI; ++it) {
-            const int i = tid + it * 256;
-            if (i < KQ * NPIX && !(a.ablate & 2)) {
-                const int oct = i / NPIX, v = i % NPIX;
-                const int gy = y0 * SHW - 1 + v / BWC, gx = x0 * SHW - 1 + v % BWC;
-                const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-                float px[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) px[e] = in ? pre[it][e] : 0.0f;
-                const Split3 sp = split3(px);
-                unsigned char* dst = lds + ((v / BWC) * BWC + Cfg::col_index(v % BWC)) * PB + oct * 16;
+        for (int it = 0; it < NI; ++it)
+            if (ldst[it] >= 0) {
+                const Split3 sp = split3(pre[it]);
+                unsigned char* dst = lds + ldst[it];
                 *reinterpret_cast<bf16x8*>(dst) = sp.h;
                 *reinterpret_cast<bf16x8*>(dst + TERM_BYTES) = sp.m;
                 *reinterpret_cast<bf16x8*>(dst + 2 * TERM_BYTES) = sp.l;
             }
-        }
     };
     auto load_b = [&](int s, int nt, bf16x8 (&bf)[3]) {
         const unsigned char* bp = lds + (SHW * (wave * NT + nt)) * (BWC * PB) + boff[s];
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
         __syncthreads();
         // ---- the depth taps of this plane; the buffer parity flips after each one (STEPS is odd) ----
         int pos = 0;
-        if (!(a.ablate & 4)) {
+        {
             if (kd_lo == 0) {
                 kd_steps(ic<0>{}, ic<0>{}, wk, kd_hi >= 1);
                 wk += Cfg::FRAGS_PER_KD;
@@ -302,245 +309,16 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
         }
     }
     if (p_last == D - 1 && d_hi == D) store_plane(D - 1, acc[0]);
-    if (a.ablate & 8) __threadfence();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Round 4: the same convolution with the NEXT pass's staging running UNDER the current pass's MFMAs.
-// In x3_conv_kernel a pass is [all loads] [wait] [barrier] [split + LDS stores] [barrier] [MFMA phase] and the parts ADD (measured: conv2
-// at stage 4 = 0.068 MFMA + 0.057 staging + 0.041 skeleton/epilogue -> 0.147 ms): two or three co-resident blocks run the same part at the
-// same time.  Here the activations have TWO LDS buffers and one pass is
-//     first depth-tap group, step 0 : the next pass's loads are issued right AFTER that step's weight prefetch (vmcnt retires in order: a
-//                                     wait for weights only has to leave the younger staging loads in flight - the compiler counts that)
-//     ... every step's MFMAs ...
-//     last depth-tap group, last step: split + store into the OTHER buffer (the loads have had the whole MFMA phase to arrive)
-//     one barrier
-// so a wavefront never sits in a staging phase.  The first weights of the next pass are prefetched into a third fragment set during the
-// last step (a pass always starts at buffer parity 0), the staging loads are BUFFER loads (one 32-bit lane offset per item for the whole
-// kernel, channel / depth plane in the scalar offset, out-of-volume pixels read 0 through the descriptor's range check: no 64-bit address
-// arithmetic, no select).  Two buffers of 31 KB mean two blocks per CU for the NT = 4 instance instead of three - with 256 registers each.
+// Round 4, built / measured / removed: `x3_conv_db_kernel`, the same convolution with two activation buffers and the
+// NEXT pass's staging loads issued behind step 0's weight prefetch, split + stored after the last step, one barrier per pass.  It passed
+// tests/test_hip_x3.py and was SLOWER (stage 4: conv2 0.145 vs 0.131 ms, conv4 0.155 vs 0.132, conv6 0.157 vs 0.136).  Why, from its ISA:
+// vmcnt retires IN ORDER and the weight fragments are global loads too, so the wait for step 2's weights (issued after the staging
+// loads) drains the staging loads - they get two steps (~800 clk) of cover, not the pass; and two 31 KB buffers cost the NT = 4
+// instance its third block per CU.  Long-latency prefetch and a weight stream cannot share one wavefront's vmcnt queue.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <class Cfg>
-__global__ __launch_bounds__(256, 2) void x3_conv_db_kernel(const X3Args a) {
-    const int seg = blockIdx.z % a.nseg;
-    constexpr int CK = Cfg::CK, SHW = Cfg::SHW, NT = Cfg::NT, MTB = Cfg::MTB, KQ = Cfg::KQ, STEPS = Cfg::STEPS, BWC = Cfg::BWC, PB = Cfg::PB,
-                  TERM_BYTES = Cfg::TERM_BYTES, NPIX = Cfg::BH * Cfg::BWC, BUF = Cfg::LDS_BYTES;
-    static_assert(2 * BUF <= 64 * 1024, "two activation buffers must fit the static LDS limit");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 15, kb = lane >> 4;
-    const int tile = blockIdx.x, ctb = blockIdx.y, b = blockIdx.z / a.nseg;
-    const int x0 = (tile % a.tiles_x) * Cfg::TW, y0 = (tile / a.tiles_x) * Cfg::TH;       // output coordinates
-    const int Cin = a.Cin, Cout = a.Cout, D = a.D, H = a.H, W = a.W;
-    const int NCH = Cin / CK;
-    const size_t HW = (size_t)H * W, DHW = (size_t)D * HW, HWo = (size_t)a.Ho * a.Wo;
-
-    const int d_lo = seg * a.seg_planes, d_hi = min(D, d_lo + a.seg_planes);
-    if (d_lo >= D) return;
-    const int p_first = max(0, d_lo - 1), p_last = min(D - 1, d_hi);
-    const int NP = (p_last - p_first + 1) * NCH;           // passes: (input plane, channel chunk)
-
-    unsigned boff[STEPS];
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-        const int q = min(4 * s + kb, Cfg::NKB - 1), tap9 = q / KQ, kh = tap9 / 3, kw = tap9 % 3;
-        boff[s] = (unsigned)((kh * BWC + Cfg::col_index(SHW * n + kw)) * PB + (q % KQ) * 16);
-    }
-
-    f32x4 acc[3][MTB][NT];
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int mt = 0; mt < MTB; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[s][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const bool vec_ok = (a.Wo & 3) == 0;
-    auto store_plane = [&](int od, const f32x4 (&c)[MTB][NT]) {
-#pragma unroll
-        for (int mt = 0; mt < MTB; ++mt) {
-            const int co = (ctb * MTB + mt) * 16 + n;
-            if (co >= Cout) continue;
-            const float sc = a.scale ? a.scale[co] : 1.0f, sh = a.shift ? a.shift[co] : 0.0f;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int gy = y0 + wave * NT + nt, gx = x0 + kb * 4;
-                if (gy >= a.Ho || gx >= a.Wo) continue;
-                const size_t o = ((size_t)(b * Cout + co) * D + od) * HWo + (size_t)gy * a.Wo + gx;
-                f32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = a.scale ? fmaf(c[mt][nt][r], sc, sh) : c[mt][nt][r] + sh;
-                    if (a.relu) v[r] = fmaxf(v[r], 0.0f);
-                }
-                if (vec_ok) {
-                    if (a.residual) {
-                        const f32x4 rs = *reinterpret_cast<const f32x4*>(a.residual + o);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = v[r] + rs[r];
-                    }
-                    *reinterpret_cast<f32x4*>(a.y + o) = v;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (gx + r < a.Wo) a.y[o + r] = a.residual ? v[r] + a.residual[o + r] : v[r];
-                }
-            }
-        }
-    };
-
-    // ---- staging through buffer loads: item i = tid + it * 256 -> (channel octet, box pixel); voff = the item's byte offset inside
-    //      (8 channels of the chunk's first octet ...) for depth plane 0 of chunk 0; plane and chunk go into the scalar offset ----
-    constexpr int NI = (KQ * NPIX + 255) / 256;
-    const rsrc_t xin = make_rsrc(a.x + (size_t)b * Cin * DHW, (unsigned)((size_t)Cin * DHW * 4));
-    unsigned voff[NI];
-    int ldst[NI];                                          // LDS byte offset of the item's h row (-1: no item)
-#pragma unroll
-    for (int it = 0; it < NI; ++it) {
-        const int i = tid + it * 256;
-        const int oct = i / NPIX, v = i % NPIX;
-        const int gy = y0 * SHW - 1 + v / BWC, gx = x0 * SHW - 1 + v % BWC;
-        const bool item = i < KQ * NPIX;
-        voff[it] = (item && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (unsigned)(((size_t)(oct * 8) * DHW + (size_t)gy * W + gx) * 4) : OOB;
-        ldst[it] = item ? ((v / BWC) * BWC + Cfg::col_index(v % BWC)) * PB + oct * 16 : -1;
-    }
-    float pre[NI][8];
-    auto issue_all = [&](int pp, int cc) {
-        const size_t base = (size_t)(cc * CK) * DHW + (size_t)pp * HW;
-#pragma unroll
-        for (int it = 0; it < NI; ++it)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pre[it][e] = (a.ablate & 1) ? 1.0f : buf_load(xin, voff[it], (unsigned)((base + (size_t)e * DHW) * 4));
-    };
-    auto commit_all = [&](unsigned char* buf) {
-#pragma unroll
-        for (int it = 0; it < NI; ++it)
-            if (ldst[it] >= 0 && !(a.ablate & 2)) {
-                const Split3 sp = split3(pre[it]);
-                unsigned char* dst = buf + ldst[it];
-                *reinterpret_cast<bf16x8*>(dst) = sp.h;
-                *reinterpret_cast<bf16x8*>(dst + TERM_BYTES) = sp.m;
-                *reinterpret_cast<bf16x8*>(dst + 2 * TERM_BYTES) = sp.l;
-            }
-    };
-
-    bf16x8 wbuf[2][MTB][3];                                // ping-pong weight fragments; the parity runs on ACROSS passes (see kd_steps)
-    auto load_w = [&](const bf16x8* wk, bf16x8 (&aw)[MTB][3]) {
-#pragma unroll
-        for (int mt = 0; mt < MTB; ++mt)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) aw[mt][t] = wk[(size_t)mt * NCH * 3 * Cfg::FRAGS_PER_KD + t * 64];
-    };
-    // weights of (chunk, first valid depth tap) of the pass that stages plane p
-    auto first_weights = [&](int p, int chunk) {
-        const int kd_lo = max(0, p + 2 - d_hi);
-        return a.wp + ((size_t)((ctb * MTB) * NCH + chunk) * 3 + kd_lo) * Cfg::FRAGS_PER_KD + lane;
-    };
-
-    const unsigned char* cur_buf = lds;                    // block-uniform, set per pass
-    unsigned char* nxt_buf = lds + BUF;
-    int np = 0, nchunk = 0;                                // the next pass's (plane, chunk); has_next says whether there is one
-    bool has_next = false;
-    const bf16x8* wk_next = a.wp;
-
-    auto load_b = [&](int s, int nt, bf16x8 (&bf)[3]) {
-        const unsigned char* bp = cur_buf + (SHW * (wave * NT + nt)) * (BWC * PB) + boff[s];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) bf[t] = *reinterpret_cast<const bf16x8*>(bp + t * TERM_BYTES);
-    };
-    // one depth tap (STEPS steps).  do_issue: this is the pass's FIRST group - the next pass's loads go out behind step 0's weight prefetch;
-    // do_commit: this is its LAST group - after the last step's MFMAs the loads are split and stored into the other buffer.
-    auto kd_steps = [&](auto kd_tag, auto p_tag, const bf16x8* wk, bool more, bool do_issue, bool do_commit) {
-        constexpr int KD = decltype(kd_tag)::value, P = decltype(p_tag)::value, SET = 2 - KD;
-        bf16x8 bf[2][3];
-        load_b(0, 0, bf[0]);
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            const int cur = (P + s) & 1;
-            // the next step's weights; at a pass's very last step the buffer is free for the NEXT pass's first step, which therefore
-            // starts at the flipped parity (STEPS is odd: every group flips it once)
-            if (s + 1 < STEPS || more) load_w(wk + (size_t)(s + 1) * 192, wbuf[cur ^ 1]);
-            else if (has_next) load_w(wk_next, wbuf[cur ^ 1]);
-            if (s == 0 && do_issue && has_next) issue_all(np, nchunk);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int j = s * NT + nt;
-                if (j + 1 < STEPS * NT) load_b((j + 1) / NT, (j + 1) % NT, bf[(j + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 xh = bf[j & 1][0], xm = bf[j & 1][1], xl = bf[j & 1][2];
-#pragma unroll
-                for (int mt = 0; mt < MTB; ++mt) {
-                    f32x4 c = acc[SET][mt][nt];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, wbuf[cur][mt][1], c, 0, 0, 0);     // smallest products first
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wbuf[cur][mt][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wbuf[cur][mt][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wbuf[cur][mt][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, wbuf[cur][mt][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wbuf[cur][mt][0], c, 0, 0, 0);
-                    acc[SET][mt][nt] = c;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (do_commit && has_next) commit_all(nxt_buf);
-    };
-
-    // ---- prologue: the first pass's plane is staged the plain way; its first weights travel meanwhile ----
-    load_w(first_weights(p_first, 0), wbuf[0]);
-    issue_all(p_first, 0);
-    commit_all(lds);
-    __syncthreads();
-
-    int par = 0;                                           // buffer parity of the next depth-tap group's first step
-    for (int pass = 0; pass < NP; ++pass) {
-        const int p = p_first + pass / NCH, chunk = pass % NCH;
-        cur_buf = lds + (pass & 1) * BUF;
-        nxt_buf = lds + ((pass & 1) ^ 1) * BUF;
-        has_next = pass + 1 < NP;
-        np = p_first + (pass + 1) / NCH;
-        nchunk = (pass + 1) % NCH;
-        wk_next = first_weights(np, nchunk);
-        // depth taps of input plane p whose output plane od = p + 1 - kd lies in [d_lo, d_hi): a contiguous, block-uniform range
-        const int kd_lo = max(0, p + 2 - d_hi), kd_hi = min(2, p + 1 - d_lo);
-        const bf16x8* wk = a.wp + ((size_t)((ctb * MTB) * NCH + chunk) * 3 + kd_lo) * Cfg::FRAGS_PER_KD + lane;
-        if (!(a.ablate & 4)) {
-            if (kd_lo == 0) {
-                if (par == 0) kd_steps(ic<0>{}, ic<0>{}, wk, kd_hi >= 1, true, kd_hi == 0); else kd_steps(ic<0>{}, ic<1>{}, wk, kd_hi >= 1, true, kd_hi == 0);
-                wk += Cfg::FRAGS_PER_KD;
-                par ^= 1;
-            }
-            if (kd_lo <= 1 && kd_hi >= 1) {
-                const bool first = kd_lo == 1;
-                if (par == 0) kd_steps(ic<1>{}, ic<0>{}, wk, kd_hi >= 2, first, kd_hi == 1); else kd_steps(ic<1>{}, ic<1>{}, wk, kd_hi >= 2, first, kd_hi == 1);
-                wk += Cfg::FRAGS_PER_KD;
-                par ^= 1;
-            }
-            if (kd_hi >= 2) {
-                const bool first = kd_lo == 2;
-                if (par == 0) kd_steps(ic<2>{}, ic<0>{}, wk, false, first, true); else kd_steps(ic<2>{}, ic<1>{}, wk, false, first, true);
-                par ^= 1;
-            }
-        } else if (has_next) {                             // diagnostics: staging without the MFMA phase
-            issue_all(np, nchunk);
-            commit_all(nxt_buf);
-        }
-        if (chunk == NCH - 1) {
-            if (p - 1 >= d_lo) store_plane(p - 1, acc[0]);
-#pragma unroll
-            for (int mt = 0; mt < MTB; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[0][mt][nt] = acc[1][mt][nt];
-                    acc[1][mt][nt] = acc[2][mt][nt];
-                    acc[2][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-        }
-        if (has_next) __syncthreads();                     // this pass's fragment reads are done, the next pass's plane is visible
-    }
-    if (p_last == D - 1 && d_hi == D) store_plane(D - 1, acc[0]);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Transposed convolution, stride (1,2,2), kernel 3, padding 1, output_padding (0,1,1) (CostRegNet3D's conv7 / conv9 / conv11,
 // models/module.py:562-575), same split form.  out[od, oh, ow] gathers in[od + 1 - kd, (oh + 1 - kh) / 2, (ow + 1 - kw) / 2] where
@@ -596,6 +374,9 @@ __global__ void x3_deconv_pack_kernel(const float* __restrict__ w, int Cin, int 
     out[idx] = v;
 }
 
+#ifndef X3_DECONV_PREFETCH
+#define X3_DECONV_PREFETCH 1
+#endif
 // H, W = INPUT size; output [B,Cout,D,2H,2W]
 __global__ __launch_bounds__(256, 2) void x3_deconv_kernel(const X3Args a) {
     using namespace dcv;
@@ -631,6 +412,28 @@ __global__ __launch_bounds__(256, 2) void x3_deconv_kernel(const X3Args a) {
     // 8kb .. 8kb+7 of the row are two 16-byte stores
     const int co = ctb * 16 + n;
     const float sc = (a.scale && co < Cout) ? a.scale[co] : 1.0f, sh = (a.shift && co < Cout) ? a.shift[co] : 0.0f;
+    // The skip tensor of a finished plane (round 4): its 16-byte loads go out TOGETHER with the staging loads of the plane's last channel chunk,
+    // so the one wait that staging needs anyway covers them too (vmcnt retires in order; issued in the epilogue they cost a second
+    // exposed HBM round trip per plane); buffer loads: rows / columns outside the output read 0 and are never stored.
+    const rsrc_t rin = make_rsrc(a.residual ? a.residual + (size_t)b * Cout * D * HWo : a.x, a.residual ? (unsigned)((size_t)Cout * D * HWo * 4) : 0u);
+    unsigned roff[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const int oy = 2 * (y0 + wave * 2 + r) + ph, ox = 2 * (x0 + kb * 4);
+            roff[r][ph] = (co < Cout && oy < Ho && ox < Wo) ? (unsigned)(((size_t)co * D * HWo + (size_t)oy * Wo + ox) * 4) : OOB;
+        }
+    f32x4 rs[2][2][2];
+    auto issue_residual = [&](int od) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    rs[r][ph][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, roff[r][ph] + 16u * h, (unsigned)((size_t)od * HWo * 4), 0));
+    };
     auto store_plane = [&](int od, const f32x4 (&c)[4][2]) {
         if (co >= Cout) return;
 #pragma unroll
@@ -654,13 +457,10 @@ __global__ __launch_bounds__(256, 2) void x3_deconv_kernel(const X3Args a) {
                 // Wo = 2W with W even: a multiple of 4, so each 16-byte half is either fully inside the row or fully outside
                 const bool second = ox + 4 < Wo;
                 if (a.residual) {
-                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.residual + o);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] += r0[q];
-                    if (second) {
-                        const f32x4 r1 = *reinterpret_cast<const f32x4*>(a.residual + o + 4);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[4 + q] += r1[q];
+                    for (int q = 0; q < 4; ++q) {
+                        v[q] += rs[r][ph][0][q];
+                        v[4 + q] += rs[r][ph][1][q];       // (second half beyond the row: the load returned 0, the value is not stored)
                     }
                 }
                 *reinterpret_cast<f32x4*>(a.y + o) = f32x4{v[0], v[1], v[2], v[3]};
@@ -699,6 +499,19 @@ __global__ __launch_bounds__(256, 2) void x3_deconv_kernel(const X3Args a) {
         }
     };
 
+    // staging through BUFFER loads (round 4, as x3_conv_kernel): one lane offset per item for the whole kernel, chunk / plane in the scalar
+    // offset, pixels outside the volume read 0 through the descriptor's range check
+    constexpr int NI = (2 * NPIX + 255) / 256;
+    const rsrc_t xin = make_rsrc(xb, (unsigned)((size_t)Cin * DHW * 4));
+    unsigned voff[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int i = tid + it * 256;
+        const int oct = i / NPIX, v = i % NPIX;
+        const int gy = y0 + v / BW, gx = x0 + v % BW;
+        voff[it] = (i < 2 * NPIX && gy < H && gx < W) ? (unsigned)(((size_t)(oct * 8) * DHW + (size_t)gy * W + gx) * 4) : OOB;
+    }
+
     const int d_lo = seg * a.seg_planes, d_hi = min(D, d_lo + a.seg_planes);
     if (d_lo >= D) return;                                 // empty segment (block-uniform)
     const int p_first = max(0, d_lo - 1), p_last = min(D - 1, d_hi);
@@ -708,32 +521,25 @@ __global__ __launch_bounds__(256, 2) void x3_deconv_kernel(const X3Args a) {
         for (int chunk = 0; chunk < NCH; ++chunk) {
             const bf16x8* wk = a.wp + ((size_t)(ctb * NCH + chunk) * 3 + kd_lo) * FRAGS_PER_KD + lane;
             load_w(wk, wbuf[0]);
+#if X3_DECONV_PREFETCH
+            if (chunk == NCH - 1 && a.residual && p - 1 >= d_lo) issue_residual(p - 1);
+#endif
             // both of a thread's items' loads first (16 in flight), then the barrier, the split and the LDS stores
-            constexpr int NI = (2 * NPIX + 255) / 256;
             float pre[NI][8];
+            {
+                const size_t base = (size_t)(chunk * 16) * DHW + (size_t)p * HW;
 #pragma unroll
-            for (int it = 0; it < NI; ++it) {
-                const int i = min(tid + it * 256, 2 * NPIX - 1);
-                const int oct = i / NPIX, v = i % NPIX;
-                const int gy = y0 + v / BW, gx = x0 + v % BW;
-                const bool in = gy < H && gx < W;
-                const float* src = xb + ((size_t)(chunk * 16 + oct * 8) * D + p) * HW + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+                for (int it = 0; it < NI; ++it)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pre[it][e] = src[(size_t)e * DHW];
+                    for (int e = 0; e < 8; ++e) pre[it][e] = buf_load(xin, voff[it], (unsigned)((base + (size_t)e * DHW) * 4));
             }
             __syncthreads();
 #pragma unroll
             for (int it = 0; it < NI; ++it) {
                 const int i = tid + it * 256;
                 if (i < 2 * NPIX) {
-                    const int oct = i / NPIX, v = i % NPIX;
-                    const int gy = y0 + v / BW, gx = x0 + v % BW;
-                    const bool in = gy < H && gx < W;
-                    float f[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = in ? pre[it][e] : 0.0f;
-                    const Split3 sp = split3(f);
-                    unsigned char* dst = lds + v * PB + oct * 16;
+                    const Split3 sp = split3(pre[it]);
+                    unsigned char* dst = lds + (i % NPIX) * PB + (i / NPIX) * 16;
                     *reinterpret_cast<bf16x8*>(dst) = sp.h;
                     *reinterpret_cast<bf16x8*>(dst + TERM_BYTES) = sp.m;
                     *reinterpret_cast<bf16x8*>(dst + 2 * TERM_BYTES) = sp.l;
@@ -756,6 +562,9 @@ __global__ __launch_bounds__(256, 2) void x3_deconv_kernel(const X3Args a) {
             }
         }
         // output plane p-1 has seen input planes p-2, p-1, p
+#if !X3_DECONV_PREFETCH
+        if (a.residual && p - 1 >= d_lo) issue_residual(p - 1);
+#endif
         if (p - 1 >= d_lo) store_plane(p - 1, acc[0]);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -766,7 +575,10 @@ __global__ __launch_bounds__(256, 2) void x3_deconv_kernel(const X3Args a) {
                 acc[2][c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
     }
-    if (p_last == D - 1 && d_hi == D) store_plane(D - 1, acc[0]);
+    if (p_last == D - 1 && d_hi == D) {
+        if (a.residual) issue_residual(D - 1);
+        store_plane(D - 1, acc[0]);
+    }
 }
 
 // which instance serves a layer: CK, rows per wavefront, M tiles per block
@@ -795,20 +607,7 @@ int launch_x3(X3Args a, int B, hipStream_t s) {
     a.seg_planes = mvs::ceil_div(a.D, nseg);
     nseg = mvs::ceil_div(a.D, a.seg_planes);               // no empty segments (D = 9: 4 x 3 planes would leave segment 3 = [9, 9) writing plane D-1)
     a.nseg = nseg;
-    {
-        const char* e = getenv("MVS_X3_ABLATE");
-        a.ablate = e ? atoi(e) : 0;
-    }
-    const dim3 grid(a.tiles_x * ty, mvs::ceil_div(a.Cout, 16 * Cfg::MTB), B * nseg);
-    if constexpr (2 * Cfg::LDS_BYTES <= 64 * 1024) {
-        // the double-buffered form (staging under the MFMAs) wherever two activation buffers fit; MVS_X3_DB=0: the round-3 kernel (diagnostics)
-        const char* e = getenv("MVS_X3_DB");
-        if (!e || atoi(e) != 0) {
-            hipLaunchKernelGGL((x3_conv_db_kernel<Cfg>), grid, dim3(256), 0, s, a);
-            return mvs::finish_launch("mvs_conv3d_x3_fwd");
-        }
-    }
-    hipLaunchKernelGGL((x3_conv_kernel<Cfg>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((x3_conv_kernel<Cfg>), dim3(a.tiles_x * ty, mvs::ceil_div(a.Cout, 16 * Cfg::MTB), B * nseg), dim3(256), 0, s, a);
     return mvs::finish_launch("mvs_conv3d_x3_fwd");
 }
 
@@ -880,6 +679,7 @@ extern "C" int mvs_deconv3d_x3_fwd(const float* x, const void* wpacked, const fl
     MVS_REQUIRE(mvs_deconv3d_x3_supported(Cin, Cout, sd), "mvs_deconv3d_x3_fwd: Cin=%d Cout=%d sd=%d is not built", Cin, Cout, sd);
     MVS_REQUIRE(B >= 1 && B <= 65535 && D >= 1 && H >= 1 && W >= 1 && (W % 2) == 0, "mvs_deconv3d_x3_fwd: bad shape B=%d D=%d H=%d W=%d (W even)", B, D, H, W);
     MVS_REQUIRE(!scale || shift, "mvs_deconv3d_x3_fwd: scale without shift");
+    MVS_REQUIRE((int64_t)Cin * D * H * W * 4 < ((int64_t)1 << 31), "mvs_deconv3d_x3_fwd: one sample's input exceeds the 2 GiB buffer window");
     X3Args a;
     a.x = x; a.wp = static_cast<const bf16x8*>(wpacked); a.scale = scale; a.shift = shift; a.residual = residual; a.y = y;
     a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = relu; a.Ho = 2 * H; a.Wo = 2 * W;
@@ -891,10 +691,6 @@ extern "C" int mvs_deconv3d_x3_fwd(const float* x, const void* wpacked, const fl
     a.seg_planes = mvs::ceil_div(D, nseg);
     nseg = mvs::ceil_div(D, a.seg_planes);                 // no empty segments
     a.nseg = nseg;
-    {
-        const char* e = getenv("MVS_X3_ABLATE");
-        a.ablate = e ? atoi(e) : 0;
-    }
     hipLaunchKernelGGL(x3_deconv_kernel, dim3(a.tiles_x * ty, cts, B * nseg), dim3(256), 0, MVS_STREAM(stream), a);
     return mvs::finish_launch("mvs_deconv3d_x3_fwd");
 }

@@ -25,6 +25,10 @@
 //   volume_mean once; also the eval-only similarity arg-max depth (mvsformer_model.py:81-85,151-158).
 //
 // Algorithmic HBM bytes per stage: 4*H*W*(V*C + D + G*D)  (features once, hypotheses once, volume once).
+//
+// Round 4, built / measured / removed: a 4-lanes-per-sample "pair" layout for C = 8 (the two horizontal taps of a row as
+// ONE 64-byte quad access; 0.238 -> 0.177 ms of pure gather in tools/probe/gather_probe.hip) lost in the real kernels - sweep A 0.231 ->
+// 0.277 ms, sweep B 0.291 -> 0.333 ms at stage 4 - even with sweep A's vector work cut below the generic kernel's (dot before blend).
 #include "common.h"
 #include "geometry.h"
 
@@ -855,6 +859,8 @@ StoreLayout store_layout(int B, int V, int C, int D, int H, int W) {
 
 extern "C" int64_t mvs_cv_corr_store_bytes(int B, int V, int C, int Gin, int D, int H, int W) {
     if (B < 1 || V < 2 || D < 1 || H < 1 || W < 1 || Gin != G || (C != 32 && C != 64)) return -1;
+    // mvs_cv_corr_fwd keeps D values per pixel in LDS: beyond 64 KiB the path is not built for the shape either (-1: the caller recomputes)
+    if ((C == 64 ? CorrCfg<16>::lds_bytes(D) : CorrCfg<8>::lds_bytes(D)) > 64 * 1024) return -1;
     const StoreLayout l = store_layout(B, V, C, D, H, W);
     return (l.corr_floats + l.sim_floats) * (int64_t)sizeof(float);
 }

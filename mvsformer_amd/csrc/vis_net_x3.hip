@@ -39,7 +39,12 @@ constexpr int A2_OCT = A2N * 16, A2_TERM = 2 * A2_OCT;
 constexpr int IN_BYTES = ((INW * INW * 4 + 255) / 256) * 256;
 constexpr int LDS_BYTES = IN_BYTES + 3 * A1_TERM + 3 * A2_TERM;
 constexpr int L2_STEPS = 5, L3_STEPS = 6;
-constexpr int L2_TILES = (A2N + 15) / 16, L1_TILES = A1N / 16;   // 21, 25
+// Layer 2's N tiles walk its 18 x 18 output region with the PITCH OF ITS INPUT (20): output index o = oy * 20 + ox, so the B fragment of tap
+// (kh, kw) is pixels o + kh * 20 + kw ... + 15 of layer 1's region - 256 contiguous bytes for every tile, where the 18-pitch walk of round
+// 3 wrapped around a row end inside most tiles (288-byte span: SQ_LDS_BANK_CONFLICT 45 % of SQ_LDS_IDX_ACTIVE).  The two junk columns per
+// row (ox = 18, 19) make 23 tiles instead of 21 - the same six tiles on the busiest wavefront - and are dropped at the store.
+constexpr int L2_FLAT = A2W * A1W;                         // 360
+constexpr int L2_TILES = (L2_FLAT + 15) / 16, L1_TILES = A1N / 16;   // 23, 25
 static_assert(A1N % 16 == 0, "layer 1 tiles are full");
 // offsets inside the MVS_VIS_PARAM_FLOATS block (vis_net.hip)
 constexpr int OFF_W0 = 0, OFF_S0 = 144, OFF_B0 = 160, OFF_W1 = 176, OFF_S1 = 2480, OFF_B1 = 2496, OFF_W2 = 2512, OFF_S2 = 3664,
@@ -90,7 +95,11 @@ __device__ __forceinline__ void store_split(unsigned char* base, int pix, int kb
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         __bf16 a, b, c;
+#ifdef VIS_SPLIT_CLAMPED
         split3(v[r], a, b, c);
+#else
+        mvsx3::split3_bounded(v[r], a, b, c);
+#endif
         h[r] = a; m[r] = b; l[r] = c;
     }
     unsigned char* dst = base + (kb >> 1) * OCT + pix * 16 + (kb & 1) * 8;
@@ -215,10 +224,10 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
         // ---- layer 2: 16 -> 16 on the 18 x 18 region; two pixel tiles per pass (independent MFMA chains) ----
 #pragma unroll 1
         for (int t = wave; t < L2_TILES; t += 8) {
-            const int o0 = min(t * 16 + n, A2N - 1), o1 = min((t + 4) * 16 + n, A2N - 1);
+            const int o0 = t * 16 + n, o1 = min(t + 4, L2_TILES - 1) * 16 + n;        // (reads of junk pixels stay inside the LDS block)
             const bool two = t + 4 < L2_TILES;             // wave-uniform
-            const unsigned char* b0 = s_a1 + ((o0 / A2W) * A1W + o0 % A2W) * 16;
-            const unsigned char* b1 = s_a1 + ((o1 / A2W) * A1W + o1 % A2W) * 16;
+            const unsigned char* b0 = s_a1 + o0 * 16;
+            const unsigned char* b1 = s_a1 + o1 * 16;
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
             bf16x8 x0f[2][3], x1f[2][3];
 #pragma unroll
@@ -243,15 +252,14 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
                 __builtin_amdgcn_sched_barrier(0);
             }
             auto finish = [&](int tt, const f32x4& c) {
-                const int o = tt * 16 + n;
-                if (o < A2N) {
-                    const int oy = o / A2W, ox = o % A2W;
+                const int o = tt * 16 + n, oy = o / A1W, ox = o % A1W;
+                if (oy < A2W && ox < A2W) {
                     const int gy = y0 - 1 + oy, gx = x0 - 1 + ox;
                     const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = inside ? fmaxf(fmaf(c[r], sc1[r], sh1[r]), 0.0f) : 0.0f;
-                    store_split<A2_OCT, A2_TERM>(s_a2, o, kb, v);
+                    store_split<A2_OCT, A2_TERM>(s_a2, oy * A2W + ox, kb, v);
                 }
             };
             if (!(ablate & 4)) {

@@ -159,6 +159,13 @@ def test_store_plan_and_vis_mode_host_logic(monkeypatch):
     assert stagenet._store_plan(f2, 16, 8) is True
     monkeypatch.setenv("MVS_CV_STORE_MAX_MB", "0")
     assert stagenet._store_plan(f1, 32, 8) is False
+    # a small map with many hypotheses: the store would fit, but mvs_cv_corr_fwd's per-pixel LDS rows do not: the size query
+    # says "not built" and the stage falls back to the recomputing sweeps instead of raising from the launch
+    monkeypatch.setenv("MVS_CV_STORE_MAX_MB", "160")
+    tiny = torch.empty(1, 3, 16, 24, 32)
+    assert stagenet._store_plan(tiny, 256, 8) is True
+    assert stagenet._store_plan(tiny, 352, 8) is False
+    assert stagenet._store_plan(torch.empty(1, 3, 16, 24, 64), 1000, 8) is False
     net = m.StageNet(dict(base_ch=8, fusion_type="cnn", depth_type="ce"), 8, 0).eval()
     monkeypatch.setenv("MVS_VIS", "winograd")
     with pytest.raises(ValueError):

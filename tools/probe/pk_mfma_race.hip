@@ -65,9 +65,18 @@ __device__ __forceinline__ void victim_wave(const float* s_in, const float* s_w,
                 T[1] = E[1] + E[2];         U2[1] = O[1] + O[2];
                 T[2] = pk_sub(E[2], E[1]);  U2[2] = pk_sub(O[2], O[1]);
                 T[3] = pk_sub(E[1], E[3]);  U2[3] = pk_sub(O[1], O[3]);
+#ifdef VICTIM_VGPR_CONST
+                // hypothesis test 3: the (1, -1) multiplier of the packed fma below normally sits in an SGPR PAIR whose HIGH half is selected
+                // by op_sel_hi (v_pk_fma_f32 ..., s[0:1], ... op_sel_hi:[0,1,1]); here it is forced into vector registers
+                float c_one, c_minus;
+                asm volatile("v_mov_b32 %0, 1.0\n v_mov_b32 %1, -1.0" : "=v"(c_one), "=v"(c_minus));
+                const f32x2 pm = {c_one, c_minus};
+#else
+                const f32x2 pm = {1.0f, -1.0f};
+#endif
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    const f32x2 m = pk_fma(f32x2{U2[a].x, U2[a].x}, f32x2{1.0f, -1.0f}, f32x2{T[a].y, T[a].y});
+                    const f32x2 m = pk_fma(f32x2{U2[a].x, U2[a].x}, pm, f32x2{T[a].y, T[a].y});
                     X[a * 4 + 0] = T[a].x - T[a].y;
                     X[a * 4 + 1] = m.x;
                     X[a * 4 + 2] = m.y;
@@ -75,6 +84,13 @@ __device__ __forceinline__ void victim_wave(const float* s_in, const float* s_w,
                 }
             }
             const float* u = s_w + c * WCH + kk * 16 + i16;
+#ifdef VICTIM_RAW_FENCE
+            // hypothesis test 2: a read-after-write window between the packed ops that produce X[] and the MFMAs that read it - all 16
+            // results are pinned in registers, the wave idles 32 wait states, then the MFMAs start
+            asm volatile("s_nop 15\n s_nop 15"
+                         : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]), "+v"(X[8]), "+v"(X[9]),
+                           "+v"(X[10]), "+v"(X[11]), "+v"(X[12]), "+v"(X[13]), "+v"(X[14]), "+v"(X[15]));
+#endif
 #pragma unroll
             for (int xi = 0; xi < 16; ++xi) Z[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[xi * 64], X[xi], Z[xi], 0, 0, 0);
 #ifdef VICTIM_FENCE
