@@ -18,7 +18,7 @@
  *     heads, schedulers, filters and the `mvs_conv3d_fwd` / `mvs_deconv3d_fwd` family compute in IEEE fp32 (VALU / fp32 MFMA); the two
  *     entry points that also offer a shortcut form (reciprocal instead of IEEE division, hardware exp2/log2) say so at their `flags`
  *     argument - the Python layer asks for the IEEE form unless told otherwise.  The entry points with `x3` in their name
- *     (`mvs_conv3d_x3_*`, `mvs_deconv3d_x3_*`, `mvs_tail_x3_*`, `mvs_vis_x3_*`: the DEFAULT regularizer / visibility-CNN path of the
+ *     (`mvs_conv3d_x3_*`, `mvs_deconv3d_x3_*`, `mvs_conv3d_small_*`, `mvs_tail_x3_*`, `mvs_vis_x3_*`: the DEFAULT regularizer / visibility-CNN path of the
  *     Python layer) are fp32-EQUIVALENT, not IEEE fp32 op for op: every operand is split exactly into three bf16 terms
  *     (v = h + m + l) and a product is the six bf16 matrix-core products xh*wh + xh*wm + xm*wh + xh*wl + xl*wh + xm*wm with fp32
  *     accumulation (dropped terms <= 2^-24 |x*w|).  Their contract, tested in tests/test_hip_x3.py against fp64:
@@ -41,7 +41,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 9
+#define MVS_ABI_VERSION 10
 
 typedef void* mvs_stream_t;
 
@@ -417,6 +417,18 @@ int64_t mvs_deconv3d_x3_packed_bytes(int Cin, int Cout, int sd);
 int mvs_deconv3d_x3_pack_weights(const float* w, int Cin, int Cout, int sd, void* wpacked, mvs_stream_t stream);
 int mvs_deconv3d_x3_fwd(const float* x, const void* wpacked, const float* scale, const float* shift, const float* residual, float* y,
                         int B, int Cin, int Cout, int D, int H, int W, int sd, int relu, mvs_stream_t stream);
+
+/* Small-volume form of the same layers, split form (csrc/conv3d_x3_small.hip): one wavefront per 16 output voxels x 16 output channels gathers its
+ * operands straight from global memory - no staging rounds, no barriers - for CostRegNet's inner layers at the coarse cascade stages
+ * (models/module.py:469-505: volumes of a few thousand voxels, where the tiled kernels are latency chains on a handful of CUs).
+ *   transposed = 0: Conv3d(k 3, padding 1, stride (s,s,s)), s in {1, 2}; w [Cout,Cin,3,3,3]; x [B,Cin,D,H,W] -> y [B,Cout,(D-1)/s+1,(H-1)/s+1,(W-1)/s+1]
+ *   transposed = 1: ConvTranspose3d(k 3, stride 2, padding 1, output_padding 1); w [Cin,Cout,3,3,3]; x [B,Cin,D,H,W] -> y [B,Cout,2D,2H,2W]
+ *   y = [relu](conv * scale + shift) [+ residual]; Cin in {8,16,32,64}, Cout a multiple of 8 up to 64. */
+int mvs_conv3d_small_supported(int Cin, int Cout, int stride, int transposed);
+int64_t mvs_conv3d_small_packed_bytes(int Cin, int Cout, int stride, int transposed);
+int mvs_conv3d_small_pack_weights(const float* w, int Cin, int Cout, int stride, int transposed, void* wpacked, mvs_stream_t stream);
+int mvs_conv3d_small_fwd(const float* x, const void* wpacked, const float* scale, const float* shift, const float* residual, float* y, int B,
+                         int Cin, int Cout, int D, int H, int W, int stride, int transposed, int relu, mvs_stream_t stream);
 
 /* CostRegNet3D's tail in one launch, split form (csrc/tail_x3.hip): logits = prob(residual + relu(bn(conv11(x)))) with conv11 =
  * ConvTranspose3d(16, 8, 3, stride (1,2,2), padding 1, output_padding (0,1,1), bias=False) and prob = Conv3d(8, 1, 1) - models/module.py:

@@ -18,7 +18,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVS_HIP_LIB: diagnostics only - another BUILD of the same library (tests/test_hip_multistream.py's variants); never a fallback
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 from ctypes import c_double  # noqa: E402
 
@@ -47,6 +47,10 @@ SIGNATURES = {
     "mvs_deconv3d_x3_packed_bytes": (L, [I, I, I]),
     "mvs_deconv3d_x3_pack_weights": (I, [P, I, I, I, P, P]),
     "mvs_deconv3d_x3_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "mvs_conv3d_small_supported": (I, [I, I, I, I]),
+    "mvs_conv3d_small_packed_bytes": (L, [I, I, I, I]),
+    "mvs_conv3d_small_pack_weights": (I, [P, I, I, I, I, P, P]),
+    "mvs_conv3d_small_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "mvs_tail_x3_packed_bytes": (L, []),
     "mvs_tail_x3_pack_weights": (I, [P, P, P]),
     "mvs_tail_x3_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),

@@ -31,9 +31,17 @@
 #include "conv_common.h"
 #include "split3.h"
 
+#ifndef X3_STAGE_AUX
+#define X3_STAGE_AUX 0      // cache policy of the staging / skip-tensor loads (aux of raw_buffer_load; 2 = nt measured 20-30 % SLOWER: the eight
+#endif                      // dword loads of a staging item share cache lines with its neighbours' and need the L1)
+
 namespace {
 using namespace mvsconv;
 using mvsx3::bf16x8;
+
+__device__ __forceinline__ float stage_load(rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, X3_STAGE_AUX));
+}
 using mvsx3::Split3;
 using mvsx3::split3;
 
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
     auto issue = [&](int it, int pp, int cc) {
         const size_t base = (size_t)(cc * CK) * DHW + (size_t)pp * HW;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pre[it][e] = buf_load(xin, voff[it], (unsigned)((base + (size_t)e * DHW) * 4));
+        for (int e = 0; e < 8; ++e) pre[it][e] = stage_load(xin, voff[it], (unsigned)((base + (size_t)e * DHW) * 4));
     };
     auto commit = [&]() {
 #pragma unroll
@@ -432,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void x3_deconv_kernel(const X3Args a) {
             for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
-                    rs[r][ph][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, roff[r][ph] + 16u * h, (unsigned)((size_t)od * HWo * 4), 0));
+                    rs[r][ph][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, roff[r][ph] + 16u * h, (unsigned)((size_t)od * HWo * 4), X3_STAGE_AUX));
     };
     auto store_plane = [&](int od, const f32x4 (&c)[4][2]) {
         if (co >= Cout) return;
@@ -531,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void x3_deconv_kernel(const X3Args a) {
 #pragma unroll
                 for (int it = 0; it < NI; ++it)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) pre[it][e] = buf_load(xin, voff[it], (unsigned)((base + (size_t)e * DHW) * 4));
+                    for (int e = 0; e < 8; ++e) pre[it][e] = stage_load(xin, voff[it], (unsigned)((base + (size_t)e * DHW) * 4));
             }
             __syncthreads();
 #pragma unroll

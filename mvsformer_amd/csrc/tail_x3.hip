@@ -26,9 +26,17 @@
 #include "conv_common.h"
 #include "split3.h"
 
+#ifndef X3_STAGE_AUX
+#define X3_STAGE_AUX 0      // cache policy of the staging / skip-tensor loads (aux of raw_buffer_load: 2 = nt)
+#endif
+
 namespace {
 using namespace mvsconv;
 using mvsx3::bf16x8;
+
+__device__ __forceinline__ float stage_load(rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff_bytes, soff_bytes, X3_STAGE_AUX));
+}
 using mvsx3::mfma6;
 using mvsx3::Split3;
 using mvsx3::split3;
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void tail_x3_kernel(const TailArgs a) {
 #pragma unroll
         for (int it = 0; it < NI; ++it)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pre[it][e] = (a.ablate & 1) ? 1.0f : buf_load(xin, voff[it], (unsigned)((base + (size_t)e * DHW) * 4));
+            for (int e = 0; e < 8; ++e) pre[it][e] = (a.ablate & 1) ? 1.0f : stage_load(xin, voff[it], (unsigned)((base + (size_t)e * DHW) * 4));
     };
     auto commit = [&](unsigned char* buf) {
 #pragma unroll
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void tail_x3_kernel(const TailArgs a) {
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rs[r][ph][e] = buf_load(rin, roff[r][ph], (unsigned)((base + (size_t)e * D * HWo) * 4));
+                for (int e = 0; e < 4; ++e) rs[r][ph][e] = stage_load(rin, roff[r][ph], (unsigned)((base + (size_t)e * D * HWo) * 4));
     };
     // finished output plane od: BatchNorm, ReLU, the 1x1x1 conv over this lane's 4 channels (+ the skip tensor's share), the other 4
     // channels from lane ^ 16, the other column parity from lane ^ 32, 8-byte stores

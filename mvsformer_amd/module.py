@@ -98,6 +98,18 @@ def _train_conv_bn_act(x, conv, bn, relu, residual, transposed_sd=None):
 # layer holders (reference models/module.py:83-165, 168-197)
 # ---------------------------------------------------------------------------------------------------------
 X3_MIN_VOXELS = 40 * 1024      # output voxels from which the split-form conv is used (MVS_CONV_X3_MIN_VOXELS overrides)
+# The small-volume split-form kernel (csrc/conv3d_x3_small.hip) serves a layer while voxels x Cin x Cout stays below these bounds (output voxels
+# of a convolution, input voxels of a transposed convolution): measured per layer at the two coarse config-2 stages (profiles/r04_bench_small.txt),
+# it wins 4-21 us per launch below them and loses above (its vector ALU bound grows with the volume, the tiled kernels' latency chains do not).
+SMALL_MAX_WORK = (16 << 20, 8 << 20)      # (Conv3d, Deconv3d); MVS_CONV_SMALL_MAX_WORK="conv,deconv" overrides, "0,0" = never
+
+
+def _small_limit(transposed: bool) -> int:
+    if os.environ.get("MVS_CONV_X3", "1") == "0":
+        return 0
+    e = os.environ.get("MVS_CONV_SMALL_MAX_WORK")
+    lim = tuple(int(v) for v in e.split(",")) if e else SMALL_MAX_WORK
+    return lim[1 if transposed else 0]
 
 
 class Conv3d(nn.Module):
@@ -141,21 +153,28 @@ class Conv3d(nn.Module):
             if x3_mode != "0" and ops.conv3d_x3_supported(conv.in_channels, conv.out_channels, (s[0], s[1])) \
                     and not (x3_mode == "strided" and s[1] == 1) and not (x3_mode == "s1" and s[1] == 2):
                 x3 = ops.conv3d_x3_pack(_f32c(conv.weight), (s[0], s[1]))
+            # small-volume split form (csrc/conv3d_x3_small.hip) for stride (1,1,1) / (2,2,2): CostRegNet's inner layers at the coarse stages
+            small = None
+            if s[0] == s[1] and _small_limit(False) > 0 and ops.conv3d_small_supported(conv.in_channels, conv.out_channels, s[0], False):
+                small = ops.conv3d_small_pack(_f32c(conv.weight), s[0], False)
             if self.bn is not None:
                 scale, shift = _bn_fold(self.bn)
             else:
                 scale = None
                 shift = _f32c(conv.bias) if conv.bias is not None else None
             _publish_cache()
-            self._cache = (key, packed, scale, shift, (s[0], s[1]), wino, x3)
+            self._cache = (key, packed, scale, shift, (s[0], s[1]), wino, x3, small)
         return self._cache[1:]
 
     def forward(self, x, residual: Optional[torch.Tensor] = None):
         if self.training:
             return _train_conv_bn_act(x, self.conv, self.bn, self.relu, residual)
-        packed, scale, shift, stride, wino, x3 = self._prepared()
+        packed, scale, shift, stride, wino, x3, small = self._prepared()
         if x3 is not None and x.shape[2] * (x.shape[3] // stride[1]) * (x.shape[4] // stride[1]) >= int(os.environ.get("MVS_CONV_X3_MIN_VOXELS", X3_MIN_VOXELS)):
             return ops.conv3d_x3(x, x3, self.conv.in_channels, self.conv.out_channels, stride, scale, shift, residual, relu=self.relu)
+        if small is not None and ((x.shape[2] - 1) // stride[0] + 1) * ((x.shape[3] - 1) // stride[1] + 1) * ((x.shape[4] - 1) // stride[1] + 1) \
+                * self.conv.in_channels * self.conv.out_channels <= _small_limit(False):
+            return ops.conv3d_small(x, small, self.conv.in_channels, self.conv.out_channels, stride[0], False, scale, shift, residual, relu=self.relu)
         if wino is not None and ops.conv3d_wino_supported(self.conv.in_channels, self.conv.out_channels, *x.shape[2:]):
             return ops.conv3d_wino(x, wino, self.conv.in_channels, self.conv.out_channels, scale, shift, residual, relu=self.relu)
         return ops.conv3d(x, packed, self.conv.in_channels, self.conv.out_channels, stride, scale, shift, residual,
@@ -181,9 +200,15 @@ class Deconv3d(nn.Module):
         key = _versions(self)
         if self._cache is None or self._cache[0] != key:
             prepared = _prepare_deconv(self.conv, self.bn)
+            cin, cout = self.conv.in_channels, self.conv.out_channels
+            small = None
+            if tuple(self.conv.stride) == (2, 2, 2) and cout >= 16 and _small_limit(True) > 0 and ops.conv3d_small_supported(cin, cout, 2, True):
+                small = ops.conv3d_small_pack(_f32c(self.conv.weight), 2, True)
             _publish_cache()
-            self._cache = (key,) + prepared
-        _, packed, scale, shift, sd = self._cache
+            self._cache = (key,) + prepared + (small,)
+        _, packed, scale, shift, sd, small = self._cache
+        if small is not None and x.shape[2] * x.shape[3] * x.shape[4] * self.conv.in_channels * self.conv.out_channels <= _small_limit(True):
+            return ops.conv3d_small(x, small, self.conv.in_channels, self.conv.out_channels, 2, True, scale, shift, residual, relu=self.relu)
         return ops.deconv3d(x, packed, self.conv.in_channels, self.conv.out_channels, sd, scale, shift, residual,
                             relu=self.relu, tag="deconv3d_%dto%d_s%d" % (self.conv.in_channels, self.conv.out_channels, sd))
 

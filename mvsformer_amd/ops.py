@@ -528,6 +528,44 @@ def deconv3d_prob1(x, wpacked, cin, scale, shift, residual, prob_w, prob_b, relu
     return logits
 
 
+def conv3d_small_supported(cin: int, cout: int, stride: int, transposed: bool) -> bool:
+    return bool(_lib.load().mvs_conv3d_small_supported(int(cin), int(cout), int(stride), int(bool(transposed))))
+
+
+def conv3d_small_pack(weight: torch.Tensor, stride: int, transposed: bool) -> torch.Tensor:
+    """Conv3d ``[Cout,Cin,3,3,3]`` / ConvTranspose3d ``[Cin,Cout,3,3,3]`` weight -> pre-split bf16 MFMA fragments for :func:`conv3d_small`."""
+    _chk(weight, "conv weight")
+    cin, cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
+    n = int(_lib.load().mvs_conv3d_small_packed_bytes(cin, cout, int(stride), int(bool(transposed))))
+    if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3) or n <= 0:
+        raise _lib.MvsHipError("conv3d_small_pack: unsupported weight %s / stride %d / transposed %s" % (tuple(weight.shape), stride, transposed))
+    packed = torch.empty(n, device=weight.device, dtype=torch.uint8)
+    _call("mvs_conv3d_small_pack_weights", None, _ptr(weight), cin, cout, int(stride), int(bool(transposed)), _ptr(packed), _stream())
+    return packed
+
+
+def conv3d_small(x, wpacked, cin, cout, stride, transposed, scale=None, shift=None, residual=None, relu=True):
+    """Small-volume split-form (transposed) convolution layer -> folded BatchNorm -> ReLU [+ residual] (include/mvs_hip.h)."""
+    _chk(x, "x"), _chk(wpacked, "packed weights", torch.uint8), _opt(scale, "scale"), _opt(shift, "shift")
+    B, C, D, H, W = x.shape
+    assert C == cin
+    s = int(stride)
+    if transposed:
+        oshape = (B, cout, 2 * D, 2 * H, 2 * W)
+    else:
+        oshape = (B, cout, (D - 1) // s + 1, (H - 1) // s + 1, (W - 1) // s + 1)
+    y = torch.empty(oshape, device=x.device, dtype=torch.float32)
+    if residual is not None:
+        _chk(residual, "residual")
+        if residual.shape != y.shape:
+            raise _lib.MvsHipError("residual shape %s != output %s" % (tuple(residual.shape), tuple(y.shape)))
+    flops = 2.0 * 27 * cin * cout * B * (D * H * W if transposed else y[0, 0].numel())
+    tag = ("x3_small_kernel<%s,%d,%d,s%d>" % ("deconv" if transposed else "conv", cin, cout, s), "flops", flops)
+    _call("mvs_conv3d_small_fwd", tag, _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), B, cin, cout, D, H, W, s,
+          int(bool(transposed)), int(relu), _stream())
+    return y
+
+
 def tail_x3_pack(weight: torch.Tensor) -> torch.Tensor:
     """conv11's ConvTranspose3d weight ``[16,8,3,3,3]`` -> pre-split bf16 MFMA fragments for :func:`tail_x3` (uint8 storage)."""
     _chk(weight, "conv11 weight")

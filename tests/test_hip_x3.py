@@ -271,3 +271,68 @@ def test_costregnet3d_logits_paths_agree(dev):
     s = outs[2].abs().max().item()
     assert (outs[0] - outs[2]).abs().max().item() < 5e-6 * s
     assert (outs[1] - outs[2]).abs().max().item() < 5e-6 * s
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Small-volume split form (csrc/conv3d_x3_small.hip): CostRegNet's inner layers, Conv3d stride (1,1,1) / (2,2,2) and the stride-2
+# ConvTranspose3d (models/module.py:469-505), against fp64 and the fp32-MFMA kernels
+# ---------------------------------------------------------------------------------------------------------------------------------
+SMALL_CONV = [(8, 16, 2, 8, 16, 24), (16, 32, 2, 5, 9, 35), (32, 64, 2, 4, 18, 24), (32, 32, 1, 8, 12, 20), (64, 64, 1, 4, 18, 24),
+              (64, 64, 1, 2, 3, 5), (16, 16, 1, 3, 7, 33), (8, 8, 1, 1, 1, 1), (16, 8, 2, 6, 6, 6)]
+
+
+@pytest.mark.parametrize("cin,cout,stride,D,H,W", SMALL_CONV)
+@pytest.mark.parametrize("epilogue", [False, True])
+def test_conv3d_small_vs_fp64(dev, cin, cout, stride, D, H, W, epilogue):
+    from mvsformer_amd import ops
+    gen = torch.Generator().manual_seed(cin * 3 + cout + D + W)
+    x = torch.randn(2, cin, D, H, W, generator=gen)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=gen) / (27 * cin) ** 0.5
+    scale = torch.rand(cout, generator=gen) + 0.5 if epilogue else None
+    shift = torch.randn(cout, generator=gen) if epilogue else None
+    want = F.conv3d(x.double(), w.double(), stride=stride, padding=1)
+    res = torch.randn(want.shape, generator=gen) if epilogue else None
+    if epilogue:
+        want = torch.relu(want * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)) + res.double()
+    g = lambda t: None if t is None else t.to(dev).contiguous()
+    assert ops.conv3d_small_supported(cin, cout, stride, False)
+    pk = ops.conv3d_small_pack(g(w), stride, False)
+    got = ops.conv3d_small(g(x), pk, cin, cout, stride, False, g(scale), g(shift), g(res), relu=epilogue)
+    assert got.shape == want.shape
+    s = want.abs().max().item()
+    err = (got.cpu().double() - want).abs().max().item() / s
+    ref32 = ops.conv3d(g(x), ops.conv3d_pack(g(w), False), cin, cout, (stride, stride), g(scale), g(shift), g(res), relu=epilogue)
+    err32 = (ref32.cpu().double() - want).abs().max().item() / s
+    assert err < 3 * err32 + 2e-7, (err, err32)
+    assert err < 2e-6, err
+    assert torch.equal(got, ops.conv3d_small(g(x), pk, cin, cout, stride, False, g(scale), g(shift), g(res), relu=epilogue))
+
+
+SMALL_DECONV = [(64, 32, 4, 18, 24), (32, 16, 8, 9, 12), (16, 8, 3, 5, 7), (64, 32, 1, 1, 1), (32, 16, 2, 4, 17), (16, 16, 5, 6, 34)]
+
+
+@pytest.mark.parametrize("cin,cout,D,H,W", SMALL_DECONV)
+@pytest.mark.parametrize("epilogue", [False, True])
+def test_deconv3d_small_vs_fp64(dev, cin, cout, D, H, W, epilogue):
+    from mvsformer_amd import ops
+    gen = torch.Generator().manual_seed(cin * 5 + cout + D + W)
+    x = torch.randn(2, cin, D, H, W, generator=gen)
+    w = torch.randn(cin, cout, 3, 3, 3, generator=gen) / (4 * cin) ** 0.5
+    scale = torch.rand(cout, generator=gen) + 0.5 if epilogue else None
+    shift = torch.randn(cout, generator=gen) if epilogue else None
+    want = F.conv_transpose3d(x.double(), w.double(), stride=2, padding=1, output_padding=1)
+    res = torch.randn(want.shape, generator=gen) if epilogue else None
+    if epilogue:
+        want = torch.relu(want * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)) + res.double()
+    g = lambda t: None if t is None else t.to(dev).contiguous()
+    assert ops.conv3d_small_supported(cin, cout, 2, True)
+    pk = ops.conv3d_small_pack(g(w), 2, True)
+    got = ops.conv3d_small(g(x), pk, cin, cout, 2, True, g(scale), g(shift), g(res), relu=epilogue)
+    assert got.shape == want.shape
+    s = want.abs().max().item()
+    err = (got.cpu().double() - want).abs().max().item() / s
+    ref32 = ops.deconv3d(g(x), ops.conv3d_pack(g(w), True, 2), cin, cout, 2, g(scale), g(shift), g(res), relu=epilogue)
+    err32 = (ref32.cpu().double() - want).abs().max().item() / s
+    assert err < 3 * err32 + 2e-7, (err, err32)
+    assert err < 2e-6, err
+    assert torch.equal(got, ops.conv3d_small(g(x), pk, cin, cout, 2, True, g(scale), g(shift), g(res), relu=epilogue))
