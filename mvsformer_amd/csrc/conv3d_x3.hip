@@ -26,6 +26,8 @@
 //   * volumes with few tiles are cut into depth segments (one halo plane re-staged per cut) so that every CU gets several blocks.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include <type_traits>
 
 #include "conv_common.h"
@@ -605,13 +607,26 @@ bool x3_plan(int Cin, int Cout, int sd, int shw, X3Plan* pl) {
     return true;
 }
 
+// Depth segments (each re-stages one halo plane per cut) are added while the grid has fewer blocks than this.  Measured per layer at config-2 stages
+// 3-4 (profiles/r04_bench_x3_segments.txt): the two-blocks-per-CU instances want a grid of ~1 block per slot and no more (conv5 / conv6 / conv7 at
+// stage 4: 432 blocks unsplit 0.077 / 0.118 / 0.091 ms against 0.090 / 0.130 / 0.102 split in two - with D = 4 a cut stages 3 planes for 2), the
+// three-blocks-per-CU instances (conv1, conv2) keep the old bound (conv2 at stage 3: 0.081 split in two against 0.086 unsplit).
+// MVS_X3_SEG_BLOCKS overrides both (diagnostics).
+int seg_blocks(int blocks_per_cu) {
+    static const int env = [] {
+        const char* e = getenv("MVS_X3_SEG_BLOCKS");
+        return e ? std::max(1, atoi(e)) : 0;
+    }();
+    return env ? env : (blocks_per_cu >= 3 ? 1536 : 384);
+}
+
 template <class Cfg>
 int launch_x3(X3Args a, int B, hipStream_t s) {
     const int ty = mvs::ceil_div(a.Ho, Cfg::TH);
     // depth segments: every segment re-stages one halo plane on each side, so split only while the grid is short of ~6 blocks per CU
     const int64_t blocks = (int64_t)a.tiles_x * ty * mvs::ceil_div(a.Cout, 16 * Cfg::MTB) * B;
     int nseg = 1;
-    while (nseg * 2 <= a.D / 2 && blocks * nseg < 1536) nseg *= 2;
+    while (nseg * 2 <= a.D / 2 && blocks * nseg < seg_blocks(Cfg::MIN_BLOCKS)) nseg *= 2;
     a.seg_planes = mvs::ceil_div(a.D, nseg);
     nseg = mvs::ceil_div(a.D, a.seg_planes);               // no empty segments (D = 9: 4 x 3 planes would leave segment 3 = [9, 9) writing plane D-1)
     a.nseg = nseg;
@@ -695,7 +710,7 @@ extern "C" int mvs_deconv3d_x3_fwd(const float* x, const void* wpacked, const fl
     const int ty = mvs::ceil_div(H, dcv::TIH), cts = (Cout + 15) / 16;
     const int64_t blocks = (int64_t)a.tiles_x * ty * cts * B;
     int nseg = 1;
-    while (nseg * 2 <= D / 2 && blocks * nseg < 1536) nseg *= 2;
+    while (nseg * 2 <= D / 2 && blocks * nseg < seg_blocks(2)) nseg *= 2;
     a.seg_planes = mvs::ceil_div(D, nseg);
     nseg = mvs::ceil_div(D, a.seg_planes);                 // no empty segments
     a.nseg = nseg;

@@ -1,12 +1,6 @@
 set -x
 mkdir -p gpurun_out/r04
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r04/pytest_all2.txt 2>&1
-tail -6 gpurun_out/r04/pytest_all2.txt
-timeout 300 python tools/stage_breakdown.py > gpurun_out/r04/stage_breakdown.txt 2>&1
-grep -E "^stage|all stages" gpurun_out/r04/stage_breakdown.txt
-timeout 300 python bench.py --steps 30 --warmup 6 --no-cpu-baseline --no-other-configs > gpurun_out/r04/bench_b.json 2> gpurun_out/r04/bench_b.err
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/r04/bench_b.json'))
-print({k:d[k] for k in ('value','ms_per_step','ms_per_step_repeats','latency_ms_single_stream','kernel_ms_sum')})
-PY
+for k in 1536 768 512 384 1536; do
+MVS_X3_SEG_BLOCKS=$k timeout 200 python tools/bench_x3.py --stages 3,4 --only conv1,conv2,conv3,conv4,conv5,conv6,conv7,conv9 --out r04/bench_segb_$k.txt > /dev/null
+echo "== seg_blocks $k"; sed -e 's/ | x3 vs.*//' -e 's/ | max diff.*//' -e 's/ GF | direct [0-9.]* ms  wino [0-9a-z.]* ms / /' -e 's/ GF | direct [0-9.]* ms / /' gpurun_out/r04/bench_segb_$k.txt
+done
