@@ -342,16 +342,25 @@ def main(args):
                    "traffic": (sum(t * e["calls_per_step"] for t, e in zip(cv_traffic, cv)) if cv and all(t is not None for t in cv_traffic) else None),
                    "launches": {e["kernel"]: e["ms_per_step"] for e in cv},
                    "note": "sum over the 4 stages of 4*H*W*(V*C + D + G*D) bytes / summed time of the sweeps (+ feature transposes)"}
-    # the measured ceiling of the gathering sweeps: tools/gather_bound.py fetches the same taps with no arithmetic (profiles/r03_gather_bound.json)
-    gb_file = os.path.join(REPO, "profiles", "r03_gather_bound.json")
+    # the measured ceiling of the gathering sweeps: tools/gather_bound.py fetches the same taps with no arithmetic (profiles/gather_bound.json,
+    # stamped with the digest of the probe sources like the traffic file; ignored when they have changed since)
+    gb_file = os.path.join(REPO, "profiles", "gather_bound.json")
     if os.path.exists(gb_file) and (args.height, args.width, args.views, args.batch) == (1152, 1536, 5, 1):
-        gb = {(r["C"], r["hyp"]): r["gather_regs_ms"] for r in json.load(open(gb_file))}
-        gathering = [e for e in cv if e["kernel"].startswith(("cv_entropy", "cv_aggregate", "cv_corr"))]
-        bound = sum(gb[(4 * int(e["kernel"].split("<")[1].split(",")[0].rstrip(">")), "cascade")] * e["calls_per_step"] for e in gathering)
-        roofline_cv["gather_only_ms_per_depth_map"] = round(bound, 4)
-        roofline_cv["frac_of_gather_bound"] = round(bound / sum(e["ms_per_step"] for e in gathering), 4)
-        roofline_cv["gather_bound_source"] = ("profiles/r03_gather_bound.json (tools/gather_bound.py: the same tap addresses, no arithmetic, one launch per "
-                                              "gathering sweep); measured on another box of the pool, not in this run")
+        import hashlib
+        gj = json.load(open(gb_file))
+        hh = hashlib.sha256()
+        for f in ("tools/probe/gather_probe.hip", "mvsformer_amd/csrc/geometry.h", "tools/gather_bound.py"):
+            hh.update(open(os.path.join(REPO, f), "rb").read())
+        if isinstance(gj, dict) and gj.get("digest") == hh.hexdigest()[:16]:
+            gb = {(r["C"], r["hyp"]): r["gather_regs_ms"] for r in gj["rows"]}
+            gathering = [e for e in cv if e["kernel"].startswith(("cv_entropy", "cv_aggregate", "cv_corr"))]
+            bound = sum(gb[(4 * int(e["kernel"].split("<")[1].split(",")[0].rstrip(">")), "cascade")] * e["calls_per_step"] for e in gathering)
+            roofline_cv["gather_only_ms_per_depth_map"] = round(bound, 4)
+            roofline_cv["frac_of_gather_bound"] = round(bound / sum(e["ms_per_step"] for e in gathering), 4)
+            roofline_cv["gather_bound_source"] = ("profiles/gather_bound.json at probe sources %s = this tree's (tools/gather_bound.py: the same tap addresses, no "
+                                                  "arithmetic, one launch per gathering sweep); measured on another box of the pool, not in this run" % gj["digest"])
+        else:
+            roofline_cv["gather_bound_source"] = "none: profiles/gather_bound.json was measured with other probe sources"
 
     # ---- extra key: the same cost-volume build on SMOOTH hypotheses (a band around the true surface - what a trained checkpoint predicts,
     #      not the noisy ones of a random-weight cascade): per stage the direct gather pair and the LDS-tiled pair (whose reuse only pays

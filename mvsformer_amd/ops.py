@@ -54,6 +54,7 @@ class KernelTimer:
         self.events: Dict[str, List[Tuple[torch.cuda.Event, torch.cuda.Event]]] = defaultdict(list)
         # algorithmic work per kernel name: {"kind": "bytes"|"flops", "amount": total over the recorded launches}
         self.work: Dict[str, Dict[str, object]] = {}
+        self.order: List[str] = []                      # tags in launch order (tools/prof_traffic.py aligns rocprofv3's dispatches with them)
 
     def add_work(self, tag: str, kind: str, amount: float) -> None:
         w = self.work.setdefault(tag, {"kind": kind, "amount": 0.0})
@@ -107,6 +108,7 @@ def _call(name: str, tag, *args):
         rc = fn(*args)
         b.record()
         _timer.events[tag].append((a, b))
+        _timer.order.append(tag)
         if work:
             _timer.add_work(tag, *work)
     else:

@@ -2,30 +2,32 @@
 # Round-end evidence on the GPU box (run from the repo root through gpurun): gather ceiling, per-stage breakdown, kernel trace of the bench,
 # HBM traffic counters (separate --pmc passes), final bench line.  Everything lands in gpurun_out/, copy what is judged into profiles/.
 set -x
+ROUND=${ROUND:-r04}
 mkdir -p gpurun_out
 REPO=$(pwd)
 python tools/gather_bound.py > gpurun_out/gather_bound.log 2>&1
 python tools/stage_breakdown.py > /dev/null 2>&1
 python tools/bench_sweeps.py --hyps cascade > /dev/null 2>&1
 python tools/bench_x3.py --stages 3,4 > /dev/null 2>&1
+python tools/bench_small.py > /dev/null 2>&1
 python tools/bench_vis.py > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
-rm -rf $REPO/gpurun_out/prof_r03 $REPO/gpurun_out/pmc_r03
-rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_r03 -o r03 -- python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs --streams 1 > $REPO/gpurun_out/bench_under_rocprof.json 2> $REPO/gpurun_out/rocprof_trace.log
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $REPO/gpurun_out/pmc_r03/fetch -- python $REPO/tools/prof_traffic.py > $REPO/gpurun_out/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $REPO/gpurun_out/pmc_r03/write -- python $REPO/tools/prof_traffic.py > $REPO/gpurun_out/pmc_write.log 2>&1
+rm -rf $REPO/gpurun_out/prof_${ROUND} $REPO/gpurun_out/pmc_${ROUND}
+rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_${ROUND} -o ${ROUND} -- python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs --streams 1 > $REPO/gpurun_out/bench_under_rocprof.json 2> $REPO/gpurun_out/rocprof_trace.log
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $REPO/gpurun_out/pmc_${ROUND}/fetch -- python $REPO/tools/prof_traffic.py > $REPO/gpurun_out/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $REPO/gpurun_out/pmc_${ROUND}/write -- python $REPO/tools/prof_traffic.py > $REPO/gpurun_out/pmc_write.log 2>&1
 # SQ counters of the stage-4 regularizer + visibility CNN (two passes of 8 counters each; --pmc never together with a trace domain other than kernel-trace)
 for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   tag=$(echo $pass | cut -d" " -f1)
-  rocprofv3 --kernel-trace --output-format csv --pmc $pass -d $REPO/gpurun_out/pmc_r03/sq_$tag -- python $REPO/tools/prof_cv.py --stage 4 --what vis,reg > $REPO/gpurun_out/pmc_sq_$tag.log 2>&1
+  rocprofv3 --kernel-trace --output-format csv --pmc $pass -d $REPO/gpurun_out/pmc_${ROUND}/sq_$tag -- python $REPO/tools/prof_cv.py --stage 4 --what vis,reg > $REPO/gpurun_out/pmc_sq_$tag.log 2>&1
 done
 cd $REPO
-python tools/pmc_table.py gpurun_out/pmc_r03/sq_SQ_WAVES gpurun_out/pmc_r03/sq_SQ_ACTIVE_INST_ANY > gpurun_out/r03_pmc_reg_stage4.txt 2> gpurun_out/pmc_table.err
-DB=$(find gpurun_out/prof_r03 -name "*.db" | head -1)
-python tools/rocpd_stats.py $DB > gpurun_out/r03_kernel_stats.csv 2> gpurun_out/rocpd_stats.err
-python tools/pmc_traffic.py gpurun_out/pmc_r03/fetch gpurun_out/pmc_r03/write gpurun_out/traffic_by_kernel.json > gpurun_out/pmc_traffic.log 2>&1
-cp gpurun_out/traffic_by_kernel.json profiles/traffic_by_kernel.json; cp gpurun_out/gather_bound.json profiles/r03_gather_bound.json   # the final bench line below reads them
-rm -rf gpurun_out/pmc_r03 gpurun_out/prof_r03
-python bench.py --steps 200 --warmup 10 > gpurun_out/r03_final_bench.json 2> gpurun_out/r03_final_bench.err
-tail -c 400 gpurun_out/r03_final_bench.err
+python tools/pmc_table.py gpurun_out/pmc_${ROUND}/sq_SQ_WAVES gpurun_out/pmc_${ROUND}/sq_SQ_ACTIVE_INST_ANY > gpurun_out/${ROUND}_pmc_reg_stage4.txt 2> gpurun_out/pmc_table.err
+DB=$(find gpurun_out/prof_${ROUND} -name "*.db" | head -1)
+python tools/rocpd_stats.py $DB > gpurun_out/${ROUND}_kernel_stats.csv 2> gpurun_out/rocpd_stats.err
+python tools/pmc_traffic.py gpurun_out/pmc_${ROUND}/fetch gpurun_out/pmc_${ROUND}/write gpurun_out/traffic_by_kernel.json > gpurun_out/pmc_traffic.log 2>&1
+cp gpurun_out/traffic_by_kernel.json profiles/traffic_by_kernel.json; cp gpurun_out/gather_bound.json profiles/gather_bound.json; cp gpurun_out/gather_bound.txt gpurun_out/${ROUND}_gather_bound.txt   # the final bench line below reads them
+rm -rf gpurun_out/pmc_${ROUND} gpurun_out/prof_${ROUND}
+python bench.py --steps 200 --warmup 10 > gpurun_out/${ROUND}_final_bench.json 2> gpurun_out/${ROUND}_final_bench.err
+tail -c 400 gpurun_out/${ROUND}_final_bench.err
 ls -la gpurun_out | tail -20

@@ -99,7 +99,13 @@ def main():
             print(line, flush=True)
             lines.append(line)
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-    json.dump(rows, open(os.path.join(REPO, "gpurun_out", "gather_bound.json"), "w"), indent=1)
+    # stamped with the digest of the sources that define the measurement (the probe, the shared tap geometry): bench.py only uses the file
+    # while they are unchanged
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("tools/probe/gather_probe.hip", "mvsformer_amd/csrc/geometry.h", "tools/gather_bound.py"):
+        h.update(open(os.path.join(REPO, f), "rb").read())
+    json.dump({"digest": h.hexdigest()[:16], "rows": rows}, open(os.path.join(REPO, "gpurun_out", "gather_bound.json"), "w"), indent=1)
     open(os.path.join(REPO, "gpurun_out", "gather_bound.txt"), "w").write("\n".join(lines) + "\n")
 
 

@@ -44,17 +44,54 @@ def tagname(k):
     return k
 
 
-def collect(d, counter):
-    acc = defaultdict(list)
+def family(tag):
+    """tag or kernel name -> the part both spell the same way ('x3_conv', 'cv_entropy', 'vis_x3', 'schedule_inverse', ...)."""
+    t = re.sub(r"_kernel.*|<.*", "", tag)
+    t = re.sub(r"^mvs_", "", t)
+    t = re.sub(r"_fwd$", "", t)
+    return {"x3_tail": "tail_x3"}.get(t, t)
+
+
+def same_family(a, b):
+    fa, fb = family(a), family(b)
+    return fa.startswith(fb) or fb.startswith(fa)
+
+
+def collect(d, counter, order=None):
+    """Mean counter value per tag.  With `order` (the tags of ONE cascade in launch order, tools/prof_traffic.py) the dispatches of the process's
+    LAST cascade are aligned with it from the end, so launches that share a kernel instance (two layers, two stages) land on their own tag;
+    a tag with no matching dispatch within the next three is skipped, and kernels are always keyed by (mapped) name as well."""
+    rows = []
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] == counter:
-                acc[tagname(short(row["Kernel_Name"]))].append(float(row["Counter_Value"]) * 1024.0)
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+                rows.append((int(row.get("Dispatch_Id", len(rows))), short(row["Kernel_Name"]), float(row["Counter_Value"]) * 1024.0))
+    rows.sort()
+    acc = defaultdict(list)
+    for _, k, v in rows:
+        acc[tagname(k)].append(v)
+    out = {k: sum(v) / len(v) for k, v in acc.items()}
+    if order:
+        lib = [(k, v) for _, k, v in rows if not k.startswith(("at::", "__amd"))]
+        j, got, missed = len(lib) - 1, {}, 0
+        for tag in reversed(order):
+            hit = next((q for q in range(4) if j - q >= 0 and same_family(lib[j - q][0], tag)), None)
+            if hit is None:
+                missed += 1
+                continue
+            got.setdefault(tag, []).append(lib[j - hit][1])
+            j -= hit + 1
+        print("launch-order alignment: %d tags, %d without a dispatch" % (len(order), missed), file=sys.stderr)
+        if missed <= len(order) // 10:
+            out.update({k: sum(v) / len(v) for k, v in got.items()})
+    return out
 
 
 def main():
-    fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+    import os
+    order_file = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "launch_order.json")
+    order = json.load(open(order_file)) if os.path.exists(order_file) else None
+    fetch, write = collect(sys.argv[1], "FETCH_SIZE", order), collect(sys.argv[2], "WRITE_SIZE", order)
     # calibration on a kernel of THIS library with a known byte count: the stage-4 feature transpose of config 2 reads and writes
     # exactly 4 * (5 views * 8 ch * 1152 * 1536) bytes, streaming, larger than the Infinity Cache
     calk = "nchw_to_nhwc_kernel<8>"
@@ -74,7 +111,7 @@ def main():
                     "of the same run (exact for 16 B/lane streams; 'narrow' kernels load dwords and are only indicative)", "kernels": {}}
     wide = ("cv_entropy_kernel", "cv_aggregate_kernel", "cv_corr_kernel", "cv_merge_kernel", "nchw_to_nhwc", "cv_tiled")
     for k in sorted(set(fetch) | set(write)):
-        if not re.search(r"cv_|vis_|conv3d|deconv|head|prob3|nchw|schedule|init_inv|wino|x3_", k):
+        if not re.search(r"cv_|vis_|conv3d|deconv|head|prob3|nchw|schedule|init_inv|wino|x3_|tail", k):
             continue
         fr, wr = fetch.get(k, 0.0), write.get(k, 0.0)
         out["kernels"][k] = {"fetch_raw": fr, "write_raw": wr, "hbm_bytes_per_launch": fr * ffac + wr * wfac, "narrow": not k.startswith(wide)}
