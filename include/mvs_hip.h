@@ -41,7 +41,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 10
+#define MVS_ABI_VERSION 11
 
 typedef void* mvs_stream_t;
 
@@ -143,6 +143,16 @@ int mvs_cv_corr_fwd(const float* feat, const float* rt, const float* depth, int 
                     float* entropy, void* store, int flags, mvs_stream_t stream);
 int mvs_cv_merge_fwd(const void* store, const float* depth, const float* weight, int B, int V, int C, int G, int D, int H, int W,
                      float* volume, float* sim_depth, mvs_stream_t stream);
+/* The same pair on a BAND of reference rows, for stages whose whole store would not stay in the Infinity Cache (config-2 stage 2: 254 MB):
+ *   mvs_cv_corr_rows_fwd   image rows y0 .. y0+rows-1 of the reference view (features, rt, depth: the whole image as above) -> BAND-LOCAL
+ *                          entropy [B,V-1,rows,W] and store (mvs_cv_corr_store_bytes with H = rows)
+ *   mvs_cv_merge_rows_fwd  band-local store + weight [B,V-1,rows,W]; band rows r_lo .. r_lo+nrows-1 (the band without the halo rows the
+ *                          visibility CNN needed) -> rows y0+r_lo ... of the whole-image volume [B,G,D,H,W] / sim_depth [B,H,W]
+ * Per row the arithmetic is that of the whole-image calls: a banded stage is bit-identical to an unbanded one. */
+int mvs_cv_corr_rows_fwd(const float* feat, const float* rt, const float* depth, int B, int V, int C, int G, int D, int H, int W, int y0,
+                         int rows, float* entropy, void* store, int flags, mvs_stream_t stream);
+int mvs_cv_merge_rows_fwd(const void* store, const float* depth, const float* weight, int B, int V, int C, int G, int D, int H, int W,
+                          int y0, int rows, int r_lo, int nrows, float* volume, float* sim_depth, mvs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * LDS-tiled form of the same two sweeps (cost_volume_tiled.hip) - the default eval path of StageNet.  Same math as

@@ -18,7 +18,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVS_HIP_LIB: diagnostics only - another BUILD of the same library (tests/test_hip_multistream.py's variants); never a fallback
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 from ctypes import c_double  # noqa: E402
 
@@ -38,6 +38,8 @@ SIGNATURES = {
     "mvs_cv_corr_store_bytes": (L, [I, I, I, I, I, I, I]),
     "mvs_cv_corr_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, P]),
     "mvs_cv_merge_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P, P]),
+    "mvs_cv_corr_rows_fwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P, P, I, P]),
+    "mvs_cv_merge_rows_fwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, P]),
     "mvs_cv_tiled_workspace_bytes": (L, [I, I, I, I, I, I]),
     "mvs_conv3d_x3_supported": (I, [I, I, I, I]),
     "mvs_conv3d_x3_packed_bytes": (L, [I, I, I, I]),

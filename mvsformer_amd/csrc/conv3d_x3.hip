@@ -113,6 +113,19 @@ struct X3Args {
 template <int V>
 using ic = std::integral_constant<int, V>;
 
+#ifdef X3_TIMELINE
+// experiment build only (make exp EXPFLAGS=-DX3_TIMELINE): wavefront 0 of every block adds the s_memtime ticks of each phase of a pass
+__device__ unsigned long long x3_phase_ticks[8];
+#define X3_STAMP(slot)                                                              \
+    do {                                                                            \
+        const unsigned long long now_ = __builtin_readcyclecounter();               \
+        tl_acc_[slot] += now_ - t_prev_;                                            \
+        t_prev_ = now_;                                                             \
+    } while (0)
+#else
+#define X3_STAMP(slot)
+#endif
+
 template <class Cfg>
 __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3Args a) {
     const int seg = blockIdx.z % a.nseg;
@@ -148,12 +161,19 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
     // D[m = pixel][n = output channel] (the activations are the MFMA's A operand): a lane holds 4 consecutive pixels (4*kb .. 4*kb+3) of
     // output channel n of each (M tile, row) -> one 16-byte store, and one scale / shift pair per lane
     const bool vec_ok = (a.Wo & 3) == 0;
+    float ep_sc[MTB], ep_sh[MTB];                          // read once: inside store_plane the loads would sit behind a full L2 round trip per plane
+#pragma unroll
+    for (int mt = 0; mt < MTB; ++mt) {
+        const int co = min((ctb * MTB + mt) * 16 + n, Cout - 1);
+        ep_sc[mt] = a.scale ? a.scale[co] : 1.0f;
+        ep_sh[mt] = a.shift ? a.shift[co] : 0.0f;
+    }
     auto store_plane = [&](int od, const f32x4 (&c)[MTB][NT]) {
 #pragma unroll
         for (int mt = 0; mt < MTB; ++mt) {
             const int co = (ctb * MTB + mt) * 16 + n;
             if (co >= Cout) continue;
-            const float sc = a.scale ? a.scale[co] : 1.0f, sh = a.shift ? a.shift[co] : 0.0f;
+            const float sc = ep_sc[mt], sh = ep_sh[mt];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int gy = y0 + wave * NT + nt, gx = x0 + kb * 4;
@@ -181,7 +201,11 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
         }
     };
 
-    bf16x8 wbuf[2][MTB][3];                                // ping-pong weight fragments [buffer][M tile][h | m | l]
+    // ping-pong weight fragments [buffer][M tile][h | m | l].  A ring of three (two steps of weights in flight) was measured in round 4
+    // (profiles/r04_bench_x3_wring.txt): 4-29 spilled registers in four of the five instances and 2-15 % slower everywhere - the MFMA
+    // phase is not waiting for weights (tools/x3_timeline.py: its length follows the LDS fragment reads and the other wavefronts' MFMAs)
+    constexpr int WR = 2, WAHEAD = 1;
+    bf16x8 wbuf[WR][MTB][3];
     auto load_w = [&](const bf16x8* wk, bf16x8 (&aw)[MTB][3]) {
 #pragma unroll
         for (int mt = 0; mt < MTB; ++mt)
@@ -235,8 +259,8 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
         if (Cfg::BPIPE) load_b(0, 0, bf[0]);
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
-            const int cur = (P + s) & 1;
-            if (s + 1 < STEPS || more) load_w(wk + (size_t)(s + 1) * 192, wbuf[cur ^ 1]);      // no load left in flight at the end of the pass
+            const int cur = (P + s) % WR;
+            if (s + WAHEAD < STEPS || more) load_w(wk + (size_t)(s + WAHEAD) * 192, wbuf[(P + s + WAHEAD) % WR]);   // no load left in flight at the end of the pass
             // one step's (BPIPE: one item's) operands + the prefetches in flight at a time: left alone, the scheduler hoists every step's loads
             if (!Cfg::BPIPE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -271,43 +295,56 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
     if (d_lo >= D) return;                                 // an empty segment owns no output plane (block-uniform; the launchers never create one)
     const int p_first = max(0, d_lo - 1), p_last = min(D - 1, d_hi);
     const int NP = (p_last - p_first + 1) * NCH;           // passes: (input plane, channel chunk)
+#ifdef X3_TIMELINE
+    unsigned long long tl_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int pass = 0; pass < NP; ++pass) {
         const int p = p_first + pass / NCH, chunk = pass % NCH;
         // depth taps of input plane p whose output plane od = p + 1 - kd lies in [d_lo, d_hi): a contiguous, block-uniform range
         const int kd_lo = max(0, p + 2 - d_hi), kd_hi = min(2, p + 1 - d_lo);
         const bf16x8* wk = a.wp + ((size_t)((ctb * MTB) * NCH + chunk) * 3 + kd_lo) * Cfg::FRAGS_PER_KD + lane;
-        load_w(wk, wbuf[0]);                               // the first step's weights travel while the plane is staged
+#pragma unroll
+        for (int k = 0; k < WAHEAD; ++k) load_w(wk + (size_t)k * 192, wbuf[k]);      // the first steps' weights travel while the plane is staged
         // ---- stage plane p, channels [CK*chunk, CK*chunk + CK): fp32 -> (h, m, l) bf16 channel-last: all of a thread's loads first (NI
         //      items x 8 channel planes in flight), then the split and the LDS stores.  Measured and dropped: the NEXT pass's loads in
         //      FRONT of this pass's MFMA phase (-10...25 %: the weight fragments are global loads too, vmcnt retires in order, so the
         //      first weight wait drains the whole prefetch), and INSIDE it, a few per step behind each step's weight prefetch, held in
         //      registers until the pass ends (+2 % for the 32/64-channel stride-1 layers, -12...-40 % elsewhere: 24-40 more live
         //      registers through the MFMA phase) ----
+#ifdef X3_TIMELINE
+        unsigned long long t_prev_ = __builtin_readcyclecounter();
+#endif
 #pragma unroll
         for (int it = 0; it < NI; ++it) issue(it, p, chunk);
+        X3_STAMP(0);                                       // loads issued
         __syncthreads();                                   // the previous pass's fragment reads are done
+        X3_STAMP(1);
+#ifdef X3_TIMELINE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        X3_STAMP(2);                                       // staging loads (and the first weights) have arrived
+#endif
         commit();
+        X3_STAMP(3);
         __syncthreads();
+        X3_STAMP(4);
         // ---- the depth taps of this plane; the buffer parity flips after each one (STEPS is odd) ----
-        int pos = 0;
-        {
-            if (kd_lo == 0) {
-                kd_steps(ic<0>{}, ic<0>{}, wk, kd_hi >= 1);
-                wk += Cfg::FRAGS_PER_KD;
-                pos = 1;
-            }
-            if (kd_lo <= 1 && kd_hi >= 1) {
-                if (pos == 0) kd_steps(ic<1>{}, ic<0>{}, wk, kd_hi >= 2); else kd_steps(ic<1>{}, ic<1>{}, wk, kd_hi >= 2);
-                wk += Cfg::FRAGS_PER_KD;
-                pos ^= 1;
-            }
-            if (kd_hi >= 2) {
-                if (pos == 0) kd_steps(ic<2>{}, ic<0>{}, wk, false); else kd_steps(ic<2>{}, ic<1>{}, wk, false);
-            }
+        // ring position of each depth tap's first step: STEPS % WR further on per executed tap (compile-time per branch)
+        constexpr int ADV = STEPS % WR, P1 = ADV, P2 = (2 * ADV) % WR;
+        if (kd_lo == 0) {
+            kd_steps(ic<0>{}, ic<0>{}, wk, kd_hi >= 1);
+            if (kd_hi >= 1) kd_steps(ic<1>{}, ic<P1>{}, wk + Cfg::FRAGS_PER_KD, kd_hi >= 2);
+            if (kd_hi >= 2) kd_steps(ic<2>{}, ic<P2>{}, wk + 2 * Cfg::FRAGS_PER_KD, false);
+        } else if (kd_lo == 1) {
+            kd_steps(ic<1>{}, ic<0>{}, wk, kd_hi >= 2);
+            if (kd_hi >= 2) kd_steps(ic<2>{}, ic<P1>{}, wk + Cfg::FRAGS_PER_KD, false);
+        } else {
+            kd_steps(ic<2>{}, ic<0>{}, wk, false);
         }
+        X3_STAMP(5);                                       // MFMA phase
         if (chunk == NCH - 1) {
             // output plane p-1 has seen its three input planes
             if (p - 1 >= d_lo) store_plane(p - 1, acc[0]);
+            X3_STAMP(6);
 #pragma unroll
             for (int mt = 0; mt < MTB; ++mt)
 #pragma unroll
@@ -319,6 +356,10 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
         }
     }
     if (p_last == D - 1 && d_hi == D) store_plane(D - 1, acc[0]);
+#ifdef X3_TIMELINE
+    if (tid == 0)
+        for (int i = 0; i < 7; ++i) atomicAdd(&x3_phase_ticks[i], tl_acc_[i]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -717,3 +758,14 @@ extern "C" int mvs_deconv3d_x3_fwd(const float* x, const void* wpacked, const fl
     hipLaunchKernelGGL(x3_deconv_kernel, dim3(a.tiles_x * ty, cts, B * nseg), dim3(256), 0, MVS_STREAM(stream), a);
     return mvs::finish_launch("mvs_deconv3d_x3_fwd");
 }
+
+#ifdef X3_TIMELINE
+extern "C" int mvs_x3_timeline(unsigned long long* out8, int reset) {
+    if (out8) hipMemcpyFromSymbol(out8, HIP_SYMBOL(x3_phase_ticks), 64);
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        hipMemcpyToSymbol(HIP_SYMBOL(x3_phase_ticks), z, 64);
+    }
+    return 0;
+}
+#endif

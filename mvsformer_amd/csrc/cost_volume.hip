@@ -510,7 +510,9 @@ struct CorrCfg {
 template <int LPP, bool FAST>
 __global__ __launch_bounds__(64 * NW) void cv_corr_kernel(const float* __restrict__ feat /*[B,V,H,W,C]*/, const float* __restrict__ rt_all,
                                                           const float* __restrict__ depth, int V, int D, int H, int W, float* __restrict__ entropy,
-                                                          float* __restrict__ corr, float* __restrict__ simv, int gx, int total) {
+                                                          float* __restrict__ corr, float* __restrict__ simv, int gx, int total, int y0, int Hs) {
+    // (y0, Hs): the band of reference rows this launch covers - image rows y0 .. y0 + Hs - 1; entropy and store are band-local ([..][Hs][..]),
+    // features / hypotheses are the whole image.  y0 = 0, Hs = H is the whole image.
     using Cfg = CorrCfg<LPP>;
     constexpr int C = Cfg::C, CPG = Cfg::CPG, PPW = Cfg::PPW;
     static_assert(LPP == 8 || LPP == 16, "stored-correlation sweeps are built for C = 32 and C = 64");
@@ -525,10 +527,10 @@ __global__ __launch_bounds__(64 * NW) void cv_corr_kernel(const float* __restric
     float* stage = fbase + (size_t)NW * (PPW * D + Cfg::RED_FLOATS) + wave * Cfg::STAGE_FLOATS;   // [LPP][G][PPW]
     float* sstage = fbase + (size_t)NW * (PPW * D + Cfg::RED_FLOATS + Cfg::STAGE_FLOATS) + wave * Cfg::SSTAGE_FLOATS;   // [LPP][PPW]
 
-    const BlockId bid = xcd_block(gx, H, total);
+    const BlockId bid = xcd_block(gx, Hs, total);
     if (!bid.valid) return;
     const int xgi = bid.x * NW + wave;                      // pixel group of this wavefront
-    const int x0 = xgi * PPW, y = bid.y;
+    const int x0 = xgi * PPW, ys = bid.y, y = y0 + ys;
     const int b = bid.z / (V - 1), sv = bid.z % (V - 1);
     if (x0 >= W) return;                                   // wave-uniform; only wavefront-level barriers below
     const int XG = (W + PPW - 1) / PPW;
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(64 * NW) void cv_corr_kernel(const float* __restric
     const float* rt = rt_all + (size_t)(b * (V - 1) + sv) * 12;
     const float* depth_row = depth + (size_t)b * D * HW + (size_t)y * W;
     const float half_w = (float)((W - 1) / 2.0), half_h = (float)((H - 1) / 2.0);
-    const size_t tile = ((size_t)(b * (V - 1) + sv) * H + y) * XG + xgi;
+    const size_t tile = ((size_t)(b * (V - 1) + sv) * Hs + ys) * XG + xgi;
     float* ctile = corr + tile * ((size_t)D * G * PPW);
     float* stile = simv + tile * ((size_t)D * PPW);
 
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(64 * NW) void cv_corr_kernel(const float* __restric
         }
 #pragma unroll
         for (int s = PPW; s < 64; s <<= 1) ent += __shfl_xor(ent, s, 64);
-        if (k == 0 && x0 + p < W) entropy[((size_t)(b * (V - 1) + sv) * H + y) * W + x0 + p] = ent;
+        if (k == 0 && x0 + p < W) entropy[((size_t)(b * (V - 1) + sv) * Hs + ys) * W + x0 + p] = ent;
     }
 }
 
@@ -654,28 +656,30 @@ __global__ __launch_bounds__(64 * NW) void cv_corr_kernel(const float* __restric
 template <int TPX>
 __global__ __launch_bounds__(64 * NW) void cv_merge_kernel(const float* __restrict__ corr, const float* __restrict__ simv, const float* __restrict__ depth,
                                                            const float* __restrict__ weight, int V, int D, int H, int W, float* __restrict__ volume,
-                                                           float* __restrict__ sim_depth, int gx, int total) {
+                                                           float* __restrict__ sim_depth, int gx, int total, int y0, int Hs, int r_lo, int nrows) {
+    // store and weight are band-local ([..][Hs][..], band row 0 = image row y0); this launch merges band rows r_lo .. r_lo + nrows - 1 (the
+    // band without its halo) into the whole-image volume / sim_depth.  y0 = 0, Hs = H, r_lo = 0, nrows = H is the whole image.
     constexpr int LPR = TPX / 4;                          // lanes (float4s) per (plane, group) row
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const BlockId bid = xcd_block(gx, H, total);
+    const BlockId bid = xcd_block(gx, nrows, total);
     if (!bid.valid) return;
     const int XG = (W + TPX - 1) / TPX;
-    const int xgi = bid.x * NW + wave, y = bid.y, b = bid.z;
+    const int xgi = bid.x * NW + wave, ys = r_lo + bid.y, y = y0 + ys, b = bid.z;
     if (xgi >= XG) return;
     const int x0 = xgi * TPX;
     const size_t HW = (size_t)H * W;
     const int nv = V - 1;
-    const size_t vstride_c = (size_t)H * XG * D * G * TPX, vstride_s = (size_t)H * XG * D * TPX;
-    const float* ct = corr + (size_t)(b * nv) * vstride_c + ((size_t)y * XG + xgi) * ((size_t)D * G * TPX);
-    const float* stl = simv + (size_t)(b * nv) * vstride_s + ((size_t)y * XG + xgi) * ((size_t)D * TPX);
-    const float* wp = weight + (size_t)(b * nv) * HW + (size_t)y * W;
+    const size_t vstride_c = (size_t)Hs * XG * D * G * TPX, vstride_s = (size_t)Hs * XG * D * TPX, HWs = (size_t)Hs * W;
+    const float* ct = corr + (size_t)(b * nv) * vstride_c + ((size_t)ys * XG + xgi) * ((size_t)D * G * TPX);
+    const float* stl = simv + (size_t)(b * nv) * vstride_s + ((size_t)ys * XG + xgi) * ((size_t)D * TPX);
+    const float* wp = weight + (size_t)(b * nv) * HWs + (size_t)ys * W;
     {
         const int part = lane % LPR, xs = x0 + part * 4;
         f32x4 wsum = {0.f, 0.f, 0.f, 0.f};
         for (int v = 0; v < nv; ++v)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wsum[i] = wsum[i] + wp[(size_t)v * HW + min(xs + i, W - 1)];
+            for (int i = 0; i < 4; ++i) wsum[i] = wsum[i] + wp[(size_t)v * HWs + min(xs + i, W - 1)];
         f32x4 denom;
 #pragma unroll
         for (int i = 0; i < 4; ++i) denom[i] = wsum[i] + 1e-6f;
@@ -687,7 +691,7 @@ __global__ __launch_bounds__(64 * NW) void cv_merge_kernel(const float* __restri
             for (int v = 0; v < nv; ++v) {
                 const f32x4 c4 = *reinterpret_cast<const f32x4*>(ct + (size_t)v * vstride_c + (size_t)f * 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = acc[i] + c4[i] * wp[(size_t)v * HW + min(xs + i, W - 1)];
+                for (int i = 0; i < 4; ++i) acc[i] = acc[i] + c4[i] * wp[(size_t)v * HWs + min(xs + i, W - 1)];
             }
             const int d = row / G, g = row % G;
             float* o = volume + ((size_t)(b * G + g) * D + d) * HW + (size_t)y * W + xs;
@@ -865,48 +869,73 @@ extern "C" int64_t mvs_cv_corr_store_bytes(int B, int V, int C, int Gin, int D, 
     return (l.corr_floats + l.sim_floats) * (int64_t)sizeof(float);
 }
 
-extern "C" int mvs_cv_corr_fwd(const float* feat, const float* rt, const float* depth, int B, int V, int C, int Gin, int D, int H, int W,
-                               float* entropy, void* store, int flags, mvs_stream_t stream) {
-    MVS_REQUIRE(feat && rt && depth && entropy && store, "mvs_cv_corr_fwd: null pointer");
-    if (int rc = check_shapes("mvs_cv_corr_fwd", B, V, C, Gin, D, H, W)) return rc;
-    MVS_REQUIRE(C == 32 || C == 64, "mvs_cv_corr_fwd: the stored-correlation sweeps are built for C = 32 and C = 64 (got %d)", C);
-    MVS_REQUIRE((reinterpret_cast<uintptr_t>(store) & 15) == 0, "mvs_cv_corr_fwd: store must be 16-byte aligned");
+namespace {
+int corr_launch(const char* who, const float* feat, const float* rt, const float* depth, int B, int V, int C, int Gin, int D, int H, int W, int y0, int Hs,
+                float* entropy, void* store, int flags, mvs_stream_t stream) {
+    MVS_REQUIRE(feat && rt && depth && entropy && store, "%s: null pointer", who);
+    if (int rc = check_shapes(who, B, V, C, Gin, D, H, W)) return rc;
+    MVS_REQUIRE(C == 32 || C == 64, "%s: the stored-correlation sweeps are built for C = 32 and C = 64 (got %d)", who, C);
+    MVS_REQUIRE(y0 >= 0 && Hs >= 1 && y0 + Hs <= H, "%s: rows [%d, %d) outside the image (H = %d)", who, y0, y0 + Hs, H);
+    MVS_REQUIRE((reinterpret_cast<uintptr_t>(store) & 15) == 0, "%s: store must be 16-byte aligned", who);
     const int LPP = C / 4, PPW = 64 / LPP;
     const size_t lds = LPP == 16 ? CorrCfg<16>::lds_bytes(D) : CorrCfg<8>::lds_bytes(D);
-    MVS_REQUIRE(lds <= 64 * 1024, "mvs_cv_corr_fwd: D=%d with C=%d needs %zu bytes of LDS (> 64 KiB)", D, C, lds);
-    const StoreLayout l = store_layout(B, V, C, D, H, W);
+    MVS_REQUIRE(lds <= 64 * 1024, "%s: D=%d with C=%d needs %zu bytes of LDS (> 64 KiB)", who, D, C, lds);
+    const StoreLayout l = store_layout(B, V, C, D, Hs, W);
     float* corr = static_cast<float*>(store);
     float* simv = corr + l.corr_floats;
     const int gx = mvs::ceil_div(W, NW * PPW);
-    const int64_t total64 = (int64_t)gx * H * B * (V - 1);
-    MVS_REQUIRE(total64 < ((int64_t)1 << 30), "mvs_cv_corr_fwd: too many blocks");
+    const int64_t total64 = (int64_t)gx * Hs * B * (V - 1);
+    MVS_REQUIRE(total64 < ((int64_t)1 << 30), "%s: too many blocks", who);
     const int total = (int)total64;
     dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(64 * NW);
     hipStream_t s = MVS_STREAM(stream);
     const bool fast = !(flags & 1);
-#define MVS_LAUNCH_CORR(L)                                                                                                                 \
-    if (fast) hipLaunchKernelGGL((cv_corr_kernel<L, true>), grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy, corr, simv, gx, total); \
-    else hipLaunchKernelGGL((cv_corr_kernel<L, false>), grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy, corr, simv, gx, total)
+#define MVS_LAUNCH_CORR(L)                                                                                                                          \
+    if (fast) hipLaunchKernelGGL((cv_corr_kernel<L, true>), grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy, corr, simv, gx, total, y0, Hs); \
+    else hipLaunchKernelGGL((cv_corr_kernel<L, false>), grid, block, lds, s, feat, rt, depth, V, D, H, W, entropy, corr, simv, gx, total, y0, Hs)
     if (LPP == 16) { MVS_LAUNCH_CORR(16); } else { MVS_LAUNCH_CORR(8); }
 #undef MVS_LAUNCH_CORR
-    return mvs::finish_launch("mvs_cv_corr_fwd");
+    return mvs::finish_launch(who);
+}
+
+int merge_launch(const char* who, const void* store, const float* depth, const float* weight, int B, int V, int C, int Gin, int D, int H, int W, int y0, int Hs,
+                 int r_lo, int nrows, float* volume, float* sim_depth, mvs_stream_t stream) {
+    MVS_REQUIRE(store && depth && weight && volume, "%s: null pointer", who);
+    if (int rc = check_shapes(who, B, V, C, Gin, D, H, W)) return rc;
+    MVS_REQUIRE(C == 32 || C == 64, "%s: the stored-correlation sweeps are built for C = 32 and C = 64 (got %d)", who, C);
+    MVS_REQUIRE(y0 >= 0 && Hs >= 1 && y0 + Hs <= H && r_lo >= 0 && nrows >= 1 && r_lo + nrows <= Hs, "%s: band rows [%d, %d) of a band [%d, %d) of H = %d", who, r_lo,
+                r_lo + nrows, y0, y0 + Hs, H);
+    const StoreLayout l = store_layout(B, V, C, D, Hs, W);
+    const float* corr = static_cast<const float*>(store);
+    const float* simv = corr + l.corr_floats;
+    const int gx = mvs::ceil_div(l.XG, NW);
+    const int64_t total64 = (int64_t)gx * nrows * B;
+    MVS_REQUIRE(total64 < ((int64_t)1 << 30), "%s: too many blocks", who);
+    const int total = (int)total64;
+    dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(64 * NW);
+    hipStream_t s = MVS_STREAM(stream);
+    if (l.TPX == 4) hipLaunchKernelGGL((cv_merge_kernel<4>), grid, block, 0, s, corr, simv, depth, weight, V, D, H, W, volume, sim_depth, gx, total, y0, Hs, r_lo, nrows);
+    else hipLaunchKernelGGL((cv_merge_kernel<8>), grid, block, 0, s, corr, simv, depth, weight, V, D, H, W, volume, sim_depth, gx, total, y0, Hs, r_lo, nrows);
+    return mvs::finish_launch(who);
+}
+}  // namespace
+
+extern "C" int mvs_cv_corr_fwd(const float* feat, const float* rt, const float* depth, int B, int V, int C, int Gin, int D, int H, int W,
+                               float* entropy, void* store, int flags, mvs_stream_t stream) {
+    return corr_launch("mvs_cv_corr_fwd", feat, rt, depth, B, V, C, Gin, D, H, W, 0, H, entropy, store, flags, stream);
+}
+
+extern "C" int mvs_cv_corr_rows_fwd(const float* feat, const float* rt, const float* depth, int B, int V, int C, int Gin, int D, int H, int W, int y0,
+                                    int rows, float* entropy, void* store, int flags, mvs_stream_t stream) {
+    return corr_launch("mvs_cv_corr_rows_fwd", feat, rt, depth, B, V, C, Gin, D, H, W, y0, rows, entropy, store, flags, stream);
+}
+
+extern "C" int mvs_cv_merge_rows_fwd(const void* store, const float* depth, const float* weight, int B, int V, int C, int Gin, int D, int H, int W, int y0,
+                                     int rows, int r_lo, int nrows, float* volume, float* sim_depth, mvs_stream_t stream) {
+    return merge_launch("mvs_cv_merge_rows_fwd", store, depth, weight, B, V, C, Gin, D, H, W, y0, rows, r_lo, nrows, volume, sim_depth, stream);
 }
 
 extern "C" int mvs_cv_merge_fwd(const void* store, const float* depth, const float* weight, int B, int V, int C, int Gin, int D, int H, int W,
                                 float* volume, float* sim_depth, mvs_stream_t stream) {
-    MVS_REQUIRE(store && depth && weight && volume, "mvs_cv_merge_fwd: null pointer");
-    if (int rc = check_shapes("mvs_cv_merge_fwd", B, V, C, Gin, D, H, W)) return rc;
-    MVS_REQUIRE(C == 32 || C == 64, "mvs_cv_merge_fwd: the stored-correlation sweeps are built for C = 32 and C = 64 (got %d)", C);
-    const StoreLayout l = store_layout(B, V, C, D, H, W);
-    const float* corr = static_cast<const float*>(store);
-    const float* simv = corr + l.corr_floats;
-    const int gx = mvs::ceil_div(l.XG, NW);
-    const int64_t total64 = (int64_t)gx * H * B;
-    MVS_REQUIRE(total64 < ((int64_t)1 << 30), "mvs_cv_merge_fwd: too many blocks");
-    const int total = (int)total64;
-    dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(64 * NW);
-    hipStream_t s = MVS_STREAM(stream);
-    if (l.TPX == 4) hipLaunchKernelGGL((cv_merge_kernel<4>), grid, block, 0, s, corr, simv, depth, weight, V, D, H, W, volume, sim_depth, gx, total);
-    else hipLaunchKernelGGL((cv_merge_kernel<8>), grid, block, 0, s, corr, simv, depth, weight, V, D, H, W, volume, sim_depth, gx, total);
-    return mvs::finish_launch("mvs_cv_merge_fwd");
+    return merge_launch("mvs_cv_merge_fwd", store, depth, weight, B, V, C, Gin, D, H, W, 0, H, 0, H, volume, sim_depth, stream);
 }

@@ -316,6 +316,40 @@ def cv_merge(store: torch.Tensor, depth: torch.Tensor, weight: torch.Tensor, V: 
     return vol, sim
 
 
+def cv_corr_rows(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, G: int, y0: int, rows: int, store: Optional[torch.Tensor] = None,
+                 exact: Optional[bool] = None):
+    """Sweep A' on the band of reference rows ``[y0, y0 + rows)``: band-local entropy ``[B,V-1,rows,W]`` + store (``store``: a buffer to reuse)."""
+    _chk(feat, "features"), _chk(rt, "rt"), _chk(depth, "depth_values")
+    B, V, H, W, C = feat.shape
+    D = depth.shape[1]
+    if depth.shape != (B, D, H, W):
+        raise _lib.MvsHipError("depth_values must be [B,D,H,W]=%s, got %s" % ((B, D, H, W), tuple(depth.shape)))
+    nbytes = int(_lib.load().mvs_cv_corr_store_bytes(B, V, C, G, D, rows, W))
+    if nbytes <= 0:
+        raise _lib.MvsHipError("stored-correlation sweeps are not built for C=%d, G=%d, D=%d" % (C, G, D))
+    if store is None or store.numel() * 4 < nbytes:
+        store = torch.empty(nbytes // 4, device=feat.device, dtype=torch.float32)
+    ent = torch.empty(B, V - 1, rows, W, device=feat.device, dtype=torch.float32)
+    tag = ("cv_corr_kernel<%d>" % (C // 4), "bytes", 4.0 * B * rows * W * (V * C + D))
+    _call("mvs_cv_corr_rows_fwd", tag, _ptr(feat), _ptr(rt), _ptr(depth), B, V, C, G, D, H, W, int(y0), int(rows), _ptr(ent), _ptr(store),
+          _cv_flags(exact), _stream())
+    return ent, store
+
+
+def cv_merge_rows(store: torch.Tensor, depth: torch.Tensor, weight: torch.Tensor, V: int, C: int, G: int, y0: int, r_lo: int, nrows: int,
+                  volume: torch.Tensor, sim_depth: Optional[torch.Tensor]) -> None:
+    """Sweep B' over a band's store: band rows ``[r_lo, r_lo + nrows)`` of band-local ``weight [B,V-1,rows,W]`` into the whole-image
+    ``volume [B,G,D,H,W]`` / ``sim_depth [B,H,W]`` (rows ``y0 + r_lo ...``)."""
+    _chk(store, "correlation store"), _chk(depth, "depth_values"), _chk(weight, "vis_weight"), _chk(volume, "volume"), _opt(sim_depth, "sim_depth")
+    B, D, H, W = depth.shape
+    rows = weight.shape[2]
+    if weight.shape != (B, V - 1, rows, W) or volume.shape != (B, G, D, H, W) or store.numel() * 4 < int(_lib.load().mvs_cv_corr_store_bytes(B, V, C, G, D, rows, W)):
+        raise _lib.MvsHipError("cv_merge_rows: weight %s / volume %s / store size do not match the shape" % (tuple(weight.shape), tuple(volume.shape)))
+    tag = ("cv_merge_kernel<%d>" % (256 // C), "bytes", 4.0 * B * nrows * W * (G * D))
+    _call("mvs_cv_merge_rows_fwd", tag, _ptr(store), _ptr(depth), _ptr(weight), B, V, C, G, D, H, W, int(y0), int(rows), int(r_lo), int(nrows),
+          _ptr(volume), _ptr(sim_depth), _stream())
+
+
 def cv_tiled_supported(feat: torch.Tensor) -> bool:
     """The LDS-tiled sweeps take the FPN decoder's NCHW ``[B,V,C,H,W]`` maps directly (C in 8/16/32/64, contiguous fp32)."""
     return (isinstance(feat, torch.Tensor) and feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 5 and feat.is_contiguous()

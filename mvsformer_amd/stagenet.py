@@ -29,14 +29,28 @@ from ._lib import MvsHipError
 from .module import ConvBnReLU, CostRegNet, CostRegNet3D, _versions, pack_vis_params
 
 
-def _store_plan(feat_cl, D, G) -> bool:
-    """True when the stage should keep its per-view correlation volumes (stored-correlation sweeps): built for C = 32 | 64 and only
-    worth it while the store AND the feature maps stay inside the 256 MB Infinity Cache together (MVS_CV_STORE_MAX_MB, default 160;
-    0 disables the path).  Measured at config 2 (profiles/r03_bench_sweeps.txt): stage 1 (127 MB) 0.30 -> 0.20 ms for the pair,
-    stage 2 (254 MB: the round trip goes to HBM) 0.29 -> 0.32 ms - so stage 2 recomputes."""
-    limit = float(os.environ.get("MVS_CV_STORE_MAX_MB", "160"))
+VIS_HALO = 3          # receptive-field radius of the visibility CNN (three 3x3 layers): rows a band needs beyond its own
+
+
+def _store_plan(feat_cl, D, G) -> int:
+    """How the stage builds its cost volume: 0 = recompute the correlation in sweep B; 1 = keep the per-view correlation volumes of the whole
+    image (stored-correlation sweeps, built for C = 32 | 64); k > 1 = the same in k bands of reference rows, each band's store small enough to
+    stay inside the 256 MB Infinity Cache next to the feature maps (MVS_CV_STORE_MAX_MB, default 160; 0 disables the path; MVS_CV_STORE_BANDS caps
+    k, default 1 - banding is opt-in until it is measured faster at config-2 stage 2).  Measured at config 2 (profiles/r03_bench_sweeps.txt): stage 1 (127 MB) 0.30 -> 0.20 ms for
+    the pair; stage 2 in one piece (254 MB: the round trip goes to HBM) 0.29 -> 0.32 ms."""
+    limit = float(os.environ.get("MVS_CV_STORE_MAX_MB", "160")) * 2 ** 20
+    max_bands = int(os.environ.get("MVS_CV_STORE_BANDS", "1"))
     nbytes = ops.cv_store_bytes(feat_cl, D, G)
-    return 0 < nbytes <= limit * 2 ** 20
+    if nbytes <= 0 or limit <= 0:
+        return 0
+    if nbytes <= limit:
+        return 1
+    H = feat_cl.shape[2]
+    for k in range(2, max_bands + 1):
+        rows = -(-H // k) + 2 * VIS_HALO + 1                  # (+1: a band's first row is rounded down to even)
+        if rows < H and nbytes * rows / H <= limit:
+            return k
+    return 0
 
 
 class StageNet(nn.Module):
@@ -108,10 +122,29 @@ class StageNet(nn.Module):
             volume, sim_depth = ops.cv_tiled_aggregate(feat, rt, hyp, weight, G, want_sim_depth=True)
         else:                                                   # direct gather sweeps over channel-last maps (zero-copy if NHWC already)
             feat = ops.to_channels_last(feat)
-            if _store_plan(feat, hyp.shape[1], G):
+            bands = _store_plan(feat, hyp.shape[1], G)
+            if bands == 1:
                 entropy, store = ops.cv_corr(feat, rt, hyp, G)
                 weight = self._vis_weight(entropy, vis_params, vis_prepared)
                 volume, sim_depth = ops.cv_merge(store, hyp, weight, feat.shape[1], feat.shape[4], G, want_sim_depth=True)
+            elif bands > 1:
+                # row bands: sweep A' on the band + VIS_HALO rows either side (the rows the visibility CNN's 7 x 7 receptive field reaches),
+                # the CNN on the band as an image of its own (exact inside the band: its zero padding only touches the halo rows or the true
+                # image border), sweep B' on the band without the halo - the band's store is read back while it is still in the cache
+                B_, V_, H_, W_, C_ = feat.shape
+                D_ = hyp.shape[1]
+                volume = torch.empty(B_, G, D_, H_, W_, device=feat.device, dtype=torch.float32)
+                sim_depth = torch.empty(B_, H_, W_, device=feat.device, dtype=torch.float32)
+                hb = -(-H_ // bands)
+                store = None
+                for r0 in range(0, H_, hb):
+                    r1 = min(H_, r0 + hb)
+                    # an EVEN first row: the MFMA visibility kernels compute output rows in pairs (x3: one tile holds rows 2p and 2p + 1 with the
+                    # taps at different K positions; wino: F(2x2,3x3)), so a row's rounding depends on its parity in the image the CNN is given
+                    y0, y1 = max(0, (r0 - VIS_HALO) & ~1), min(H_, r1 + VIS_HALO)
+                    entropy, store = ops.cv_corr_rows(feat, rt, hyp, G, y0, y1 - y0, store)
+                    weight = self._vis_weight(entropy, vis_params, vis_prepared)
+                    ops.cv_merge_rows(store, hyp, weight, V_, C_, G, y0, r0 - y0, r1 - r0, volume, sim_depth)
             else:
                 entropy = ops.cv_entropy(feat, rt, hyp, G)
                 weight = self._vis_weight(entropy, vis_params, vis_prepared)

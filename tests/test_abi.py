@@ -152,20 +152,27 @@ def test_store_plan_and_vis_mode_host_logic(monkeypatch):
     f1 = torch.empty(1, 5, 144, 192, 64)                  # [B,V,H,W,C] channel-last, stage 1 of config 2
     f2 = torch.empty(1, 5, 288, 384, 32)
     f3 = torch.empty(1, 5, 576, 768, 16)
-    assert stagenet._store_plan(f1, 32, 8) is True
-    assert stagenet._store_plan(f2, 16, 8) is False
-    assert stagenet._store_plan(f3, 8, 8) is False          # C = 16: not built (zero bytes)
+    monkeypatch.delenv("MVS_CV_STORE_BANDS", raising=False)
+    assert stagenet._store_plan(f1, 32, 8) == 1                # one store for the whole image
+    assert stagenet._store_plan(f2, 16, 8) == 0                # 254 MB: recompute (banding is opt-in)
+    assert stagenet._store_plan(f3, 8, 8) == 0                 # C = 16: not built
+    monkeypatch.setenv("MVS_CV_STORE_BANDS", "4")
+    assert stagenet._store_plan(f2, 16, 8) == 2                # two bands of 144 + 7 rows: 133 MB each
+    assert stagenet._store_plan(f1, 32, 8) == 1
+    monkeypatch.setenv("MVS_CV_STORE_MAX_MB", "70")
+    assert stagenet._store_plan(f2, 16, 8) == 4                # 72 + 7 rows: 69.7 MB
+    assert stagenet._store_plan(f1, 32, 8) == 2
     monkeypatch.setenv("MVS_CV_STORE_MAX_MB", "400")
-    assert stagenet._store_plan(f2, 16, 8) is True
+    assert stagenet._store_plan(f2, 16, 8) == 1
     monkeypatch.setenv("MVS_CV_STORE_MAX_MB", "0")
-    assert stagenet._store_plan(f1, 32, 8) is False
+    assert stagenet._store_plan(f1, 32, 8) == 0
     # a small map with many hypotheses: the store would fit, but mvs_cv_corr_fwd's per-pixel LDS rows do not: the size query
     # says "not built" and the stage falls back to the recomputing sweeps instead of raising from the launch
     monkeypatch.setenv("MVS_CV_STORE_MAX_MB", "160")
     tiny = torch.empty(1, 3, 16, 24, 32)
-    assert stagenet._store_plan(tiny, 256, 8) is True
-    assert stagenet._store_plan(tiny, 352, 8) is False
-    assert stagenet._store_plan(torch.empty(1, 3, 16, 24, 64), 1000, 8) is False
+    assert stagenet._store_plan(tiny, 256, 8) == 1
+    assert stagenet._store_plan(tiny, 352, 8) == 0
+    assert stagenet._store_plan(torch.empty(1, 3, 16, 24, 64), 1000, 8) == 0
     net = m.StageNet(dict(base_ch=8, fusion_type="cnn", depth_type="ce"), 8, 0).eval()
     monkeypatch.setenv("MVS_VIS", "winograd")
     with pytest.raises(ValueError):

@@ -227,6 +227,83 @@ def test_tiled_sweeps_equal_direct_sweeps_exactly(dev):
     assert seen[False] == 0.0 and seen[True] > 0.5, seen
 
 
+def _band_case(dev, C, D, H, W, V, B):
+    from mvsformer_amd import ops, synth
+    scale = {64: 8, 32: 4}[C]
+    scene = synth.make_scene(V, H * scale, W * scale, seed=C + H)
+    feat = synth.render_features(scene, scale, C, batch=B, device=dev).contiguous()
+    proj = synth.proj_matrices(scene, (scale,), B, device=dev)["stage1"]
+    z = synth.plane_depth(scene, scale, device=dev)
+    hyp = (1.0 / (1.0 / z[None, None] + torch.linspace(1, -1, D, device=dev).view(1, D, 1, 1) * (1e-5 * D))).repeat(B, 1, 1, 1).contiguous()
+    return feat, proj, hyp
+
+
+@pytest.mark.parametrize("C,D,H,W,V,B,bands", [(32, 16, 40, 56, 5, 1, 2), (64, 32, 32, 48, 3, 2, 3), (32, 8, 16, 24, 2, 1, 2), (32, 16, 64, 96, 5, 1, 4)])
+def test_banded_stored_correlation_stage_equals_unbanded_exactly(dev, C, D, H, W, V, B, bands):
+    """StageNet with the stored-correlation sweeps in row bands (mvs_cv_corr_rows_fwd / mvs_cv_merge_rows_fwd + the visibility CNN per band with
+    a 3-row halo) against the same stage with ONE store: every output bit for bit - per row the arithmetic is the same, and the CNN's zero
+    padding at a band's inner edge only reaches halo rows (bands start on even rows: the MFMA CNN computes row pairs).  Band heights that do not divide the image, bands shorter than the CNN's tile,
+    a batch of 2, both regularizers (D = 8: CostRegNet3D)."""
+    import mvsformer_amd as m
+    from mvsformer_amd import ops, stagenet
+    torch.manual_seed(C + H)
+    net = m.StageNet(dict(base_ch=8, fusion_type="cnn", depth_type="ce"), D, 0).eval()
+    m.randomize_bn_(net, 3)
+    net = net.to(dev)
+    feat, proj, hyp = _band_case(dev, C, D, H, W, V, B)
+    fcl = ops.to_channels_last(feat)
+    full_mb = ops.cv_store_bytes(fcl, D, 8) / 2 ** 20
+    assert full_mb > 0
+    band_rows = -(-H // bands) + 2 * stagenet.VIS_HALO + 1
+    outs = []
+    for limit_mb, max_bands in ((full_mb * 1.01, 1), (full_mb * band_rows / H * 1.001, 8)):
+        old = {k: os.environ.get(k) for k in ("MVS_CV_STORE_MAX_MB", "MVS_CV_STORE_BANDS")}
+        os.environ["MVS_CV_STORE_MAX_MB"] = repr(limit_mb)
+        os.environ["MVS_CV_STORE_BANDS"] = str(max_bands)
+        try:
+            outs.append((stagenet._store_plan(fcl, D, 8), net(feat, proj, hyp, tmp=2.0)))
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    assert outs[0][0] == 1 and outs[1][0] == bands, (outs[0][0], outs[1][0])
+    for k in ("depth", "prob_volume_pre", "photometric_confidence", "sim_depth"):
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
+def test_banded_sweeps_equal_whole_image_sweeps_exactly(dev):
+    """Op level, ragged shapes the regularizer would not take: mvs_cv_corr_rows_fwd on rows [y0, y0+rows) writes exactly those rows of the
+    whole-image entropy, and mvs_cv_merge_rows_fwd with the whole-image visibility weights writes exactly those rows of the volume and
+    the similarity arg-max; one-row bands, a band that is the whole image, a reused (larger) store buffer, the empty band is refused."""
+    from mvsformer_amd import ops
+    from mvsformer_amd._lib import MvsHipError
+    for C, D, H, W, V, B in ((32, 16, 37, 50, 3, 2), (64, 7, 9, 37, 2, 1), (64, 32, 21, 40, 5, 1)):
+        feat, proj, hyp = _band_case(dev, C, D, H, W, V, B)
+        g = torch.Generator().manual_seed(H)
+        w = torch.rand(B, V - 1, H, W, generator=g).to(dev)
+        rt = ops.proj_prepare(proj)
+        fcl = ops.to_channels_last(feat)
+        e0, store0 = ops.cv_corr(fcl, rt, hyp, 8)
+        v0, s0 = ops.cv_merge(store0, hyp, w, V, C, 8, True)
+        vol = torch.full_like(v0, float("nan"))
+        sim = torch.full_like(s0, float("nan"))
+        store = None
+        cuts = sorted({0, 1, 5, H // 2, H - 1, H})
+        for r0, r1 in zip(cuts[:-1], cuts[1:]):
+            y0, y1 = max(0, r0 - 2), min(H, r1 + 1)
+            e, store = ops.cv_corr_rows(fcl, rt, hyp, 8, y0, y1 - y0, store)
+            assert e.shape == (B, V - 1, y1 - y0, W), e.shape
+            assert torch.equal(e, e0[:, :, y0:y1]), (C, r0)
+            wb = w[:, :, y0:y1].contiguous()
+            ops.cv_merge_rows(store, hyp, wb, V, C, 8, y0, r0 - y0, r1 - r0, vol, sim)
+        assert torch.equal(vol, v0) and torch.equal(sim, s0), (C, D)
+        e, store = ops.cv_corr_rows(fcl, rt, hyp, 8, 0, H, store)
+        assert torch.equal(e, e0)
+        with pytest.raises(MvsHipError):
+            ops.cv_corr_rows(fcl, rt, hyp, 8, 3, 0, store)
+        with pytest.raises(MvsHipError):
+            ops.cv_corr_rows(fcl, rt, hyp, 8, H - 2, 3, store)
+
+
 def test_stored_correlation_sweeps_equal_recomputing_sweeps_exactly(dev):
     """mvs_cv_corr_fwd + mvs_cv_merge_fwd are the recomputing sweeps with the per-view correlation parked in memory: entropy and
     volume BIT FOR BIT (both arithmetic modes), the similarity arg-max up to ties (its sums over groups run in another order);
