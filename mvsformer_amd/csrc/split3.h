@@ -31,17 +31,40 @@ __device__ __forceinline__ void split3_bounded(float v, __bf16& h, __bf16& m, __
     l = (__bf16)(r - (float)m);
 }
 
+// Two values at once, the form the kernels use: v_cvt_pk_bf16_f32 converts a PAIR per instruction, so the split of (a, b) is 3 conversions +
+// 4 unpacks (shift / mask of the packed word: bf16 -> fp32 is exact) + 4 subtractions = 11 vector instructions (+2 clamps) against the 19 the
+// compiler makes of two scalar splits (it converts every value alone, then converts again to pack).  Bit-identical to split3 per value.
+// Each result word = {bf16(a) in the low half, bf16(b) in the high half}: consecutive elements of a bf16 vector.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+template <bool CLAMP>
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = CLAMP ? cvt_pk_bf16(__builtin_amdgcn_fmed3f(a, -BF16_MAX, BF16_MAX), __builtin_amdgcn_fmed3f(b, -BF16_MAX, BF16_MAX)) : cvt_pk_bf16(a, b);
+    const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);      // exact
+    m = cvt_pk_bf16(ra, rb);
+    l = cvt_pk_bf16(ra - __builtin_bit_cast(float, m << 16), rb - __builtin_bit_cast(float, m & 0xffff0000u));           // exact, 8 bits left
+}
+
 struct Split3 { bf16x8 h, m, l; };
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ Split3 split3(const float (&v)[8]) {
-    Split3 s;
+    u32x4_t h, m, l;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        __bf16 h, m, l;
-        split3(v[e], h, m, l);
-        s.h[e] = h;
-        s.m[e] = m;
-        s.l[e] = l;
+    for (int e = 0; e < 4; ++e) {
+        unsigned a, b, c;
+        split3_pair<true>(v[2 * e], v[2 * e + 1], a, b, c);
+        h[e] = a;
+        m[e] = b;
+        l[e] = c;
     }
+    Split3 s;
+    s.h = __builtin_bit_cast(bf16x8, h);
+    s.m = __builtin_bit_cast(bf16x8, m);
+    s.l = __builtin_bit_cast(bf16x8, l);
     return s;
 }
 

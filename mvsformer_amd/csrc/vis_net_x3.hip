@@ -91,21 +91,22 @@ __device__ __forceinline__ f32x4 mfma6(const bf16x8 (&w)[3], const bf16x8 (&x)[3
 // the lane's 4 channels (4*kb .. 4*kb+3) of pixel `pix`, split and stored: [term][octet = kb >> 1][pix][(kb & 1) * 8 bytes]
 template <int OCT, int TERM>
 __device__ __forceinline__ void store_split(unsigned char* base, int pix, int kb, const float (&v)[4]) {
-    bf16x4 h, m, l;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 h, m, l;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        __bf16 a, b, c;
+    for (int r = 0; r < 2; ++r) {
+        unsigned a, b, c;
 #ifdef VIS_SPLIT_CLAMPED
-        split3(v[r], a, b, c);
+        mvsx3::split3_pair<true>(v[2 * r], v[2 * r + 1], a, b, c);
 #else
-        mvsx3::split3_bounded(v[r], a, b, c);
+        mvsx3::split3_pair<false>(v[2 * r], v[2 * r + 1], a, b, c);    // bounded by construction (split3_bounded): no clamp
 #endif
         h[r] = a; m[r] = b; l[r] = c;
     }
     unsigned char* dst = base + (kb >> 1) * OCT + pix * 16 + (kb & 1) * 8;
-    *reinterpret_cast<bf16x4*>(dst) = h;
-    *reinterpret_cast<bf16x4*>(dst + TERM) = m;
-    *reinterpret_cast<bf16x4*>(dst + 2 * TERM) = l;
+    *reinterpret_cast<u32x2*>(dst) = h;
+    *reinterpret_cast<u32x2*>(dst + TERM) = m;
+    *reinterpret_cast<u32x2*>(dst + 2 * TERM) = l;
 }
 
 __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict__ entropy, const float* __restrict__ prm,
@@ -213,10 +214,11 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
 #pragma unroll
             for (int k = 0; k < 3; ++k) z = mfma4(W1A[k], src[tap_off[k]], z);
             const int gy = y0 - 2 + py, gx = x0 - 2 + px;
-            const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            // ReLU and the zero padding outside the image in one v_med3_f32: med3(x, 0, +inf) = max(x, 0), med3(x, 0, 0) = 0
+            const float cap = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? __builtin_inff() : 0.0f;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = inside ? fmaxf(fmaf(z[r], sc0[r], sh0[r]), 0.0f) : 0.0f;
+            for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(fmaf(z[r], sc0[r], sh0[r]), 0.0f, cap);
             store_split<A1_OCT, A1_TERM>(s_a1, p, kb, v);
         }
         __syncthreads();
@@ -255,10 +257,10 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
                 const int o = tt * 16 + n, oy = o / A1W, ox = o % A1W;
                 if (oy < A2W && ox < A2W) {
                     const int gy = y0 - 1 + oy, gx = x0 - 1 + ox;
-                    const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                    const float cap = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? __builtin_inff() : 0.0f;
                     float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = inside ? fmaxf(fmaf(c[r], sc1[r], sh1[r]), 0.0f) : 0.0f;
+                    for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(fmaf(c[r], sc1[r], sh1[r]), 0.0f, cap);
                     store_split<A2_OCT, A2_TERM>(s_a2, oy * A2W + ox, kb, v);
                 }
             };
@@ -298,17 +300,19 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
                 __builtin_amdgcn_sched_barrier(0);
             }
             // D[m = (dy, co)][n = x]: this lane holds dy = kb >> 1, channels (kb & 1) * 4 + r; the other 4 channels sit 16 lanes away
-            auto finish = [&](int pair, const f32x4& c) {
+            auto reduce = [&](const f32x4& c) {
                 float part = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) part = fmaf(wl[r], fmaxf(fmaf(c[r], sc2[r], sh2[r]), 0.0f), part);
-                part += __shfl_xor(part, 16, 64);
-                const int gy = y0 + 2 * pair + (kb >> 1), gx = x0 + n;
-                if ((kb & 1) == 0 && gy < H && gx < W) weight[(size_t)img * H * W + (size_t)gy * W + gx] = 1.0f / (1.0f + expf(-(part + b3)));
+                return part + __shfl_xor(part, 16, 64);      // both channel halves now hold the pixel's sum
             };
             if (!(ablate & 16)) {
-                finish(wave, c0);
-                finish(wave + 4, c1);
+                // the even channel-half lanes finish row pair `wave`, the odd ones row pair `wave + 4`: one sigmoid per lane instead of two
+                const float p0 = reduce(c0), p1 = reduce(c1);
+                const bool second = (kb & 1) != 0;
+                const float part = second ? p1 : p0;
+                const int gy = y0 + 2 * (second ? wave + 4 : wave) + (kb >> 1), gx = x0 + n;
+                if (gy < H && gx < W) weight[(size_t)img * H * W + (size_t)gy * W + gx] = 1.0f / (1.0f + expf(-(part + b3)));
             }
         }
         // (no barrier here: the next tile's layer 1 reads s_in / writes s_a1, both released by the barrier above; its barrier then
