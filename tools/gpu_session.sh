@@ -1,10 +1,9 @@
 mkdir -p gpurun_out/r04
-L=/root/repo/mvsformer_amd
-timeout 900 python -m pytest tests/test_hip_parity.py tests/test_hip_x3.py -x -q -m gpu -k "vis or golden or cascade or stage" 2>&1 | tail -3
-for rep in 1 2; do
-for v in base ""; do
-  echo "## variant '${v:-new}' $rep"
-  if [ -z "$v" ]; then lib=$L/libmvs_hip.so; else lib=$L/libmvs_hip_$v.so; fi
-  MVS_HIP_LIB=$lib timeout 300 python tools/bench_vis.py 2>&1 | grep stage | sed 's/| valu.*x3 \([0-9.]* ms\).*max diff vs valu\(.*\)/| vis x3 \1 \2/'
-done
-done
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r04/pytest_all.txt 2>&1; tail -4 gpurun_out/r04/pytest_all.txt
+ROUND=r04 timeout 1500 bash tools/collect_profiles.sh > gpurun_out/r04/collect.log 2>&1; tail -5 gpurun_out/r04/collect.log
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r04_final_bench.json').read().strip().splitlines()[-1])
+print({k:d[k] for k in ('value','ms_per_step','latency_ms_single_stream','kernel_ms_sum') if k in d})
+print(d.get('roofline')); print(d.get('roofline_cost_volume')); print(d.get('cpu_baseline'))
+PY
