@@ -79,6 +79,20 @@ struct TailArgs {
     int B, D, H, W, relu, tiles_x, tiles, seg_planes, nseg, ablate;
 };
 
+#ifdef X3_TIMELINE
+// experiment build only (make exp NAME=tl EXPSRC="conv3d_x3 tail_x3" EXPFLAGS=-DX3_TIMELINE, tools/x3_timeline.py): wavefront 0 of every block
+// sums the clock ticks of each phase of a pass
+__device__ unsigned long long tail_phase_ticks[8];
+#define TAIL_STAMP(slot)                                                    \
+    do {                                                                    \
+        const unsigned long long now_ = __builtin_readcyclecounter();       \
+        tl_acc_[slot] += now_ - t_prev_;                                    \
+        t_prev_ = now_;                                                     \
+    } while (0)
+#else
+#define TAIL_STAMP(slot)
+#endif
+
 // PERSISTENT: a block walks the work items (batch, depth segment, tile) item = blockIdx.x, + gridDim.x, ... with the weights loaded once;
 // the staging pipeline runs ACROSS items (the last plane of a tile prefetches the first plane of the block's next tile), so the only
 // exposed load latency is the block's very first plane.  (The first version launched one block per tile: with D = 4 planes a block lived
@@ -224,6 +238,9 @@ __global__ __launch_bounds__(256, 2) void tail_x3_kernel(const TailArgs a) {
     commit(lds);
     __syncthreads();
     int cur = 0;
+#ifdef X3_TIMELINE
+    unsigned long long tl_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev_ = __builtin_readcyclecounter();
+#endif
 
     for (;;) {
         residual_offsets(I);
@@ -245,16 +262,38 @@ __global__ __launch_bounds__(256, 2) void tail_x3_kernel(const TailArgs a) {
             const int kd_lo = max(0, I.d_lo + 1 - p), kd_hi = min(2, I.d_hi - p);
             const bool fin = p - 1 >= I.d_lo;              // output plane p-1 completes with this input plane
             const bool res_now = a.residual != nullptr && p >= I.d_lo && p < I.d_hi;
-            if (res_now) issue_residual(I, p);
+#ifndef TAIL_INTERLEAVE
+#define TAIL_INTERLEAVE 1
+#endif
             // the next pass's plane: the next plane of this tile, or the first plane of the block's next tile
             const bool stage_next = p < I.p_last || has_next;
-            if (p < I.p_last) {
-                issue(I, p + 1);
-            } else if (has_next) {
+            int np = p + 1;
+            if (p == I.p_last && has_next) {
                 J = decode(next_item);
                 staging_offsets(J);
-                issue(J, J.p_first);
+                np = J.p_first;
             }
+            const Item& S = (p < I.p_last) ? I : J;
+#if TAIL_INTERLEAVE
+            // The pass's 32 dword loads per lane (16 of the skip tensor, 16 of the next plane) go out BETWEEN the MFMA groups, a few per group:
+            // as one burst at the top of the pass they took half of it (tools/x3_timeline.py: ~100 clocks per load instruction with the vector
+            // memory queue full, the matrix pipe idle meanwhile); the weights sit in registers, so nothing in the MFMA phase waits for vmcnt.
+            const size_t rbase = ((size_t)I.b * COUT * D + p) * HWo, sbase = (size_t)S.b * CIN * DHW + (size_t)np * HW;
+            auto load_slot = [&](int k) {                  // k = 0 .. 31, compile-time at every call site
+                if (k < 16) {
+                    const int r = k >> 3, ph = (k >> 2) & 1, e = k & 3;
+                    if (res_now && r < R) rs[r][ph][e] = stage_load(rin, roff[r][ph], (unsigned)((rbase + (size_t)e * D * HWo) * 4));
+                } else {
+                    const int it = (k - 16) >> 3, e = (k - 16) & 7;
+                    if (stage_next && it < NI) pre[it][e] = stage_load(xin, voff[it], (unsigned)((sbase + (size_t)e * DHW) * 4));
+                }
+            };
+            static_assert(R == 2 && NI == 2, "load_slot's schedule is written for two rows per wavefront and two staging items per thread");
+#else
+            if (res_now) issue_residual(I, p);
+            if (stage_next) issue(S, np);
+#endif
+            TAIL_STAMP(0);                                 // loads issued (TAIL_INTERLEAVE: nothing yet)
             if (!(a.ablate & 4)) {
                 // row fragments roll: F(row) serves tile P and step 0 of tile Q of its own row, and step 1 of tile Q of the row above
                 bf16x8 f0[3], f1[3];
@@ -269,6 +308,13 @@ __global__ __launch_bounds__(256, 2) void tail_x3_kernel(const TailArgs a) {
                     for (int t = 0; t < 3; ++t) fb[t] = *reinterpret_cast<const bf16x8*>(fp + (r + 1) * (BW * PB) + t * TERM_BYTES);
 #pragma unroll
                     for (int kd = 0; kd < 3; ++kd) {
+#if TAIL_INTERLEAVE
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 0; k < 6; ++k)
+                            if ((r * 3 + kd) * 6 + k < 32) load_slot((r * 3 + kd) * 6 + k);
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
                         if (kd < kd_lo || kd > kd_hi) continue;             // block-uniform
                         acc[kd][r][0] = mfma6(wf[kd][0][0], wf[kd][0][1], wf[kd][0][2], fa[0], fa[1], fa[2], acc[kd][r][0]);
                         f32x4 q = acc[kd][r][1];
@@ -278,7 +324,19 @@ __global__ __launch_bounds__(256, 2) void tail_x3_kernel(const TailArgs a) {
                     }
                 }
             }
+#if TAIL_INTERLEAVE
+            else {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) load_slot(k);
+            }
+#endif
+            TAIL_STAMP(1);                                 // MFMA phase
             if (fin && !(a.ablate & 8)) finish_plane(I, p - 1, acc[0], rprev);
+            TAIL_STAMP(2);                                 // epilogue + stores of the finished plane
+#ifdef X3_TIMELINE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TAIL_STAMP(3);                                 // waiting for the skip tensor's and the next plane's loads
+#endif
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -294,10 +352,13 @@ __global__ __launch_bounds__(256, 2) void tail_x3_kernel(const TailArgs a) {
                     }
                     rprev[r][ph] = t;
                 }
+            TAIL_STAMP(4);                                 // skip tensor reduced
             if (stage_next) {
                 commit(lds + (cur ^ 1) * BUF_BYTES);
+                TAIL_STAMP(5);                             // split + LDS stores
                 __syncthreads();                           // this plane's fragment reads are done, the next plane is visible
                 cur ^= 1;
+                TAIL_STAMP(6);                             // barrier
             }
         }
         if (I.p_last == D - 1 && I.d_hi == D && !(a.ablate & 8)) finish_plane(I, D - 1, acc[0], rprev);
@@ -305,6 +366,10 @@ __global__ __launch_bounds__(256, 2) void tail_x3_kernel(const TailArgs a) {
         I = J;
         item = next_item;
     }
+#ifdef X3_TIMELINE
+    if (tid == 0)
+        for (int i = 0; i < 7; ++i) atomicAdd(&tail_phase_ticks[i], tl_acc_[i]);
+#endif
 }
 
 }  // namespace
@@ -346,3 +411,14 @@ extern "C" int mvs_tail_x3_fwd(const float* x, const void* wpacked, const float*
     hipLaunchKernelGGL(tail_x3_kernel, dim3((unsigned)(nitems < resident ? nitems : resident)), dim3(256), 0, MVS_STREAM(stream), a);
     return mvs::finish_launch("mvs_tail_x3_fwd");
 }
+
+#ifdef X3_TIMELINE
+extern "C" int mvs_tail_timeline(unsigned long long* out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(tail_phase_ticks), 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(tail_phase_ticks), z, 64) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -1,9 +1,11 @@
 mkdir -p gpurun_out/r04
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r04/pytest_all.txt 2>&1; tail -4 gpurun_out/r04/pytest_all.txt
-ROUND=r04 timeout 1500 bash tools/collect_profiles.sh > gpurun_out/r04/collect.log 2>&1; tail -5 gpurun_out/r04/collect.log
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r04_final_bench.json').read().strip().splitlines()[-1])
-print({k:d[k] for k in ('value','ms_per_step','latency_ms_single_stream','kernel_ms_sum') if k in d})
-print(d.get('roofline')); print(d.get('roofline_cost_volume')); print(d.get('cpu_baseline'))
-PY
+L=/root/repo/mvsformer_amd
+timeout 600 python -m pytest tests/test_hip_x3.py -x -q -m gpu -k "tail or logits" 2>&1 | tail -3
+for rep in 1 2 3; do
+for v in noil ""; do
+  if [ -z "$v" ]; then lib=$L/libmvs_hip.so; else lib=$L/libmvs_hip_$v.so; fi
+  echo "## ${v:-interleaved} $rep"
+  MVS_HIP_LIB=$lib timeout 300 python tools/bench_x3.py --stages 3,4 --only tail --out r04/tmp_x3.txt 2>&1 | grep tail | sed 's/| fp32 tail.*x3 tail \([0-9.]* ms\).*/| x3 tail \1/'
+done
+done
+MVS_HIP_LIB=$L/libmvs_hip_tl.so timeout 300 python tools/x3_timeline.py 2>&1 | grep tail

@@ -41,3 +41,32 @@ for st in (3, 4):
         tot = float(sum(buf[:7])) or 1.0
         print("stage%d %s %d->%d s%s: %.4f ms | " % (st, name, cin, cout, stride, a.elapsed_time(b)) +
               "  ".join("%s %.0f%%" % (PH[i], 100.0 * buf[i] / tot) for i in range(7)) + "  | ticks/launch %.3g" % tot, flush=True)
+
+# the fused tail (conv11 + BatchNorm + ReLU + skip + prob): make ... EXPSRC="conv3d_x3 tail_x3"
+ttl = getattr(ctypes.CDLL(_lib.LIB_PATH), "mvs_tail_timeline", None)
+if ttl is not None:
+    ttl.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    TPH = ["issue loads", "MFMA phase", "epilogue + stores", "wait loads", "reduce skip", "split + LDS stores", "barrier"]
+    for st in (3, 4):
+        D, H, W = STAGES[st]
+        h, w = H // 2, W // 2
+        x = torch.randn(1, 16, D, h, w, device=dev)
+        wt = torch.randn(16, 8, 3, 3, 3, device=dev) * 0.05
+        res = torch.randn(1, 8, D, H, W, device=dev)
+        scale, shift = torch.rand(8, device=dev) + 0.5, torch.randn(8, device=dev)
+        pw, pb = torch.randn(8, device=dev), torch.randn(1, device=dev)
+        pk = ops.tail_x3_pack(wt)
+        for _ in range(3):
+            ops.tail_x3(x, pk, scale, shift, res, pw, pb, True)
+        torch.cuda.synchronize()
+        ttl(None, 1)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ops.tail_x3(x, pk, scale, shift, res, pw, pb, True)
+        b.record()
+        torch.cuda.synchronize()
+        buf = (ctypes.c_ulonglong * 8)()
+        ttl(buf, 1)
+        tot = float(sum(buf[:7])) or 1.0
+        print("stage%d tail 16->8+prob: %.4f ms | " % (st, a.elapsed_time(b)) + "  ".join("%s %.0f%%" % (TPH[i], 100.0 * buf[i] / tot) for i in range(7)) +
+              "  | ticks/launch %.3g" % tot, flush=True)
