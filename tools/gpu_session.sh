@@ -1,13 +1,9 @@
 mkdir -p gpurun_out/r04
-MVS_X3_TILE_ROWS=12 timeout 900 python -m pytest tests/test_hip_x3.py -x -q -m gpu 2>&1 | tail -2
-timeout 900 python -m pytest tests/test_hip_x3.py -x -q -m gpu 2>&1 | tail -2
-rm -f gpurun_out/r04/bench_x3_rows.txt
-for rep in 1 2; do
-for v in 16 12 auto; do
-  echo "## tile rows $v ($rep)" >> gpurun_out/r04/bench_x3_rows.txt
-  if [ $v = auto ]; then unset MVS_X3_TILE_ROWS; else export MVS_X3_TILE_ROWS=$v; fi
-  timeout 300 python tools/bench_x3.py --stages 2,3,4 --only conv1,conv2 --out r04/tmp_x3.txt > /dev/null 2>&1
-  sed 's/| direct.*x3 \([0-9.]* ms\).*/| x3 \1/' gpurun_out/r04/tmp_x3.txt >> gpurun_out/r04/bench_x3_rows.txt
-done
-done
-cat gpurun_out/r04/bench_x3_rows.txt
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r04/pytest_all.txt 2>&1; grep -n "passed\|failed" gpurun_out/r04/pytest_all.txt | tail -2
+ROUND=r04 timeout 1500 bash tools/collect_profiles.sh > gpurun_out/r04/collect.log 2>&1; tail -3 gpurun_out/r04/collect.log
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r04_final_bench.json').read().strip().splitlines()[-1])
+print({k:d[k] for k in ('value','ms_per_step','ms_per_step_repeats','latency_ms_single_stream','kernel_ms_sum','max_rel_depth_err') if k in d})
+print(d.get('roofline')); print(d['roofline_cost_volume']['frac'], d['roofline_cost_volume']['frac_of_gather_bound']); print(d.get('cpu_baseline')); print(d.get('traffic_source')); print(d.get('other_configs'))
+PY
