@@ -22,6 +22,8 @@
 //   * weights of both layers, pre-split and laid out per lane by mvs_vis_x3_prepare, live in 132 VGPRs for the whole (persistent) kernel.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "conv_common.h"
 #include "split3.h"
 
@@ -37,7 +39,8 @@ constexpr int A1N = A1W * A1W, A2N = A2W * A2W;            // 400, 324 pixels
 constexpr int A1_OCT = A1N * 16, A1_TERM = 2 * A1_OCT;     // bytes
 constexpr int A2_OCT = A2N * 16, A2_TERM = 2 * A2_OCT;
 constexpr int IN_BYTES = ((INW * INW * 4 + 255) / 256) * 256;
-constexpr int LDS_BYTES = IN_BYTES + 3 * A1_TERM + 3 * A2_TERM;
+constexpr int IDX_BYTES = A1N * 4;                          // layer 1's walk: per flattened pixel {byte offset in the entropy tile, row, column}
+constexpr int LDS_BYTES = IN_BYTES + 3 * A1_TERM + 3 * A2_TERM + IDX_BYTES;
 constexpr int L2_STEPS = 5, L3_STEPS = 6;
 // Layer 2's N tiles walk its 18 x 18 output region with the PITCH OF ITS INPUT (20): output index o = oy * 20 + ox, so the B fragment of tap
 // (kh, kw) is pixels o + kh * 20 + kw ... + 15 of layer 1's region - 256 contiguous bytes for every tile, where the 18-pitch walk of round
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
     float* s_in = reinterpret_cast<float*>(smem);          // [INW][INW]
     unsigned char* s_a1 = smem + IN_BYTES;                 // [3][2][A1N][16 B]
     unsigned char* s_a2 = s_a1 + 3 * A1_TERM;              // [3][2][A2N][16 B]
+    unsigned* s_idx = reinterpret_cast<unsigned*>(s_a2 + 3 * A2_TERM);   // [A1N]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kb = lane >> 4;
@@ -197,6 +201,10 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
     if (tile >= ntiles) return;
     fetch_entropy(tile);
     commit_entropy();
+    for (int p = tid; p < A1N; p += 256) {
+        const int py = p / A1W, px = p % A1W;
+        s_idx[p] = (unsigned)((py * INW + px) * 4) | (unsigned)py << 16 | (unsigned)px << 24;
+    }
     __syncthreads();
     for (; tile < ntiles; tile += gridDim.x) {
         int img, x0, y0;
@@ -205,22 +213,35 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
         const bool has_next = next < ntiles;               // block-uniform
         if (has_next) fetch_entropy(next);
 
-        // ---- layer 1: 1 -> 16 on the 20 x 20 region, N = 16 consecutive pixels of the flattened region ----
+        // A tile whose 20 x 20 layer-1 region lies inside the image (95 % of them at stage 4) needs no padding mask in either epilogue:
+        // block-uniform, so both forms of the two loops exist and a tile takes one branch
+        const bool interior = x0 >= 2 && y0 >= 2 && x0 + T + 2 <= W && y0 + T + 2 <= H;
+
+        // ---- layer 1: 1 -> 16 on the 20 x 20 region, N = 16 consecutive pixels of the flattened region; the walk's divisions by 20 come
+        //      from a table built once per block ----
+        auto layer1 = [&](auto inner) {
+            constexpr bool INNER = decltype(inner)::value;
 #pragma unroll 1
-        for (int t = wave; t < L1_TILES && !(ablate & 1); t += 4) {
-            const int p = t * 16 + n, py = p / A1W, px = p % A1W;
-            const float* src = s_in + py * INW + px;
-            f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int t = wave; t < L1_TILES && !(ablate & 1); t += 4) {
+                const int p = t * 16 + n;
+                const unsigned ix = s_idx[p];
+                const float* src = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(s_in) + (ix & 0xffffu));
+                f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int k = 0; k < 3; ++k) z = mfma4(W1A[k], src[tap_off[k]], z);
-            const int gy = y0 - 2 + py, gx = x0 - 2 + px;
-            // ReLU and the zero padding outside the image in one v_med3_f32: med3(x, 0, +inf) = max(x, 0), med3(x, 0, 0) = 0
-            const float cap = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? __builtin_inff() : 0.0f;
-            float v[4];
+                for (int k = 0; k < 3; ++k) z = mfma4(W1A[k], src[tap_off[k]], z);
+                // ReLU and the zero padding outside the image in one v_med3_f32: med3(x, 0, +inf) = max(x, 0), med3(x, 0, 0) = 0
+                float cap = __builtin_inff();
+                if (!INNER) {
+                    const int gy = y0 - 2 + (int)((ix >> 16) & 0xffu), gx = x0 - 2 + (int)(ix >> 24);
+                    cap = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? __builtin_inff() : 0.0f;
+                }
+                float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(fmaf(z[r], sc0[r], sh0[r]), 0.0f, cap);
-            store_split<A1_OCT, A1_TERM>(s_a1, p, kb, v);
-        }
+                for (int r = 0; r < 4; ++r) v[r] = INNER ? fmaxf(fmaf(z[r], sc0[r], sh0[r]), 0.0f) : __builtin_amdgcn_fmed3f(fmaf(z[r], sc0[r], sh0[r]), 0.0f, cap);
+                store_split<A1_OCT, A1_TERM>(s_a1, p, kb, v);
+            }
+        };
+        if (interior) layer1(std::true_type{}); else layer1(std::false_type{});
         __syncthreads();
 
         // ---- layer 2: 16 -> 16 on the 18 x 18 region; two pixel tiles per pass (independent MFMA chains) ----
@@ -256,11 +277,16 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
             auto finish = [&](int tt, const f32x4& c) {
                 const int o = tt * 16 + n, oy = o / A1W, ox = o % A1W;
                 if (oy < A2W && ox < A2W) {
-                    const int gy = y0 - 1 + oy, gx = x0 - 1 + ox;
-                    const float cap = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? __builtin_inff() : 0.0f;
                     float v[4];
+                    if (interior) {                        // block-uniform
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(fmaf(c[r], sc1[r], sh1[r]), 0.0f, cap);
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(c[r], sc1[r], sh1[r]), 0.0f);
+                    } else {
+                        const int gy = y0 - 1 + oy, gx = x0 - 1 + ox;
+                        const float cap = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? __builtin_inff() : 0.0f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(fmaf(c[r], sc1[r], sh1[r]), 0.0f, cap);
+                    }
                     store_split<A2_OCT, A2_TERM>(s_a2, oy * A2W + ox, kb, v);
                 }
             };
