@@ -53,7 +53,9 @@ static_assert(A1N % 16 == 0, "layer 1 tiles are full");
 constexpr int OFF_W0 = 0, OFF_S0 = 144, OFF_B0 = 160, OFF_W1 = 176, OFF_S1 = 2480, OFF_B1 = 2496, OFF_W2 = 2512, OFF_S2 = 3664,
               OFF_B2 = 3672, OFF_W3 = 3680, OFF_B3 = 3688;
 
-// prepared[(layer 2: step 0..4 | layer 3: step 5..10)][term][lane][8]:  the MFMA A operand, lane = kb * 16 + m.
+// prepared[(layer 2: step 0..4 | layer 3: step 5..10)][term][lane][8]:  the MFMA A operand, lane = kb * 16 + m.  The folded BatchNorm SCALE of
+// the output channel is multiplied into the weight before the split and the SHIFT is the accumulator's start value, so the epilogue of a
+// layer is one v_max / v_med3 per value (the sums then round as shift + products instead of (products) * scale + shift: fp32-equivalent).
 //   layer 2: m = output channel, K block 2*step + (kb >> 1) = tap (9 = zero), channels (kb & 1) * 8 + e
 //   layer 3: m = (dy = m >> 3, co = m & 7), K block 2*step + (kb >> 1) = (input row t, kw), weight of kh = t - dy (outside 0..2: zero)
 __global__ void vis_x3_prepare_kernel(const float* __restrict__ prm, bf16x8* __restrict__ out) {
@@ -68,10 +70,10 @@ __global__ void vis_x3_prepare_kernel(const float* __restrict__ prm, bf16x8* __r
         float f = 0.0f;
         if (step < L2_STEPS) {
             const int tap = 2 * step + (kb >> 1);
-            if (tap < 9) f = prm[OFF_W1 + (ci * 9 + tap) * 16 + m];
+            if (tap < 9) f = prm[OFF_W1 + (ci * 9 + tap) * 16 + m] * prm[OFF_S1 + m];
         } else {
             const int kblk = 2 * (step - L2_STEPS) + (kb >> 1), t = kblk / 3, kw = kblk % 3, dy = m >> 3, co = m & 7, kh = t - dy;
-            if (kh >= 0 && kh <= 2) f = prm[OFF_W2 + (ci * 9 + kh * 3 + kw) * 8 + co];
+            if (kh >= 0 && kh <= 2) f = prm[OFF_W2 + (ci * 9 + kh * 3 + kw) * 8 + co] * prm[OFF_S2 + co];
         }
         __bf16 h, mm, l;
         split3(f, h, mm, l);
@@ -141,20 +143,18 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int tap = 4 * t + kb;
-        W1A[t] = tap < 9 ? prm[OFF_W0 + tap * 16 + n] : 0.0f;
+        W1A[t] = tap < 9 ? prm[OFF_W0 + tap * 16 + n] * prm[OFF_S0 + n] : 0.0f;
         const int tc = tap < 9 ? tap : 8;
         tap_off[t] = (tc / 3) * INW + tc % 3;
     }
     // this lane's 4 output channels of layers 1 and 2 (4*kb + r), of layer 3 ((kb & 1) * 4 + r)
-    float sc0[4], sh0[4], sc1[4], sh1[4], sc2[4], sh2[4], wl[4];
+    f32x4 sh0, sh1, sh2;
+    float wl[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        sc0[r] = prm[OFF_S0 + 4 * kb + r];
         sh0[r] = prm[OFF_B0 + 4 * kb + r];
-        sc1[r] = prm[OFF_S1 + 4 * kb + r];
         sh1[r] = prm[OFF_B1 + 4 * kb + r];
         const int co = (kb & 1) * 4 + r;
-        sc2[r] = prm[OFF_S2 + co];
         sh2[r] = prm[OFF_B2 + co];
         wl[r] = prm[OFF_W3 + co];
     }
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
                 const int p = t * 16 + n;
                 const unsigned ix = s_idx[p];
                 const float* src = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(s_in) + (ix & 0xffffu));
-                f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                f32x4 z = sh0;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) z = mfma4(W1A[k], src[tap_off[k]], z);
                 // ReLU and the zero padding outside the image in one v_med3_f32: med3(x, 0, +inf) = max(x, 0), med3(x, 0, 0) = 0
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
                 }
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = INNER ? fmaxf(fmaf(z[r], sc0[r], sh0[r]), 0.0f) : __builtin_amdgcn_fmed3f(fmaf(z[r], sc0[r], sh0[r]), 0.0f, cap);
+                for (int r = 0; r < 4; ++r) v[r] = INNER ? fmaxf(z[r], 0.0f) : __builtin_amdgcn_fmed3f(z[r], 0.0f, cap);
                 store_split<A1_OCT, A1_TERM>(s_a1, p, kb, v);
             }
         };
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
             const bool two = t + 4 < L2_TILES;             // wave-uniform
             const unsigned char* b0 = s_a1 + o0 * 16;
             const unsigned char* b1 = s_a1 + o1 * 16;
-            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+            f32x4 c0 = sh1, c1 = sh1;
             bf16x8 x0f[2][3], x1f[2][3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -280,12 +280,12 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
                     float v[4];
                     if (interior) {                        // block-uniform
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(c[r], sc1[r], sh1[r]), 0.0f);
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(c[r], 0.0f);
                     } else {
                         const int gy = y0 - 1 + oy, gx = x0 - 1 + ox;
                         const float cap = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? __builtin_inff() : 0.0f;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(fmaf(c[r], sc1[r], sh1[r]), 0.0f, cap);
+                        for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(c[r], 0.0f, cap);
                     }
                     store_split<A2_OCT, A2_TERM>(s_a2, oy * A2W + ox, kb, v);
                 }
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
         {
             const unsigned char* b0 = s_a2 + ((2 * wave) * A2W + n) * 16;
             const unsigned char* b1 = s_a2 + ((2 * (wave + 4)) * A2W + n) * 16;
-            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+            f32x4 c0 = sh2, c1 = sh2;
             bf16x8 x0f[2][3], x1f[2][3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
             auto reduce = [&](const f32x4& c) {
                 float part = 0.0f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) part = fmaf(wl[r], fmaxf(fmaf(c[r], sc2[r], sh2[r]), 0.0f), part);
+                for (int r = 0; r < 4; ++r) part = fmaf(wl[r], fmaxf(c[r], 0.0f), part);
                 return part + __shfl_xor(part, 16, 64);      // both channel halves now hold the pixel's sum
             };
             if (!(ablate & 16)) {
