@@ -658,6 +658,12 @@ def test_vis_x3_matches_valu_kernel(dev, shape):
     prm2[3680:3688] *= 30.0
     a2, b2 = ops.vis(ent, prm2), ops.vis_x3(ent, prm2, ops.vis_x3_prepare(prm2))
     assert (a2 - b2).abs().max().item() < 2e-4, (a2 - b2).abs().max().item()
+    # BatchNorm scales of either sign and tiny ones (the kernel folds them into the split weights, the shifts into the accumulators' start)
+    prm3 = prm.clone()
+    for lo, hi in ((144, 160), (2480, 2496), (3664, 3672)):
+        prm3[lo:hi] *= torch.tensor([1.0, -1.0, 1e-3, -2.5] * ((hi - lo) // 4), device=dev)
+    a3, b3 = ops.vis(ent, prm3), ops.vis_x3(ent, prm3, ops.vis_x3_prepare(prm3))
+    assert (a3 - b3).abs().max().item() < 5e-6, (a3 - b3).abs().max().item()
 
 
 @pytest.mark.parametrize("shape", [(2, 96, 128), (1, 67, 83), (3, 160, 64)])
