@@ -128,14 +128,29 @@ __device__ unsigned long long x3_phase_ticks[8];
 
 template <class Cfg>
 __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3Args a) {
+#ifndef X3_XCD_ORDER
+#define X3_XCD_ORDER 1
+#endif
+    // Block order (round 4): every XCD works on one contiguous slab of the logical order (output-channel block fastest, then depth segment,
+    // then the tile in raster order, then the batch), so that the blocks sharing input - the channel blocks and depth segments of a tile,
+    // the tiles next to it - find it in ONE L2 (counters before: 2-9x the layer's input fetched, profiles/traffic_by_kernel.json)
+#if X3_XCD_ORDER
+    unsigned nid_ = mvsconv::xcd_linear_block_id();
+    const int ctb = (int)(nid_ % gridDim.y);
+    nid_ /= gridDim.y;
+    const int seg = (int)(nid_ % (unsigned)a.nseg);
+    nid_ /= (unsigned)a.nseg;
+    const int tile = (int)(nid_ % gridDim.x), b = (int)(nid_ / gridDim.x);
+#else
     const int seg = blockIdx.z % a.nseg;
+    const int tile = blockIdx.x, ctb = blockIdx.y, b = blockIdx.z / a.nseg;
+#endif
     constexpr int CK = Cfg::CK, SHW = Cfg::SHW, NT = Cfg::NT, MTB = Cfg::MTB, KQ = Cfg::KQ, STEPS = Cfg::STEPS, BWC = Cfg::BWC, PB = Cfg::PB,
                   TERM_BYTES = Cfg::TERM_BYTES, NPIX = Cfg::BH * Cfg::BWC;
     __shared__ __attribute__((aligned(16))) unsigned char lds[Cfg::LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kb = lane >> 4;
-    const int tile = blockIdx.x, ctb = blockIdx.y, b = blockIdx.z / a.nseg;
     const int x0 = (tile % a.tiles_x) * Cfg::TW, y0 = (tile / a.tiles_x) * Cfg::TH;       // output coordinates
     const int Cin = a.Cin, Cout = a.Cout, D = a.D, H = a.H, W = a.W;
     const int NCH = Cin / CK;
@@ -435,7 +450,16 @@ __global__ __launch_bounds__(256, 2) void x3_deconv_kernel(const X3Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kb = lane >> 4;               // as the A (activation) operand: pixel column j = n; as the accumulator: channel n
+#if X3_XCD_ORDER
+    unsigned nid_ = mvsconv::xcd_linear_block_id();            // (the block order of x3_conv_kernel)
+    const int ctb = (int)(nid_ % gridDim.y);
+    nid_ /= gridDim.y;
+    const int seg = (int)(nid_ % (unsigned)a.nseg);
+    nid_ /= (unsigned)a.nseg;
+    const int tile = (int)(nid_ % gridDim.x), b = (int)(nid_ / gridDim.x);
+#else
     const int tile = blockIdx.x, ctb = blockIdx.y, b = blockIdx.z / a.nseg, seg = blockIdx.z % a.nseg;
+#endif
     const int x0 = (tile % a.tiles_x) * TIW, y0 = (tile / a.tiles_x) * TIH;              // input coordinates
     const int Cin = a.Cin, Cout = a.Cout, D = a.D, H = a.H, W = a.W, Ho = 2 * H, Wo = 2 * W;
     const int NCH = Cin / 16;

@@ -52,6 +52,13 @@ __device__ __forceinline__ void xcd_block_coords(unsigned& bx, unsigned& by, uns
     bz = nid / (gx * gy);
 }
 
+// The same remap as a linear id (for kernels that choose their own decomposition of it).
+__device__ __forceinline__ unsigned xcd_linear_block_id() {
+    const unsigned gx = gridDim.x, gy = gridDim.y, nb = gx * gy * gridDim.z;
+    const unsigned id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned q = nb / 8, r = nb % 8, xcd = id % 8, loc = id / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
 inline int check_conv_args(const char* who, int B, int Cin, int Cout, int Di, int Hi, int Wi) {
     MVS_REQUIRE(B >= 1 && Di >= 1 && Hi >= 1 && Wi >= 1, "%s: bad shape B=%d D=%d H=%d W=%d", who, B, Di, Hi, Wi);
     MVS_REQUIRE(Cin >= 4 && Cin % 4 == 0, "%s: Cin must be a multiple of 4 (got %d)", who, Cin);
