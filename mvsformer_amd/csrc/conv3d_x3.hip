@@ -342,6 +342,10 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
         X3_STAMP(3);
         __syncthreads();
         X3_STAMP(4);
+#ifndef X3_SETPRIO
+#define X3_SETPRIO 1
+#endif
+        if (X3_SETPRIO) __builtin_amdgcn_s_setprio(1);     // co-resident blocks are in other phases: the MFMA phase wins the issue arbitration
         // ---- the depth taps of this plane; the buffer parity flips after each one (STEPS is odd) ----
         // ring position of each depth tap's first step: STEPS % WR further on per executed tap (compile-time per branch)
         constexpr int ADV = STEPS % WR, P1 = ADV, P2 = (2 * ADV) % WR;
@@ -355,6 +359,7 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
         } else {
             kd_steps(ic<2>{}, ic<0>{}, wk, false);
         }
+        if (X3_SETPRIO) __builtin_amdgcn_s_setprio(0);
         X3_STAMP(5);                                       // MFMA phase
         if (chunk == NCH - 1) {
             // output plane p-1 has seen its three input planes
@@ -621,6 +626,7 @@ __global__ __launch_bounds__(256, 2) void x3_deconv_kernel(const X3Args a) {
                 }
             }
             __syncthreads();
+            if (X3_SETPRIO) __builtin_amdgcn_s_setprio(1);
             int pos = 0;
             if (kd_lo == 0 && kd_hi >= 0) {
                 kd_steps(ic<0>{}, ic<0>{}, wk, kd_hi >= 1);
@@ -635,6 +641,7 @@ __global__ __launch_bounds__(256, 2) void x3_deconv_kernel(const X3Args a) {
             if (kd_lo <= 2 && kd_hi >= 2) {
                 if (pos == 0) kd_steps(ic<2>{}, ic<0>{}, wk, false); else kd_steps(ic<2>{}, ic<1>{}, wk, false);
             }
+            if (X3_SETPRIO) __builtin_amdgcn_s_setprio(0);
         }
         // output plane p-1 has seen input planes p-2, p-1, p
 #if !X3_DECONV_PREFETCH

@@ -258,6 +258,10 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
                 x0f[0][k] = *reinterpret_cast<const bf16x8*>(b0 + off2[0] + k * A1_TERM);
                 x1f[0][k] = *reinterpret_cast<const bf16x8*>(b1 + off2[0] + k * A1_TERM);
             }
+#ifndef VIS_SETPRIO
+#define VIS_SETPRIO 1
+#endif
+            if (VIS_SETPRIO) __builtin_amdgcn_s_setprio(1);    // the other block of the CU is in another phase: the MFMA steps win the issue arbitration
 #pragma unroll
             for (int s = 0; s < L2_STEPS; ++s) {
                 if (s + 1 < L2_STEPS) {
@@ -274,6 +278,7 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (VIS_SETPRIO) __builtin_amdgcn_s_setprio(0);
             auto finish = [&](int tt, const f32x4& c) {
                 const int o = tt * 16 + n, oy = o / A1W, ox = o % A1W;
                 if (oy < A2W && ox < A2W) {
@@ -309,6 +314,7 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
                 x0f[0][k] = *reinterpret_cast<const bf16x8*>(b0 + off3[0] + k * A2_TERM);
                 x1f[0][k] = *reinterpret_cast<const bf16x8*>(b1 + off3[0] + k * A2_TERM);
             }
+            if (VIS_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < L3_STEPS; ++s) {
                 if (s + 1 < L3_STEPS) {
@@ -326,6 +332,7 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
                 __builtin_amdgcn_sched_barrier(0);
             }
             // D[m = (dy, co)][n = x]: this lane holds dy = kb >> 1, channels (kb & 1) * 4 + r; the other 4 channels sit 16 lanes away
+            if (VIS_SETPRIO) __builtin_amdgcn_s_setprio(0);
             auto reduce = [&](const f32x4& c) {
                 float part = 0.0f;
 #pragma unroll
