@@ -45,6 +45,10 @@ for _ in range(args.iters):
     if "cv" in args.what:
         vol, sim = ops.cv_aggregate(feat, rt, hyp, w, 8, True)
     if "reg" in args.what:
-        net.cost_reg.features(vol if "cv" in args.what else torch.randn(1, 8, D, H, W, device=dev))
+        x = vol if "cv" in args.what else torch.randn(1, 8, D, H, W, device=dev)
+        if hasattr(net.cost_reg, "logits"):
+            net.cost_reg.logits(x)                          # CostRegNet3D: the path StageNet takes (conv11 + prob as the fused tail)
+        else:
+            net.cost_reg.features(x)
 torch.cuda.synchronize()
 print("done", H, W, C, D)
