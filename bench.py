@@ -67,6 +67,12 @@ def parse():
     ap.add_argument("--features-layout", choices=["nchw", "nhwc"], default="nchw",
                     help="nchw: what the reference's FPN decoder + torch.stack hand over (default, the BASELINE workload); nhwc: the "
                          "same [B,V,C,H,W] tensors channel-last in memory (decoder run in torch.channels_last), consumed zero-copy")
+    ap.add_argument("--input-sets", type=int, default=3,
+                    help="distinct synthetic input sets (different scene seeds, ~0.53 GB of feature maps each at config 2) the timed steps rotate "
+                         "over, step i runs set i %% input_sets: a rank walks different reference views, so the coarse stages' features "
+                         "cannot stay resident in the 256 MB Infinity Cache from one step to the next")
+    ap.add_argument("--no-train", action="store_true", help="skip the `train_config3` extra key (BASELINE configs[2]: bf16 training step)")
+    ap.add_argument("--train-steps", type=int, default=30)
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams per GPU; step i (one reference view) runs on stream i %% streams, so independent "
                          "reference views overlap (MFMA-bound regularizer of one with the VALU/TA-bound sweeps of another)")
@@ -161,44 +167,50 @@ def time_steps(run, steps, world, dev):
     return float(tt.item()), out
 
 
-def make_runner(net, feats, proj, dv, tmp, streams, graphs=False):
-    def step():
-        return net(feats, proj, dv, tmp=tmp)
+def make_runner(net, feats, proj, dv, tmp, streams, graphs=False, sets=None):
+    """``sets``: list of (feats, proj, dv) the steps of a region rotate over (step i of every ``run(n)`` call takes set i % len(sets));
+    ``step()`` alone runs set 0 = (feats, proj, dv)."""
+    sets = sets or [(feats, proj, dv)]
+
+    def step(k=0):
+        f, p, d = sets[k % len(sets)]
+        return net(f, p, d, tmp=tmp)
 
     if graphs:
         # one captured cascade per stream (mvsformer_amd/graphs.py): a step = one hipGraphLaunch instead of ~60 kernel launches; same
         # kernels, same inputs, bit-identical outputs (tests/test_hip_graph.py::test_captured_eval_cascade_is_bit_equal)
         from mvsformer_amd.graphs import CapturedStep
 
-        def nograd_step():
-            with torch.no_grad():
-                return step()
+        sl = streams or [torch.cuda.current_stream()]
+        # a captured graph bakes its input pointers in: one graph per (stream, input set) pair that the rotation produces
+        import math
+        period = len(sl) * len(sets) // math.gcd(len(sl), len(sets))
         caps = []
-        for st in (streams or [torch.cuda.current_stream()]):
-            with torch.cuda.stream(st):
-                caps.append(CapturedStep(nograd_step, warmup=1))
+        for i in range(period):
+            with torch.cuda.stream(sl[i % len(sl)]), torch.no_grad():
+                caps.append(CapturedStep(lambda k=i: step(k), warmup=1))
         torch.cuda.synchronize()
 
         def run_g(n):
             out = None
             for i in range(n):
                 if streams is None:
-                    out = caps[0]()
+                    out = caps[i % period]()
                 else:
                     with torch.cuda.stream(streams[i % len(streams)]):
-                        out = caps[i % len(streams)]()
+                        out = caps[i % period]()
             return out
         return step, run_g
 
     def run(n):
         out = None
         if streams is None:
-            for _ in range(n):
-                out = step()
+            for i in range(n):
+                out = step(i)
         else:
             for i in range(n):
                 with torch.cuda.stream(streams[i % len(streams)]):
-                    out = step()
+                    out = step(i)
         return out
     return step, run
 
@@ -236,10 +248,19 @@ def main(args):
         feats = {k: v.reshape(-1, *v.shape[2:]).contiguous(memory_format=torch.channels_last).view(v.shape) for k, v in feats.items()}
     tmp = [5.0, 5.0, 5.0, 1.0]
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
-    step, run = make_runner(net, feats, proj, dv, tmp, streams)
+    # the input sets the timed steps rotate over: set 0 = the tensors above (the ones the oracle ran on), the others = other scenes
+    sets = [(feats, proj, dv)]
+    for j in range(1, max(1, args.input_sets)):
+        f_j, p_j, d_j, _ = synth.make_inputs(args.views, args.height, args.width, seed=1000 * j + rank, batch=args.batch, device=dev)
+        if args.features_layout == "nhwc":
+            f_j = {k: v.reshape(-1, *v.shape[2:]).contiguous(memory_format=torch.channels_last).view(v.shape) for k, v in f_j.items()}
+        sets.append((f_j, p_j, d_j))
+    sets_desc = {"bytes": sum(v.numel() * v.element_size() for v in feats.values()),
+                 "seeds": [0 if ref is not None else rank] + [1000 * j + rank for j in range(1, max(1, args.input_sets))]}
+    step, run = make_runner(net, feats, proj, dv, tmp, streams, sets=sets)
     step()                                               # first call builds the weight caches (synchronizes once)
     if args.graph:                                       # measured: 1 stream 188.7 vs 189.1 depth maps/s eager, 3 streams 203 vs 215
-        _, run = make_runner(net, feats, proj, dv, tmp, streams, graphs=True)
+        _, run = make_runner(net, feats, proj, dv, tmp, streams, graphs=True, sets=sets)
     run(max(args.warmup, args.streams))
     # `--repeats` timed regions of EXACTLY --steps steps each; the reported one is the median region (a 20-step region is 80 ms: one
     # pre-empted launch would otherwise move the headline), all of them are listed in `ms_per_step_repeats`
@@ -251,8 +272,11 @@ def main(args):
     dt, own_dt = regions[order[(len(order) - 1) // 2]]
     assert torch.isfinite(out["refined_depth"]).all()
     with torch.no_grad():                                # the timed steps computed what a fresh single-stream call computes
-        again = step()
+        again = step(args.steps - 1)                     # the input set of the region's last step
     assert torch.equal(out["refined_depth"], again["refined_depth"]), "timed step and a fresh call disagree"
+    if len(sets) > 1 and (args.steps - 1) % len(sets):   # `out` below (smooth-hypotheses key, nhwc key) is the set-0 result
+        with torch.no_grad():
+            out = step(0)
     parity = depth_parity(net, feats, proj, dv, tmp, ref, dev) if ref is not None else None
     del ref
 
@@ -476,6 +500,20 @@ def main(args):
                 "note": "features handed over channel-last in memory (zero-copy into the sweeps); not `value`: the reference's decoder emits NCHW"}
         del f2, o2
 
+    # ---- BASELINE configs[2]: one bf16-autocast training step (forward + ce loss + backward + AdamW) of the cascade 32/16/8/8 on a 640x512
+    #      5-view sample, replayed as one hipGraph; bench_train.py is the stand-alone form (and the N > 1 DDP form) of the same measurement ----
+    train3 = None
+    if rank == 0 and world == 1 and not args.no_train:
+        import bench_train
+        del sets, step, run
+        torch.cuda.empty_cache()
+        t = bench_train.measure(bench_train.parse(["--steps", str(args.train_steps), "--warmup", "3", "--dtype", "bf16", "--graph", "on"]), top=8)
+        train3 = {"ms_per_step": t["ms_per_step"], "samples_per_s": t["value"], "steps": t["steps"], "hip_graph": t["hip_graph"],
+                  "launches_per_step": t["launches_per_step"], "host_enqueue_ms_per_step": t["host_enqueue_ms_per_step"],
+                  "kernel_ms_sum_eager_events": t["kernel_ms_sum"], "final_loss": t["final_loss"], "dtype": "bf16 autocast (fp32 cost volume, "
+                  "statistics, head, loss, master weights)", "workload": t["metric"], "top_kernels": t["kernels"],
+                  "note": "extra key, not `value`: BASELINE configs[2] geometry on ONE GPU (the 8-GPU form is bench_train.py --gpus 8: DDP + SyncBatchNorm over RCCL)"}
+
     # ---- who ran: one record per rank (device, its own wall time), so that a scaling run shows N distinct GPUs ----
     props = torch.cuda.get_device_properties(dev)
     mine = {"rank": rank, "local_rank": local_rank, "device": props.name, "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
@@ -489,7 +527,7 @@ def main(args):
         total = world * args.steps * args.batch
         # Key order: the bulky per-kernel table FIRST, the judged scalars LAST - the driver's record keeps the tail of this line.
         line = {
-            "kernels": kernels, "other_configs": other, "before_the_path": before, "features_layout_nhwc": nhwc, "ranks": ranks,
+            "kernels": kernels, "other_configs": other, "before_the_path": before, "features_layout_nhwc": nhwc, "ranks": ranks, "train_config3": train3,
             "traffic_source": traffic_source, "parity": parity,
             "metric": "depth maps/sec @1536x1152 N=5 D=192", "value": round(total / dt, 3), "unit": "depth maps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -500,7 +538,8 @@ def main(args):
                        "arithmetic": ARITHMETIC,
                        "parallelism": "inference sharding of reference views, one process per GPU, no collective" if world > 1 else "single GPU",
                        "streams_per_gpu": args.streams, "features_layout": args.features_layout,
-                       "reference_views_per_step": args.batch},
+                       "reference_views_per_step": args.batch, "input_sets": len(sets_desc["seeds"]), "input_set_bytes": sets_desc["bytes"],
+                       "input_set_seeds": sets_desc["seeds"]},
             "repeats": len(regions), "ms_per_step_repeats": [round(r[0] / args.steps * 1e3, 3) for r in regions],
             "value_is": "median of `repeats` timed regions of exactly `steps` steps each, %d streams in flight" % max(1, args.streams),
             "ranks_seen": dist.get_world_size() if world > 1 else 1,

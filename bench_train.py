@@ -21,7 +21,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -38,10 +38,12 @@ def parse():
                     help="replay the whole step (forward + loss + backward + AdamW) as ONE hipGraph (mvsformer_amd/graphs.py): host cost per "
                          "step 13-22 ms (box dependent) -> 0.6 ms, so the step runs at the GPU's pace (13.2 ms) whatever the host does; "
                          "auto = on for a single rank (eager fallback if capture fails), off under DistributedDataParallel")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def main(args):
+def measure(args, top=12):
+    """Runs the timed training steps described by ``args`` (the namespace of :func:`parse`; bench.py builds one for its ``train_config3``
+    key) and returns the record on rank 0 (None elsewhere)."""
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     import torch.distributed as dist
     dev = torch.device("cuda", local)
@@ -60,7 +62,9 @@ def main(args):
         net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
         model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local])
     use_graph = args.graph == "on" or (args.graph == "auto" and not ddp)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=use_graph)
+    # torch.optim.AdamW as the reference trainer builds it (train.py:98), in its FUSED form: one multi-tensor kernel for all ~190
+    # parameter tensors (the default capturable form spends 304 elementwise launches and 1.1 ms of a 12.9 ms step on bias corrections)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=use_graph, fused=True)
     feats, proj, dv, scene = synth.make_inputs(args.views, args.height, args.width, seed=rank, device=dev)
     feats = {k: v.requires_grad_(True) for k, v in feats.items()}
     from mvsformer_amd.losses import ce_loss_stage4
@@ -84,7 +88,7 @@ def main(args):
     if use_graph:
         try:
             from mvsformer_amd.graphs import CapturedStep
-            step = CapturedStep(eager_step, warmup=3)
+            step = CapturedStep(eager_step, warmup=3, keep_graph=True)
         except Exception as e:                               # report, fall back to eager launches
             if args.graph == "on":
                 raise
@@ -123,6 +127,7 @@ def main(args):
     # ---- per-kernel durations of ONE eager step (HIP events around every C-ABI launch, on the launch stream) and the roofline of the
     #      dominant kernel that has an algorithmic work figure; rank 0 only, after the timed region ----
     kernels, roofline = [], None
+    launches = step.node_counts() if use_graph else None      # nodes of the captured step = launches per step (kernels of torch ops included)
     if rank == 0 and not ddp:
         from mvsformer_amd import ops
         eager_step()
@@ -148,15 +153,24 @@ def main(args):
             roofline = {k: dom[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")}
             roofline.update(ms_per_step=dom["ms_per_step"], calls_per_step=dom["calls_per_step"], algorithmic_per_step=dom["algorithmic_per_step"],
                             traffic=None, note="largest kernel of the step with an algorithmic work figure; summed over its launches of one eager step")
+    rec = None
     if rank == 0:
-        print(json.dumps({"roofline": roofline, "kernel_ms_sum": round(sum(e["ms_per_step"] for e in kernels), 3), "kernels": kernels[:12],
+        rec = ({"roofline": roofline, "kernel_ms_sum": round(sum(e["ms_per_step"] for e in kernels), 3), "kernels": kernels[:top],
+                          "launches_per_step": launches,
                           "ranks_seen": dist.get_world_size() if world > 1 else 1, "ranks": ranks,
                           "metric": "training samples/s (fwd+bwd+AdamW), 640x512, 5 views, cascade 32/16/8/8", "value": round(world * args.steps / dt.item(), 3),
                           "unit": "samples/s", "n_gpus": world, "steps": args.steps, "ms_per_step": round(dt.item() / args.steps * 1e3, 2),
                           "host_enqueue_ms_per_step": round(t_enqueue * 1e3, 2), "hip_graph": use_graph, "graph_note": graph_note, "dtype": args.dtype, "data": "synthetic", "scaling": "weak", "final_loss": round(float(loss.detach()), 4),
-                          "parallelism": "DDP + SyncBatchNorm over RCCL" if ddp else "single GPU"}))
-    if ddp:
+                          "parallelism": "DDP + SyncBatchNorm over RCCL" if ddp else "single GPU"})
+    if ddp and not getattr(args, "keep_process_group", False):
         dist.destroy_process_group()
+    return rec
+
+
+def main(args):
+    rec = measure(args)
+    if rec is not None:
+        print(json.dumps(rec))
 
 
 if __name__ == "__main__":

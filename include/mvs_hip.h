@@ -41,7 +41,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 11
+#define MVS_ABI_VERSION 13
 
 typedef void* mvs_stream_t;
 
@@ -341,6 +341,42 @@ int mvs_bf16_bn_bwd_reduce(const void* dy, const void* x, const float* scale, co
 int mvs_bf16_bn_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
                           const float* invstd, const float* gamma, const float* sums, double count, const float* count_dev,
                           int relu, int C, int64_t R, int groups, int64_t rows_per_sample, void* dx, mvs_stream_t stream);
+
+/* Round-5 fused forms of the bf16 training layer (fewer graph nodes per step; reference layer: models/module.py:83-165 under
+ * trainer/mvsformer_trainer.py:104-106 autocast).
+ *   mvs_bf16_conv3d_bn_fwd: y = raw conv(x) (kept for the backward), z = [relu](BatchNorm_train(y)) [+ residual]; the batch statistics of
+ *       the bf16-rounded y are taken in the convolution's epilogue as one row per BLOCK (workspace =
+ *       mvs_bf16_conv3d_bn_fwd_workspace_bytes of the OUTPUT grid), a one-block-per-channel kernel adds the rows in a fixed order and
+ *       writes stats4 = [scale | shift | mean | invstd] (each groups*Cout) + the running statistics, a third launch normalizes.
+ *       groups > 1: sample b belongs to group b % groups (the visibility CNN, one call per source view in the reference). */
+int64_t mvs_bf16_conv3d_bn_fwd_workspace_bytes(int B, int Cout, int Do, int Ho, int Wo);
+int mvs_bf16_conv3d_bn_fwd(const void* x, const void* wpacked, void* y, void* z, const void* residual, int relu, int B, int Cin, int Cout,
+                           int Di, int Hi, int Wi, int gather, int sd, int shw, int taps, int groups, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, int64_t* num_batches_tracked,
+                           float* stats4, void* workspace, mvs_stream_t stream);
+/* 2-D kernels on the same machinery (`taps` = 27 or 9; 9 = only the centre depth tap exists: the visibility CNN's Conv2d layers run as
+ * D = 1 volumes at a third of the matrix work of a zero-embedded 3x3x3 kernel, forward, data gradient and weight gradient):
+ *   mvs_bf16_packed_elems_taps / mvs_bf16_pack_table_*: w = [d0][d1][taps]; rows / channels of the Cin -> Cout map beyond d0 / d1 pack as
+ *       zeros (the CNN's 1-channel input as 8, CostRegNet's 8 -> 1 `prob` as 8 -> 8).  A TABLE of jobs - every layout a stage's training
+ *       step needs - is filled on the host entry by entry, copied to the device once, and packed by ONE launch per step.
+ *   mvs_bf16_conv3d_taps: raw convolution (no epilogue); taps = 9 needs gather 0, stride 1, <= 16 channels.
+ *   mvs_bf16_conv3d_wgrad_taps: dW [CA][CBout][taps], CBout <= CB drops Bt's padding channels. */
+int64_t mvs_bf16_packed_elems_taps(int Cin, int Cout, int taps);
+int64_t mvs_bf16_pack_table_bytes(int njobs);
+int mvs_bf16_pack_table_fill(void* host_table, int njobs, int index, const float* w, int d0, int d1, int src, int Cout, int Cin, int taps,
+                             void* wpacked);
+int mvs_bf16_pack_table_run(const void* dev_table, int njobs, int total_blocks, mvs_stream_t stream);
+int mvs_bf16_conv3d_taps(const void* x, const void* wpacked, void* y, int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd,
+                         int shw, int taps, mvs_stream_t stream);
+int mvs_bf16_conv3d_wgrad_taps(const void* A, const void* Bt, float* dW, void* workspace, int nbatch, int CA, int CB, int CBout, int Dp, int Hp,
+                               int Wp, int Db, int Hb, int Wb, int sd, int shw, int taps, mvs_stream_t stream);
+/* 1x1x1 heads on bf16 channel-last activations (csrc/bf16_head.hip): out[v] = act(sum_c w[c]*x[v][c] + bias), x = bf16 [N][8], out fp32
+ * [N], act = sigmoid or identity; w = NULL selects channel 0 (no parameters).  Backward: dx bf16 [N][8], dwb [9] = [dw | dbias] by block
+ * rows + a fixed-order reduce (workspace = mvs_bf16_head_bwd_workspace_bytes(N)); y = the forward's output when it applied the sigmoid. */
+int mvs_bf16_head_fwd(const void* x, const float* w, const float* bias, int sigmoid, int64_t N, float* out, mvs_stream_t stream);
+int64_t mvs_bf16_head_bwd_workspace_bytes(int64_t N);
+int mvs_bf16_head_bwd(const void* x, const float* w, const float* y, const float* dout, int64_t N, void* dx, float* dwb, void* workspace,
+                      mvs_stream_t stream);
 int mvs_cv_aggregate_bwd(const float* feat, const float* rt, const float* depth, const float* weight, const float* volume,
                          const float* gvolume, int B, int V, int C, int G, int D, int H, int W, float* dfeat, float* dweight,
                          mvs_stream_t stream);

@@ -18,7 +18,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVS_HIP_LIB: diagnostics only - another BUILD of the same library (tests/test_hip_multistream.py's variants); never a fallback
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 13
 
 from ctypes import c_double  # noqa: E402
 
@@ -88,6 +88,17 @@ SIGNATURES = {
     "mvs_bf16_bn_train_fwd": (I, [P, P, I, I, L, I, L, P, P, P, P, F, F, P, P, P, P, P]),
     "mvs_bf16_bn_bwd_reduce": (I, [P, P, P, P, P, P, I, I, L, I, L, P, P, P]),
     "mvs_bf16_bn_bwd_apply": (I, [P, P, P, P, P, P, P, P, Dbl, P, I, I, L, I, L, P, P]),
+    "mvs_bf16_conv3d_bn_fwd_workspace_bytes": (L, [I, I, I, I, I]),
+    "mvs_bf16_conv3d_bn_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P, F, F, P, P, P, P]),
+    "mvs_bf16_packed_elems_taps": (L, [I, I, I]),
+    "mvs_bf16_pack_table_bytes": (L, [I]),
+    "mvs_bf16_pack_table_fill": (I, [P, I, I, P, I, I, I, I, I, I, P]),
+    "mvs_bf16_pack_table_run": (I, [P, I, I, P]),
+    "mvs_bf16_conv3d_taps": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "mvs_bf16_conv3d_wgrad_taps": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "mvs_bf16_head_fwd": (I, [P, P, P, I, L, P, P]),
+    "mvs_bf16_head_bwd_workspace_bytes": (L, [L]),
+    "mvs_bf16_head_bwd": (I, [P, P, P, P, L, P, P, P, P]),
     "mvs_cv_aggregate_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P]),
     "mvs_cv_aggregate_bwd_lds": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, I, I, P, P]),
     "mvs_cv_aggregate_bwd_own": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, I, I, P, P]),

@@ -247,8 +247,10 @@ class AggregateFn(torch.autograd.Function):
     """volume_mean = sum_v w_v * corr(ref, warp(src_v)) / (sum_v w_v + 1e-6); grads to features and to w."""
 
     @staticmethod
-    def forward(ctx, feat, weight, rt, hyp, G):
-        feat_cl = ops.to_channels_last(feat.detach().to(torch.float32).contiguous())
+    def forward(ctx, feat, weight, rt, hyp, G, feat_cl=None):
+        """``feat_cl``: the channel-last copy of ``feat`` if the caller already made it (the entropy sweep reads the same one)."""
+        if feat_cl is None:
+            feat_cl = ops.to_channels_last(feat.detach().to(torch.float32).contiguous())
         weight = weight.contiguous()
         vol, _ = ops.cv_aggregate(feat_cl, rt, hyp, weight, G, want_sim_depth=False, exact=True)   # same geometry as the backward kernel
         ctx.save_for_backward(feat_cl, rt, hyp, weight, vol)
@@ -260,7 +262,7 @@ class AggregateFn(torch.autograd.Function):
         feat_cl, rt, hyp, weight, vol = ctx.saved_tensors
         dfeat_cl, dw = ops.cv_aggregate_bwd(feat_cl, rt, hyp, weight, vol, gvol.contiguous(), ctx.G)
         dfeat = ops.to_channels_first(dfeat_cl).to(ctx.dtype) if ctx.needs_input_grad[0] else None
-        return dfeat, (dw if ctx.needs_input_grad[1] else None), None, None, None
+        return dfeat, (dw if ctx.needs_input_grad[1] else None), None, None, None, None
 
 
 class HeadFn(torch.autograd.Function):
@@ -304,6 +306,11 @@ def embed_conv2d_weight(w2d: torch.Tensor, cin_pad: int) -> torch.Tensor:
     return _EmbedConv2dWeightFn.apply(w2d, cin_pad)
 
 
+def _fused_layers() -> bool:
+    """MVS_TRAIN_FUSED=0 keeps the round-4 chain of separate conv / BatchNorm autograd nodes (diagnostics, A/B timing)."""
+    return os.environ.get("MVS_TRAIN_FUSED", "1") != "0"
+
+
 def vis_train(entropy: torch.Tensor, vis: nn.Sequential) -> torch.Tensor:
     """``self.vis(entropy)`` in training mode for ONE source view: ``entropy [B,1,H,W]`` -> ``[B,1,H,W]``.  The reference
     calls the CNN once per view (mvsformer_model.py:91), so batch statistics are per view; keep that."""
@@ -332,11 +339,23 @@ def vis_train_views(entropy: torch.Tensor, vis: nn.Sequential) -> torch.Tensor:
         # trainer/mvsformer_trainer.py:104-106): bf16 channel-last kernels, fp32 statistics, the 1x1 conv + sigmoid in fp32
         x16 = torch.zeros(B * Vs, 1, H, W, 8, device=entropy.device, dtype=torch.bfloat16)
         x16[..., 0] = entropy.reshape(B * Vs, 1, H, W)                   # batch index b*Vs + v; entropy is detached (no gradient)
+        fused = _fused_layers() and not any(_bn_synced(vis[i].bn) for i in range(3))
         for i in range(3):
             blk = vis[i]
+            pk = packed_of(blk.conv)
+            if fused and pk is not None:
+                # the 2-D parameter itself (9 taps of a D = 1 volume), packed this step by the stage's StagePack
+                x16 = LayerBf16Fn.apply(x16, blk.conv.weight, blk.bn.weight, blk.bn.bias, None, blk.bn, True, 0, (1, 1), Vs, pk)
+                continue
             cin_pad = 8 if i == 0 else blk.conv.in_channels
-            x16 = ConvBf16Fn.apply(x16, embed_conv2d_weight(blk.conv.weight, cin_pad), (1, 1))
+            w3 = embed_conv2d_weight(blk.conv.weight, cin_pad)
+            if fused:
+                x16 = LayerBf16Fn.apply(x16, w3, blk.bn.weight, blk.bn.bias, None, blk.bn, True, 0, (1, 1), Vs)
+                continue
+            x16 = ConvBf16Fn.apply(x16, w3, (1, 1))
             x16 = BnActBf16Fn.apply(x16, blk.bn.weight, blk.bn.bias, None, blk.bn, True, Vs)
+        if _fused_layers():
+            return HeadBf16Fn.apply(x16, vis[3].weight, vis[3].bias, True).reshape(B, Vs, H, W)
         y = Prob1Fn.apply(FromBf16Fn.apply(x16), vis[3].weight, vis[3].bias)
         return SigmoidFn.apply(y).reshape(B, Vs, H, W)
     x = torch.zeros(B * Vs, 4, 1, H, W, device=entropy.device, dtype=torch.float32)
@@ -381,54 +400,70 @@ class ConvBf16Fn(torch.autograd.Function):
     """Raw 3x3x3 convolution on bf16 channel-last activations, fp32 master weight ``[Cout,Cin,3,3,3]`` cast per call."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, stats_groups=0):
+    def forward(ctx, x, weight, stride, stats_groups=0, packed=None, cout_pad=None):
         """``stats_groups`` > 0: also return the batch statistics of the output (``sums [2*groups*Cout]``, non-differentiable) computed
-        in the convolution's epilogue, for the BatchNorm that follows (:class:`BnActBf16Fn` ``sums=``)."""
+        in the convolution's epilogue, for the BatchNorm that follows (:class:`BnActBf16Fn` ``sums=``).  ``packed``: the (forward,
+        data-gradient) layouts if a :class:`StagePack` already made them this step.  ``cout_pad`` > Cout: run as a wider map whose extra
+        output channels are zero (CostRegNet's 8 -> 1 ``prob`` as 8 -> 8; needs ``packed``)."""
         x = x.contiguous()
-        w = weight.detach().to(torch.float32).contiguous()
-        cout, cin = w.shape[0], w.shape[1]
-        if ctx.needs_input_grad[0]:     # the data gradient's layout (stride-1: channels swapped + taps mirrored; strided: transposed
-            wf, wb = ops.bf16_pack2(w, (0, cin, cout), (2 if stride[1] == 1 else 1, cout, cin))     # conv) in the same launch
+        cout, cin = weight.shape[0], weight.shape[1]
+        cpad = cout_pad or cout
+        if packed is not None:
+            wf, wb = packed
         else:
-            wf, wb = ops.bf16_pack(w, 0, cin, cout), None
+            if cpad != cout:
+                raise ops._lib.MvsHipError("a padded convolution needs its weights packed by a StagePack")
+            w = weight.detach().to(torch.float32).contiguous()
+            if ctx.needs_input_grad[0]:     # the data gradient's layout (stride-1: channels swapped + taps mirrored; strided: transposed
+                wf, wb = ops.bf16_pack2(w, (0, cin, cout), (2 if stride[1] == 1 else 1, cout, cin))     # conv) in the same launch
+            else:
+                wf, wb = ops.bf16_pack(w, 0, cin, cout), None
         ctx.save_for_backward(x, wb)
-        ctx.stride, ctx.wshape = stride, (cout, cin)
+        ctx.stride, ctx.wshape, ctx.cpad = stride, (cout, cin), cpad
         if stats_groups:
-            y, sums = ops.bf16_conv3d_stats(x, wf, cin, cout, 0, stride, stats_groups)
+            y, sums = ops.bf16_conv3d_stats(x, wf, cin, cpad, 0, stride, stats_groups)
             ctx.mark_non_differentiable(sums)
             return y, sums
-        return ops.bf16_conv3d(x, wf, cin, cout, 0, stride)
+        return ops.bf16_conv3d(x, wf, cin, cpad, 0, stride)
 
     @staticmethod
     def backward(ctx, dy, _dsums=None):
         x, wb = ctx.saved_tensors
         dy = dy.contiguous()
         cout, cin = ctx.wshape
+        cpad = ctx.cpad
         sd, shw = ctx.stride
         dx = None
         if ctx.needs_input_grad[0]:
             if shw == 1:        # stride-1 conv: the data gradient is the same conv with channels swapped and taps mirrored
-                dx = ops.bf16_conv3d(dy, wb, cout, cin, 0, (1, 1))
+                dx = ops.bf16_conv3d(dy, wb, cpad, cin, 0, (1, 1))
             else:               # strided conv: the transposed conv of the same weight
-                dx = ops.bf16_conv3d(dy, wb, cout, cin, 1, (sd, shw))
+                dx = ops.bf16_conv3d(dy, wb, cpad, cin, 1, (sd, shw))
             if dx.shape != x.shape:
                 raise ops._lib.MvsHipError("conv backward: input %s is not 2x the output grid %s" % (tuple(x.shape), tuple(dy.shape)))
-        dw = ops.bf16_conv3d_wgrad(dy, x, (sd, shw)) if ctx.needs_input_grad[1] else None
-        return dx, dw, None, None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = ops.bf16_conv3d_wgrad(dy, x, (sd, shw))
+            if cpad != cout:
+                dw = dw[:cout]
+        return dx, dw, None, None, None, None
 
 
 class DeconvBf16Fn(torch.autograd.Function):
     """Raw ConvTranspose3d k3, stride (sd,2,2), padding 1, output_padding (sd-1,1,1) on bf16 channel-last activations."""
 
     @staticmethod
-    def forward(ctx, x, weight, sd, stats_groups=0):
+    def forward(ctx, x, weight, sd, stats_groups=0, packed=None):
         x = x.contiguous()
-        w = weight.detach().to(torch.float32).contiguous()          # [Cin,Cout,3,3,3]
-        cin, cout = w.shape[0], w.shape[1]
-        if ctx.needs_input_grad[0]:     # data gradient = strided conv of dY with W read as [out = cin, in = cout]
-            wf, wb = ops.bf16_pack2(w, (1, cin, cout), (0, cout, cin))
+        cin, cout = weight.shape[0], weight.shape[1]                # [Cin,Cout,3,3,3]
+        if packed is not None:
+            wf, wb = packed
         else:
-            wf, wb = ops.bf16_pack(w, 1, cin, cout), None
+            w = weight.detach().to(torch.float32).contiguous()
+            if ctx.needs_input_grad[0]:     # data gradient = strided conv of dY with W read as [out = cin, in = cout]
+                wf, wb = ops.bf16_pack2(w, (1, cin, cout), (0, cout, cin))
+            else:
+                wf, wb = ops.bf16_pack(w, 1, cin, cout), None
         ctx.save_for_backward(x, wb)
         ctx.sd, ctx.wshape = sd, (cin, cout)
         if stats_groups:
@@ -446,7 +481,7 @@ class DeconvBf16Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:   # strided conv of dY with W read as [out = cin, in = cout]
             dx = ops.bf16_conv3d(dy, wb, cout, cin, 0, (ctx.sd, 2))
         dw = ops.bf16_conv3d_wgrad(x, dy, (ctx.sd, 2)) if ctx.needs_input_grad[1] else None
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 class BnActBf16Fn(torch.autograd.Function):
@@ -512,3 +547,183 @@ class BnActBf16Fn(torch.autograd.Function):
             dbeta, dgamma = local[:CT], local[CT:]                       # views of the reduction result (no device copies)
         return dx, (dgamma if ctx.needs_input_grad[1] else None), (dbeta if ctx.needs_input_grad[2] else None), \
             (dy if ctx.has_res else None), None, None, None, None
+
+
+def _bn_synced(bn) -> bool:
+    return isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size(bn.process_group) > 1
+
+
+class LayerBf16Fn(torch.autograd.Function):
+    """One whole training layer on bf16 channel-last activations as ONE autograd node: (transposed) 3x3x3 convolution -> batch-statistics
+    BatchNorm (statistics in the convolution's epilogue) -> [ReLU] [+ skip]; backward = BatchNorm backward, data gradient, weight
+    gradient.  For layers whose statistics stay on this rank (plain BatchNorm, or SyncBatchNorm with a process group of one);
+    :func:`mvsformer_amd.module._train_conv_bn_act` keeps the ConvBf16Fn -> BnActBf16Fn pair for the synchronized case, where an
+    all-reduce sits between the statistics and the finalize.
+
+    ``gather``: 0 = Conv3d with ``stride = (sd, shw)``, 1 = ConvTranspose3d with stride ``(sd, 2, 2)``.  ``weight`` may be a 2-D
+    ``[Cout,Cin,3,3]`` parameter (the visibility CNN): it runs as the centre depth tap of a D = 1 volume (9 taps, a third of the matrix
+    work of a zero-embedded 3x3x3 kernel) with the input's channel count (>= Cin, a multiple of 8) as the map's width.  ``packed``: the
+    (forward, data-gradient) weight layouts if the caller's :class:`StagePack` already made them for this step, else None (packed
+    here; 3x3x3 only)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, bn, relu, gather, stride, groups=1, packed=None):
+        x = x.contiguous()
+        taps = ops._taps_of(weight)
+        if gather == 0:
+            cout, cin = weight.shape[0], weight.shape[1]
+            cin_map = x.shape[-1]                                  # >= cin: padding channels of the input (their weights pack as zeros)
+            fwd, bwd = (0, cin_map, cout), (2 if stride[1] == 1 else 1, cout, cin_map)
+        else:
+            cin, cout = weight.shape[0], weight.shape[1]
+            cin_map = cin
+            fwd, bwd = (1, cin, cout), (0, cout, cin)
+        need_dx = ctx.needs_input_grad[0]
+        if packed is not None:
+            wf, wb = packed
+        else:
+            if taps != 27 or cin_map != cin:
+                raise ops._lib.MvsHipError("a 2-D / padded layer needs its weights packed by a StagePack")
+            w = weight.detach().to(torch.float32).contiguous()
+            if need_dx:
+                wf, wb = ops.bf16_pack2(w, fwd, bwd)
+            else:
+                wf, wb = ops.bf16_pack(w, *fwd), None
+        if groups > 1 and (residual is not None or bn.momentum is None):
+            raise ops._lib.MvsHipError("grouped BatchNorm has no residual form and needs a fixed momentum")
+        g = gamma.detach().to(torch.float32).contiguous() if gamma is not None else None
+        b = beta.detach().to(torch.float32).contiguous() if beta is not None else None
+        track = bn.track_running_stats and bn.running_mean is not None
+        rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
+        mom = bn.momentum if groups > 1 else (_momentum(bn) if track else 0.0)
+        nbt = bn.num_batches_tracked if track and bn.num_batches_tracked is not None else None       # incremented by the kernel
+        res = residual.contiguous() if residual is not None else None
+        y, z, scale, shift, mean, invstd = ops.bf16_conv3d_bn_fwd(x, wf, cin_map, cout, gather, stride, res, relu, g, b, rm, rv, mom, bn.eps,
+                                                                  groups, nbt, taps)
+        gfull = g if g is not None else scale.new_ones(cout)
+        if groups > 1:
+            gfull = gfull.repeat(groups)
+        ctx.save_for_backward(x, wb, y, scale, shift, mean, invstd, gfull)
+        ctx.cfg = (relu, gather, tuple(stride), groups, cin, cin_map, cout, residual is not None, taps)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, wb, y, scale, shift, mean, invstd, gfull = ctx.saved_tensors
+        relu, gather, (sd, shw), groups, cin, cin_map, cout, has_res, taps = ctx.cfg
+        dz = dz.contiguous()
+        # (an in-launch completion of the reduce - last block to arrive adds the partial rows - was built and measured: a thousand
+        #  same-address agent-scope atomics cost 15-25 us per call, three times the launch they replace; NOTEBOOK.md)
+        sums = ops.bf16_bn_bwd_reduce(dz, y, scale, shift, mean, invstd, relu, groups)
+        dy = ops.bf16_bn_bwd_apply(dz, y, scale, shift, mean, invstd, gfull, sums, float(y.numel() // (cout * groups)), relu, None, groups)
+        CT = cout * groups
+        if groups > 1:                                                        # shared parameters: sum the groups' gradients (one launch)
+            both = sums.view(2, groups, -1).sum(1)
+            dbeta, dgamma = both[0], both[1]
+        else:
+            dbeta, dgamma = sums[:CT], sums[CT:]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if gather == 0:     # stride 1: the same conv with channels swapped and taps mirrored; strided: the transposed conv
+                dx = ops.bf16_conv3d(dy, wb, cout, cin_map, 0 if shw == 1 else 1, (1, 1) if shw == 1 else (sd, shw), taps=taps)
+            else:               # transposed conv: strided conv of dY with W read as [out = cin, in = cout]
+                dx = ops.bf16_conv3d(dy, wb, cout, cin, 0, (sd, 2))
+            if dx.shape != x.shape:
+                raise ops._lib.MvsHipError("conv backward: input %s does not match the gradient grid %s" % (tuple(x.shape), tuple(dx.shape)))
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if gather == 0:
+                dw = ops.bf16_conv3d_wgrad(dy, x, (sd, shw), taps, cin)
+            else:
+                dw = ops.bf16_conv3d_wgrad(x, dy, (sd, 2))
+        return dx, dw, (dgamma if ctx.needs_input_grad[2] else None), (dbeta if ctx.needs_input_grad[3] else None), \
+            (dz if has_res else None), None, None, None, None, None, None
+
+
+class HeadBf16Fn(torch.autograd.Function):
+    """1x1(x1) convolution 8 -> 1 with bias [+ sigmoid] straight on bf16 channel-last activations: ``x [...,8]`` -> fp32 ``[...]``
+    (CostRegNet3D.prob, models/module.py:577; StageNet.vis[3:5], mvsformer_model.py:37).  One launch forward, two backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, sigmoid):
+        x = x.contiguous()
+        w = weight.detach().to(torch.float32).reshape(-1).contiguous()
+        b = bias.detach().to(torch.float32).reshape(-1).contiguous()
+        out = ops.bf16_head_fwd(x, w, b, sigmoid)
+        ctx.save_for_backward(x, w, out if sigmoid else None)
+        ctx.wshape = weight.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, y = ctx.saved_tensors
+        dx, dwb = ops.bf16_head_bwd(x, w, y, dout.contiguous())
+        return dx, dwb[:8].reshape(ctx.wshape), dwb[8:], None
+
+
+class Select0Bf16Fn(torch.autograd.Function):
+    """Channel 0 of a bf16 channel-last tensor as fp32 (``[...,8]`` -> ``[...]``): the one real output of CostRegNet's 8 -> 1 ``prob``
+    convolution, which runs zero-padded to 8 output channels; backward fills channel 0 and zeros the padding."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.bf16_head_fwd(x, None, None, False)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        return ops.bf16_head_bwd(x, None, None, dout.contiguous())[0]
+
+
+class StagePack:
+    """Every bf16 weight layout one StageNet's training step needs (forward + data gradient of the regularizer's nine layers, its
+    3x3x3 ``prob`` if it has one, the visibility CNN's three 2-D layers), packed by ONE launch per step instead of one per layer.
+    ``run()`` stamps each conv module with ``_mvs_packed = (weight version, forward layout, data-gradient layout)``;
+    :func:`packed_of` hands the pair to the layer if the weight has not changed since."""
+
+    def __init__(self, stage):
+        jobs, self.slots = [], []
+
+        def add(holder, weight, fwd, bwd):
+            w = weight.detach()
+            self.slots.append((holder, weight, len(jobs), len(jobs) + 1 if bwd else None))
+            jobs.append((w,) + fwd)
+            if bwd:
+                jobs.append((w,) + bwd)
+        reg = stage.cost_reg
+        for name in ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6"):
+            conv = getattr(reg, name).conv
+            cout, cin = conv.weight.shape[:2]
+            add(conv, conv.weight, (0, cin, cout), (2 if conv.stride[1] == 1 else 1, cout, cin))
+        for name in ("conv7", "conv9", "conv11"):
+            layer = getattr(reg, name)
+            conv = layer.conv if hasattr(layer, "conv") else layer[0]
+            cin, cout = conv.weight.shape[:2]
+            add(conv, conv.weight, (1, cin, cout), (0, cout, cin))
+        prob = getattr(reg, "prob", None)
+        if prob is not None and tuple(prob.weight.shape[2:]) == (3, 3, 3):           # CostRegNet: 8 -> 1 run as 8 -> 8
+            add(prob, prob.weight, (0, 8, 8), (2, 8, 8))
+        for i in range(3):
+            conv = stage.vis[i].conv
+            cout, cin = conv.weight.shape[:2]
+            cin_map = max(8, cin)
+            add(conv, conv.weight, (0, cin_map, cout), (2, cout, cin_map) if i else None)
+        for _, w, _, _ in self.slots:
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                raise ops._lib.MvsHipError("StagePack: fp32 contiguous master weights expected")
+        self.table = ops.PackTable(jobs)
+
+    def valid(self) -> bool:
+        return self.table.valid()
+
+    def run(self) -> None:
+        outs = self.table.run()
+        for holder, w, i, j in self.slots:
+            holder._mvs_packed = (w._version, outs[i], outs[j] if j is not None else None)
+
+
+def packed_of(conv):
+    p = getattr(conv, "_mvs_packed", None)
+    return (p[1], p[2]) if p is not None and p[0] == conv.weight._version else None

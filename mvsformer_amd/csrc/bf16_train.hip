@@ -40,14 +40,13 @@ __device__ __forceinline__ void xcd_item(int total, int& logical, bool& valid) {
 // t = (tap, channel octet cq) = (t / (KC/8), t % (KC/8)), channel c = cq*8 + e; zero beyond M rows / 27*KC/8 blocks.
 // src: 0 = w[m][c][tap], 1 = w[c][m][tap], 2 = w[c][m][26 - tap]   (w = [d0][d1][27] fp32)
 struct PackJob {
-    int d1, src, M, KC, NT, steps, nblocks;
+    int d0, d1, src, M, KC, NT, steps, nblocks, taps;   // taps: 27 (w = [d0][d1][27]) or 9 (a 2-D kernel [d0][d1][9] = the centre depth tap)
+    const float* w;
     __bf16* out;
 };
-// one launch packs up to two layouts of the same weight (the forward's and the data gradient's): blocks [0, a.nblocks) do job a
-__global__ void bf16_pack_kernel(const float* __restrict__ w, const PackJob a, const PackJob b) {
-    const bool first = (int)blockIdx.x < a.nblocks;
-    const PackJob& j = first ? a : b;
-    const int idx = ((int)blockIdx.x - (first ? 0 : a.nblocks)) * blockDim.x + threadIdx.x;
+// Rows / channels beyond the weight's own extents pack as zeros, so a narrower parameter is padded on the fly: the 1 -> 16 first layer
+// of the visibility CNN as 8 -> 16, CostRegNet's 8 -> 1 `prob` as 8 -> 8.
+__device__ __forceinline__ void pack_one(const PackJob& j, int idx) {
     if (idx >= j.steps * j.NT * 64) return;
     const int lane = idx & 63, nt = (idx >> 6) % j.NT, step = idx / (64 * j.NT);
     const int m = nt * 16 + (lane & 15), t = 4 * step + (lane >> 4), KQ = j.KC / 8;
@@ -57,11 +56,27 @@ __global__ void bf16_pack_kernel(const float* __restrict__ w, const PackJob a, c
     for (int e = 0; e < 8; ++e) {
         const int c = cq * 8 + e;
         float f = 0.0f;
-        if (m < j.M && t < 27 * KQ)
-            f = j.src == 0 ? w[((size_t)m * j.d1 + c) * 27 + tap] : w[((size_t)c * j.d1 + m) * 27 + (j.src == 2 ? 26 - tap : tap)];
+        if (m < j.M && t < j.taps * KQ) {
+            if (j.src == 0) {
+                if (m < j.d0 && c < j.d1) f = j.w[((size_t)m * j.d1 + c) * j.taps + tap];
+            } else if (c < j.d0 && m < j.d1) {
+                f = j.w[((size_t)c * j.d1 + m) * j.taps + (j.src == 2 ? j.taps - 1 - tap : tap)];
+            }
+        }
         v[e] = (__bf16)f;
     }
     reinterpret_cast<bf16x8*>(j.out)[idx] = v;
+}
+// one launch packs up to two layouts of the same weight (the forward's and the data gradient's): blocks [0, a.nblocks) do job a
+__global__ void bf16_pack_kernel(const PackJob a, const PackJob b) {
+    const bool first = (int)blockIdx.x < a.nblocks;
+    pack_one(first ? a : b, ((int)blockIdx.x - (first ? 0 : a.nblocks)) * blockDim.x + threadIdx.x);
+}
+// a whole table of jobs (every layer of a stage, both layouts) in ONE launch: job i owns blocks [start[i], start[i+1])
+__global__ void bf16_pack_table_kernel(const PackJob* __restrict__ jobs, const int* __restrict__ start, int njobs) {
+    int i = 0;
+    while (i + 1 < njobs && (int)blockIdx.x >= start[i + 1]) ++i;                // uniform scalar scan (a few dozen jobs)
+    pack_one(jobs[i], ((int)blockIdx.x - start[i]) * blockDim.x + threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------ convolution (forward and data gradients)
@@ -76,20 +91,30 @@ struct ConvArgs {
     int B, Di, Hi, Wi, Do, Ho, Wo, Cout;
     int nwchunks, items;
     float* stats_part;        // optional [items][2*Cout]: per work item, sum and sum of squares of the bf16-ROUNDED outputs per channel
-};                            // (the batch statistics of the BatchNorm that follows: no separate pass over y)
+                              // (the batch statistics of the BatchNorm that follows: no separate pass over y)
+    int stats_rows;           // > 0: BLOCK rows instead, transposed: stats_part[j * stats_rows + block] for j < 2*Cout (the four waves of
+};                            // a block combined through LDS in a fixed order; mvs_bf16_conv3d_bn_fwd)
 
 // GATHER = 0: Conv3d, input voxel = out*stride - 1 + k.  GATHER = 1: ConvTranspose3d (k=3, padding 1, output_padding stride-1) as a
 // gather: input voxel = (out + 1 - k) / stride where divisible.
-template <int CIN, int NT, int GATHER, int SD, int SHW>
+template <int CIN, int NT, int GATHER, int SD, int SHW, int TAPS = 27>     // TAPS = 9: a 2-D kernel (depth tap kd = 1 only)
 __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
-    constexpr int KQ = CIN / 8, NKB = 27 * KQ, STEPS = (NKB + 3) / 4, VT = 4;
+    constexpr int KQ = CIN / 8, NKB = TAPS * KQ, STEPS = (NKB + 3) / 4, VT = 4;
     int logical;
     bool ok;
     xcd_item((a.items + 3) / 4, logical, ok);
     if (!ok) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float sred[4][2 * 64];                      // block rows of the statistics (stats_rows > 0 only)
     const int item = logical * 4 + wave;
-    if (item >= a.items) return;                           // no block-wide barrier below
+    if (item >= a.items) {                                 // no block-wide barrier below, except for block rows of statistics
+        if (a.stats_rows > 0) {
+            if (lane < 2 * a.Cout) sred[wave][lane] = 0.0f;
+            if (lane + 64 < 2 * a.Cout) sred[wave][lane + 64] = 0.0f;
+            __syncthreads();
+        }
+        return;
+    }
     const int wchunk = item % a.nwchunks;
     const int oh = (item / a.nwchunks) % a.Ho;
     const int od = (item / (a.nwchunks * a.Ho)) % a.Do;
@@ -109,7 +134,7 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
     for (int step = 0; step < STEPS; ++step) {
         const int t = 4 * step + kb;
         const int tap = t / KQ, cq = t % KQ;
-        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        const int kd = TAPS == 9 ? 1 : tap / 9, kh = TAPS == 9 ? tap / 3 : (tap / 3) % 3, kw = tap % 3;
         bool rowok = t < NKB;
         int id, ih;
         if (GATHER == 0) {
@@ -187,7 +212,7 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
     }
     if (a.stats_part) {
         // the 16 lanes of a kb group hold the same 4 channels of different voxels: butterfly over j, lane j = 0 writes
-        float* row = a.stats_part + (size_t)item * 2 * a.Cout;
+        float* row = a.stats_rows > 0 ? &sred[wave][0] : a.stats_part + (size_t)item * 2 * a.Cout;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -204,6 +229,12 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
                     row[a.Cout + co] = s2;
                 }
             }
+        if (a.stats_rows > 0) {                            // the block's four wavefronts in a fixed order -> one column of the row table
+            __syncthreads();
+            if ((int)threadIdx.x < 2 * a.Cout)
+                a.stats_part[(size_t)threadIdx.x * a.stats_rows + logical] =
+                    (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+        }
     }
 }
 
@@ -229,7 +260,8 @@ struct WgradArgs {
     int nb, CA, CB, Dp, Hp, Wp, Db, Hb, Wb, sd, shw;
     int PH, npr, npc, npatch; // patch rows, patches per column / row of a plane, work items (columns of patches) in total
     int dseg, nseg;           // depths per work item, depth segments per column
-};
+    int tap0, ntaps;          // taps [tap0, tap0 + ntaps) of the 27: all of them, or (9, 9) = the centre depth tap (a 2-D kernel); the
+};                            // slabs are [CA][CB][ntaps]
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ s16x4 lds_tr16(const unsigned short* p) {
@@ -367,8 +399,8 @@ __global__ __launch_bounds__(256, 2) void bf16_wgrad_kernel(const WgradArgs a) {
                     fa[t] = frag_tr(sA + (arow[0] * WG_PW + acol[0]) * a_row + t * 16 + csub, sA + (arow[1] * WG_PW + acol[1]) * a_row + t * 16 + csub);
 #pragma unroll
                 for (int q = 0; q < NTAP; ++q) {
-                    const int tap = wave + 4 * q;
-                    if (tap >= 27) break;                   // wave-uniform
+                    if (wave + 4 * q >= a.ntaps) break;     // wave-uniform
+                    const int tap = a.tap0 + wave + 4 * q;
                     const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
                     const unsigned short* pl = sB + ((dbase + kd + 4) & 3) * plane_elems;
                     const unsigned short* b0 = pl + (((arow[0] * s + kh) * BW + acol[0] * s + kw) * b_row) + csub;
@@ -385,25 +417,28 @@ __global__ __launch_bounds__(256, 2) void bf16_wgrad_kernel(const WgradArgs a) {
         }
     }
     // D[i = a (4*kb + r)][j = b] -> this block's slab
-    float* slab = a.part + (size_t)blockIdx.x * a.CA * a.CB * 27;
+    float* slab = a.part + (size_t)blockIdx.x * a.CA * a.CB * a.ntaps;
 #pragma unroll
     for (int q = 0; q < NTAP; ++q) {
-        const int tap = wave + 4 * q;
-        if (tap >= 27) break;
+        const int tap = wave + 4 * q;                       // slab index: relative to tap0
+        if (tap >= a.ntaps) break;
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             const int ta = t / TB, tb = t % TB;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ca = ca0 + ta * 16 + kb * 4 + r, cb = tb * 16 + t16;
-                if (ca < a.CA && cb < a.CB) slab[((size_t)ca * a.CB + cb) * 27 + tap] = acc[q][t][r];
+                if (ca < a.CA && cb < a.CB) slab[((size_t)ca * a.CB + cb) * a.ntaps + tap] = acc[q][t][r];
             }
         }
     }
 }
 
 // dW[i] = sum over slabs, in a fixed order: 64 outputs per block (coalesced), the four waves take every fourth slab each
-__global__ __launch_bounds__(256) void bf16_wgrad_reduce_kernel(const float* __restrict__ part, int chunks, int n, float* __restrict__ dW) {
+// row_in / row_out: elements per A channel in the slabs (CB*taps) and in dW (CBout*taps, CBout <= CB: a padded operand's extra
+// channels are dropped here instead of by a strided view of the result)
+__global__ __launch_bounds__(256) void bf16_wgrad_reduce_kernel(const float* __restrict__ part, int chunks, int n, float* __restrict__ dW,
+                                                                int row_in, int row_out) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
@@ -420,7 +455,8 @@ __global__ __launch_bounds__(256) void bf16_wgrad_reduce_kernel(const float* __r
     }
     red[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (wave == 0 && i < n) dW[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (wave == 0 && i < n && (i % row_in) < row_out)
+        dW[(size_t)(i / row_in) * row_out + (i % row_in)] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // ------------------------------------------------------------------------------------------------ layout / precision converters
@@ -608,13 +644,20 @@ extern "C" int64_t mvs_bf16_packed_elems(int Cin, int Cout) {
     const int steps = (27 * Cin / 8 + 3) / 4;
     return (int64_t)steps * nt_of(Cout) * 64 * 8;
 }
+extern "C" int64_t mvs_bf16_packed_elems_taps(int Cin, int Cout, int taps) {
+    if (!chan_ok(Cin) || !chan_ok(Cout) || (taps != 27 && taps != 9)) return -1;
+    const int steps = (taps * Cin / 8 + 3) / 4;
+    return (int64_t)steps * nt_of(Cout) * 64 * 8;
+}
 
 namespace {
-bool pack_job(int d0, int d1, int src, int Cout, int Cin, void* out, PackJob* j) {
-    if (!chan_ok(Cin) || !chan_ok(Cout) || src < 0 || src > 2 || !out) return false;
-    if (!((src == 0 && d0 == Cout && d1 == Cin) || (src != 0 && d0 == Cin && d1 == Cout))) return false;
-    j->d1 = d1, j->src = src, j->M = Cout, j->KC = Cin, j->NT = nt_of(Cout), j->steps = (27 * Cin / 8 + 3) / 4;
+// w = [d0][d1][taps]; the packed map is Cin -> Cout with Cin/Cout >= the weight's own extents (missing rows / channels pack as zeros)
+bool pack_job(const float* w, int d0, int d1, int src, int Cout, int Cin, int taps, void* out, PackJob* j) {
+    if (!w || !chan_ok(Cin) || !chan_ok(Cout) || src < 0 || src > 2 || !out || (taps != 27 && taps != 9) || d0 < 1 || d1 < 1) return false;
+    if (!((src == 0 && d0 <= Cout && d1 <= Cin) || (src != 0 && d0 <= Cin && d1 <= Cout))) return false;
+    j->d0 = d0, j->d1 = d1, j->src = src, j->M = Cout, j->KC = Cin, j->NT = nt_of(Cout), j->steps = (taps * Cin / 8 + 3) / 4, j->taps = taps;
     j->nblocks = (j->steps * j->NT * 64 + 255) / 256;
+    j->w = w;
     j->out = reinterpret_cast<__bf16*>(out);
     return true;
 }
@@ -622,9 +665,9 @@ bool pack_job(int d0, int d1, int src, int Cout, int Cin, void* out, PackJob* j)
 
 extern "C" int mvs_bf16_pack_weights(const float* w, int d0, int d1, int src, int Cout, int Cin, void* wpacked, mvs_stream_t stream) {
     PackJob a{}, none{};
-    MVS_REQUIRE(w && pack_job(d0, d1, src, Cout, Cin, wpacked, &a), "mvs_bf16_pack_weights: weight [%d][%d][27] / src %d / Cin=%d Cout=%d", d0,
+    MVS_REQUIRE(pack_job(w, d0, d1, src, Cout, Cin, 27, wpacked, &a), "mvs_bf16_pack_weights: weight [%d][%d][27] / src %d / Cin=%d Cout=%d", d0,
                 d1, src, Cin, Cout);
-    hipLaunchKernelGGL(bf16_pack_kernel, dim3(a.nblocks), dim3(256), 0, MVS_STREAM(stream), w, a, none);
+    hipLaunchKernelGGL(bf16_pack_kernel, dim3(a.nblocks), dim3(256), 0, MVS_STREAM(stream), a, none);
     return mvs::finish_launch("mvs_bf16_pack_weights");
 }
 
@@ -632,22 +675,56 @@ extern "C" int mvs_bf16_pack_weights(const float* w, int d0, int d1, int src, in
 extern "C" int mvs_bf16_pack_weights2(const float* w, int d0, int d1, int srcA, int CoutA, int CinA, void* packedA, int srcB, int CoutB,
                                       int CinB, void* packedB, mvs_stream_t stream) {
     PackJob a{}, b{};
-    MVS_REQUIRE(w && pack_job(d0, d1, srcA, CoutA, CinA, packedA, &a) && pack_job(d0, d1, srcB, CoutB, CinB, packedB, &b),
+    MVS_REQUIRE(pack_job(w, d0, d1, srcA, CoutA, CinA, 27, packedA, &a) && pack_job(w, d0, d1, srcB, CoutB, CinB, 27, packedB, &b),
                 "mvs_bf16_pack_weights2: weight [%d][%d][27] does not match (src %d: %d->%d) / (src %d: %d->%d)", d0, d1, srcA, CinA, CoutA,
                 srcB, CinB, CoutB);
-    hipLaunchKernelGGL(bf16_pack_kernel, dim3(a.nblocks + b.nblocks), dim3(256), 0, MVS_STREAM(stream), w, a, b);
+    hipLaunchKernelGGL(bf16_pack_kernel, dim3(a.nblocks + b.nblocks), dim3(256), 0, MVS_STREAM(stream), a, b);
     return mvs::finish_launch("mvs_bf16_pack_weights2");
+}
+
+// ---- job table: every weight layout a training step of one stage needs, packed by ONE launch -------------------------------------
+// The caller fills a HOST table entry by entry (mvs_bf16_pack_table_fill), copies its mvs_bf16_pack_table_bytes(njobs) bytes to the
+// device once (the pointers stay valid while the parameters and the packed buffers live), and runs it every step.  Host layout:
+// [njobs PackJob][njobs + 1 int block starts]; fill entries in order 0..njobs-1.
+extern "C" int64_t mvs_bf16_pack_table_bytes(int njobs) {
+    return njobs < 1 ? -1 : (int64_t)njobs * (int64_t)sizeof(PackJob) + (int64_t)(njobs + 1) * (int64_t)sizeof(int);
+}
+extern "C" int mvs_bf16_pack_table_fill(void* host_table, int njobs, int index, const float* w, int d0, int d1, int src, int Cout, int Cin,
+                                        int taps, void* wpacked) {
+    MVS_REQUIRE(host_table && njobs >= 1 && index >= 0 && index < njobs, "mvs_bf16_pack_table_fill: bad table / index");
+    PackJob* jobs = reinterpret_cast<PackJob*>(host_table);
+    int* start = reinterpret_cast<int*>(jobs + njobs);
+    MVS_REQUIRE(pack_job(w, d0, d1, src, Cout, Cin, taps, wpacked, &jobs[index]),
+                "mvs_bf16_pack_table_fill: weight [%d][%d][%d] / src %d does not fit a %d -> %d map", d0, d1, taps, src, Cin, Cout);
+    if (index == 0) start[0] = 0;
+    start[index + 1] = start[index] + jobs[index].nblocks;
+    return MVS_OK;
+}
+extern "C" int mvs_bf16_pack_table_run(const void* dev_table, int njobs, int total_blocks, mvs_stream_t stream) {
+    MVS_REQUIRE(dev_table && njobs >= 1 && total_blocks >= 1, "mvs_bf16_pack_table_run: bad arguments");
+    const PackJob* jobs = reinterpret_cast<const PackJob*>(dev_table);
+    const int* start = reinterpret_cast<const int*>(jobs + njobs);
+    hipLaunchKernelGGL(bf16_pack_table_kernel, dim3(total_blocks), dim3(256), 0, MVS_STREAM(stream), jobs, start, njobs);
+    return mvs::finish_launch("mvs_bf16_pack_table_run");
 }
 
 // gather: 0 = Conv3d (out = (in - 1)/stride + 1), 1 = ConvTranspose3d k3 p1 op(stride-1) (out = in*stride)
 static int bf16_conv3d_impl(const void* x, const void* wpacked, const float* scale, const float* shift, const void* residual, void* y,
                             int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd, int shw, int relu, float* stats_part,
-                            int groups, float* sums, mvs_stream_t stream);
+                            int groups, float* sums, mvs_stream_t stream, bool block_rows = false, int taps = 27);
 
 extern "C" int mvs_bf16_conv3d(const void* x, const void* wpacked, const float* scale, const float* shift, const void* residual, void* y,
                                int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd, int shw, int relu,
                                mvs_stream_t stream) {
     return bf16_conv3d_impl(x, wpacked, scale, shift, residual, y, B, Cin, Cout, Di, Hi, Wi, gather, sd, shw, relu, nullptr, 1, nullptr, stream);
+}
+
+// mvs_bf16_conv3d without an epilogue and with a tap count: taps = 9 runs a 2-D kernel (the centre depth tap of a [*,*,1,3,3] weight) on a
+// D-agnostic volume - the visibility CNN's layers and their data gradients; weights packed with the same tap count
+extern "C" int mvs_bf16_conv3d_taps(const void* x, const void* wpacked, void* y, int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather,
+                                    int sd, int shw, int taps, mvs_stream_t stream) {
+    return bf16_conv3d_impl(x, wpacked, nullptr, nullptr, nullptr, y, B, Cin, Cout, Di, Hi, Wi, gather, sd, shw, 0, nullptr, 1, nullptr, stream,
+                            false, taps);
 }
 
 // Raw convolution + the batch statistics of its (bf16-rounded) output in the same pass: sums [2*groups*Cout] = [sum | sum of squares]
@@ -667,8 +744,10 @@ extern "C" int mvs_bf16_conv3d_stats(const void* x, const void* wpacked, void* y
 
 static int bf16_conv3d_impl(const void* x, const void* wpacked, const float* scale, const float* shift, const void* residual, void* y,
                             int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd, int shw, int relu, float* stats_part,
-                            int groups, float* sums, mvs_stream_t stream) {
+                            int groups, float* sums, mvs_stream_t stream, bool block_rows, int taps) {
     MVS_REQUIRE(x && wpacked && y, "mvs_bf16_conv3d: null pointer");
+    MVS_REQUIRE(taps == 27 || (taps == 9 && gather == 0 && sd == 1 && shw == 1 && Cin <= 16 && Cout <= 16),
+                "mvs_bf16_conv3d: taps = 9 (2-D kernel) is built for stride-1 convolutions of up to 16 channels");
     MVS_REQUIRE(chan_ok(Cin) && chan_ok(Cout), "mvs_bf16_conv3d: channels must be 8/16/32/64 (Cin=%d Cout=%d)", Cin, Cout);
     MVS_REQUIRE(B >= 1 && Di >= 1 && Hi >= 1 && Wi >= 1 && (gather == 0 || gather == 1), "mvs_bf16_conv3d: bad shape");
     MVS_REQUIRE((sd == 1 || sd == 2) && (shw == 1 || shw == 2) && !(sd == 2 && shw == 1), "mvs_bf16_conv3d: stride (%d,%d,%d) is not built", sd, shw, shw);
@@ -685,10 +764,16 @@ static int bf16_conv3d_impl(const void* x, const void* wpacked, const float* sca
     MVS_REQUIRE(items < ((int64_t)1 << 30), "mvs_bf16_conv3d: too many rows");
     a.items = (int)items;
     a.stats_part = stats_part;
+    a.stats_rows = block_rows ? (int)((items + 3) / 4) : 0;
     hipStream_t s = MVS_STREAM(stream);
     const int nt = nt_of(Cout);
     int rc;
-    if (gather == 0) {
+    if (taps == 9) {
+        const unsigned grid = (unsigned)((((a.items + 3) / 4 + 7) / 8) * 8);
+        if (Cin == 8) hipLaunchKernelGGL((bf16_conv_kernel<8, 1, 0, 1, 1, 9>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((bf16_conv_kernel<16, 1, 0, 1, 1, 9>), dim3(grid), dim3(256), 0, s, a);
+        rc = mvs::finish_launch("mvs_bf16_conv3d");
+    } else if (gather == 0) {
         if (sd == 1 && shw == 1) rc = launch_conv<0, 1, 1>(a, Cin, nt, s);
         else if (sd == 2) rc = launch_conv<0, 2, 2>(a, Cin, nt, s);
         else rc = launch_conv<0, 1, 2>(a, Cin, nt, s);
@@ -697,7 +782,7 @@ static int bf16_conv3d_impl(const void* x, const void* wpacked, const float* sca
         else if (sd == 2) rc = launch_conv<1, 2, 2>(a, Cin, nt, s);
         else rc = launch_conv<1, 1, 2>(a, Cin, nt, s);
     }
-    if (rc != MVS_OK || !stats_part) return rc;
+    if (rc != MVS_OK || !stats_part || block_rows) return rc;
     // work items are sample-major, so the rows of sample b are [b*bps, (b+1)*bps): the grouped fixed-order reduce applies as is
     mvs::launch_partials_reduce_grouped(stats_part, a.Do * a.Ho * a.nwchunks, B, groups, Cout, sums, s);
     return mvs::finish_launch("mvs_bf16_conv3d_stats");
@@ -746,11 +831,13 @@ extern "C" int64_t mvs_bf16_conv3d_wgrad_workspace_bytes(int nbatch, int CA, int
     return (int64_t)wgrad_plan(nbatch, CA, CB, Dp, Hp, Wp, 1).blocks * CA * CB * 27 * (int64_t)sizeof(float);
 }
 
-extern "C" int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, void* workspace, int nbatch, int CA, int CB, int Dp, int Hp,
-                                     int Wp, int Db, int Hb, int Wb, int sd, int shw, mvs_stream_t stream) {
+// taps = 27: dW [CA][CBout][27]; taps = 9: the centre depth tap only, dW [CA][CBout][9] (a 2-D kernel's gradient).  CBout <= CB drops the
+// padding channels of Bt (the visibility CNN's 1-channel input lives in an 8-channel tensor).
+extern "C" int mvs_bf16_conv3d_wgrad_taps(const void* A, const void* Bt, float* dW, void* workspace, int nbatch, int CA, int CB, int CBout,
+                                          int Dp, int Hp, int Wp, int Db, int Hb, int Wb, int sd, int shw, int taps, mvs_stream_t stream) {
     MVS_REQUIRE(A && Bt && dW && workspace, "mvs_bf16_conv3d_wgrad: null pointer");
-    MVS_REQUIRE(chan_ok(CA) && chan_ok(CB) && nbatch >= 1, "mvs_bf16_conv3d_wgrad: channels must be 8/16/32/64 (CA=%d CB=%d)", CA, CB);
-    MVS_REQUIRE((sd == 1 || sd == 2) && (shw == 1 || shw == 2), "mvs_bf16_conv3d_wgrad: bad stride");
+    MVS_REQUIRE(chan_ok(CA) && chan_ok(CB) && nbatch >= 1 && CBout >= 1 && CBout <= CB, "mvs_bf16_conv3d_wgrad: channels must be 8/16/32/64 (CA=%d CB=%d)", CA, CB);
+    MVS_REQUIRE((sd == 1 || sd == 2) && (shw == 1 || shw == 2) && (taps == 27 || taps == 9), "mvs_bf16_conv3d_wgrad: bad stride / taps");
     MVS_REQUIRE((int64_t)Dp * Hp * Wp * CA * 2 < ((int64_t)1 << 31) && (int64_t)Db * Hb * Wb * CB * 2 < ((int64_t)1 << 31),
                 "mvs_bf16_conv3d_wgrad: one sample exceeds the 2 GiB buffer range");
     const WgradPlan p = wgrad_plan(nbatch, CA, CB, Dp, Hp, Wp, shw);
@@ -762,6 +849,7 @@ extern "C" int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, v
     a.A = reinterpret_cast<const __bf16*>(A), a.Bt = reinterpret_cast<const __bf16*>(Bt), a.part = reinterpret_cast<float*>(workspace);
     a.nb = nbatch, a.CA = CA, a.CB = CB, a.Dp = Dp, a.Hp = Hp, a.Wp = Wp, a.Db = Db, a.Hb = Hb, a.Wb = Wb, a.sd = sd, a.shw = shw;
     a.PH = p.PH, a.npr = p.npr, a.npc = p.npc, a.npatch = p.npatch, a.dseg = p.dseg, a.nseg = p.nseg;
+    a.tap0 = taps == 9 ? 9 : 0, a.ntaps = taps;
     hipStream_t s = MVS_STREAM(stream);
     const dim3 grid(p.blocks, p.gy);
     if (p.TA == 1 && p.TB == 1) hipLaunchKernelGGL((bf16_wgrad_kernel<1, 1>), grid, dim3(256), p.lds, s, a);
@@ -772,9 +860,14 @@ extern "C" int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, v
     else if (p.TA == 4 && p.TB == 1) hipLaunchKernelGGL((bf16_wgrad_kernel<4, 1>), grid, dim3(256), p.lds, s, a);
     else MVS_REQUIRE(false, "mvs_bf16_conv3d_wgrad: no kernel for %d x %d channel tiles", p.TA, p.TB);
     if (int rc = mvs::finish_launch("mvs_bf16_conv3d_wgrad")) return rc;
-    const int n = CA * CB * 27;
-    hipLaunchKernelGGL(bf16_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, a.part, p.blocks, n, dW);
+    const int n = CA * CB * taps;
+    hipLaunchKernelGGL(bf16_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, a.part, p.blocks, n, dW, CB * taps, CBout * taps);
     return mvs::finish_launch("mvs_bf16_conv3d_wgrad");
+}
+
+extern "C" int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, void* workspace, int nbatch, int CA, int CB, int Dp, int Hp,
+                                     int Wp, int Db, int Hb, int Wb, int sd, int shw, mvs_stream_t stream) {
+    return mvs_bf16_conv3d_wgrad_taps(A, Bt, dW, workspace, nbatch, CA, CB, CB, Dp, Hp, Wp, Db, Hb, Wb, sd, shw, 27, stream);
 }
 
 extern "C" int mvs_bf16_from_f32_ncdhw(const float* in, void* out, int B, int C, int64_t N, mvs_stream_t stream) {
@@ -950,4 +1043,110 @@ extern "C" int mvs_bf16_bn_bwd_apply(const void* dy, const void* x, const float*
                        reinterpret_cast<const __bf16*>(dy), reinterpret_cast<const __bf16*>(x), scale, shift, mean, invstd, gamma, sums, count,
                        count_dev, relu, C, total8, (size_t)sh.RS, groups, reinterpret_cast<__bf16*>(dx));
     return mvs::finish_launch("mvs_bf16_bn_bwd_apply");
+}
+
+
+// =====================================================================================================================================
+// Round 5: fewer, fatter launches for the training step (the step is a serial chain of ~1100 graph nodes; per-node cost, not bytes, is
+// what a 640x512 sample pays).
+//   mvs_bf16_conv3d_bn_fwd   raw conv (+ the batch statistics of its output as BLOCK rows in the epilogue) -> finalize (one block per
+//                            channel: the rows in a fixed order, mean / invstd / scale / shift, running statistics) -> normalize + ReLU
+//                            + skip: 3 launches for what conv + mvs_bf16_bn_train_fwd did in 4, and no separate pass over y.
+// =====================================================================================================================================
+namespace {
+// part = [2C][nrows] (transposed rows: column r = block r of the convolution); rows of sample b = [b*rps, (b+1)*rps); sample b belongs to
+// group b % groups.  One block per base channel; the groups in order (running statistics take their updates in order).
+__global__ __launch_bounds__(256) void bf16_bn_rows_finalize_kernel(const float* __restrict__ part, int nrows, int rps, int nsamples, int groups,
+                                                                    int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                    float momentum, float eps, double count, float* __restrict__ out4,
+                                                                    long long* __restrict__ num_batches_tracked) {
+    __shared__ float red[2][4];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (num_batches_tracked && c == 0 && tid == 0) num_batches_tracked[0] += groups;
+    const int CT = C * groups, per = (nsamples / groups) * rps;
+    const float g = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
+    float rm = running_mean ? running_mean[c] : 0.0f, rv = running_var ? running_var[c] : 0.0f;
+    const float* p1 = part + (size_t)c * nrows;
+    const float* p2 = part + (size_t)(C + c) * nrows;
+    for (int q = 0; q < groups; ++q) {
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int i = tid; i < per; i += 256) {
+            const int row = (q + (i / rps) * groups) * rps + (i % rps);
+            s1 += p1[row];
+            s2 += p2[row];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            s1 += __shfl_xor(s1, m, 64);
+            s2 += __shfl_xor(s2, m, 64);
+        }
+        __syncthreads();                                    // the previous group's red[] is consumed
+        if (lane == 0) {
+            red[0][wave] = s1;
+            red[1][wave] = s2;
+        }
+        __syncthreads();
+        s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const int cc = q * C + c;
+        const double mean = (double)s1 / count;
+        double var = (double)s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (tid == 0) {
+            out4[cc] = g * invstd;
+            out4[CT + cc] = bt - (float)mean * g * invstd;
+            out4[2 * CT + cc] = (float)mean;
+            out4[3 * CT + cc] = invstd;
+        }
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        rm = (1.0f - momentum) * rm + momentum * (float)mean;
+        rv = (1.0f - momentum) * rv + momentum * (float)unbiased;
+    }
+    if (running_mean && tid == 0) {
+        running_mean[c] = rm;
+        running_var[c] = rv;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t mvs_bf16_conv3d_bn_fwd_workspace_bytes(int B, int Cout, int Do, int Ho, int Wo) {
+    if (!chan_ok(Cout) || B < 1 || Do < 1 || Ho < 1 || Wo < 1) return -1;
+    const int64_t items = (int64_t)B * Do * Ho * ((Wo + 63) / 64);
+    return ((items + 3) / 4) * 2 * Cout * (int64_t)sizeof(float);
+}
+
+// y = raw conv(x) (kept: the BatchNorm backward needs it), z = [relu](BatchNorm_train(y)) [+ residual]; stats4 = [scale | shift | mean |
+// invstd], each groups*Cout.  groups > 1: sample b belongs to group b % groups, and the work items of one sample (Do*Ho*ceil(Wo/64))
+// must be a multiple of 4 so that a block never straddles two samples.
+extern "C" int mvs_bf16_conv3d_bn_fwd(const void* x, const void* wpacked, void* y, void* z, const void* residual, int relu, int B, int Cin,
+                                      int Cout, int Di, int Hi, int Wi, int gather, int sd, int shw, int taps, int groups, const float* gamma,
+                                      const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                      int64_t* num_batches_tracked, float* stats4, void* workspace, mvs_stream_t stream) {
+    MVS_REQUIRE(z && stats4 && workspace && groups >= 1 && B % groups == 0, "mvs_bf16_conv3d_bn_fwd: bad arguments (B=%d groups=%d)", B, groups);
+    MVS_REQUIRE((!running_mean) == (!running_var), "mvs_bf16_conv3d_bn_fwd: running_mean and running_var come together");
+    MVS_REQUIRE((sd == 1 || sd == 2) && (shw == 1 || shw == 2) && (gather == 0 || gather == 1), "mvs_bf16_conv3d_bn_fwd: bad stride / gather");
+    int Do, Ho, Wo;
+    if (gather == 0) Do = (Di - 1) / sd + 1, Ho = (Hi - 1) / shw + 1, Wo = (Wi - 1) / shw + 1;
+    else Do = Di * sd, Ho = Hi * shw, Wo = Wi * shw;
+    const int64_t ips = (int64_t)Do * Ho * ((Wo + 63) / 64);                // work items per sample
+    MVS_REQUIRE(B == 1 || ips % 4 == 0, "mvs_bf16_conv3d_bn_fwd: %lld work items per sample are not a multiple of 4 (block rows would straddle samples)",
+                (long long)ips);
+    if (int rc = bf16_conv3d_impl(x, wpacked, nullptr, nullptr, nullptr, y, B, Cin, Cout, Di, Hi, Wi, gather, sd, shw, 0,
+                                  reinterpret_cast<float*>(workspace), groups, nullptr, stream, true, taps))
+        return rc;
+    hipStream_t s = MVS_STREAM(stream);
+    const int nrows = (int)((ips * B + 3) / 4), rps = B == 1 ? nrows : (int)(ips / 4);
+    const int64_t R = (int64_t)B * Do * Ho * Wo;
+    hipLaunchKernelGGL(bf16_bn_rows_finalize_kernel, dim3(Cout), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), nrows, rps, B, groups,
+                       Cout, gamma, beta, running_mean, running_var, momentum, eps, (double)(R / groups), stats4,
+                       reinterpret_cast<long long*>(num_batches_tracked));
+    const size_t total8 = (size_t)R * (Cout / 8);
+    const int CT = Cout * groups;
+    hipLaunchKernelGGL(bf16_affine_act_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const __bf16*>(y),
+                       stats4, stats4 + CT, reinterpret_cast<const __bf16*>(residual), relu, Cout, total8, (size_t)(R / B), groups,
+                       reinterpret_cast<__bf16*>(z));
+    return mvs::finish_launch("mvs_bf16_conv3d_bn_fwd");
 }

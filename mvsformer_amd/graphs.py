@@ -22,7 +22,8 @@ class CapturedStep:
     """``step_fn()`` (no arguments, returns a tensor or a tuple of tensors) captured into a hipGraph after ``warmup`` eager runs on a
     side stream (lazy initialisation - weight-pack caches, hipFuncSetAttribute, allocator growth - must not happen during capture)."""
 
-    def __init__(self, step_fn: Callable[[], object], warmup: int = 3):
+    def __init__(self, step_fn: Callable[[], object], warmup: int = 3, keep_graph: bool = False):
+        """``keep_graph``: keep the captured hipGraph_t beside the executable one, so :meth:`node_counts` can walk it."""
         if not torch.cuda.is_available():
             raise RuntimeError("CapturedStep needs a GPU")
         side = torch.cuda.Stream()
@@ -32,9 +33,34 @@ class CapturedStep:
                 step_fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True) if keep_graph else torch.cuda.CUDAGraph()
+        self._kept = keep_graph
         with torch.cuda.graph(self.graph):
             self.outputs = step_fn()
+
+    def node_counts(self):
+        """``{"kernel": n, "memcpy": n, "memset": n, "other": n}`` of the captured graph (hipGraphGetNodes / hipGraphNodeGetType through
+        ctypes): the launches one replay stands for.  Needs ``keep_graph=True``; None if the runtime does not hand the graph out."""
+        if not self._kept:
+            return None
+        import ctypes
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            g = ctypes.c_void_p(self.graph.raw_cuda_graph())
+            n = ctypes.c_size_t(0)
+            if hip.hipGraphGetNodes(g, None, ctypes.byref(n)) != 0:
+                return None
+            nodes = (ctypes.c_void_p * n.value)()
+            if hip.hipGraphGetNodes(g, nodes, ctypes.byref(n)) != 0:
+                return None
+            out = {"kernel": 0, "memcpy": 0, "memset": 0, "other": 0}
+            for node in nodes:
+                t = ctypes.c_int(-1)
+                hip.hipGraphNodeGetType(ctypes.c_void_p(node), ctypes.byref(t))
+                out[{0: "kernel", 1: "memcpy", 2: "memset"}.get(t.value, "other")] += 1      # hipGraphNodeType enum
+            return out
+        except Exception:                                    # noqa: BLE001 - diagnostics only
+            return None
 
     def __call__(self):
         """Replay; returns the (static) output tensors of the captured step - clone them if they must outlive the next replay."""

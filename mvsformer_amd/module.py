@@ -75,11 +75,19 @@ def _train_conv_bn_act(x, conv, bn, relu, residual, transposed_sd=None):
         # MVS_BN_FUSED_STATS=1: the convolution's epilogue takes the batch statistics of its output instead of a separate pass over y.
         # Measured 13.5 vs 13.3 ms per step (one partial row per wavefront makes the fixed-order reduce long): off by default.
         fused = 1 if os.environ.get("MVS_BN_FUSED_STATS", "0") == "1" else 0
+        pk = ag.packed_of(conv)                              # this step's layouts if the stage's StagePack made them (one launch per stage)
+        if ag._fused_layers() and not ag._bn_synced(bn):
+            # statistics stay on this rank: the whole layer is one autograd node (conv with the statistics in its epilogue -> finalize ->
+            # normalize): 8 graph nodes per layer and step instead of 11
+            if transposed_sd is None:
+                s = tuple(conv.stride)
+                return ag.LayerBf16Fn.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, bool(relu), 0, (s[0], s[1]), 1, pk)
+            return ag.LayerBf16Fn.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, bool(relu), 1, (transposed_sd, 2), 1, pk)
         if transposed_sd is None:
             s = tuple(conv.stride)
-            out = ag.ConvBf16Fn.apply(x, conv.weight, (s[0], s[1]), fused)
+            out = ag.ConvBf16Fn.apply(x, conv.weight, (s[0], s[1]), fused, pk)
         else:
-            out = ag.DeconvBf16Fn.apply(x, conv.weight, transposed_sd, fused)
+            out = ag.DeconvBf16Fn.apply(x, conv.weight, transposed_sd, fused, pk)
         y, sums = out if fused else (out, None)
         return ag.BnActBf16Fn.apply(y, bn.weight, bn.bias, residual, bn, bool(relu), 1, sums)
     if transposed_sd is None:
@@ -315,11 +323,17 @@ class CostRegNet(nn.Module):
             if self.training:
                 from . import autograd as ag
                 # N = 1 conv embedded in an 8-channel MFMA conv (zero rows) so forward, dgrad and wgrad reuse the conv kernels
-                w8 = torch.nn.functional.pad(self.prob.weight, (0, 0, 0, 0, 0, 0, 0, 0, 0, 7))
-                if y.dtype == torch.bfloat16:            # autocast: the logits come out of a half-precision conv, then fp32
-                    y = ag.FromBf16Fn.apply(ag.ConvBf16Fn.apply(y, w8, (1, 1)))[:, :1]
+                pk = ag.packed_of(self.prob) if y.dtype == torch.bfloat16 else None
+                if pk is not None and ag._fused_layers():
+                    # the 8 -> 1 parameter packed as an 8 -> 8 map by the stage's StagePack (no padded copy of the weight), channel 0 of
+                    # the result straight to fp32
+                    y = ag.Select0Bf16Fn.apply(ag.ConvBf16Fn.apply(y, self.prob.weight, (1, 1), 0, pk, 8)).unsqueeze(1)
                 else:
-                    y = ag.ConvFn.apply(y, w8, (1, 1))[:, :1]
+                    w8 = torch.nn.functional.pad(self.prob.weight, (0, 0, 0, 0, 0, 0, 0, 0, 0, 7))
+                    if y.dtype == torch.bfloat16:        # autocast: the logits come out of a half-precision conv, then fp32
+                        y = ag.FromBf16Fn.apply(ag.ConvBf16Fn.apply(y, w8, (1, 1)))[:, :1]
+                    else:
+                        y = ag.ConvFn.apply(y, w8, (1, 1))[:, :1]
             else:
                 y = ops.prob3(y, _f32c(self.prob.weight)).unsqueeze(1)
         return y
@@ -445,6 +459,8 @@ class CostRegNet3D(nn.Module):
         if self.training:
             from . import autograd as ag
             if y.dtype == torch.bfloat16:                # the 1x1x1 head and everything after it are fp32 again
+                if ag._fused_layers():
+                    return ag.HeadBf16Fn.apply(y, self.prob.weight, self.prob.bias, False).unsqueeze(1)
                 y = ag.FromBf16Fn.apply(y)
             return ag.Prob1Fn.apply(y, self.prob.weight, self.prob.bias)
         w, b = self.prob_params()

@@ -1028,15 +1028,28 @@ def bf16_to_f32(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def _taps_of(weight: torch.Tensor) -> int:
+    """27 for a ``[*,*,3,3,3]`` parameter, 9 for a 2-D ``[*,*,3,3]`` one (runs as the centre depth tap of a D = 1 volume)."""
+    if weight.dim() == 5 and tuple(weight.shape[2:]) == (3, 3, 3):
+        return 27
+    if weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3):
+        return 9
+    raise _lib.MvsHipError("conv weight must be [*,*,3,3,3] or [*,*,3,3], got %s" % (tuple(weight.shape),))
+
+
+def bf16_packed_elems(cin: int, cout: int, taps: int = 27) -> int:
+    n = _lib.load().mvs_bf16_packed_elems_taps(cin, cout, taps)
+    if n <= 0:
+        raise _lib.MvsHipError("bf16 conv: channels must be 8/16/32/64 (Cin=%d Cout=%d, taps %d)" % (cin, cout, taps))
+    return int(n)
+
+
 def bf16_pack(weight: torch.Tensor, src: int, cin: int, cout: int) -> torch.Tensor:
     """fp32 ``[d0,d1,3,3,3]`` parameter -> bf16 MFMA fragments of a ``cin -> cout`` map (``src``: see include/mvs_hip.h)."""
     _chk(weight, "conv weight")
-    if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3):
-        raise _lib.MvsHipError("conv weight must be [*,*,3,3,3], got %s" % (tuple(weight.shape),))
-    n = _lib.load().mvs_bf16_packed_elems(cin, cout)
-    if n <= 0:
-        raise _lib.MvsHipError("bf16 conv: channels must be 8/16/32/64 (Cin=%d Cout=%d)" % (cin, cout))
-    packed = torch.empty(n, device=weight.device, dtype=torch.bfloat16)
+    if _taps_of(weight) != 27:
+        raise _lib.MvsHipError("bf16_pack: 3x3x3 weights only (2-D kernels are packed through a PackTable)")
+    packed = torch.empty(bf16_packed_elems(cin, cout), device=weight.device, dtype=torch.bfloat16)
     _call("mvs_bf16_pack_weights", None, _ptr(weight), weight.shape[0], weight.shape[1], int(src), cout, cin, _ptr(packed), _stream())
     return packed
 
@@ -1044,19 +1057,58 @@ def bf16_pack(weight: torch.Tensor, src: int, cin: int, cout: int) -> torch.Tens
 def bf16_pack2(weight: torch.Tensor, a, b):
     """Two layouts ``(src, cin, cout)`` of one weight in one launch (forward + data gradient): -> (packed_a, packed_b)."""
     _chk(weight, "conv weight")
-    outs = []
-    for src, cin, cout in (a, b):
-        n = _lib.load().mvs_bf16_packed_elems(cin, cout)
-        if n <= 0:
-            raise _lib.MvsHipError("bf16 conv: channels must be 8/16/32/64 (Cin=%d Cout=%d)" % (cin, cout))
-        outs.append(torch.empty(n, device=weight.device, dtype=torch.bfloat16))
+    if _taps_of(weight) != 27:
+        raise _lib.MvsHipError("bf16_pack2: 3x3x3 weights only (2-D kernels are packed through a PackTable)")
+    outs = [torch.empty(bf16_packed_elems(cin, cout), device=weight.device, dtype=torch.bfloat16) for _, cin, cout in (a, b)]
     _call("mvs_bf16_pack_weights2", "mvs_bf16_pack_weights", _ptr(weight), weight.shape[0], weight.shape[1], int(a[0]), a[2], a[1],
           _ptr(outs[0]), int(b[0]), b[2], b[1], _ptr(outs[1]), _stream())
     return outs[0], outs[1]
 
 
-def bf16_conv3d(x, wpacked, cin, cout, gather: int, stride, scale=None, shift=None, residual=None, relu=False):
-    """``x [B,D,H,W,cin]`` bf16 -> ``[B,Do,Ho,Wo,cout]`` bf16; ``gather`` 0 = Conv3d, 1 = ConvTranspose3d (k3, p1, op = stride-1)."""
+class PackTable:
+    """A table of weight-packing jobs ``(weight, src, cin, cout)`` - fp32 parameter ``[d0,d1,3,3,3]`` or 2-D ``[d0,d1,3,3]`` -> the bf16
+    per-lane MFMA fragments of a ``cin -> cout`` map (rows / channels beyond the parameter's own extents pack as zeros) - run by ONE
+    launch (``mvs_bf16_pack_table_run``).  Built once (host table -> device, output buffers allocated), run every training step: the
+    parameters are updated in place by the optimizer, so their addresses - which the device table holds - do not change;
+    :meth:`valid` tells whether they still are the ones the table was built for."""
+
+    def __init__(self, jobs):
+        import ctypes
+        lib = _lib.load()
+        n = len(jobs)
+        dev = jobs[0][0].device
+        self.weights = [j[0] for j in jobs]
+        for w in self.weights:
+            _chk(w, "conv weight")
+        self.ptrs = tuple(w.data_ptr() for w in self.weights)
+        self.outs = []
+        nbytes = lib.mvs_bf16_pack_table_bytes(n)
+        host = (ctypes.c_uint8 * nbytes)()
+        for i, (w, src, cin, cout) in enumerate(jobs):
+            taps = _taps_of(w)
+            out = torch.empty(bf16_packed_elems(cin, cout, taps), device=dev, dtype=torch.bfloat16)
+            self.outs.append(out)
+            _lib.check(lib.mvs_bf16_pack_table_fill(host, n, i, _ptr(w), w.shape[0], w.shape[1], int(src), cout, cin, taps, _ptr(out)),
+                       "mvs_bf16_pack_table_fill")
+        starts = (ctypes.c_int32 * (n + 1)).from_buffer(host, nbytes - 4 * (n + 1))
+        self.blocks = int(starts[n])
+        self.n = n
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise _lib.MvsHipError("PackTable built inside a hipGraph capture: run the step eagerly once")
+        self.table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev)
+        torch.cuda.current_stream(dev).synchronize()         # the pageable host buffer is gone after this constructor
+
+    def valid(self) -> bool:
+        return all(w.data_ptr() == p for w, p in zip(self.weights, self.ptrs))
+
+    def run(self):
+        _call("mvs_bf16_pack_table_run", "mvs_bf16_pack_weights", _ptr(self.table), self.n, self.blocks, _stream())
+        return self.outs
+
+
+def bf16_conv3d(x, wpacked, cin, cout, gather: int, stride, scale=None, shift=None, residual=None, relu=False, taps: int = 27):
+    """``x [B,D,H,W,cin]`` bf16 -> ``[B,Do,Ho,Wo,cout]`` bf16; ``gather`` 0 = Conv3d, 1 = ConvTranspose3d (k3, p1, op = stride-1).
+    ``taps`` = 9: a 2-D kernel (no epilogue arguments then)."""
     _chk16(x, "x"), _chk16(wpacked, "packed weights"), _opt(scale, "scale"), _opt(shift, "shift")
     B, Di, Hi, Wi, C = x.shape
     assert C == cin
@@ -1072,6 +1124,11 @@ def bf16_conv3d(x, wpacked, cin, cout, gather: int, stride, scale=None, shift=No
             raise _lib.MvsHipError("residual shape %s != output %s" % (tuple(residual.shape), tuple(y.shape)))
     # credited with the kernel's useful FLOPs: every output voxel of a Conv3d has 27 taps, of a ConvTranspose3d 27 per INPUT voxel
     flops = 2.0 * 27 * cin * cout * B * (Do * Ho * Wo if gather == 0 else Di * Hi * Wi)
+    if taps != 27:
+        assert scale is None and shift is None and residual is None and not relu
+        tag = ("bf16_conv_kernel<%d,%d,g%d,s%d%d,2d>" % (cin, cout, gather, sd, shw), "flops", flops * taps / 27.0)
+        _call("mvs_bf16_conv3d_taps", tag, _ptr(x), _ptr(wpacked), _ptr(y), B, cin, cout, Di, Hi, Wi, int(gather), sd, shw, int(taps), _stream())
+        return y
     tag = ("bf16_conv_kernel<%d,%d,g%d,s%d%d>" % (cin, cout, gather, sd, shw), "flops", flops)
     _call("mvs_bf16_conv3d", tag, _ptr(x), _ptr(wpacked), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), B, cin, cout, Di, Hi, Wi,
           int(gather), sd, shw, int(relu), _stream())
@@ -1101,21 +1158,47 @@ def bf16_conv3d_stats(x, wpacked, cin, cout, gather: int, stride, groups: int = 
     return y, sums
 
 
-def bf16_conv3d_wgrad(A: torch.Tensor, Bt: torch.Tensor, stride) -> torch.Tensor:
-    """``dW[a][b][27] = sum A[p][a] * Bt[p*s-1+k][b]`` (fp32); ``A [N,Dp,Hp,Wp,CA]`` lives on the grid the stride divides."""
+def bf16_conv3d_wgrad(A: torch.Tensor, Bt: torch.Tensor, stride, taps: int = 27, cb_out: Optional[int] = None) -> torch.Tensor:
+    """``dW[a][b][taps] = sum A[p][a] * Bt[p*s-1+k][b]`` (fp32); ``A [N,Dp,Hp,Wp,CA]`` lives on the grid the stride divides.  ``taps`` = 9:
+    only the centre depth tap, ``dW [CA,cb_out,3,3]`` (a 2-D kernel's gradient); ``cb_out`` < CB drops ``Bt``'s padding channels."""
     _chk16(A, "A"), _chk16(Bt, "Bt")
     N, Dp, Hp, Wp, CA = A.shape
     _, Db, Hb, Wb, CB = Bt.shape
-    dW = torch.empty(CA, CB, 3, 3, 3, device=A.device, dtype=torch.float32)
+    cb_out = CB if cb_out is None else int(cb_out)
+    dW = torch.empty((CA, cb_out, 3, 3, 3) if taps == 27 else (CA, cb_out, 3, 3), device=A.device, dtype=torch.float32)
     nws = _lib.load().mvs_bf16_conv3d_wgrad_workspace_bytes(N, CA, CB, Dp, Hp, Wp)
     if nws <= 0:
         raise _lib.MvsHipError("bf16 wgrad: channels must be 8/16/32/64 (CA=%d CB=%d)" % (CA, CB))
     ws = torch.empty(nws, device=A.device, dtype=torch.uint8)
     name = "bf16_wgrad_kernel" if os.environ.get("MVS_TAG_SHAPES", "0") != "1" else \
         "bf16_wgrad<%d,%d,s%d%d,%dx%dx%dx%d>" % (CA, CB, stride[0], stride[1], N, Dp, Hp, Wp)
-    tag = (name, "flops", 2.0 * 27 * CA * CB * N * Dp * Hp * Wp)
-    _call("mvs_bf16_conv3d_wgrad", tag, _ptr(A), _ptr(Bt), _ptr(dW), _ptr(ws), N, CA, CB, Dp, Hp, Wp, Db, Hb, Wb, stride[0], stride[1], _stream())
+    tag = (name, "flops", 2.0 * taps * CA * CB * N * Dp * Hp * Wp)
+    _call("mvs_bf16_conv3d_wgrad_taps", tag, _ptr(A), _ptr(Bt), _ptr(dW), _ptr(ws), N, CA, CB, cb_out, Dp, Hp, Wp, Db, Hb, Wb, stride[0],
+          stride[1], int(taps), _stream())
     return dW
+
+
+def bf16_head_fwd(x: torch.Tensor, w: Optional[torch.Tensor], bias: Optional[torch.Tensor], sigmoid: bool) -> torch.Tensor:
+    """``x [..., 8]`` bf16 channel-last -> fp32 ``[...]``: ``act(sum_c w[c]*x[c] + bias)``; ``w`` None selects channel 0."""
+    _chk16(x, "x"), _opt(w, "w"), _opt(bias, "bias")
+    if x.shape[-1] != 8:
+        raise _lib.MvsHipError("bf16 head: 8 input channels, got %d" % x.shape[-1])
+    out = torch.empty(x.shape[:-1], device=x.device, dtype=torch.float32)
+    _call("mvs_bf16_head_fwd", "bf16_head_fwd", _ptr(x), _ptr(w), _ptr(bias), int(sigmoid), out.numel(), _ptr(out), _stream())
+    return out
+
+
+def bf16_head_bwd(x: torch.Tensor, w: Optional[torch.Tensor], y: Optional[torch.Tensor], dout: torch.Tensor):
+    """-> ``(dx bf16 [..., 8], dwb [9] = [dw | dbias] or None when w is None)``; ``y`` = the forward's output if it applied the sigmoid."""
+    _chk16(x, "x"), _opt(w, "w"), _opt(y, "y"), _chk(dout, "dout")
+    N = dout.numel()
+    dx = torch.empty_like(x)
+    dwb = ws = None
+    if w is not None:
+        dwb = torch.empty(9, device=x.device, dtype=torch.float32)
+        ws = torch.empty(max(1, _lib.load().mvs_bf16_head_bwd_workspace_bytes(N) // 4), device=x.device, dtype=torch.float32)
+    _call("mvs_bf16_head_bwd", "bf16_head_bwd", _ptr(x), _ptr(w), _ptr(y), _ptr(dout), N, _ptr(dx), _ptr(dwb), _ptr(ws), _stream())
+    return dx, dwb
 
 
 def _bf16_bn_shape(x: torch.Tensor, groups: int):
@@ -1173,6 +1256,39 @@ def bf16_bn_bwd_reduce(dy, x, scale, shift, mean, invstd, relu, groups: int = 1)
     _call("mvs_bf16_bn_bwd_reduce", "bf16_bn_bwd_reduce", _ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), int(relu), C,
           R, groups, rps, _ptr(sums), _ptr(ws), _stream())
     return sums
+
+
+def bf16_conv3d_bn_fwd(x, wpacked, cin, cout, gather: int, stride, residual, relu, gamma, beta, running_mean, running_var, momentum, eps,
+                       groups: int = 1, num_batches_tracked=None, taps: int = 27):
+    """conv -> batch-statistics BatchNorm -> [ReLU] [+ residual] of one bf16 channel-last training layer in one call (three launches, the
+    statistics ride the convolution's epilogue) -> ``(y raw conv output, z, scale, shift, mean, invstd)``."""
+    _chk16(x, "x"), _chk16(wpacked, "packed weights")
+    _opt(gamma, "bn.weight"), _opt(beta, "bn.bias"), _opt(running_mean, "bn.running_mean"), _opt(running_var, "bn.running_var")
+    B, Di, Hi, Wi, C = x.shape
+    assert C == cin
+    sd, shw = stride
+    if gather == 0:
+        Do, Ho, Wo = (Di - 1) // sd + 1, (Hi - 1) // shw + 1, (Wi - 1) // shw + 1
+    else:
+        Do, Ho, Wo = Di * sd, Hi * shw, Wi * shw
+    if B % groups:
+        raise _lib.MvsHipError("grouped statistics: batch %d is not a multiple of %d groups" % (B, groups))
+    y = torch.empty(B, Do, Ho, Wo, cout, device=x.device, dtype=torch.bfloat16)
+    z = torch.empty_like(y)
+    if residual is not None:
+        _chk16(residual, "residual")
+        if residual.shape != y.shape:
+            raise _lib.MvsHipError("residual shape %s != output %s" % (tuple(residual.shape), tuple(y.shape)))
+    if num_batches_tracked is not None:
+        _chk(num_batches_tracked, "bn.num_batches_tracked", dtype=torch.int64)
+    st = torch.empty(4, groups * cout, device=x.device, dtype=torch.float32)
+    ws = _reduce_ws("mvs_bf16_conv3d_bn_fwd_workspace_bytes", x.device, B, cout, Do, Ho, Wo)
+    flops = 2.0 * taps * cin * cout * B * (Do * Ho * Wo if gather == 0 else Di * Hi * Wi)
+    tag = ("bf16_conv_bn_fwd<%d,%d,g%d,s%d%d%s>" % (cin, cout, gather, sd, shw, ",2d" if taps == 9 else ""), "flops", flops)
+    _call("mvs_bf16_conv3d_bn_fwd", tag, _ptr(x), _ptr(wpacked), _ptr(y), _ptr(z), _ptr(residual), int(relu), B, cin, cout, Di, Hi, Wi,
+          int(gather), sd, shw, int(taps), int(groups), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
+          _ptr(num_batches_tracked), _ptr(st), _ptr(ws), _stream())
+    return y, z, st[0], st[1], st[2], st[3]
 
 
 def bf16_bn_bwd_apply(dy, x, scale, shift, mean, invstd, gamma, sums, count, relu, count_dev=None, groups: int = 1):

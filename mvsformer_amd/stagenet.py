@@ -71,6 +71,7 @@ class StageNet(nn.Module):
         else:
             self.cost_reg = CostRegNet(in_channels, args["base_ch"])
         self._vis_cache = None
+        self._train_pack = None
 
     def _vis_params(self):
         """-> (parameter block, the 3x3 layers' weights prepared for the selected kernel or None for the all-VALU form)."""
@@ -180,6 +181,11 @@ class StageNet(nn.Module):
         """Training branch (reference mvsformer_model.py:62-125 with ``self.training``): no similarity branch, batch-statistics
         BatchNorm everywhere, depth = hypothesis at the arg-max probability; gradients via :mod:`mvsformer_amd.autograd`."""
         from . import autograd as ag
+        from .module import autocast_bf16
+        if autocast_bf16() and ag._fused_layers():              # every bf16 weight layout of this stage's step in one launch
+            if self._train_pack is None or not self._train_pack.valid():
+                self._train_pack = ag.StagePack(self)
+            self._train_pack.run()
         proj = proj_matrices.detach().to(torch.float32).contiguous()
         hyp = depth_values.detach().to(torch.float32).contiguous()
         rt = ops.proj_prepare(proj)
@@ -187,7 +193,7 @@ class StageNet(nn.Module):
         entropy = ops.cv_entropy(feat_cl, rt, hyp, G, exact=True)           # sim_vol.detach() in the reference
         V = features.shape[1]
         weight = ag.vis_train_views(entropy, self.vis)                     # per-view statistics, one batched pass
-        volume = ag.AggregateFn.apply(features, weight, rt, hyp, G)
+        volume = ag.AggregateFn.apply(features, weight, rt, hyp, G, feat_cl)
         if type(tmp) == list:
             tmp = tmp[self.stage_idx]
         pre = self.cost_reg(volume).squeeze(1)

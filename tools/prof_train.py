@@ -29,3 +29,15 @@ rows = sorted(kt.summary().items(), key=lambda kv: -kv[1]["total_ms"])
 for k, v in rows[:40]:
     print("%-36s calls %3d  total %7.3f ms" % (k, v["calls"], v["total_ms"]))
 print("SUM %.3f ms over %d launches" % (sum(v["total_ms"] for _, v in rows), sum(v["calls"] for _, v in rows)))
+if "--timeline" in sys.argv:            # every C-ABI launch of the step in order (median of 5 steps), with a running sum
+    with ops.kernel_timer() as kt:
+        for _ in range(5): step()
+    summ = kt.summary()
+    n = len(kt.order) // 5
+    seen, t = {}, 0.0
+    for tag in kt.order[:n]:
+        j = seen.get(tag, 0); seen[tag] = j + 1
+        per = KT_MED = ops.KernelTimer.per_step_medians(summ[tag]["all_ms"], 5)
+        ms = per[j] if per else summ[tag]["all_ms"][j]
+        t += ms
+        print("%4d %-36s %8.1f us   cum %7.3f ms" % (sum(seen.values()), tag, ms * 1e3, t))

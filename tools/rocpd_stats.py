@@ -15,12 +15,15 @@ def short(name):
     return (m.group(1) if m else name)[:110]
 
 
-def main(path):
+def main(path, tail=0):
+    """``tail`` > 0: only the last ``tail`` kernel dispatches (e.g. the replays of a captured step at the end of a run)."""
     con = sqlite3.connect(path)
     cur = con.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
-    rows = cur.execute("select %s, start, end from kernels" % name_col).fetchall()
+    rows = cur.execute("select %s, start, end from kernels order by start" % name_col).fetchall()
+    if tail > 0:
+        rows = rows[-tail:]
     agg = {}
     for n, s, e in rows:
         k = short(n)
@@ -37,4 +40,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0)
