@@ -366,25 +366,29 @@ def main(args):
                    "traffic": (sum(t * e["calls_per_step"] for t, e in zip(cv_traffic, cv)) if cv and all(t is not None for t in cv_traffic) else None),
                    "launches": {e["kernel"]: e["ms_per_step"] for e in cv},
                    "note": "sum over the 4 stages of 4*H*W*(V*C + D + G*D) bytes / summed time of the sweeps (+ feature transposes)"}
-    # the measured ceiling of the gathering sweeps: tools/gather_bound.py fetches the same taps with no arithmetic (profiles/gather_bound.json,
-    # stamped with the digest of the probe sources like the traffic file; ignored when they have changed since)
-    gb_file = os.path.join(REPO, "profiles", "gather_bound.json")
-    if os.path.exists(gb_file) and (args.height, args.width, args.views, args.batch) == (1152, 1536, 5, 1):
-        import hashlib
-        gj = json.load(open(gb_file))
-        hh = hashlib.sha256()
-        for f in ("tools/probe/gather_probe.hip", "mvsformer_amd/csrc/geometry.h", "tools/gather_bound.py"):
-            hh.update(open(os.path.join(REPO, f), "rb").read())
-        if isinstance(gj, dict) and gj.get("digest") == hh.hexdigest()[:16]:
-            gb = {(r["C"], r["hyp"]): r["gather_regs_ms"] for r in gj["rows"]}
-            gathering = [e for e in cv if e["kernel"].startswith(("cv_entropy", "cv_aggregate", "cv_corr"))]
-            bound = sum(gb[(4 * int(e["kernel"].split("<")[1].split(",")[0].rstrip(">")), "cascade")] * e["calls_per_step"] for e in gathering)
-            roofline_cv["gather_only_ms_per_depth_map"] = round(bound, 4)
-            roofline_cv["frac_of_gather_bound"] = round(bound / sum(e["ms_per_step"] for e in gathering), 4)
-            roofline_cv["gather_bound_source"] = ("profiles/gather_bound.json at probe sources %s = this tree's (tools/gather_bound.py: the same tap addresses, no "
-                                                  "arithmetic, one launch per gathering sweep); measured on another box of the pool, not in this run" % gj["digest"])
+    # the measured ceiling of the gathering sweeps, in THIS run on THIS box: tools/gather_bound.py's probe (tools/probe/gather_probe.hip) fetches
+    # exactly the taps each gathering sweep fetches - same inputs, the cascade's own hypotheses - with no arithmetic; one launch per sweep
+    if rank == 0:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("gather_bound", os.path.join(REPO, "tools", "gather_bound.py"))
+        gbm = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(gbm)
+        glib = gbm.probe_lib()
+        if glib is None:
+            roofline_cv["gather_bound_source"] = "none: tools/probe/libgather_probe.so is not built (python -c 'import __graft_entry__ as g; g.build()')"
         else:
-            roofline_cv["gather_bound_source"] = "none: profiles/gather_bound.json was measured with other probe sources"
+            with torch.no_grad():
+                ref_out = step(0)
+            g_ms = gbm.gather_only_ms(glib, feats, proj, ref_out)
+            gathering = [e for e in cv if e["kernel"].startswith(("cv_entropy", "cv_aggregate", "cv_corr"))]
+            by_c = {feats["stage%d" % i].shape[2]: g_ms[i] for i in g_ms}
+            bound = sum(by_c[4 * int(e["kernel"].split("<")[1].split(",")[0].rstrip(">"))] * e["calls_per_step"] for e in gathering)
+            roofline_cv["gather_only_ms_per_depth_map"] = round(bound, 4)
+            roofline_cv["gather_only_ms_by_stage"] = {"stage%d" % i: round(v, 4) for i, v in g_ms.items()}
+            roofline_cv["frac_of_gather_bound"] = round(bound / sum(e["ms_per_step"] for e in gathering), 4)
+            roofline_cv["gather_bound_source"] = ("this run: tools/gather_bound.py gather_only_ms (probe sources %s) after the timed region, on the timed inputs "
+                                                  "(input set 0) and the cascade's own hypotheses; one gather-only launch per gathering sweep" % gbm.digest())
+            del ref_out
 
     # ---- extra key: the same cost-volume build on SMOOTH hypotheses (a band around the true surface - what a trained checkpoint predicts,
     #      not the noisy ones of a random-weight cascade): per stage the direct gather pair and the LDS-tiled pair (whose reuse only pays

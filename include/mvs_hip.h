@@ -24,7 +24,10 @@
  *     accumulation (dropped terms <= 2^-24 |x*w|).  Their contract, tested in tests/test_hip_x3.py against fp64:
  *       * error against the exact result <= 3x the fp32-MFMA kernel's own error on the same operands (+ 2e-7 of the output scale);
  *       * any finite fp32 input is accepted, including |v| above the largest finite bf16 (3.3895e38; h is clamped, m and l carry
- *         the remainder exactly) and inputs scaled by 2^+-100, as long as the exact products and sums stay inside the fp32 range;
+ *         the remainder exactly) and inputs scaled by 2^+-100, as long as the exact products and sums stay inside the fp32 range.
+ *         ONE exception: the INTERNAL activations of mvs_vis_x3_fwd are split without the clamp (csrc/split3.h split3_pair<false>):
+ *         a layer-1/2 activation above 3.3895e38 - reachable only through BatchNorm statistics that scale the entropy map
+ *         (range [0, ln D]) by ~1e37 - turns into NaN instead of being carried exactly; its fp32 INPUT obeys the rule above;
  *       * subnormal operands may be flushed to zero by the matrix cores: absolute error <= K * 2^-126 * max|other operand|;
  *       * a non-finite input (+-Inf, NaN) makes exactly the outputs whose receptive field contains it non-finite; the value is NaN
  *         where IEEE fp32 arithmetic would give +-Inf (Inf - Inf in the remainder terms).
@@ -41,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 13
+#define MVS_ABI_VERSION 15
 
 typedef void* mvs_stream_t;
 
@@ -101,6 +104,9 @@ int mvs_warp_fwd(const float* src, const float* rt, const float* depth, int dept
  * LDS per block (<= 64 KiB).
  * ------------------------------------------------------------------------------------------------------- */
 int mvs_nchw_to_nhwc(const float* in, float* out, int N, int C, int64_t HW, mvs_stream_t stream);
+/* the same for up to four independent tensors in ONE launch (host arrays of njobs pointers / shapes: the four stages' feature maps) */
+int mvs_nchw_to_nhwc_multi(const float* const* in, float* const* out, const int* N, const int* C, const int64_t* HW, int njobs,
+                           mvs_stream_t stream);
 int mvs_cv_entropy_fwd(const float* feat, const float* rt, const float* depth,
                        int B, int V, int C, int G, int D, int H, int W, float* entropy, int flags, mvs_stream_t stream);
 #define MVS_VIS_PARAM_FLOATS 3689
@@ -373,6 +379,8 @@ int mvs_bf16_conv3d_wgrad_taps(const void* A, const void* Bt, float* dW, void* w
 /* 1x1x1 heads on bf16 channel-last activations (csrc/bf16_head.hip): out[v] = act(sum_c w[c]*x[v][c] + bias), x = bf16 [N][8], out fp32
  * [N], act = sigmoid or identity; w = NULL selects channel 0 (no parameters).  Backward: dx bf16 [N][8], dwb [9] = [dw | dbias] by block
  * rows + a fixed-order reduce (workspace = mvs_bf16_head_bwd_workspace_bytes(N)); y = the forward's output when it applied the sigmoid. */
+/* fp32 [N] -> bf16 [N][8] with the value in channel 0 and zeros in channels 1..7 (the entropy map enters the visibility CNN) */
+int mvs_bf16_embed_ch0(const float* in, void* out, int64_t N, mvs_stream_t stream);
 int mvs_bf16_head_fwd(const void* x, const float* w, const float* bias, int sigmoid, int64_t N, float* out, mvs_stream_t stream);
 int64_t mvs_bf16_head_bwd_workspace_bytes(int64_t N);
 int mvs_bf16_head_bwd(const void* x, const float* w, const float* y, const float* dout, int64_t N, void* dx, float* dwb, void* workspace,
@@ -546,16 +554,18 @@ int mvs_prob_filter(const float* conf, int n, int C, int64_t HW, const float* th
  * (models/losses.py:304-350, focal=False).
  *   logits [B,D,HW] = prob_volume_pre (D >= 2), depth_values [B,D,HW], depth_gt [B,HW], mask [B,HW] (valid where > 0.5)
  *   inverse_depth != 0: hypotheses run far -> near and are read in flipped order, as the reference flips them
- * fwd: acc2[0] = sum over valid pixels of -log softmax(logits)[gt bin], acc2[1] = number of valid pixels,
- *      loss[0] = weight * acc2[0] / acc2[1] (NaN when no pixel is valid, like F.cross_entropy on an empty selection);
+ * fwd: acc = mvs_ce_loss_acc_floats(B, HW) floats: acc[0] = sum over valid pixels of -log softmax(logits)[gt bin], acc[1] = number of
+ *      valid pixels (both written by the finalize launch from the per-block rows that follow them: fixed order, no atomics),
+ *      loss[0] = weight * acc[0] / acc[1] (NaN when no pixel is valid, like F.cross_entropy on an empty selection);
  *      grad_unscaled [B,D,HW] (may be NULL) = (softmax - onehot) on valid pixels, 0 elsewhere;
  *      valid [B,HW] uint8 and gt_index [B,HW] int32 (index in FLIPPED order when inverse_depth) may be NULL.
- * bwd_scale: grad_inplace *= weight * grad_out[0] / acc2[1]   (grad_out: device scalar, dL/dloss)
+ * bwd_scale: grad = grad_unscaled * weight * grad_out[0] / acc[1]   (grad_out: device scalar, dL/dloss; grad may alias grad_unscaled)
  * ------------------------------------------------------------------------------------------------------- */
+int64_t mvs_ce_loss_acc_floats(int B, int64_t HW);
 int mvs_ce_loss_fwd(const float* logits, const float* depth_values, const float* depth_gt, const float* mask, int B, int D, int64_t HW,
-                    int inverse_depth, float weight, float* grad_unscaled, float* acc2, float* loss, uint8_t* valid, int* gt_index,
+                    int inverse_depth, float weight, float* grad_unscaled, float* acc, float* loss, uint8_t* valid, int* gt_index,
                     mvs_stream_t stream);
-int mvs_ce_loss_bwd_scale(float* grad_inplace, int64_t numel, const float* acc2, const float* grad_out, float weight,
+int mvs_ce_loss_bwd_scale(const float* grad_unscaled, float* grad, int64_t numel, const float* acc, const float* grad_out, float weight,
                           mvs_stream_t stream);
 
 #ifdef __cplusplus

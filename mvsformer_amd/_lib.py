@@ -18,7 +18,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVS_HIP_LIB: diagnostics only - another BUILD of the same library (tests/test_hip_multistream.py's variants); never a fallback
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 15
 
 from ctypes import c_double  # noqa: E402
 
@@ -32,6 +32,7 @@ SIGNATURES = {
     "mvs_proj_relative": (I, [P, P, I, P, P]),
     "mvs_warp_fwd": (I, [P, P, P, I, I, I, I, I, I, P, P, P]),
     "mvs_nchw_to_nhwc": (I, [P, P, I, I, L, P]),
+    "mvs_nchw_to_nhwc_multi": (I, [P, P, P, P, P, I, P]),
     "mvs_cv_entropy_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, I, P]),
     "mvs_vis_fwd": (I, [P, P, I, I, I, P, P]),
     "mvs_cv_aggregate_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, I, P]),
@@ -117,7 +118,9 @@ SIGNATURES = {
     "mvs_geo_filter_dynamic_fwd": (I, [P, P, P, P, I, I, I, I, F, F, P, P, P, P, P, P, P, P]),
     "mvs_vis_filter_dynamic_fwd": (I, [P, P, I, I, I, I, F, F, P, P, P, P, P]),
     "mvs_ce_loss_fwd": (I, [P, P, P, P, I, I, L, I, F, P, P, P, P, P, P]),
-    "mvs_ce_loss_bwd_scale": (I, [P, L, P, P, F, P]),
+    "mvs_ce_loss_bwd_scale": (I, [P, P, L, P, P, F, P]),
+    "mvs_ce_loss_acc_floats": (L, [I, L]),
+    "mvs_bf16_embed_ch0": (I, [P, P, L, P]),
     "mvs_conv3d_wino_supported": (I, [I, I, I, I, I]),
     "mvs_conv3d_wino_packed_floats": (L, [I, I]),
     "mvs_conv3d_wino_pack_weights": (I, [P, I, I, P, P]),

@@ -337,8 +337,8 @@ def vis_train_views(entropy: torch.Tensor, vis: nn.Sequential) -> torch.Tensor:
     if autocast_bf16() and os.environ.get("MVS_VIS_BF16", "1") != "0":
         # under autocast the reference runs this CNN in half precision too (it is inside the autocast region,
         # trainer/mvsformer_trainer.py:104-106): bf16 channel-last kernels, fp32 statistics, the 1x1 conv + sigmoid in fp32
-        x16 = torch.zeros(B * Vs, 1, H, W, 8, device=entropy.device, dtype=torch.bfloat16)
-        x16[..., 0] = entropy.reshape(B * Vs, 1, H, W)                   # batch index b*Vs + v; entropy is detached (no gradient)
+        # batch index b*Vs + v; entropy is detached (no gradient)
+        x16 = ops.bf16_embed_ch0(entropy.detach().to(torch.float32).contiguous().reshape(B * Vs, 1, H, W))
         fused = _fused_layers() and not any(_bn_synced(vis[i].bn) for i in range(3))
         for i in range(3):
             blk = vis[i]

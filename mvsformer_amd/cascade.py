@@ -5,6 +5,7 @@ start from precomputed per-stage feature maps (the bench, the tests, inference s
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Sequence
 
 import torch
@@ -47,6 +48,11 @@ class CascadeMVS(nn.Module):
         prob_maps = torch.zeros(B, Hf, Wf, dtype=torch.float32, device=last.device)
         outputs: Dict[str, object] = {}
         stage_out = None
+        if not self.training and n <= 4 and last.is_cuda and os.environ.get("MVS_TRANSPOSE_MULTI", "1") != "0":
+            # eval: the four stages' NCHW -> NHWC transposes in ONE launch up front (each stage then finds its map channel-last already)
+            keys = ["stage%d" % (i + 1) for i in range(n)]
+            cl = ops.to_channels_last_multi([features[k].detach().to(torch.float32) for k in keys])
+            features = dict(features, **dict(zip(keys, cl)))
         for i in range(n):
             f = features["stage%d" % (i + 1)]
             H, W = f.shape[-2:]

@@ -65,7 +65,23 @@ __global__ __launch_bounds__(256) void bf16_head_bwd_kernel(const __bf16* __rest
     __syncthreads();
     if (threadIdx.x < 9) part[(size_t)blockIdx.x * 9 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+__global__ __launch_bounds__(256) void bf16_embed_ch0_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t N) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    bf16x8 v;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = (__bf16)0.0f;
+    v[0] = (__bf16)in[i];
+    reinterpret_cast<bf16x8*>(out)[i] = v;
+}
 }  // namespace
+
+extern "C" int mvs_bf16_embed_ch0(const float* in, void* out, int64_t N, mvs_stream_t stream) {
+    MVS_REQUIRE(in && out && N >= 1, "mvs_bf16_embed_ch0: bad arguments");
+    hipLaunchKernelGGL(bf16_embed_ch0_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, MVS_STREAM(stream), in,
+                       reinterpret_cast<__bf16*>(out), (size_t)N);
+    return mvs::finish_launch("mvs_bf16_embed_ch0");
+}
 
 extern "C" int mvs_bf16_head_fwd(const void* x, const float* w, const float* bias, int sigmoid, int64_t N, float* out, mvs_stream_t stream) {
     MVS_REQUIRE(x && out && N >= 1 && N < ((int64_t)1 << 40), "mvs_bf16_head_fwd: bad arguments");

@@ -276,7 +276,7 @@ __device__ __forceinline__ bf16x8 frag_tr(const unsigned short* p0, const unsign
 constexpr int WG_PW = 16;                                   // patch columns
 
 template <int TA, int TB>                                   // channel tiles per block
-__global__ __launch_bounds__(256, 2) void bf16_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, TA * TB == 1 ? 3 : 2) void bf16_wgrad_kernel(const WgradArgs a) {
     constexpr int TT = TA * TB;
     constexpr int NIB = 4;                                  // 16-byte pieces of ONE Bt plane tile per thread, at most
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -809,7 +809,10 @@ WgradPlan wgrad_plan(int nbatch, int CA, int CB, int Dp, int Hp, int Wp, int shw
     while (p.PH > 2 && (size_t)4 * (p.PH * shw + 2) * (WG_PW * shw + 2) * b_row * 2 > WG_RING_B) p.PH >>= 1;
     p.npr = (Hp + p.PH - 1) / p.PH;
     p.npc = (Wp + WG_PW - 1) / WG_PW;
-    const int target = 512 / p.gy;                           // two resident blocks per CU over all channel groups
+    // resident blocks over all channel groups: two per CU, three for the single-tile instance (8 / 16 channels on both sides: 14 KB of
+    // LDS, 139 VGPRs; four would spill) - its depth steps are latency chains (load -> LDS -> barrier -> 28 MFMAs), and more blocks
+    // per CU is what hides them
+    const int target = (p.TA * p.TB == 1 ? 768 : 512) / p.gy;
     p.nseg = wgrad_nseg(nbatch * p.npr * p.npc, Dp, target);
     p.dseg = (Dp + p.nseg - 1) / p.nseg;
     p.nseg = (Dp + p.dseg - 1) / p.dseg;

@@ -775,6 +775,9 @@ extern "C" int mvs_deconv3d_x3_fwd(const float* x, const void* wpacked, const fl
     MVS_REQUIRE(B >= 1 && B <= 65535 && D >= 1 && H >= 1 && W >= 1 && (W % 2) == 0, "mvs_deconv3d_x3_fwd: bad shape B=%d D=%d H=%d W=%d (W even)", B, D, H, W);
     MVS_REQUIRE(!scale || shift, "mvs_deconv3d_x3_fwd: scale without shift");
     MVS_REQUIRE((int64_t)Cin * D * H * W * 4 < ((int64_t)1 << 31), "mvs_deconv3d_x3_fwd: one sample's input exceeds the 2 GiB buffer window");
+    // the skip tensor is read through a buffer descriptor too (32-bit size and offsets): one sample's OUTPUT [Cout, D, 2H, 2W] must fit
+    MVS_REQUIRE(!residual || (int64_t)Cout * D * 4 * H * W * 4 < ((int64_t)1 << 32),
+                "mvs_deconv3d_x3_fwd: one sample's skip tensor exceeds the 4 GiB buffer window");
     X3Args a;
     a.x = x; a.wp = static_cast<const bf16x8*>(wpacked); a.scale = scale; a.shift = shift; a.residual = residual; a.y = y;
     a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = relu; a.Ho = 2 * H; a.Wo = 2 * W;

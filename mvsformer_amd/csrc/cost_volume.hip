@@ -729,12 +729,10 @@ __global__ __launch_bounds__(64 * NW) void cv_merge_kernel(const float* __restri
 // (HW not a multiple of 4, or a ragged last block) falls back to dword reads.
 // ---------------------------------------------------------------------------------------------------------
 template <int C, int TP>
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, size_t HW, int vec_ok) {
+__device__ __forceinline__ void nchw_to_nhwc_tile(const float* __restrict__ in, float* __restrict__ out, size_t HW, int vec_ok, size_t p0,
+                                                  size_t n, float* __restrict__ tile) {
     constexpr int LD = TP + 4;                               // row stride: 16-byte aligned rows, rows 4 banks apart
-    __shared__ __attribute__((aligned(16))) float tile[C * LD];
     const int tid = threadIdx.x;
-    const size_t p0 = (size_t)blockIdx.x * TP;
-    const size_t n = blockIdx.y;
     const int npix = (int)min((size_t)TP, HW - p0);
     if (vec_ok && npix == TP) {
         for (int i = tid; i < C * (TP / 4); i += 256) {
@@ -753,6 +751,36 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
         const int p = (i * 4) / C, c = (i * 4) % C;
         const f32x4 v = {tile[c * LD + p], tile[(c + 1) * LD + p], tile[(c + 2) * LD + p], tile[(c + 3) * LD + p]};
         *reinterpret_cast<f32x4*>(o + (size_t)i * 4) = v;
+    }
+}
+
+template <int C, int TP>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, size_t HW, int vec_ok) {
+    __shared__ __attribute__((aligned(16))) float tile[C * (TP + 4)];
+    nchw_to_nhwc_tile<C, TP>(in, out, HW, vec_ok, (size_t)blockIdx.x * TP, blockIdx.y, tile);
+}
+
+// up to four transposes (the four stages' feature maps of one cascade) in ONE launch: job j owns blocks [start[j], start[j+1])
+struct TransposeJobs {
+    const float* in[4];
+    float* out[4];
+    long long HW[4];
+    int C[4], vec[4], start[5], n;
+};
+__device__ __forceinline__ int tp_of(int C) { return C <= 16 ? 256 : (C == 32 ? 128 : 64); }
+__global__ __launch_bounds__(256) void nchw_to_nhwc_multi_kernel(const TransposeJobs jobs) {
+    __shared__ __attribute__((aligned(16))) float tile[64 * 68];          // the largest of the four tile shapes (17 KB)
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.start[j + 1]) ++j;
+    const int local = (int)blockIdx.x - jobs.start[j], C = jobs.C[j], TP = tp_of(C);
+    const size_t HW = (size_t)jobs.HW[j];
+    const int bps = (int)((HW + TP - 1) / TP);
+    const size_t n = local / bps, p0 = (size_t)(local % bps) * TP;
+    switch (C) {
+        case 8: nchw_to_nhwc_tile<8, 256>(jobs.in[j], jobs.out[j], HW, jobs.vec[j], p0, n, tile); break;
+        case 16: nchw_to_nhwc_tile<16, 256>(jobs.in[j], jobs.out[j], HW, jobs.vec[j], p0, n, tile); break;
+        case 32: nchw_to_nhwc_tile<32, 128>(jobs.in[j], jobs.out[j], HW, jobs.vec[j], p0, n, tile); break;
+        default: nchw_to_nhwc_tile<64, 64>(jobs.in[j], jobs.out[j], HW, jobs.vec[j], p0, n, tile); break;
     }
 }
 
@@ -783,6 +811,27 @@ extern "C" int mvs_nchw_to_nhwc(const float* in, float* out, int N, int C, int64
     }
 #undef MVS_LAUNCH_T
     return mvs::finish_launch("mvs_nchw_to_nhwc");
+}
+
+// njobs <= 4 transposes [N_j, C_j, HW_j] -> [N_j, HW_j, C_j] in one launch (the cascade's four stages: three launch gaps less per depth map)
+extern "C" int mvs_nchw_to_nhwc_multi(const float* const* in, float* const* out, const int* N, const int* C, const int64_t* HW, int njobs,
+                                      mvs_stream_t stream) {
+    MVS_REQUIRE(in && out && N && C && HW && njobs >= 1 && njobs <= 4, "mvs_nchw_to_nhwc_multi: 1..4 jobs");
+    TransposeJobs jobs{};
+    jobs.n = njobs;
+    jobs.start[0] = 0;
+    for (int j = 0; j < njobs; ++j) {
+        MVS_REQUIRE(in[j] && out[j] && N[j] >= 1 && HW[j] >= 1, "mvs_nchw_to_nhwc_multi: job %d: bad shape", j);
+        MVS_REQUIRE(C[j] == 8 || C[j] == 16 || C[j] == 32 || C[j] == 64, "mvs_nchw_to_nhwc_multi: C must be 8, 16, 32 or 64 (got %d)", C[j]);
+        const int tp = C[j] <= 16 ? 256 : (C[j] == 32 ? 128 : 64);
+        const int64_t blocks = (int64_t)N[j] * ((HW[j] + tp - 1) / tp);
+        MVS_REQUIRE(jobs.start[j] + blocks < ((int64_t)1 << 31), "mvs_nchw_to_nhwc_multi: too many tiles");
+        jobs.in[j] = in[j], jobs.out[j] = out[j], jobs.HW[j] = HW[j], jobs.C[j] = C[j];
+        jobs.vec[j] = (HW[j] % 4 == 0) && ((reinterpret_cast<uintptr_t>(in[j]) & 15) == 0);
+        jobs.start[j + 1] = jobs.start[j] + (int)blocks;
+    }
+    hipLaunchKernelGGL(nchw_to_nhwc_multi_kernel, dim3(jobs.start[njobs]), dim3(256), 0, MVS_STREAM(stream), jobs);
+    return mvs::finish_launch("mvs_nchw_to_nhwc_multi");
 }
 
 extern "C" int mvs_cv_entropy_fwd(const float* feat, const float* rt, const float* depth, int B, int V, int C, int Gin, int D,

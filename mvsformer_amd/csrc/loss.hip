@@ -14,8 +14,9 @@ namespace {
 template <bool INVERSE>
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ logits, const float* __restrict__ hyp,
                                                       const float* __restrict__ gt, const float* __restrict__ mask, int D, size_t HW,
-                                                      float* __restrict__ grad, float* __restrict__ acc /*[2]: loss sum, count*/,
+                                                      float* __restrict__ grad, float* __restrict__ rows /*[blocks][2]: loss sum, count*/,
                                                       uint8_t* __restrict__ valid_out, int* __restrict__ index_out) {
+    __shared__ float red[2][4];
     const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     float lsum = 0.0f, cnt = 0.0f;
@@ -64,37 +65,68 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
             }
         }
     }
-    // block reduction -> 2 atomics per wave
+    // block reduction -> one row per block
     for (int o = 32; o > 0; o >>= 1) {
         lsum += __shfl_down(lsum, o, 64);
         cnt += __shfl_down(cnt, o, 64);
     }
-    if ((threadIdx.x & 63) == 0 && cnt > 0.0f) {
-        atomicAdd(acc, lsum);
-        atomicAdd(acc + 1, cnt);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = lsum;
+        red[1][threadIdx.x >> 6] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        rows[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + threadIdx.x] =
+            (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// acc[0..1] = the rows (acc + 2) added in a fixed order; loss = weight * acc[0] / acc[1]
+__global__ __launch_bounds__(256) void ce_finalize_kernel(float* __restrict__ acc, int nrows, float weight, float* __restrict__ loss) {
+    __shared__ float red[2][4];
+    const float* rows = acc + 2;
+    float s = 0.0f, c = 0.0f;
+    for (int i = threadIdx.x; i < nrows; i += 256) {
+        s += rows[2 * i];
+        c += rows[2 * i + 1];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o, 64);
+        c += __shfl_down(c, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s;
+        red[1][threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        c = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        acc[0] = s;
+        acc[1] = c;
+        loss[0] = weight * (s / c);                   // N = 0 -> 0/0 = NaN, as F.cross_entropy on an empty selection
     }
 }
 
-__global__ void ce_finalize_kernel(const float* __restrict__ acc, float weight, float* __restrict__ loss) {
-    loss[0] = weight * (acc[0] / acc[1]);             // N = 0 -> 0/0 = NaN, as F.cross_entropy on an empty selection
-}
-
-__global__ __launch_bounds__(256) void ce_scale_kernel(float* __restrict__ grad, size_t n, const float* __restrict__ acc,
-                                                       const float* __restrict__ gout, float weight) {
+__global__ __launch_bounds__(256) void ce_scale_kernel(const float* __restrict__ grad, float* __restrict__ out, size_t n,
+                                                       const float* __restrict__ acc, const float* __restrict__ gout, float weight) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) grad[i] *= weight * gout[0] / acc[1];
+    if (i < n) out[i] = grad[i] * (weight * gout[0] / acc[1]);
 }
 
 }  // namespace
 
+extern "C" int64_t mvs_ce_loss_acc_floats(int B, int64_t HW) {
+    return (B < 1 || HW < 1) ? -1 : 2 + 2 * (int64_t)B * ((HW + 255) / 256);
+}
+
 extern "C" int mvs_ce_loss_fwd(const float* logits, const float* depth_values, const float* depth_gt, const float* mask, int B, int D,
-                               int64_t HW, int inverse_depth, float weight, float* grad_unscaled, float* acc2, float* loss,
+                               int64_t HW, int inverse_depth, float weight, float* grad_unscaled, float* acc, float* loss,
                                uint8_t* valid, int* gt_index, mvs_stream_t stream) {
-    MVS_REQUIRE(logits && depth_values && depth_gt && mask && acc2 && loss, "mvs_ce_loss_fwd: null pointer");
+    float* acc2 = acc ? acc + 2 : nullptr;                   // the block rows; acc[0..1] are written by the finalize kernel
+    MVS_REQUIRE(logits && depth_values && depth_gt && mask && acc && loss, "mvs_ce_loss_fwd: null pointer");
     MVS_REQUIRE(B >= 1 && B <= 65535 && D >= 2 && HW >= 1, "mvs_ce_loss_fwd: bad shape B=%d D=%d (>= 2: bins need an interval) HW=%lld", B, D,
                 (long long)HW);
     hipStream_t s = MVS_STREAM(stream);
-    if (hipMemsetAsync(acc2, 0, 2 * sizeof(float), s) != hipSuccess) return mvs::finish_launch("mvs_ce_loss_fwd(memset)");
     dim3 grid((unsigned)mvs::ceil_div((long long)HW, 256LL), B);
     if (inverse_depth)
         hipLaunchKernelGGL(ce_loss_kernel<true>, grid, dim3(256), 0, s, logits, depth_values, depth_gt, mask, D, (size_t)HW, grad_unscaled,
@@ -102,14 +134,14 @@ extern "C" int mvs_ce_loss_fwd(const float* logits, const float* depth_values, c
     else
         hipLaunchKernelGGL(ce_loss_kernel<false>, grid, dim3(256), 0, s, logits, depth_values, depth_gt, mask, D, (size_t)HW,
                            grad_unscaled, acc2, valid, gt_index);
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1), 0, s, acc2, weight, loss);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, acc, (int)(grid.x * grid.y), weight, loss);
     return mvs::finish_launch("mvs_ce_loss_fwd");
 }
 
-extern "C" int mvs_ce_loss_bwd_scale(float* grad_inplace, int64_t numel, const float* acc2, const float* grad_out, float weight,
-                                     mvs_stream_t stream) {
-    MVS_REQUIRE(grad_inplace && acc2 && grad_out && numel >= 1, "mvs_ce_loss_bwd_scale: bad arguments");
+extern "C" int mvs_ce_loss_bwd_scale(const float* grad_unscaled, float* grad, int64_t numel, const float* acc, const float* grad_out,
+                                     float weight, mvs_stream_t stream) {
+    MVS_REQUIRE(grad_unscaled && grad && acc && grad_out && numel >= 1, "mvs_ce_loss_bwd_scale: bad arguments");
     hipLaunchKernelGGL(ce_scale_kernel, dim3((unsigned)mvs::ceil_div((long long)numel, 256LL)), dim3(256), 0, MVS_STREAM(stream),
-                       grad_inplace, (size_t)numel, acc2, grad_out, weight);
+                       grad_unscaled, grad, (size_t)numel, acc, grad_out, weight);
     return mvs::finish_launch("mvs_ce_loss_bwd_scale");
 }

@@ -30,6 +30,13 @@
 #define X3_STAGE_AUX 0      // cache policy of the staging / skip-tensor loads (aux of raw_buffer_load: 2 = nt)
 #endif
 
+// the ablation switches of the timeline experiments exist only in experiment builds: the shipped kernel has no environment-dependent path
+#ifdef X3_ABLATE
+#define TAIL_ABLATE(a, bit) (((a).ablate & (bit)) != 0)
+#else
+#define TAIL_ABLATE(a, bit) false
+#endif
+
 namespace {
 using namespace mvsconv;
 using mvsx3::bf16x8;
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void tail_x3_kernel(const TailArgs a) {
 #pragma unroll
         for (int it = 0; it < NI; ++it)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pre[it][e] = (a.ablate & 1) ? 1.0f : stage_load(xin, voff[it], (unsigned)((base + (size_t)e * DHW) * 4));
+            for (int e = 0; e < 8; ++e) pre[it][e] = TAIL_ABLATE(a, 1) ? 1.0f : stage_load(xin, voff[it], (unsigned)((base + (size_t)e * DHW) * 4));
     };
     auto commit = [&](unsigned char* buf) {
 #pragma unroll
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void tail_x3_kernel(const TailArgs a) {
             if (stage_next) issue(S, np);
 #endif
             TAIL_STAMP(0);                                 // loads issued (TAIL_INTERLEAVE: nothing yet)
-            if (!(a.ablate & 4)) {
+            if (!TAIL_ABLATE(a, 4)) {
                 // row fragments roll: F(row) serves tile P and step 0 of tile Q of its own row, and step 1 of tile Q of the row above
                 bf16x8 f0[3], f1[3];
                 const unsigned char* fp = buf + (wave * R) * (BW * PB) + foff;
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void tail_x3_kernel(const TailArgs a) {
             }
 #endif
             TAIL_STAMP(1);                                 // MFMA phase
-            if (fin && !(a.ablate & 8)) finish_plane(I, p - 1, acc[0], rprev);
+            if (fin && !TAIL_ABLATE(a, 8)) finish_plane(I, p - 1, acc[0], rprev);
             TAIL_STAMP(2);                                 // epilogue + stores of the finished plane
 #ifdef X3_TIMELINE
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void tail_x3_kernel(const TailArgs a) {
                 TAIL_STAMP(6);                             // barrier
             }
         }
-        if (I.p_last == D - 1 && I.d_hi == D && !(a.ablate & 8)) finish_plane(I, D - 1, acc[0], rprev);
+        if (I.p_last == D - 1 && I.d_hi == D && !TAIL_ABLATE(a, 8)) finish_plane(I, D - 1, acc[0], rprev);
         if (!has_next) break;
         I = J;
         item = next_item;
@@ -402,10 +409,14 @@ extern "C" int mvs_tail_x3_fwd(const float* x, const void* wpacked, const float*
     a.seg_planes = mvs::ceil_div(D, nseg);
     nseg = mvs::ceil_div(D, a.seg_planes);
     a.nseg = nseg;
+#ifdef X3_ABLATE            // experiment builds only (make exp EXPFLAGS=-DX3_ABLATE): bit 0 constant inputs, bit 2 no MFMAs, bit 3 no stores
     {
         const char* e = getenv("MVS_X3_ABLATE");
         a.ablate = e ? atoi(e) : 0;
     }
+#else
+    a.ablate = 0;
+#endif
     const int64_t nitems = blocks * nseg;
     const int resident = 2 * mvs::device_cus();            // two blocks per CU (launch bounds), persistent over the work items
     hipLaunchKernelGGL(tail_x3_kernel, dim3((unsigned)(nitems < resident ? nitems : resident)), dim3(256), 0, MVS_STREAM(stream), a);

@@ -30,9 +30,8 @@ class CeLossFn(torch.autograd.Function):
         acc, grad = ctx.saved_tensors
         if not ctx.has_grad:
             return None, None, None, None, None, None
-        g = grad.clone()            # the saved buffer stays unscaled: a second backward (retain_graph) scales a fresh copy
-        ops.ce_loss_bwd_scale(g, acc, gout.contiguous().reshape(1), ctx.weight)
-        return g, None, None, None, None, None
+        # out of place: the saved buffer stays unscaled, a second backward (retain_graph) scales it again
+        return ops.ce_loss_bwd_scale(grad, acc, gout.contiguous().reshape(1), ctx.weight), None, None, None, None, None
 
 
 def ce_loss_stage4(inputs, depth_gt_ms, mask_ms, dlossw, focal=False, gamma=0.0, inverse_depth=True):

@@ -112,12 +112,29 @@ X3_MIN_VOXELS = 40 * 1024      # output voxels from which the split-form conv is
 SMALL_MAX_WORK = (16 << 20, 8 << 20)      # (Conv3d, Deconv3d); MVS_CONV_SMALL_MAX_WORK="conv,deconv" overrides, "0,0" = never
 
 
+def _parse_small_limit(text) -> Tuple[int, int]:
+    """``"conv,deconv"`` or one value for both; anything else is a configuration error reported at import, not in the middle of a forward."""
+    if not text:
+        return SMALL_MAX_WORK
+    try:
+        v = [int(t) for t in text.split(",")]
+    except ValueError:
+        v = []
+    if len(v) == 1:
+        v = v * 2
+    if len(v) != 2 or min(v) < 0:
+        raise ValueError("MVS_CONV_SMALL_MAX_WORK must be 'conv,deconv' or one non-negative integer, got %r" % (text,))
+    return v[0], v[1]
+
+
+_SMALL_LIMITS = _parse_small_limit(os.environ.get("MVS_CONV_SMALL_MAX_WORK"))      # read once: not on every forward of every layer
+_WINDOW = 1 << 31        # bytes a buffer descriptor of the split-form kernels addresses (per sample for conv / deconv, per call for the tail)
+
+
 def _small_limit(transposed: bool) -> int:
     if os.environ.get("MVS_CONV_X3", "1") == "0":
         return 0
-    e = os.environ.get("MVS_CONV_SMALL_MAX_WORK")
-    lim = tuple(int(v) for v in e.split(",")) if e else SMALL_MAX_WORK
-    return lim[1 if transposed else 0]
+    return _SMALL_LIMITS[1 if transposed else 0]
 
 
 class Conv3d(nn.Module):
@@ -178,7 +195,9 @@ class Conv3d(nn.Module):
         if self.training:
             return _train_conv_bn_act(x, self.conv, self.bn, self.relu, residual)
         packed, scale, shift, stride, wino, x3, small = self._prepared()
-        if x3 is not None and x.shape[2] * (x.shape[3] // stride[1]) * (x.shape[4] // stride[1]) >= int(os.environ.get("MVS_CONV_X3_MIN_VOXELS", X3_MIN_VOXELS)):
+        # (a sample beyond the split-form kernel's 2 GiB buffer window falls through to the 64-bit-addressed fp32-MFMA kernel below)
+        if x3 is not None and x.shape[2] * (x.shape[3] // stride[1]) * (x.shape[4] // stride[1]) >= int(os.environ.get("MVS_CONV_X3_MIN_VOXELS", X3_MIN_VOXELS)) \
+                and x[0].numel() * 4 < _WINDOW:
             return ops.conv3d_x3(x, x3, self.conv.in_channels, self.conv.out_channels, stride, scale, shift, residual, relu=self.relu)
         if small is not None and ((x.shape[2] - 1) // stride[0] + 1) * ((x.shape[3] - 1) // stride[1] + 1) * ((x.shape[4] - 1) // stride[1] + 1) \
                 * self.conv.in_channels * self.conv.out_channels <= _small_limit(False):
@@ -384,7 +403,8 @@ class CostRegNet3D(nn.Module):
         # split-form transposed conv (csrc/conv3d_x3.hip) where it beats the fp32-MFMA kernel: conv7 / conv9 at real sizes; conv11
         # (8 output channels fill half a matrix tile, and its fp32 kernel fuses the 1x1x1 prob) stays
         if cout >= 16 and os.environ.get("MVS_CONV_X3", "1") != "0" and ops.deconv3d_x3_supported(cin, cout, sd) and x.shape[4] % 2 == 0 \
-                and 4 * x.shape[2] * x.shape[3] * x.shape[4] >= int(os.environ.get("MVS_CONV_X3_MIN_VOXELS", X3_MIN_VOXELS)):
+                and 4 * x.shape[2] * x.shape[3] * x.shape[4] >= int(os.environ.get("MVS_CONV_X3_MIN_VOXELS", X3_MIN_VOXELS)) \
+                and x[0].numel() * 4 < _WINDOW and (residual is None or residual[0].numel() * 4 < 2 * _WINDOW):
             px = self._dcache.get(name + ".x3")
             if px is None or px[0] != key:
                 px = (key, ops.deconv3d_x3_pack(_f32c(seq[0].weight), sd))
@@ -409,8 +429,10 @@ class CostRegNet3D(nn.Module):
                 self._dcache["conv11"] = c
             _, packed, scale, shift, _sd = c
             # split form (csrc/tail_x3.hip) for the shape it is built for (16 -> 8) from X3_MIN_VOXELS up; MVS_TAIL=fp32 keeps the fp32-MFMA tail
+            # (the tail's window covers the whole batch of the skip volume: a larger call takes the fp32-MFMA tail below)
             if seq[0].in_channels == 16 and os.environ.get("MVS_CONV_X3", "1") != "0" and os.environ.get("MVS_TAIL", "x3") == "x3" \
-                    and 4 * y.shape[2] * y.shape[3] * y.shape[4] >= int(os.environ.get("MVS_CONV_X3_MIN_VOXELS", X3_MIN_VOXELS)):
+                    and 4 * y.shape[2] * y.shape[3] * y.shape[4] >= int(os.environ.get("MVS_CONV_X3_MIN_VOXELS", X3_MIN_VOXELS)) \
+                    and skip.numel() * 4 < _WINDOW:
                 px = self._dcache.get("conv11.x3")
                 if px is None or px[0] != key:
                     px = (key, ops.tail_x3_pack(_f32c(seq[0].weight)))

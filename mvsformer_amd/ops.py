@@ -185,6 +185,36 @@ def to_channels_last(feat: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def to_channels_last_multi(feats: List[torch.Tensor]) -> List[torch.Tensor]:
+    """:func:`to_channels_last` of up to four ``[B,V,C,H,W]`` tensors (the cascade's stages) in ONE launch.  Each result is returned as a
+    ``[B,V,C,H,W]`` VIEW of channel-last memory, which every consumer's :func:`to_channels_last` passes through without a copy."""
+    import ctypes
+    outs, jobs = list(feats), []
+    for i, f in enumerate(feats):
+        if f.is_cuda and f.dtype == torch.float32 and f.dim() == 5 and not f.is_contiguous() and f.permute(0, 1, 3, 4, 2).is_contiguous():
+            continue                                             # channel-last already
+        _chk(f, "features")
+        jobs.append(i)
+    if not jobs:
+        return outs
+    if len(jobs) > 4:
+        raise _lib.MvsHipError("to_channels_last_multi: at most four tensors per launch")
+    n = len(jobs)
+    bufs = [torch.empty(feats[i].shape[0], feats[i].shape[1], feats[i].shape[3], feats[i].shape[4], feats[i].shape[2],
+                        device=feats[i].device, dtype=torch.float32) for i in jobs]
+    P = ctypes.c_void_p
+    a_in = (P * n)(*[feats[i].data_ptr() for i in jobs])
+    a_out = (P * n)(*[b.data_ptr() for b in bufs])
+    a_n = (ctypes.c_int * n)(*[feats[i].shape[0] * feats[i].shape[1] for i in jobs])
+    a_c = (ctypes.c_int * n)(*[feats[i].shape[2] for i in jobs])
+    a_hw = (ctypes.c_int64 * n)(*[feats[i].shape[3] * feats[i].shape[4] for i in jobs])
+    nbytes = sum(8.0 * feats[i].numel() for i in jobs)
+    _call("mvs_nchw_to_nhwc_multi", ("nchw_to_nhwc_multi", "bytes", nbytes), a_in, a_out, a_n, a_c, a_hw, n, _stream())
+    for i, b in zip(jobs, bufs):
+        outs[i] = b.permute(0, 1, 4, 2, 3)
+    return outs
+
+
 def cv_entropy(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, G: int, exact: Optional[bool] = None) -> torch.Tensor:
     """``feat`` is channel-last ``[B,V,H,W,C]`` (see :func:`to_channels_last`)."""
     _chk(feat, "features"), _chk(rt, "rt"), _chk(depth, "depth_values")
@@ -980,14 +1010,15 @@ def vis_filter_dynamic(ref_depth, reproj_xyd, dist_base, rel_diff_base, want=("m
 # ------------------------------------------------------------------------------------- fused CE loss (§8 f3)
 def ce_loss(logits, depth_values, depth_gt, mask, inverse_depth: bool, weight: float = 1.0, want_grad: bool = True,
             want_index: bool = False):
-    """-> ``(loss [] , acc [2] = (sum, count), grad_unscaled [B,D,H,W] or None)`` (+ ``valid``, ``gt_index`` with ``want_index``)."""
+    """-> ``(loss [] , acc [2 + rows] with acc[:2] = (sum, count), grad_unscaled [B,D,H,W] or None)`` (+ ``valid``, ``gt_index`` with
+    ``want_index``)."""
     _chk(logits, "prob_volume_pre"), _chk(depth_values, "depth_values"), _chk(depth_gt, "depth_gt"), _chk(mask, "mask")
     B, D, H, W = logits.shape
     if depth_values.shape != logits.shape or depth_gt.shape != (B, H, W) or mask.shape != (B, H, W):
         raise _lib.MvsHipError("ce_loss: shapes %s %s %s %s" % (tuple(logits.shape), tuple(depth_values.shape), tuple(depth_gt.shape),
                                                                tuple(mask.shape)))
     dev = logits.device
-    acc = torch.empty(2, device=dev, dtype=torch.float32)
+    acc = torch.empty(_lib.load().mvs_ce_loss_acc_floats(B, H * W), device=dev, dtype=torch.float32)
     loss = torch.empty((), device=dev, dtype=torch.float32)
     grad = torch.empty_like(logits) if want_grad else None
     valid = torch.empty(B, H, W, device=dev, dtype=torch.uint8) if want_index else None
@@ -1000,9 +1031,20 @@ def ce_loss(logits, depth_values, depth_gt, mask, inverse_depth: bool, weight: f
     return loss, acc, grad
 
 
-def ce_loss_bwd_scale(grad, acc, gout, weight: float) -> None:
+def ce_loss_bwd_scale(grad, acc, gout, weight: float) -> torch.Tensor:
+    """-> ``grad * weight * gout / count`` as a NEW tensor (the saved unscaled gradient stays intact for a second backward)."""
     _chk(grad, "grad"), _chk(acc, "acc"), _chk(gout, "grad_out")
-    _call("mvs_ce_loss_bwd_scale", "ce_loss_bwd_scale", _ptr(grad), grad.numel(), _ptr(acc), _ptr(gout), float(weight), _stream())
+    out = torch.empty_like(grad)
+    _call("mvs_ce_loss_bwd_scale", "ce_loss_bwd_scale", _ptr(grad), _ptr(out), grad.numel(), _ptr(acc), _ptr(gout), float(weight), _stream())
+    return out
+
+
+def bf16_embed_ch0(x: torch.Tensor) -> torch.Tensor:
+    """fp32 ``[...]`` -> bf16 ``[..., 8]`` with the value in channel 0, zeros elsewhere (one launch instead of a fill and a strided copy)."""
+    _chk(x, "x")
+    out = torch.empty(tuple(x.shape) + (8,), device=x.device, dtype=torch.bfloat16)
+    _call("mvs_bf16_embed_ch0", "bf16_embed_ch0", _ptr(x), _ptr(out), x.numel(), _stream())
+    return out
 
 
 # ------------------------------------------------------------------ bf16 channel-last regularizer (training under autocast)

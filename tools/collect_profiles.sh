@@ -2,7 +2,7 @@
 # Round-end evidence on the GPU box (run from the repo root through gpurun): gather ceiling, per-stage breakdown, kernel trace of the bench,
 # HBM traffic counters (separate --pmc passes), final bench line.  Everything lands in gpurun_out/, copy what is judged into profiles/.
 set -x
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 mkdir -p gpurun_out
 REPO=$(pwd)
 python tools/gather_bound.py > gpurun_out/gather_bound.log 2>&1

@@ -16,6 +16,62 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 
+def probe_lib():
+    """tools/probe/libgather_probe.so (built by __graft_entry__.build() / make -C tools/probe) or None."""
+    path = os.path.join(REPO, "tools", "probe", "libgather_probe.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    P, I = ctypes.c_void_p, ctypes.c_int
+    lib.probe_taps.argtypes = [P, P, I, I, I, I, I, P, P]
+    lib.probe_gather.argtypes = [P, P, I, I, I, I, I, I, P, I, P]
+    return lib
+
+
+def digest():
+    """sha256[:16] of the sources that define the measurement (the probe, the shared tap geometry, this file)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("tools/probe/gather_probe.hip", "mvsformer_amd/csrc/geometry.h", "tools/gather_bound.py"):
+        h.update(open(os.path.join(REPO, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def gather_only_ms(lib, feats, proj, out, stages=(1, 2, 3, 4), iters=20):
+    """{stage: ms of ONE gather-only launch} - the taps a sweep over all source views of that stage fetches (the cascade's own
+    hypotheses ``out['stageK']['depth_values']``), buffer_load_dwordx4 into registers, no arithmetic.  bench.py calls this after its
+    timed region: same box, same run, same inputs."""
+    import torch
+    from mvsformer_amd import ops
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for i in stages:
+        f = feats["stage%d" % i]
+        fcl = ops.to_channels_last(f.contiguous() if f.is_contiguous() else f)
+        B, V, H, W, C = fcl.shape
+        hyp = out["stage%d" % i]["depth_values"].contiguous()
+        D = hyp.shape[1]
+        rt = ops.proj_prepare(proj["stage%d" % i])
+        o00 = torch.empty(B * (V - 1), D, H, W, dtype=torch.int32, device=fcl.device)
+        sink = torch.zeros(16, device=fcl.device)
+        assert lib.probe_taps(rt.data_ptr(), hyp.data_ptr(), B, V, D, H, W, o00.data_ptr(), st) == 0
+
+        def g():
+            assert lib.probe_gather(fcl.data_ptr(), o00.data_ptr(), B, V, C, D, H, W, sink.data_ptr(), 0, st) == 0
+        for _ in range(3):
+            g()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            g()
+        b.record()
+        torch.cuda.synchronize()
+        res[i] = a.elapsed_time(b) / iters
+        del o00
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stages", type=int, nargs="+", default=[1, 2, 3, 4])
@@ -25,10 +81,8 @@ def main():
     import mvsformer_amd as m
     from mvsformer_amd import ops, synth
 
-    lib = ctypes.CDLL(os.path.join(REPO, "tools", "probe", "libgather_probe.so"))
-    P, I = ctypes.c_void_p, ctypes.c_int
-    lib.probe_taps.argtypes = [P, P, I, I, I, I, I, P, P]
-    lib.probe_gather.argtypes = [P, P, I, I, I, I, I, I, P, I, P]
+    lib = probe_lib()
+    assert lib is not None, "make -C tools/probe libgather_probe.so first"
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     net = m.CascadeMVS().eval()
@@ -101,11 +155,7 @@ def main():
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     # stamped with the digest of the sources that define the measurement (the probe, the shared tap geometry): bench.py only uses the file
     # while they are unchanged
-    import hashlib
-    h = hashlib.sha256()
-    for f in ("tools/probe/gather_probe.hip", "mvsformer_amd/csrc/geometry.h", "tools/gather_bound.py"):
-        h.update(open(os.path.join(REPO, f), "rb").read())
-    json.dump({"digest": h.hexdigest()[:16], "rows": rows}, open(os.path.join(REPO, "gpurun_out", "gather_bound.json"), "w"), indent=1)
+    json.dump({"digest": digest(), "rows": rows}, open(os.path.join(REPO, "gpurun_out", "gather_bound.json"), "w"), indent=1)
     open(os.path.join(REPO, "gpurun_out", "gather_bound.txt"), "w").write("\n".join(lines) + "\n")
 
 
