@@ -590,3 +590,41 @@ def gen_fpn_encoder():
 
 if __name__ == "__main__" and os.environ.get("GEN_FPN", "1") == "1":
     gen_fpn_encoder()
+
+
+def gen_vit():
+    """The DINO ViT-small branch of the shipped MVSFormer-P config (configs/config_mvsformer-p.json: vit_small, patch 16, qk_scale
+    'default', rescale 0.5, att_fusion, out_ch 64, nhead 6) run with the reference's OWN classes: ``models.vision_transformer`` imports
+    nothing but torch and ``utils.trunc_normal_`` (the stubs above cover ``utils``' own imports; ``timm`` is needed by Twins only,
+    models/gvt.py:6-7).  One 256x320 image -> bicubic 128x160 -> 8x10 patches.  Weights: oracle/weights.make_vit_state_dict (seeds 21 /
+    22), loaded with strict=True; the file holds the image (float16-exact), the resized image, the normalized tokens, the CLS attention
+    row of the last block and the decoder output that is added to conv31."""
+    import models.vision_transformer as vits
+    from models.module import VITDecoderStage4Single
+    from oracle.weights import make_vit_state_dict
+    vit_args = dict(rescale=0.5, patch_size=16, qk_scale="default", vit_arch="vit_small", vit_ch=384, out_ch=64, att_fusion=True, nhead=6)
+    vit = vits.__dict__["vit_small"](patch_size=16, qk_scale="default")
+    dec = VITDecoderStage4Single(vit_args)
+    shapes = {"vit_small": {k: list(v.shape) for k, v in vit.state_dict().items()},
+              "vit_decoder": {k: list(v.shape) for k, v in dec.state_dict().items()}}
+    with open(os.path.join(OUT, "vit_shapes.json"), "w") as f:
+        json.dump(shapes, f, indent=0)
+    vit.load_state_dict(make_vit_state_dict(shapes["vit_small"], 21), strict=True)
+    dec.load_state_dict(make_vit_state_dict(shapes["vit_decoder"], 22), strict=True)
+    vit.eval(), dec.eval()
+    B, H, W = 1, 256, 320
+    img = f16exact(torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(23)))
+    with torch.no_grad():                                   # mvsformer_model.py:243-262, one view
+        vit_h, vit_w = int(H * vit_args["rescale"]), int(W * vit_args["rescale"])
+        vit_imgs = F.interpolate(img, (vit_h, vit_w), mode="bicubic", align_corners=False)
+        vit_feat, vit_att = vit.forward_with_last_att(vit_imgs)
+        feat = vit_feat[:, 1:].reshape(B, vit_h // 16, vit_w // 16, 384).permute(0, 3, 1, 2).contiguous()
+        att = vit_att[:, :, 0, 1:].reshape(B, -1, vit_h // 16, vit_w // 16)
+        vit_out = dec.forward(feat, att)
+    save("vit_small.npz", img=np32(img).astype(np.float16), vit_imgs=np32(vit_imgs), vit_feat=np32(vit_feat),
+         att_cls=np32(vit_att[:, :, 0, 1:]), vit_out=np32(vit_out), seeds=np.array([21, 22, 23]))
+    print("vit_small params %.1f M, decoder %.1f M" % (sum(p.numel() for p in vit.parameters()) / 1e6, sum(p.numel() for p in dec.parameters()) / 1e6))
+
+
+if __name__ == "__main__" and os.environ.get("GEN_VIT", "1") == "1":
+    gen_vit()

@@ -54,3 +54,43 @@ def make_state_dict(shapes: Dict[str, list], seed: int) -> Dict[str, torch.Tenso
                 fan = shp[1] * math.prod(shp[2:])
             sd[key] = torch.randn(shp, generator=g) * math.sqrt(2.0 / max(fan, 1.0))
     return sd
+
+
+_VIT_SHAPES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "vit_shapes.json")
+
+
+def load_vit_shapes(kind: str) -> Dict[str, list]:
+    """``kind`` in {'vit_small', 'vit_decoder'}: key -> shape of the reference modules' ``state_dict()`` (``vits.vit_small(patch_size=16)``,
+    ``VITDecoderStage4Single``), dumped by ``oracle/gen_golden.py`` from the reference's own classes."""
+    with open(_VIT_SHAPES) as f:
+        return json.load(f)[kind]
+
+
+def make_vit_state_dict(shapes: Dict[str, list], seed: int) -> Dict[str, torch.Tensor]:
+    """Seeded weights for the DINO ViT-small branch (21.7 M + 3.4 M parameters: not stored, rebuilt from the seed on both sides).  Linear
+    layers get unit-gain fan-in scaling (the default trunc_normal(0.02) init makes every attention map uniform and the test blind), the
+    q/k/v projection a gain of 2 so that the softmax is peaked; LayerNorm / BatchNorm parameters and running statistics are randomized."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for key in shapes:
+        shp = tuple(shapes[key])
+        if key.endswith("num_batches_tracked"):
+            sd[key] = torch.zeros(shp, dtype=torch.int64)
+        elif key.endswith("running_var"):
+            sd[key] = 0.5 + torch.rand(shp, generator=g)
+        elif key.endswith("running_mean"):
+            sd[key] = 0.2 * torch.randn(shp, generator=g)
+        elif key in ("cls_token", "pos_embed"):
+            sd[key] = 0.5 * torch.randn(shp, generator=g)
+        elif len(shp) == 1 and key.endswith("weight"):
+            sd[key] = 0.5 + torch.rand(shp, generator=g)            # LayerNorm / BatchNorm gains
+        elif len(shp) == 1:
+            sd[key] = 0.1 * torch.randn(shp, generator=g)           # biases
+        else:
+            if key.startswith("decoder.") and len(shp) == 4:        # ConvTranspose2d k4 s2: 4 taps per output
+                fan = shp[0] * 4.0
+            else:
+                fan = float(math.prod(shp[1:]))
+            gain = 2.0 if key.endswith("attn.qkv.weight") else 1.0
+            sd[key] = torch.randn(shp, generator=g) * (gain / math.sqrt(max(fan, 1.0)))
+    return sd

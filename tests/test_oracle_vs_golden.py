@@ -244,3 +244,23 @@ def test_fpn_encoder_oracle_vs_reference():
     assert [tuple(o.shape) for o in outs] == [(1, 8, 40, 48), (1, 16, 20, 24), (1, 32, 10, 12), (1, 64, 5, 6)]
     for i, o in enumerate(outs):
         assert max_abs(o, g["out%d" % i]) < TOL * max(1.0, float(np.abs(g["out%d" % i]).max())), i
+
+
+def test_vit_branch_oracle_vs_reference_golden():
+    """oracle/ref_vit.py (plain-torch restatement of the DINO ViT-small branch of configs/config_mvsformer-p.json) against the outputs of
+    the reference's own ``vits.vit_small`` + ``VITDecoderStage4Single`` (tests/golden/vit_small.npz, oracle/gen_golden.py::gen_vit)."""
+    from oracle import ref_vit
+    from oracle.weights import load_vit_shapes, make_vit_state_dict
+    g = load_golden("vit_small.npz")
+    sd_vit = make_vit_state_dict(load_vit_shapes("vit_small"), int(g["seeds"][0]))
+    sd_dec = make_vit_state_dict(load_vit_shapes("vit_decoder"), int(g["seeds"][1]))
+    assert sum(v.numel() for k, v in sd_vit.items()) > 21_000_000           # the real ViT-small, not a toy
+    with torch.no_grad():
+        out = ref_vit.vit_branch(sd_vit, sd_dec, torch.from_numpy(g["img"].astype(np.float32)))
+    for k, tol in (("vit_imgs", 1e-6), ("vit_feat", 2e-5), ("att_cls", 2e-6), ("vit_out", 2e-5)):
+        want = torch.from_numpy(g[k])
+        err = (out[k] - want).abs().max().item() / max(1e-6, want.abs().max().item())
+        assert err < tol, (k, err)
+    # the attention the decoder consumes is a real distribution, not the uniform one of a default-initialised ViT
+    att = torch.from_numpy(g["att_cls"])
+    assert att.max() > 4.0 / att.shape[-1] and (att.sum(-1) < 1.0).all()
