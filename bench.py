@@ -488,7 +488,30 @@ def main(args):
                   "fpn_encoder_ms_per_depth_map": round(ems, 3), "encoder_algorithmic_tflops": round(eflops / (ems * 1e-3) / 1e12, 1),
                   "peak_tflops_fp32_mfma": 157.3, "outputs": "channel-last [N,H,W,C]: consumed by the sweeps without nchw_to_nhwc",
                   "note": "FPNEncoder / FPNDecoder.forward (models/module.py:226-270), eval BatchNorm, %d views, random inputs; not in `value`" % args.views}
-        del dec, enc, outs, fenc, img
+        del dec, enc, outs, fenc
+        # the DINO ViT-small branch of MVSFormer-P (csrc/vit.hip): half-size bicubic resize, 12 blocks, attention-gated decoder, all views batched
+        from mvsformer_amd import vit as V
+        torch.manual_seed(0)
+        vnet = V.vit_small(patch_size=16, qk_scale="default").eval().to(dev)
+        vdec = V.VITDecoderStage4Single(dict(out_ch=64, vit_ch=384, att_fusion=True, nhead=6)).eval().to(dev)
+        for _ in range(2):
+            V.vit_branch(vnet, vdec, img)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(5):
+            vo = V.vit_branch(vnet, vdec, img)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        vms = e0.elapsed_time(e1) / 5
+        vh, vw = args.height // 2 // 16, args.width // 2 // 16
+        ntok = vh * vw + 1
+        vflops = args.views * 12 * (2.0 * ntok * 384 * 1152 + 4.0 * 6 * ntok * ntok * 64 + 2.0 * ntok * 384 * 384 + 4.0 * ntok * 384 * 1536) + \
+            args.views * 2.0 * (ntok - 1) * (768 * 384 + 9 * 390 * 384 + 9 * 384 * 384 + 384 * 256 + 4 * 4 * 256 * 128 + 16 * 4 * 128 * 64)
+        before.update(vit_ms_per_depth_map=round(vms, 3), vit_algorithmic_tflops=round(vflops / (vms * 1e-3) / 1e12, 1),
+                      vit_peak_tflops_split_form=round(BF16_MFMA_PEAK_TF / 6.0, 1),
+                      vit_note="vits.vit_small(patch 16) + VITDecoderStage4Single on %d views at %dx%d (half size), random weights; fp32-equivalent "
+                               "split-form GEMMs (csrc/vit.hip); not in `value`" % (args.views, args.width // 2, args.height // 2))
+        del vnet, vdec, vo, img
         torch.cuda.empty_cache()
 
     # ---- the same workload with channel-last features (what mvsformer_amd.FPNDecoder emits): no nchw_to_nhwc launches (extra key) ----

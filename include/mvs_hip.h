@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 15
+#define MVS_ABI_VERSION 16
 
 typedef void* mvs_stream_t;
 
@@ -567,6 +567,30 @@ int mvs_ce_loss_fwd(const float* logits, const float* depth_values, const float*
                     mvs_stream_t stream);
 int mvs_ce_loss_bwd_scale(const float* grad_unscaled, float* grad, int64_t numel, const float* acc, const float* grad_out, float weight,
                           mvs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * the DINO ViT-small feature branch of MVSFormer-P (csrc/vit.hip; models/vision_transformer.py:104-154,194-214,324-451,
+ * models/module.py:353-368,450-466, models/mvsformer_model.py:243-262), eval mode.  fp32 in / fp32 out; every matrix product on the bf16
+ * matrix cores in the three-term split form (fp32-equivalent, see "Arithmetic" above).
+ *   mvs_gemm_x3: C[b1][b2] = epi(alpha * A[b1][b2] . B[b1][b2]^T) for nb1 x nb2 batches with element strides s?1 / s?2 per operand;
+ *       A [M][K] rows lda apart; B [N][K] rows ldb apart (b_kn = 0) or [K][N] (b_kn = 1); C [M][N] rows ldc apart.
+ *       a_mode 1: A is the implicit im2col of a 3x3 / pad-1 convolution over a channel-last map [H][W][Cp] (M = H*W, K = 9*Cp, k = tap*Cp + c);
+ *       a_mode 2: the 2x2 taps of output-parity class b2 (ph = b2 / 2, pw = b2 % 2; nb2 = 4) of a ConvTranspose2d(kernel 4, stride 2,
+ *       padding 1) over [H][W][Cp] (M = H*W input pixels, K = 4*Cp; class output (y, x) is output pixel (2y + ph, 2x + pw)).  Cp % 8 == 0.
+ *       epi(v) = act(v*scale[n] + shift[n]) * mul + res   (scale / shift / mul / res may be NULL; act 0 none, 1 GELU(erf), 2 Swish;
+ *       mul and res are C-shaped with C's strides).
+ *   mvs_layernorm: y = (x - mean) * rsqrt(var + eps) * gamma + beta over rows of C <= 1024 features.
+ *   mvs_softmax_rows: y = softmax(scale * x) over rows of N <= 8192 (in place allowed).
+ *   mvs_bicubic_resize: ATen's upsample_bicubic2d, align_corners = False (A = -0.75, clamped taps), [planes][H][W] -> [planes][Ho][Wo];
+ *       rscale = input / output size, or 1 / scale_factor when the caller resized by a scale factor (vision_transformer.py:407-411).
+ * ------------------------------------------------------------------------------------------------------- */
+int mvs_gemm_x3(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int nb1, int nb2, int64_t sA1,
+                int64_t sA2, int64_t sB1, int64_t sB2, int64_t sC1, int64_t sC2, int b_kn, int a_mode, int H, int W, int Cp, float alpha,
+                const float* scale, const float* shift, int act, const float* mul, const float* res, mvs_stream_t stream);
+int mvs_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps, mvs_stream_t stream);
+int mvs_softmax_rows(const float* x, float* y, int64_t rows, int N, float scale, mvs_stream_t stream);
+int mvs_bicubic_resize(const float* in, float* out, int planes, int H, int W, int Ho, int Wo, float rscale_h, float rscale_w,
+                       mvs_stream_t stream);
 
 #ifdef __cplusplus
 }

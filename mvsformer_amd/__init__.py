@@ -12,7 +12,8 @@ from . import synth  # noqa: F401
 
 __all__ = ["synth", "StageNet", "DepthNet", "CostRegNet", "CostRegNet3D", "CascadeMVS", "homo_warping_3D_with_mask",
            "homo_warping_3D", "homo_warping", "depth_regression", "conf_regression", "init_inverse_range",
-           "schedule_inverse_range", "install", "fusion", "FPNDecoder", "FPNEncoder"]
+           "schedule_inverse_range", "install", "fusion", "FPNDecoder", "FPNEncoder", "vit_small", "VisionTransformer",
+           "VITDecoderStage4Single"]
 
 
 def __getattr__(name):
@@ -32,6 +33,9 @@ def __getattr__(name):
     if name in ("FPNDecoder", "FPNEncoder"):
         from . import fpn
         return getattr(fpn, name)
+    if name in ("vit_small", "VisionTransformer", "VITDecoderStage4Single"):
+        from . import vit
+        return getattr(vit, name)
     if name == "fusion":
         import importlib
         return importlib.import_module(".fusion", __name__)

@@ -12,6 +12,7 @@ import importlib
 
 from . import fpn as _f
 from . import module as _m
+from . import vit as _v
 from . import stagenet as _s
 from . import warping as _w
 
@@ -28,12 +29,15 @@ _SYMBOLS = {
     "homo_warping_3D_with_mask": _w.homo_warping_3D_with_mask,
 }
 # the rows before the path: eval-only on the HIP path, so they are rebound only on request
-_FEATURE_SYMBOLS = {"FPNDecoder": _f.FPNDecoder, "FPNEncoder": _f.FPNEncoder}
+_FEATURE_SYMBOLS = {"FPNDecoder": _f.FPNDecoder, "FPNEncoder": _f.FPNEncoder, "VITDecoderStage4Single": _v.VITDecoderStage4Single}
+# DINOMVSNet builds its backbone as ``vits.__dict__[vit_arch](...)`` (mvsformer_model.py:180): the factory is rebound in that module
+_VIT_MODULE, _VIT_FACTORIES = "models.vision_transformer", {"vit_small": _v.vit_small}
 
 
 def install(model_module: str = "models.mvsformer_model", also=("models.module", "models.warping"), features: bool = False) -> dict:
     """Rebind the hot-path names inside the reference's modules.  Returns ``{module: [names rebound]}``.
-    ``features=True`` (inference deployments) also rebinds ``FPNEncoder`` / ``FPNDecoder``, which are eval-only here: their ``forward``
+    ``features=True`` (inference deployments) also rebinds ``FPNEncoder`` / ``FPNDecoder`` / ``VITDecoderStage4Single`` and the
+    ``vit_small`` factory of ``models.vision_transformer`` (the DINO branch of MVSFormer-P), which are eval-only here: their ``forward``
     raises in training mode, so leave it off for a model that will be trained."""
     done = {}
     symbols = dict(_SYMBOLS, **(_FEATURE_SYMBOLS if features else {}))
@@ -52,4 +56,12 @@ def install(model_module: str = "models.mvsformer_model", also=("models.module",
                 setattr(mod, sym, getattr(_w, sym))
                 hit.append(sym)
         done[name] = hit
+    if features:
+        try:
+            vmod = importlib.import_module(_VIT_MODULE)
+            for sym, obj in _VIT_FACTORIES.items():
+                setattr(vmod, sym, obj)
+            done[_VIT_MODULE] = list(_VIT_FACTORIES)
+        except ImportError:
+            pass
     return done

@@ -1417,3 +1417,42 @@ def conv2d_bn_lrelu(x: torch.Tensor, packed: torch.Tensor, scale: torch.Tensor, 
     _call("mvs_conv2d_bn_lrelu", tag, _ptr(x), _ptr(packed), _ptr(scale), _ptr(shift), N, Cin, cout, k, stride, H, W, float(slope), _ptr(y),
           _stream())
     return y
+
+
+# ------------------------------------------------------------------ DINO ViT branch (csrc/vit.hip)
+def gemm_x3(A, B, C, M, N, K, lda, ldb, ldc, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), b_kn=False, a_mode=0, H=0, W=0, Cp=0, alpha=1.0,
+            scale=None, shift=None, act=0, mul=None, res=None, a_off=0, b_off=0, c_off=0):
+    """``C[b1][b2] = epi(alpha * A[b1][b2] . B[b1][b2]^T)`` on the bf16 matrix cores in three-term split form (fp32-equivalent); see
+    ``mvs_gemm_x3`` in include/mvs_hip.h.  ``?_off``: element offsets into the tensors (a head's slice of a packed qkv row)."""
+    for t, n in ((A, "A"), (B, "B"), (C, "C")):
+        _chk(t, n)
+    _opt(scale, "scale"), _opt(shift, "shift"), _opt(mul, "mul"), _opt(res, "res")
+    flops = 2.0 * M * N * K * nb1 * nb2
+    _call("mvs_gemm_x3", ("x3_gemm", "flops", flops), A.data_ptr() + 4 * a_off, B.data_ptr() + 4 * b_off, C.data_ptr() + 4 * c_off, M, N, K,
+          lda, ldb, ldc, nb1, nb2, sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], int(b_kn), int(a_mode), H, W, Cp, float(alpha), _ptr(scale),
+          _ptr(shift), int(act), (mul.data_ptr() + 4 * c_off) if mul is not None else None, (res.data_ptr() + 4 * c_off) if res is not None else None,
+          _stream())
+    return C
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    _chk(x, "x"), _chk(gamma, "gamma"), _chk(beta, "beta")
+    y = torch.empty_like(x)
+    _call("mvs_layernorm", "layernorm", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), x.numel() // x.shape[-1], x.shape[-1], float(eps), _stream())
+    return y
+
+
+def softmax_rows_(x: torch.Tensor, scale: float) -> torch.Tensor:
+    """In place: ``softmax(scale * x)`` over the last axis."""
+    _chk(x, "x")
+    _call("mvs_softmax_rows", "softmax_rows", _ptr(x), _ptr(x), x.numel() // x.shape[-1], x.shape[-1], float(scale), _stream())
+    return x
+
+
+def bicubic_resize(x: torch.Tensor, Ho: int, Wo: int, rscale_h: float, rscale_w: float) -> torch.Tensor:
+    """ATen's ``upsample_bicubic2d`` (align_corners=False) of ``[..., H, W]``; ``rscale`` = in / out, or 1 / scale_factor."""
+    _chk(x, "x")
+    H, W = x.shape[-2:]
+    out = torch.empty(tuple(x.shape[:-2]) + (Ho, Wo), device=x.device, dtype=torch.float32)
+    _call("mvs_bicubic_resize", "bicubic_resize", _ptr(x), _ptr(out), x.numel() // (H * W), H, W, Ho, Wo, float(rscale_h), float(rscale_w), _stream())
+    return out

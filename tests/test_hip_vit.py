@@ -1,0 +1,103 @@
+"""The DINO ViT-small branch (csrc/vit.hip, mvsformer_amd/vit.py) on the GPU against the reference's own outputs
+(tests/golden/vit_small.npz, made by oracle/gen_golden.py::gen_vit from the real ``vits.vit_small`` + ``VITDecoderStage4Single``) and the
+primitive kernels against plain torch (CPU, fp64 where it matters)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rel(got, want):
+    return (got.double().cpu() - want.double()).abs().max().item() / max(1e-12, want.double().abs().max().item())
+
+
+def test_vit_branch_vs_reference_golden(dev):
+    import mvsformer_amd as m
+    from mvsformer_amd import vit as V
+    from oracle.weights import load_vit_shapes, make_vit_state_dict
+    g = load_golden("vit_small.npz")
+    net = m.vit_small(patch_size=16, qk_scale="default")
+    dec = m.VITDecoderStage4Single(dict(out_ch=64, vit_ch=384, att_fusion=True, nhead=6))
+    net.load_state_dict(make_vit_state_dict(load_vit_shapes("vit_small"), int(g["seeds"][0])), strict=True)
+    dec.load_state_dict(make_vit_state_dict(load_vit_shapes("vit_decoder"), int(g["seeds"][1])), strict=True)
+    net, dec = net.to(dev).eval(), dec.to(dev).eval()
+    img = torch.from_numpy(g["img"].astype(np.float32)).to(dev)
+    out = V.vit_branch(net, dec, img)
+    torch.cuda.synchronize()
+    # fp32-equivalent arithmetic through 12 blocks: 1e-4 of the output scale, the resize to a few ulps
+    for k, tol in (("vit_imgs", 2e-6), ("vit_feat", 1e-4), ("att_cls", 1e-4), ("vit_out", 1e-4)):
+        assert _rel(out[k], torch.from_numpy(g[k])) < tol, (k, _rel(out[k], torch.from_numpy(g[k])))
+    assert out["vit_out"].shape == (1, 64, 32, 40)
+    with pytest.raises(Exception):
+        net.train()(img)                                   # eval-only on the HIP path: fails loudly
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 70, 130, 100, False), (2, 3, 33, 64, 17, True), (1, 2, 129, 65, 384, False)])
+def test_gemm_x3_vs_fp64(dev, shape):
+    from mvsformer_amd import ops
+    nb1, nb2, M, N, K, kn = shape
+    gen = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(nb1, nb2, M, K, generator=gen)
+    B = torch.randn(nb1, nb2, K, N, generator=gen) if kn else torch.randn(nb1, nb2, N, K, generator=gen)
+    scale, shift = torch.rand(N, generator=gen) + 0.5, torch.randn(N, generator=gen)
+    res = torch.randn(nb1, nb2, M, N, generator=gen)
+    C = torch.empty(nb1, nb2, M, N, device=dev)
+    ops.gemm_x3(A.to(dev), B.to(dev), C, M, N, K, K, N if kn else K, N, nb1=nb1, nb2=nb2, sA=(nb2 * M * K, M * K), sB=(nb2 * N * K, N * K),
+                sC=(nb2 * M * N, M * N), b_kn=kn, alpha=0.5, scale=scale.to(dev), shift=shift.to(dev), act=1, res=res.to(dev))
+    want = 0.5 * (A.double() @ (B.double() if kn else B.double().transpose(-1, -2))) * scale.double() + shift.double()
+    want = F.gelu(want) + res.double()
+    fp32 = F.gelu((0.5 * (A @ (B if kn else B.transpose(-1, -2)))) * scale + shift) + res
+    err, err32 = _rel(C, want), _rel(fp32, want)
+    assert err < 3 * err32 + 2e-7, (err, err32)            # the split form's contract: as close to fp64 as an fp32 product chain
+
+
+def test_gemm_x3_implicit_convs(dev):
+    from mvsformer_amd import ops
+    from mvsformer_amd.vit import _conv3_matrix, _convT_matrices
+    gen = torch.Generator().manual_seed(5)
+    B, h, w, cin, cout = 2, 7, 9, 14, 24
+    x = torch.randn(B, cin, h, w, generator=gen)
+    w3 = torch.randn(cout, cin, 3, 3, generator=gen) * 0.2
+    cp = 16
+    xcl = torch.zeros(B, h, w, cp)
+    xcl[..., :cin] = x.permute(0, 2, 3, 1)
+    out = torch.empty(B, h * w, cout, device=dev)
+    ops.gemm_x3(xcl.to(dev), _conv3_matrix(w3.to(dev), cp), out, h * w, cout, 9 * cp, 0, 9 * cp, cout, nb1=B, sA=(h * w * cp, 0), sC=(h * w * cout, 0),
+                a_mode=1, H=h, W=w, Cp=cp)
+    want = F.conv2d(x.double(), w3.double(), padding=1).permute(0, 2, 3, 1).reshape(B, h * w, cout)
+    assert _rel(out, want) < 1e-6
+    wt = torch.randn(cp, cout, 4, 4, generator=gen) * 0.2
+    tmp = torch.empty(B, 4, h * w, cout, device=dev)
+    ops.gemm_x3(xcl.to(dev), _convT_matrices(wt.to(dev)), tmp, h * w, cout, 4 * cp, 0, 4 * cp, cout, nb1=B, nb2=4, sA=(h * w * cp, 0), sB=(0, cout * 4 * cp),
+                sC=(4 * h * w * cout, h * w * cout), a_mode=2, H=h, W=w, Cp=cp)
+    got = tmp.view(B, 2, 2, h, w, cout).permute(0, 3, 1, 4, 2, 5).reshape(B, 2 * h, 2 * w, cout)
+    want = F.conv_transpose2d(xcl.permute(0, 3, 1, 2).double(), wt.double(), stride=2, padding=1).permute(0, 2, 3, 1)
+    assert _rel(got, want) < 1e-6
+
+
+def test_layernorm_softmax_bicubic(dev):
+    from mvsformer_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(37, 384, generator=gen) * 3 + 1
+    g, b = torch.rand(384, generator=gen) + 0.5, torch.randn(384, generator=gen)
+    assert _rel(ops.layernorm(x.to(dev), g.to(dev), b.to(dev), 1e-6), F.layer_norm(x.double(), (384,), g.double(), b.double(), 1e-6)) < 2e-6
+    s = torch.randn(11, 1729, generator=gen) * 4
+    assert _rel(ops.softmax_rows_(s.clone().to(dev), 0.125), torch.softmax(s.double() * 0.125, -1)) < 2e-6
+    img = torch.randn(2, 3, 50, 62, generator=gen)
+    want = F.interpolate(img, (25, 31), mode="bicubic", align_corners=False)
+    assert _rel(ops.bicubic_resize(img.to(dev), 25, 31, 50 / 25, 62 / 31), want) < 2e-6
+    tab = torch.randn(8, 14, 14, generator=gen)
+    sh, sw = (8 + 0.1) / 14, (10 + 0.1) / 14
+    want = F.interpolate(tab[None], scale_factor=(sh, sw), mode="bicubic", align_corners=False)[0]
+    assert want.shape[-2:] == (8, 10)
+    assert _rel(ops.bicubic_resize(tab.to(dev), 8, 10, 1 / sh, 1 / sw), want) < 2e-6
