@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 16
+#define MVS_ABI_VERSION 18
 
 typedef void* mvs_stream_t;
 
@@ -591,6 +591,23 @@ int mvs_layernorm(const float* x, const float* gamma, const float* beta, float* 
 int mvs_softmax_rows(const float* x, float* y, int64_t rows, int N, float scale, mvs_stream_t stream);
 int mvs_bicubic_resize(const float* in, float* out, int planes, int H, int W, int Ho, int Wo, float rscale_h, float rscale_w,
                        mvs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * training mode of the FPN encoder / decoder (models/module.py:208-270 under train(); csrc/vit.hip, csrc/fpn_train.hip).
+ * fp32 NCHW like the reference; convolutions as split-form GEMMs with an implicit patch matrix, any odd kernel size, stride 1 / 2:
+ *   mvs_conv2d_gemm_x3 mode 1: y [nb1][Cout][Ho*Wo] = w [Cout][Cin*KS*KS] . patches(x [nb1][Cin][H][W])          (A = w, Bmap = x)
+ *                      mode 2: dx [nb1][Cin][H*W]   = wT [Cin][Cout*KS*KS] . gather(dy [nb1][Cout][Ho][Wo])     (A = w.permute(1,0,2,3), Bmap = dy)
+ *                      mode 3: part [nb1][nsplit][Cout][Cin*KS*KS] = dy . patches(x)^T over ksplit output pixels per split (A = dy, Bmap = x;
+ *                              ksplit % 32 == 0, nsplit = ceil(Ho*Wo / ksplit)); the caller adds the partial matrices in a fixed order.
+ *   The BatchNorm kernels' `relu` argument (mvs_affine_act, mvs_bn_bwd_reduce, mvs_bn_bwd_apply) is an activation code: 0 none, 1 ReLU,
+ *   2 leaky ReLU(0.1) (FPNEncoder), 3 Swish (FPNDecoder).
+ *   mvs_upsample2x_add: y = bilinear_x2(x, align_corners = True) (+ lateral); mvs_upsample2x_bwd: its adjoint (a gather: no atomics).
+ * ------------------------------------------------------------------------------------------------------- */
+int mvs_conv2d_gemm_x3(int mode, const float* A, const float* Bmap, float* C, int nb1, int Cin, int Cout, int H, int W, int Ho, int Wo, int KS,
+                       int S, int P, int ksplit, mvs_stream_t stream);
+int mvs_partials_reduce(const float* part, int nparts, int n, float* out, mvs_stream_t stream);   /* out[j] = sum_p part[p*n + j], fixed order */
+int mvs_upsample2x_add(const float* x, const float* lateral, float* y, int planes, int h, int w, mvs_stream_t stream);
+int mvs_upsample2x_bwd(const float* dy, float* dx, int planes, int h, int w, mvs_stream_t stream);
 
 #ifdef __cplusplus
 }

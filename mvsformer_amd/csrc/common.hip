@@ -85,5 +85,13 @@ void launch_partials_reduce(const float* part, int nparts, int n, float* out, hi
 }
 }  // namespace mvs
 
+// out[j] = sum_p part[p*n + j] in a fixed order (the second stage of every split reduction of the library, exposed for callers that
+// produce their own partial rows: the FPN weight gradients' split-K partial matrices)
+extern "C" int mvs_partials_reduce(const float* part, int nparts, int n, float* out, mvs_stream_t stream) {
+    MVS_REQUIRE(part && out && nparts >= 1 && n >= 1, "mvs_partials_reduce: bad arguments");
+    mvs::launch_partials_reduce(part, nparts, n, out, MVS_STREAM(stream));
+    return mvs::finish_launch("mvs_partials_reduce");
+}
+
 extern "C" int mvs_version(void) { return MVS_ABI_VERSION; }
 extern "C" const char* mvs_last_error(void) { return mvs::g_err; }

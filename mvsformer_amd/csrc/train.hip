@@ -13,6 +13,24 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int CHUNK = 4096;            // elements of one (b, c) row handled by a block (256 threads x 4 x 4)
 
+// Activation codes of the BatchNorm kernels' `relu` argument (0 / 1 keep their old meaning): 0 none, 1 ReLU (the 3-D regularizer and the
+// visibility CNN), 2 leaky ReLU with slope 0.1 (FPNEncoder's Conv2d, models/module.py:66-67), 3 Swish x*sigmoid(x) (FPNDecoder, :200-206).
+__device__ __forceinline__ float act_fwd(float z, int act) {
+    if (act == 1) return fmaxf(z, 0.0f);
+    if (act == 2) return z > 0.0f ? z : 0.1f * z;
+    if (act == 3) return z / (1.0f + __expf(-z));
+    return z;
+}
+__device__ __forceinline__ float act_grad(float z, int act) {          // d act(z) / dz
+    if (act == 1) return z > 0.0f ? 1.0f : 0.0f;
+    if (act == 2) return z > 0.0f ? 1.0f : 0.1f;
+    if (act == 3) {
+        const float sg = 1.0f / (1.0f + __expf(-z));
+        return sg * (1.0f + z * (1.0f - sg));
+    }
+    return 1.0f;
+}
+
 __device__ __forceinline__ float block_sum(float v, float* red) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
@@ -122,8 +140,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
     const float sc = scale[c], sh = shift[c];
     const size_t i0 = (size_t)blockIdx.x * CHUNK, i1 = min(i0 + CHUNK, N);
     for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
-        float v = fmaf(x[base + i], sc, sh);
-        if (relu) v = fmaxf(v, 0.0f);
+        float v = act_fwd(fmaf(x[base + i], sc, sh), relu);
         if (res) v += res[base + i];
         y[base + i] = v;
     }
@@ -144,7 +161,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
             const float xv = x[base + i];
             float g = dy[base + i];
-            if (relu && !(fmaf(xv, sc, sh) > 0.0f)) g = 0.0f;
+            if (relu) g *= act_grad(fmaf(xv, sc, sh), relu);
             s1 += g;
             s2 = fmaf(g, (xv - mu) * is, s2);
         }
@@ -175,7 +192,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
         const float xv = x[base + i];
         float g = dy[base + i];
-        if (relu && !(fmaf(xv, sc, sh) > 0.0f)) g = 0.0f;
+        if (relu) g *= act_grad(fmaf(xv, sc, sh), relu);
         dx[base + i] = gi * (g - m1 - (xv - mu) * is * m2);
     }
 }

@@ -38,7 +38,31 @@ struct GemmArgs {
     int H, W, Cp;             //    (class = second batch index: ph = class / 2, pw = class % 2; k = (th*2 + tw)*Cp + c; m = y*W + x of the INPUT grid)
     int act;                  // 0 none, 1 GELU (erf), 2 Swish
     float alpha;
+    // B as the implicit patch matrix of a 2-D convolution over an NCHW map (the FPN's training convolutions, fp32 [C][H][W] per batch item):
+    //   b_mode 1  B[k = c*KS*KS + tap][n = output pixel]   = x[c][oy*S - P + ky][ox*S - P + kx]           forward:  A = weight [Cout][Cin*KS*KS]
+    //   b_mode 2  B[k = c*KS*KS + tap][n = INPUT pixel]    = dy[c][(iy + P - ky)/S][(ix + P - kx)/S]      data gradient: A = weight as [Cin][Cout*KS*KS]
+    //   b_mode 3  B[n = c*KS*KS + tap][k = output pixel]   = x[c][oy*S - P + ky][ox*S - P + kx]           weight gradient: A = dy [Cout][Ho*Wo]
+    // (zero outside the map / where the stride does not divide); cH x cW = the gathered map, cHo x cWo = the convolution's output grid.
+    int b_mode, cH, cW, cHo, cWo, cKS, cS, cP;
+    int ksplit;               // > 0: batch index b2 owns k in [b2*ksplit, (b2+1)*ksplit) (split-K partial products, reduced by the caller)
 };
+
+// element (channel*KS*KS + tap, pixel) of the implicit patch matrices above
+__device__ __forceinline__ float conv_elem(const GemmArgs& a, const float* __restrict__ base, int ct, int pix) {
+    const int KS2 = a.cKS * a.cKS, c = ct / KS2, tap = ct % KS2, ky = tap / a.cKS, kx = tap % a.cKS;
+    if (a.b_mode == 2) {
+        const int iy = pix / a.cW, ix = pix % a.cW;         // pixel of the INPUT grid; gathered map = dy [C][cHo][cWo]
+        const int ty = iy + a.cP - ky, tx = ix + a.cP - kx;
+        if (ty < 0 || tx < 0 || ty % a.cS || tx % a.cS) return 0.0f;
+        const int oy = ty / a.cS, ox = tx / a.cS;
+        if (oy >= a.cHo || ox >= a.cWo) return 0.0f;
+        return base[((size_t)c * a.cHo + oy) * a.cWo + ox];
+    }
+    const int oy = pix / a.cWo, ox = pix % a.cWo;
+    const int iy = oy * a.cS - a.cP + ky, ix = ox * a.cS - a.cP + kx;
+    if ((unsigned)iy >= (unsigned)a.cH || (unsigned)ix >= (unsigned)a.cW) return 0.0f;
+    return base[((size_t)c * a.cH + iy) * a.cW + ix];
+}
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
@@ -102,11 +126,31 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmArgs a) {
     const int srow = tid >> 2, skseg = (tid & 3) * 8;
     const int tk = tid >> 3, tn = (tid & 7) * 8;
     float pa[8], pb[8];
+    const int k_begin = a.ksplit > 0 ? b2 * a.ksplit : 0, k_end = a.ksplit > 0 ? min(a.K, k_begin + a.ksplit) : a.K;
     auto fetch = [&](int k0) {
         load_a8(a, Ab, m0 + srow, k0 + skseg, b2, pa);
+        if (a.ksplit > 0) {                                  // a split's last tile may run past its range
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (k0 + skseg + e >= k_end) pa[e] = 0.0f;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) pb[e] = 0.0f;
-        if (a.b_kn == 0) {
+        if (a.b_mode == 3) {                                 // rows n = (channel, tap), 8 consecutive k = output pixels
+            const int n = n0 + srow, k = k0 + skseg;
+            if (n < a.N) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (k + e < k_end) pb[e] = conv_elem(a, Bb, n, k + e);
+            }
+        } else if (a.b_mode != 0) {                          // row k = (channel, tap), 8 consecutive n = pixels
+            const int k = k0 + tk, n = n0 + tn;
+            if (k < k_end) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (n + e < a.N) pb[e] = conv_elem(a, Bb, k, n + e);
+            }
+        } else if (a.b_kn == 0) {
             const int n = n0 + srow, k = k0 + skseg;
             if (n < a.N && k < a.K) {
                 const float* p = Bb + (size_t)n * a.ldb + k;
@@ -132,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmArgs a) {
     };
     auto commit = [&]() {
         store_split(tA, srow, skseg, pa);
-        if (a.b_kn == 0) {
+        if (a.b_mode == 3 || (a.b_mode == 0 && a.b_kn == 0)) {
             store_split(tB, srow, skseg, pb);
         } else {                                             // transposed into [n][k]: 2-byte stores
 #pragma unroll
@@ -147,12 +191,12 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmArgs a) {
         }
     };
 
-    fetch(0);
-    for (int k0 = 0; k0 < a.K; k0 += BK) {
+    fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         __syncthreads();                                     // the previous step's fragment reads are done
         commit();
         __syncthreads();
-        if (k0 + BK < a.K) fetch(k0 + BK);                   // the next tile's loads travel under this step's MFMAs
+        if (k0 + BK < k_end) fetch(k0 + BK);                 // the next tile's loads travel under this step's MFMAs
         const unsigned char* ap = tA + (wave * 16 + j) * ROWB + kb * 16;
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap), am = *reinterpret_cast<const bf16x8*>(ap + TERMB),
                      al = *reinterpret_cast<const bf16x8*>(ap + 2 * TERMB);
@@ -310,6 +354,40 @@ extern "C" int mvs_gemm_x3(const float* A, const float* B, float* C, int M, int 
     a.act = act, a.alpha = alpha;
     hipLaunchKernelGGL(gemm_x3_kernel, dim3((N + BN - 1) / BN, (M + BM - 1) / BM, nb1 * nb2), dim3(256), 0, MVS_STREAM(stream), a);
     return mvs::finish_launch("mvs_gemm_x3");
+}
+
+// The FPN's 2-D convolutions in training (fp32 NCHW, any odd kernel size / stride 1 or 2 / padding): forward, data gradient and weight
+// gradient as the same split-form GEMM with an implicit patch matrix (mode = 1 / 2 / 3, see GemmArgs).  Per batch item b1:
+//   mode 1: y [Cout][Ho*Wo]      = w [Cout][Cin*KS*KS] . patches(x [Cin][H][W])
+//   mode 2: dx [Cin][H*W]        = wT [Cin][Cout*KS*KS] . gather(dy [Cout][Ho][Wo])         (wT = w.permute(1,0,2,3), made by the caller)
+//   mode 3: dWpart [b1][b2][Cout][Cin*KS*KS] = dy [Cout][Ho*Wo] . patches(x)^T over the k range of split b2 (ksplit pixels per split,
+//           a multiple of 32); the caller adds the nb1 * nsplit partial matrices (mvs::launch_partials_reduce order)
+extern "C" int mvs_conv2d_gemm_x3(int mode, const float* A, const float* Bmap, float* C, int nb1, int Cin, int Cout, int H, int W, int Ho, int Wo,
+                                  int KS, int S, int P, int ksplit, mvs_stream_t stream) {
+    MVS_REQUIRE(A && Bmap && C && nb1 >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1 && Ho >= 1 && Wo >= 1 && KS >= 1 && (KS & 1) && (S == 1 || S == 2) && P >= 0,
+                "mvs_conv2d_gemm_x3: bad shape");
+    MVS_REQUIRE(mode >= 1 && mode <= 3 && (mode != 3 || (ksplit >= 32 && ksplit % 32 == 0)), "mvs_conv2d_gemm_x3: mode 1..3 (mode 3 needs ksplit %% 32 == 0)");
+    GemmArgs a{};
+    a.A = A, a.B = Bmap, a.C = C, a.alpha = 1.0f, a.nb2 = 1;
+    a.b_mode = mode, a.cH = H, a.cW = W, a.cHo = Ho, a.cWo = Wo, a.cKS = KS, a.cS = S, a.cP = P;
+    const int KK = KS * KS;
+    int nb2 = 1;
+    if (mode == 1) {
+        a.M = Cout, a.N = Ho * Wo, a.K = Cin * KK, a.lda = a.K, a.ldc = a.N;
+        a.sB1 = (long long)Cin * H * W, a.sC1 = (long long)Cout * Ho * Wo;
+    } else if (mode == 2) {
+        a.M = Cin, a.N = H * W, a.K = Cout * KK, a.lda = a.K, a.ldc = a.N;
+        a.sB1 = (long long)Cout * Ho * Wo, a.sC1 = (long long)Cin * H * W;
+    } else {
+        a.M = Cout, a.N = Cin * KK, a.K = Ho * Wo, a.lda = a.K, a.ldc = a.N;
+        nb2 = (a.K + ksplit - 1) / ksplit;
+        a.ksplit = ksplit, a.nb2 = nb2;
+        a.sA1 = (long long)Cout * Ho * Wo, a.sB1 = (long long)Cin * H * W;
+        a.sC2 = (long long)a.M * a.N, a.sC1 = a.sC2 * nb2;
+    }
+    MVS_REQUIRE((int64_t)nb1 * nb2 <= 65535, "mvs_conv2d_gemm_x3: too many batch items x splits (%d x %d)", nb1, nb2);
+    hipLaunchKernelGGL(gemm_x3_kernel, dim3((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nb1 * nb2), dim3(256), 0, MVS_STREAM(stream), a);
+    return mvs::finish_launch("mvs_conv2d_gemm_x3");
 }
 
 extern "C" int mvs_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps, mvs_stream_t stream) {

@@ -13,7 +13,12 @@ copy, so the reference's ``features['stageK'] = feat.reshape(B,V,C,H,W)`` hand-o
 ``FPNEncoder`` is eleven fused conv + BatchNorm + leaky-ReLU launches (``csrc/conv2d.hip``), NCHW like the reference, so its
 outputs (and a ViT branch added to ``conv31``, mvsformer_model.py:229) feed the decoder unchanged.
 
-Eval mode only: training the 2-D feature extractor is outside the hot path; ``forward`` in training mode raises.
+Training mode (``module.train()``; what ``TwinMVSNet`` / ``DINOMVSNet`` do with their FPN, models/mvsformer_model.py:229-233): every
+layer is raw convolution -> batch-statistics BatchNorm -> activation through autograd Functions whose forward AND backward are HIP
+kernels - the convolutions (any of the encoder's 7x7 / 5x5 / 3x3, stride 1 / 2, and the decoder's 1x1 / 3x3) as split-form GEMMs with an
+implicit patch matrix (``mvs_conv2d_gemm_x3``: forward, data gradient, split-K weight gradient), BatchNorm + leaky-ReLU / Swish through
+the fp32 BatchNorm kernels of ``csrc/train.hip`` (SyncBatchNorm statistics ride the same all-reduce as in the regularizer), the decoder's
+bilinear x2 upsampling + lateral add and its adjoint in ``csrc/fpn_train.hip``.  fp32 NCHW in and out, like the reference's modules.
 """
 from __future__ import annotations
 
@@ -24,6 +29,66 @@ import torch.nn as nn
 
 from . import _lib, ops
 from .module import _publish_cache, _versions
+
+ACT_LRELU, ACT_SWISH = 2, 3          # activation codes of the BatchNorm kernels (csrc/train.hip)
+
+
+class Conv2dFn(torch.autograd.Function):
+    """Raw 2-D convolution (no bias), fp32 NCHW; forward, data gradient and weight gradient are split-form GEMMs (csrc/vit.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        x = x.to(torch.float32).contiguous()
+        w = weight.detach().to(torch.float32).contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (int(stride), int(pad))
+        return ops.conv2d_fwd_x3(x, w, int(stride), int(pad))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.cfg
+        dy = dy.contiguous()
+        dx = ops.conv2d_dgrad_x3(dy, w, stride, pad, x.shape[2], x.shape[3]) if ctx.needs_input_grad[0] else None
+        dw = ops.conv2d_wgrad_x3(dy, x, w.shape[2], stride, pad) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None
+
+
+class BiasFn(torch.autograd.Function):
+    """``x + bias[c]`` (the decoder's convolutions have a bias in front of their BatchNorm); the bias gradient is the per-channel sum the
+    BatchNorm statistics kernel already computes."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        b = bias.detach().to(torch.float32).contiguous()
+        return ops.affine_act(x.contiguous(), torch.ones_like(b), b, None, 0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        C = dy.shape[1]
+        return dy, (ops.bn_stats(dy.contiguous())[:C] if ctx.needs_input_grad[1] else None)
+
+
+class UpsampleAddFn(torch.autograd.Function):
+    """``F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True) + lateral`` (models/module.py:261,264,267)."""
+
+    @staticmethod
+    def forward(ctx, x, lateral):
+        return ops.upsample2x_add(x.contiguous(), lateral.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        return (ops.upsample2x_bwd(dy) if ctx.needs_input_grad[0] else None), (dy if ctx.needs_input_grad[1] else None)
+
+
+def _train_layer(x, conv: nn.Conv2d, bn, act: int):
+    """conv (+ bias) -> batch-statistics BatchNorm -> activation, all autograd-tracked HIP ops."""
+    from .autograd import BnActFn
+    y = Conv2dFn.apply(x, conv.weight, conv.stride[0], conv.padding[0])
+    if conv.bias is not None:
+        y = BiasFn.apply(y, conv.bias)
+    return y if bn is None else BnActFn.apply(y, bn.weight, bn.bias, None, bn, act)
 
 
 class Swish(nn.Module):
@@ -72,10 +137,19 @@ class FPNDecoder(nn.Module):
             self._cache = (key, (self.out0[0].weight.detach().reshape(ops.FPN_CH, ops.FPN_CH).contiguous(), s0, h0), levels)
         return self._cache[1], self._cache[2]
 
+    def _forward_train(self, conv01, conv11, conv21, conv31):
+        """models/module.py:257-270 with batch statistics; NCHW fp32 outputs carrying the autograd graph."""
+        intra = conv31.to(torch.float32)
+        outs = [_train_layer(intra, self.out0[0], self.out0[1], ACT_SWISH)]
+        for k, lateral in ((1, conv21), (2, conv11), (3, conv01)):
+            inner, seq = getattr(self, "inner%d" % k), getattr(self, "out%d" % k)
+            intra = UpsampleAddFn.apply(intra, _train_layer(lateral.to(torch.float32), inner, None, 0))
+            outs.append(_train_layer(intra, seq[0], seq[1], ACT_SWISH))
+        return outs
+
     def forward(self, conv01, conv11, conv21, conv31):
         if self.training:
-            raise _lib.MvsHipError("FPNDecoder: only eval mode is built on the HIP path (training the 2-D feature extractor is "
-                                   "outside the hot path, SURVEY.md §8); call .eval()")
+            return self._forward_train(conv01, conv11, conv21, conv31)
         with torch.no_grad():
             (w0, s0, h0), levels = self._prepared()
             intra = conv31.float().contiguous()
@@ -143,9 +217,14 @@ class FPNEncoder(nn.Module):
         return self._cache[1]
 
     def forward(self, x):
-        if self.training:
-            raise _lib.MvsHipError("FPNEncoder: only eval mode is built on the HIP path (training the 2-D feature extractor is "
-                                   "outside the hot path, SURVEY.md §8); call .eval()")
+        if self.training:                                    # models/module.py:226-240 with batch statistics
+            outs = {}
+            x = x.to(torch.float32)
+            for name, _, _ in self.LAYERS:
+                m = getattr(self, name)
+                x = _train_layer(x, m.conv, m.bn, ACT_LRELU)
+                outs[name] = x
+            return [outs["conv01"], outs["conv11"], outs["conv21"], outs["conv31"]]
         with torch.no_grad():
             x = x.float().contiguous()
             outs = {}

@@ -1456,3 +1456,69 @@ def bicubic_resize(x: torch.Tensor, Ho: int, Wo: int, rscale_h: float, rscale_w:
     out = torch.empty(tuple(x.shape[:-2]) + (Ho, Wo), device=x.device, dtype=torch.float32)
     _call("mvs_bicubic_resize", "bicubic_resize", _ptr(x), _ptr(out), x.numel() // (H * W), H, W, Ho, Wo, float(rscale_h), float(rscale_w), _stream())
     return out
+
+
+# ------------------------------------------------------------------ FPN training mode (csrc/vit.hip mvs_conv2d_gemm_x3, csrc/fpn_train.hip)
+def _conv2d_out(H, W, KS, S, P):
+    return (H + 2 * P - KS) // S + 1, (W + 2 * P - KS) // S + 1
+
+
+def conv2d_fwd_x3(x: torch.Tensor, w: torch.Tensor, stride: int, pad: int) -> torch.Tensor:
+    """Raw ``F.conv2d(x, w, stride=stride, padding=pad)`` (fp32 NCHW, no bias) as a split-form GEMM with an implicit patch matrix."""
+    _chk(x, "x"), _chk(w, "weight")
+    N, Cin, H, W = x.shape
+    Cout, _, KS, _ = w.shape
+    Ho, Wo = _conv2d_out(H, W, KS, stride, pad)
+    y = torch.empty(N, Cout, Ho, Wo, device=x.device, dtype=torch.float32)
+    _call("mvs_conv2d_gemm_x3", ("x3_conv2d_fwd", "flops", 2.0 * N * Cout * Cin * KS * KS * Ho * Wo), 1, _ptr(w), _ptr(x), _ptr(y), N, Cin, Cout, H, W,
+          Ho, Wo, KS, stride, pad, 0, _stream())
+    return y
+
+
+def conv2d_dgrad_x3(dy: torch.Tensor, w: torch.Tensor, stride: int, pad: int, H: int, W: int) -> torch.Tensor:
+    """Gradient of :func:`conv2d_fwd_x3` with respect to its input ``[N,Cin,H,W]``."""
+    _chk(dy, "dy"), _chk(w, "weight")
+    N, Cout, Ho, Wo = dy.shape
+    Cin, KS = w.shape[1], w.shape[2]
+    wt = w.permute(1, 0, 2, 3).contiguous()                 # [Cin][Cout*KS*KS]
+    dx = torch.empty(N, Cin, H, W, device=dy.device, dtype=torch.float32)
+    _call("mvs_conv2d_gemm_x3", ("x3_conv2d_dgrad", "flops", 2.0 * N * Cout * Cin * KS * KS * Ho * Wo), 2, _ptr(wt), _ptr(dy), _ptr(dx), N, Cin, Cout,
+          H, W, Ho, Wo, KS, stride, pad, 0, _stream())
+    return dx
+
+
+def conv2d_wgrad_x3(dy: torch.Tensor, x: torch.Tensor, KS: int, stride: int, pad: int) -> torch.Tensor:
+    """Gradient of :func:`conv2d_fwd_x3` with respect to its weight: split-K partial matrices (one per image and pixel range) added in a
+    fixed order."""
+    _chk(dy, "dy"), _chk(x, "x")
+    N, Cout, Ho, Wo = dy.shape
+    _, Cin, H, W = x.shape
+    K = Ho * Wo
+    # enough splits to fill the chip, at most 65535 / N of them, each a multiple of the 32-pixel K step
+    want = max(1, min(65535 // N, (2048 + N - 1) // N))
+    ksplit = max(32, ((K + want - 1) // want + 31) // 32 * 32)
+    nsplit = (K + ksplit - 1) // ksplit
+    n = Cout * Cin * KS * KS
+    part = torch.empty(N * nsplit, n, device=x.device, dtype=torch.float32)
+    _call("mvs_conv2d_gemm_x3", ("x3_conv2d_wgrad", "flops", 2.0 * N * Cout * Cin * KS * KS * Ho * Wo), 3, _ptr(dy), _ptr(x), _ptr(part), N, Cin, Cout,
+          H, W, Ho, Wo, KS, stride, pad, ksplit, _stream())
+    dw = torch.empty(Cout, Cin, KS, KS, device=x.device, dtype=torch.float32)
+    _call("mvs_partials_reduce", "partials_reduce", _ptr(part), N * nsplit, n, _ptr(dw), _stream())
+    return dw
+
+
+def upsample2x_add(x: torch.Tensor, lateral: Optional[torch.Tensor]) -> torch.Tensor:
+    """``F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True) (+ lateral)``, fp32 NCHW."""
+    _chk(x, "x"), _opt(lateral, "lateral")
+    N, C, h, w = x.shape
+    y = torch.empty(N, C, 2 * h, 2 * w, device=x.device, dtype=torch.float32)
+    _call("mvs_upsample2x_add", "upsample2x_add", _ptr(x), _ptr(lateral), _ptr(y), N * C, h, w, _stream())
+    return y
+
+
+def upsample2x_bwd(dy: torch.Tensor) -> torch.Tensor:
+    _chk(dy, "dy")
+    N, C, H, W = dy.shape
+    dx = torch.empty(N, C, H // 2, W // 2, device=dy.device, dtype=torch.float32)
+    _call("mvs_upsample2x_bwd", "upsample2x_bwd", _ptr(dy), _ptr(dx), N * C, H // 2, W // 2, _stream())
+    return dx

@@ -628,3 +628,36 @@ def gen_vit():
 
 if __name__ == "__main__" and os.environ.get("GEN_VIT", "1") == "1":
     gen_vit()
+
+
+def gen_fpn_train():
+    """FPNEncoder + FPNDecoder in TRAINING mode (batch-statistics BatchNorm, models/module.py:208-270 under train(); what TwinMVSNet /
+    DINOMVSNet do with their FPN): two 32x40 images through the real modules, loss = sum_i <out_i, R_i> with seeded R, every gradient.
+    Weights: oracle/weights.make_state_dict over the modules' own key/shape lists (tests/golden/fpn_shapes.json), seeds 31 / 32."""
+    from models.module import FPNDecoder, FPNEncoder
+    enc, dec = FPNEncoder([8, 16, 32, 64], norm_type="BN"), FPNDecoder([8, 16, 32, 64])
+    shapes = {"encoder": {k: list(v.shape) for k, v in enc.state_dict().items()}, "decoder": {k: list(v.shape) for k, v in dec.state_dict().items()}}
+    with open(os.path.join(OUT, "fpn_shapes.json"), "w") as f:
+        json.dump(shapes, f, indent=0)
+    enc.load_state_dict(make_state_dict(shapes["encoder"], 31), strict=True)
+    dec.load_state_dict(make_state_dict(shapes["decoder"], 32), strict=True)
+    enc.train(), dec.train()
+    g = torch.Generator().manual_seed(33)
+    x = f16exact(torch.randn(2, 3, 32, 40, generator=g)).requires_grad_(True)
+    feats = enc(x)
+    outs = dec(*feats)
+    R = [torch.randn(o.shape, generator=g) for o in outs]
+    loss = sum((o * r).sum() for o, r in zip(outs, R))
+    loss.backward()
+    arrs = {"x": np32(x).astype(np.float16), "dx": np32(x.grad), "loss": np32(loss)}
+    arrs.update({"out%d" % i: np32(o) for i, o in enumerate(outs)})
+    arrs.update({"feat%d" % i: np32(o) for i, o in enumerate(feats)})
+    for tag, m in (("enc", enc), ("dec", dec)):
+        arrs.update({"%s.grad.%s" % (tag, k): np32(p.grad) for k, p in m.named_parameters()})
+        arrs.update({"%s.buf.%s" % (tag, k): np32(b) for k, b in m.named_buffers() if b.dtype.is_floating_point})
+    arrs["seeds"] = np.array([31, 32, 33])
+    save("fpn_train.npz", **arrs)
+
+
+if __name__ == "__main__" and os.environ.get("GEN_FPN_TRAIN", "1") == "1":
+    gen_fpn_train()

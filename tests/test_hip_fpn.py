@@ -32,8 +32,9 @@ def build_decoder(sd=None, seed=0):
     return dec.eval()
 
 
-def test_fpn_decoder_is_eval_only_and_checkpoint_compatible():
-    """CPU: the parameter names are the reference's (golden state_dict loads), training mode fails loudly."""
+def test_fpn_decoder_has_no_cpu_path_and_is_checkpoint_compatible():
+    """CPU: the parameter names are the reference's (golden state_dict loads); a forward on CPU tensors fails loudly (training mode runs
+    the HIP autograd functions: there is no CPU fallback in either mode)."""
     g = load_golden("fpn_decoder.npz")
     dec = build_decoder({k[3:]: t(v) for k, v in g.items() if k.startswith("sd.")})
     assert sorted(k for k in dec.state_dict() if not k.endswith("num_batches_tracked")) == sorted(k[3:] for k in g if k.startswith("sd."))
@@ -138,7 +139,7 @@ def build_encoder(sd=None, seed=0):
     return enc.eval()
 
 
-def test_fpn_encoder_is_eval_only_and_checkpoint_compatible():
+def test_fpn_encoder_has_no_cpu_path_and_is_checkpoint_compatible():
     g = load_golden("fpn_encoder.npz")
     enc = build_encoder({k[3:]: t(v) for k, v in g.items() if k.startswith("sd.")})
     assert sorted(k for k in enc.state_dict() if not k.endswith("num_batches_tracked")) == sorted(k[3:] for k in g if k.startswith("sd."))
@@ -188,3 +189,54 @@ def test_fpn_encoder_decoder_full_size_vs_torch_on_gpu():
         assert o.shape == ww.shape
         err = float((o - ww).abs().max() / ww.abs().max())
         assert err < 1e-4, (i, err)
+
+
+@pytest.mark.gpu
+def test_fpn_training_mode_vs_reference_gradients():
+    """FPNEncoder + FPNDecoder in TRAINING mode on the HIP path (batch-statistics BatchNorm; convolutions, their data and weight gradients
+    as split-form GEMMs; bilinear upsampling and its adjoint) against outputs, EVERY parameter gradient, the input gradient and the updated
+    running statistics of the reference's own modules (tests/golden/fpn_train.npz, oracle/gen_golden.py::gen_fpn_train)."""
+    import json
+    import os
+    import mvsformer_amd as m
+    from oracle.weights import make_state_dict
+    dev = torch.device("cuda:0")
+    g = load_golden("fpn_train.npz")
+    shapes = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fpn_shapes.json")))
+    enc, dec = m.FPNEncoder([8, 16, 32, 64]), m.FPNDecoder([8, 16, 32, 64])
+    enc.load_state_dict(make_state_dict(shapes["encoder"], int(g["seeds"][0])), strict=True)
+    dec.load_state_dict(make_state_dict(shapes["decoder"], int(g["seeds"][1])), strict=True)
+    enc, dec = enc.to(dev).train(), dec.to(dev).train()
+    x = torch.from_numpy(g["x"].astype(np.float32)).to(dev).requires_grad_(True)
+    feats = enc(x)
+    outs = dec(*feats)
+    gen = torch.Generator().manual_seed(int(g["seeds"][2]))
+    torch.randn(2, 3, 32, 40, generator=gen)               # the generator state after the image, as in gen_fpn_train
+    R = [torch.randn(o.shape, generator=gen).to(dev) for o in outs]
+    loss = sum((o * r).sum() for o, r in zip(outs, R))
+    loss.backward()
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        b = torch.from_numpy(np.asarray(b)).to(torch.float64)
+        return (a.detach().double().cpu() - b).abs().max().item() / max(1e-9, b.abs().max().item())
+    for i, (f, o) in enumerate(zip(feats, outs)):
+        assert rel(f, g["feat%d" % i]) < 2e-5, ("feat", i, rel(f, g["feat%d" % i]))
+        assert rel(o, g["out%d" % i]) < 2e-5, ("out", i, rel(o, g["out%d" % i]))
+    assert rel(x.grad, g["dx"]) < 2e-4, rel(x.grad, g["dx"])
+    worst = ("", 0.0)
+    for tag, mod in (("enc", enc), ("dec", dec)):
+        for k, p in mod.named_parameters():
+            want = g["%s.grad.%s" % (tag, k)]
+            e = rel(p.grad, want)
+            # a conv bias in front of a batch-statistics BatchNorm has an exactly-zero gradient in exact arithmetic: pure rounding noise
+            tol = 2e-4 if np.abs(want).max() > 1e-3 else None
+            if tol is None:
+                assert p.grad.abs().max().item() < 1e-3, (tag, k)
+                continue
+            worst = max(worst, ("%s.%s" % (tag, k), e), key=lambda t: t[1])
+            assert e < tol, (tag, k, e)
+        for k, b in mod.named_buffers():
+            if b.dtype.is_floating_point:
+                assert rel(b, g["%s.buf.%s" % (tag, k)]) < 2e-5, (tag, k)
+    print("worst parameter gradient", worst)
