@@ -28,6 +28,14 @@ python tools/rocpd_stats.py $DB > gpurun_out/${ROUND}_kernel_stats.csv 2> gpurun
 python tools/pmc_traffic.py gpurun_out/pmc_${ROUND}/fetch gpurun_out/pmc_${ROUND}/write gpurun_out/traffic_by_kernel.json > gpurun_out/pmc_traffic.log 2>&1
 cp gpurun_out/traffic_by_kernel.json profiles/traffic_by_kernel.json; cp gpurun_out/gather_bound.json profiles/gather_bound.json; cp gpurun_out/gather_bound.txt gpurun_out/${ROUND}_gather_bound.txt   # the final bench line below reads them
 rm -rf gpurun_out/pmc_${ROUND} gpurun_out/prof_${ROUND}
+# config 3 (training): the graph-replayed step, its per-kernel table (eager events) and a kernel trace of the replays
+python bench_train.py --steps 30 --warmup 3 > gpurun_out/${ROUND}_bench_train.json 2> gpurun_out/${ROUND}_bench_train.err
+python tools/prof_train.py --bf16 > gpurun_out/${ROUND}_train_kernels_eager.txt 2>&1
+(cd /tmp && rocprofv3 --kernel-trace -d $REPO/gpurun_out/prof_train_${ROUND} -o t -- python $REPO/bench_train.py --steps 10 --warmup 2 > $REPO/gpurun_out/train_under_rocprof.json 2>/dev/null)
+DBT=$(find gpurun_out/prof_train_${ROUND} -name "*.db" | head -1)
+NK=$(python -c "import json; print(json.load(open('gpurun_out/train_under_rocprof.json'))['launches_per_step']['kernel']*5)")
+python tools/rocpd_stats.py $DBT $NK > gpurun_out/${ROUND}_train_kernel_stats.csv 2>> gpurun_out/rocpd_stats.err
+rm -rf gpurun_out/prof_train_${ROUND}
 python bench.py --steps 200 --warmup 10 > gpurun_out/${ROUND}_final_bench.json 2> gpurun_out/${ROUND}_final_bench.err
 tail -c 400 gpurun_out/${ROUND}_final_bench.err
 ls -la gpurun_out | tail -20
