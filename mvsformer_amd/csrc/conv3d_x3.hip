@@ -108,7 +108,21 @@ struct X3Args {
     float* y;
     int Cin, Cout, D, H, W, Ho, Wo, relu, tiles_x;
     int seg_planes, nseg;           // depth segments: block z = batch * nseg + segment
+#ifdef X3_PRESPLIT                  // experiment build: activations kept in memory ALREADY SPLIT, channel-last:
+    const void* xpre;               //   [B][D][H][W][h|m|l][16] bf16 (96 bytes per voxel) read by the 16 -> 16 stride-1 instance through LDS-DMA
+    void* ypre;                     //   the same form written by the 8 -> 16 stride-2 instance's epilogue
+    int fp32_out;                   //   0: the producer writes ONLY the pre-split form
+#endif
 };
+
+#ifdef X3_PRESPLIT
+typedef __attribute__((address_space(3))) void* x3_lds_ptr_t;
+// LDS-DMA: 16 bytes per lane from src + voff (+ soff) to lds_dst + lane * 16.  In a __device__ helper on purpose (tools/probe/gather_probe.hip:
+// with the builtin directly in a __global__ template body hipcc drops the kernel's host stub).
+__device__ __forceinline__ void x3_dma16(rsrc_t src, unsigned char* lds_dst, unsigned voff_bytes, unsigned soff_bytes) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (x3_lds_ptr_t)lds_dst, 16, voff_bytes, soff_bytes, 0, 0);
+}
+#endif
 
 template <int V>
 using ic = std::integral_constant<int, V>;
@@ -126,8 +140,15 @@ __device__ unsigned long long x3_phase_ticks[8];
 #define X3_STAMP(slot)
 #endif
 
+#ifdef X3_PRESPLIT
+template <class Cfg, bool PRE_IN = false, bool PRE_OUT = false>
+#else
 template <class Cfg>
+#endif
 __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3Args a) {
+#ifndef X3_PRESPLIT
+    constexpr bool PRE_IN = false, PRE_OUT = false;
+#endif
 #ifndef X3_XCD_ORDER
 #define X3_XCD_ORDER 1
 #endif
@@ -200,6 +221,20 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
                     v[r] = a.scale ? fmaf(c[mt][nt][r], sc, sh) : c[mt][nt][r] + sh;
                     if (a.relu) v[r] = fmaxf(v[r], 0.0f);
                 }
+#ifdef X3_PRESPLIT
+                if (PRE_OUT) {                             // [b][od][gy][gx][term][16 channels] bf16: lanes n = 0..15 write 32 contiguous bytes per (pixel, term)
+                    __bf16* pp = reinterpret_cast<__bf16*>(a.ypre) + ((((size_t)b * D + od) * a.Ho + gy) * a.Wo + gx) * 48 + n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        __bf16 h, m, l;
+                        mvsx3::split3(v[r], h, m, l);
+                        pp[r * 48] = h;
+                        pp[r * 48 + 16] = m;
+                        pp[r * 48 + 32] = l;
+                    }
+                    if (!a.fp32_out) continue;
+                }
+#endif
                 if (vec_ok) {
                     if (a.residual) {
                         const f32x4 rs = *reinterpret_cast<const f32x4*>(a.residual + o);
@@ -329,6 +364,28 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
 #ifdef X3_TIMELINE
         unsigned long long t_prev_ = __builtin_readcyclecounter();
 #endif
+#ifdef X3_PRESPLIT
+        if (PRE_IN) {
+            // the box of plane p straight into LDS: item i = 2*pixel + octet -> 16 bytes at lds + term*TERM_BYTES + i*16, three DMA instructions
+            // (h, m, l) per 256 items; no staging registers, no split, no LDS stores.  (Not issued a pass ahead here: one buffer.)
+            __syncthreads();                               // the previous pass's fragment reads are done
+            const rsrc_t pin = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(a.xpre)) +
+                                                                     (size_t)b * DHW * 96, 0, (unsigned)(DHW * 96), 0x00020000);
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const int i = tid + it * 256;
+                const int v = i >> 1, oct = i & 1;
+                const int gy = y0 - 1 + v / BWC, gx = x0 - 1 + v % BWC;
+                const unsigned vo = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? (unsigned)(((size_t)gy * W + gx) * 96 + oct * 16) : OOB;
+                if (i < KQ * NPIX) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        x3_dma16(pin, lds + t * TERM_BYTES + (it * 256 + wave * 64) * 16, vo, (unsigned)((size_t)p * HW * 96 + t * 32));
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+#endif
 #pragma unroll
         for (int it = 0; it < NI; ++it) issue(it, p, chunk);
         X3_STAMP(0);                                       // loads issued
@@ -339,6 +396,9 @@ __global__ __launch_bounds__(256, Cfg::MIN_BLOCKS) void x3_conv_kernel(const X3A
         X3_STAMP(2);                                       // staging loads (and the first weights) have arrived
 #endif
         commit();
+#ifdef X3_PRESPLIT
+        }
+#endif
         X3_STAMP(3);
         __syncthreads();
         X3_STAMP(4);
@@ -748,6 +808,34 @@ extern "C" int mvs_conv3d_x3_fwd(const float* x, const void* wpacked, const floa
     if (pl.ck == 8) return launch_x3<X3Cfg<8, 2, 4, 1>>(a, B, s);
     return pl.mtb == 2 ? launch_x3<X3Cfg<16, 2, 2, 2>>(a, B, s) : launch_x3<X3Cfg<16, 2, 2, 1>>(a, B, s);
 }
+
+#ifdef X3_PRESPLIT
+// experiment entry (not in the header, experiment builds only; tools/exp_presplit.py): mode 0 = conv1 (8 -> 16, stride (1,2,2)) as shipped,
+// 1 = conv1 writing ONLY the pre-split form, 2 = conv1 writing both, 3 = conv2 (16 -> 16, stride 1) as shipped, 4 = conv2 staged from the pre-split form
+extern "C" int mvs_x3_presplit_exp(int mode, const float* x, const void* xpre, const void* wpacked, const float* scale, const float* shift, float* y,
+                                   void* ypre, int B, int D, int H, int W, int relu, mvs_stream_t stream) {
+    X3Args a{};
+    a.x = x; a.wp = static_cast<const bf16x8*>(wpacked); a.scale = scale; a.shift = shift; a.residual = nullptr; a.y = y;
+    a.xpre = xpre; a.ypre = ypre; a.fp32_out = mode != 1;
+    a.D = D; a.H = H; a.W = W; a.relu = relu; a.Cout = 16;
+    const int shw = mode <= 2 ? 2 : 1;
+    a.Cin = mode <= 2 ? 8 : 16;
+    a.Ho = (H - 1) / shw + 1;
+    a.Wo = (W - 1) / shw + 1;
+    a.tiles_x = mvs::ceil_div(a.Wo, 16);
+    hipStream_t s = MVS_STREAM(stream);
+    using C1 = X3Cfg<8, 2, 4, 1>;
+    using C2 = X3Cfg<16, 1, 4, 1>;
+    const int ty = mvs::ceil_div(a.Ho, 16);
+    a.seg_planes = D, a.nseg = 1;
+    const dim3 grid(a.tiles_x * ty, 1, B);
+    if (mode == 0) hipLaunchKernelGGL((x3_conv_kernel<C1, false, false>), grid, dim3(256), 0, s, a);
+    else if (mode <= 2) hipLaunchKernelGGL((x3_conv_kernel<C1, false, true>), grid, dim3(256), 0, s, a);
+    else if (mode == 3) hipLaunchKernelGGL((x3_conv_kernel<C2, false, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((x3_conv_kernel<C2, true, false>), grid, dim3(256), 0, s, a);
+    return mvs::finish_launch("mvs_x3_presplit_exp");
+}
+#endif
 
 extern "C" int mvs_deconv3d_x3_supported(int Cin, int Cout, int sd) {
     return sd == 1 && (Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 8 || Cout == 16 || Cout == 32);
