@@ -12,6 +12,8 @@
 // data gradient (stride-1 conv <-> flipped stride-1 conv, strided conv <-> transposed conv).  Weight gradients contract over voxels
 // on the same MFMA with fragments gathered from LDS tiles.  BatchNorm / ReLU / skip kernels are the channel-last bf16 twins of
 // train.hip (statistics, and all arithmetic, in fp32).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -97,16 +99,21 @@ struct ConvArgs {
 
 // GATHER = 0: Conv3d, input voxel = out*stride - 1 + k.  GATHER = 1: ConvTranspose3d (k=3, padding 1, output_padding stride-1) as a
 // gather: input voxel = (out + 1 - k) / stride where divisible.
-template <int CIN, int NT, int GATHER, int SD, int SHW, int TAPS = 27>     // TAPS = 9: a 2-D kernel (depth tap kd = 1 only)
+// KSPLIT (32 / 64 input channels, small launches): the four wavefronts of a block share ONE work item and take every fourth K step
+// each, their partial tiles are added through LDS in a fixed order and wavefront 0 runs the epilogue.  A wavefront's K loop is a chain
+// of STEPS (27 / 54) load -> MFMA steps with ~3 steps of loads in flight: a launch with fewer wavefronts than the chip has SIMD slots
+// is bound by the length of that chain (a 64 -> 64 layer took 50-60 us on 320 voxels as on 41 000), and this makes it 4x shorter.
+template <int CIN, int NT, int GATHER, int SD, int SHW, int TAPS = 27, bool KSPLIT = false>     // TAPS = 9: a 2-D kernel (depth tap kd = 1 only)
 __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
     constexpr int KQ = CIN / 8, NKB = TAPS * KQ, STEPS = (NKB + 3) / 4, VT = 4;
     int logical;
     bool ok;
-    xcd_item((a.items + 3) / 4, logical, ok);
+    xcd_item(KSPLIT ? a.items : (a.items + 3) / 4, logical, ok);
     if (!ok) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ float sred[4][2 * 64];                      // block rows of the statistics (stats_rows > 0 only)
-    const int item = logical * 4 + wave;
+    __shared__ f32x4 kred[KSPLIT ? 3 * NT * 4 * 64 : 1];   // KSPLIT: the partial tiles of wavefronts 1..3
+    const int item = KSPLIT ? logical : logical * 4 + wave;
     if (item >= a.items) {                                 // no block-wide barrier below, except for block rows of statistics
         if (a.stats_rows > 0) {
             if (lane < 2 * a.Cout) sred[wave][lane] = 0.0f;
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
         for (int vt = 0; vt < VT; ++vt) acc[nt][vt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll 2
-    for (int step = 0; step < STEPS; ++step) {
+    for (int step = KSPLIT ? wave : 0; step < STEPS; step += KSPLIT ? 4 : 1) {
         const int t = 4 * step + kb;
         const int tap = t / KQ, cq = t % KQ;
         const int kd = TAPS == 9 ? 1 : tap / 9, kh = TAPS == 9 ? tap / 3 : (tap / 3) % 3, kw = tap % 3;
@@ -170,6 +177,32 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt) acc[nt][vt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[vt], acc[nt][vt], 0, 0, 0);
         }
+    }
+    if (KSPLIT) {                                          // partial tiles of wavefronts 1..3 -> wavefront 0, added in that order
+        if (wave > 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt) kred[((wave - 1) * NT * VT + nt * VT + vt) * 64 + lane] = acc[nt][vt];
+        }
+        __syncthreads();
+        if (wave > 0) {
+            if (a.stats_rows > 0) {                        // only wavefront 0 has statistics: the others contribute zeros to the block row
+                if (lane < 2 * a.Cout) sred[wave][lane] = 0.0f;
+                if (lane + 64 < 2 * a.Cout) sred[wave][lane + 64] = 0.0f;
+                __syncthreads();
+                if ((int)threadIdx.x < 2 * a.Cout)         // ... and wavefront 1 writes the row's entries 64..127 (Cout = 64)
+                    a.stats_part[(size_t)threadIdx.x * a.stats_rows + logical] =
+                        (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+            }
+            return;
+        }
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int vt = 0; vt < VT; ++vt) acc[nt][vt] += kred[(w * NT * VT + nt * VT + vt) * 64 + lane];
     }
     // D[i = co (4*kb + r inside the tile)][j = voxel]: a lane owns 4 consecutive output channels of one voxel -> one 8-byte store
     float ssum[NT][4], ssq[NT][4];
@@ -614,21 +647,29 @@ __global__ __launch_bounds__(256) void bf16_bn_bwd_apply_kernel(const __bf16* __
 
 bool chan_ok(int c) { return c == 8 || c == 16 || c == 32 || c == 64; }
 
+// K split over a block's wavefronts (see bf16_conv_kernel): 32 / 64 input channels (27 / 54 steps per wavefront) while the launch has
+// fewer work items than ~8 per CU - above that there are enough wavefronts per SIMD to hide a step's latency behind other items' steps
+bool conv_ksplit(int cin, int items, int taps) {
+    static const int lim = [] { const char* e = getenv("MVS_BF16_KSPLIT_ITEMS"); return e ? atoi(e) : 2048; }();
+    return taps == 27 && cin >= 32 && items <= lim;
+}
+
 template <int GATHER, int SD, int SHW>
 int launch_conv(const ConvArgs& a, int cin, int nt, hipStream_t s) {
-    const unsigned grid = (unsigned)((((a.items + 3) / 4 + 7) / 8) * 8);
-#define MVS_BF16_GO(CINV, NTV) hipLaunchKernelGGL((bf16_conv_kernel<CINV, NTV, GATHER, SD, SHW>), dim3(grid), dim3(256), 0, s, a)
-#define MVS_BF16_NT(CINV)                      \
-    switch (nt) {                              \
-        case 1: MVS_BF16_GO(CINV, 1); break;   \
-        case 2: MVS_BF16_GO(CINV, 2); break;   \
-        default: MVS_BF16_GO(CINV, 4); break;  \
+    const bool ks = conv_ksplit(cin, a.items, 27);
+    const unsigned grid = (unsigned)((((ks ? a.items : (a.items + 3) / 4) + 7) / 8) * 8);
+#define MVS_BF16_GO(CINV, NTV, KSV) hipLaunchKernelGGL((bf16_conv_kernel<CINV, NTV, GATHER, SD, SHW, 27, KSV>), dim3(grid), dim3(256), 0, s, a)
+#define MVS_BF16_NT(CINV, KSV)                      \
+    switch (nt) {                                   \
+        case 1: MVS_BF16_GO(CINV, 1, KSV); break;   \
+        case 2: MVS_BF16_GO(CINV, 2, KSV); break;   \
+        default: MVS_BF16_GO(CINV, 4, KSV); break;  \
     }
     switch (cin) {
-        case 8: MVS_BF16_NT(8); break;
-        case 16: MVS_BF16_NT(16); break;
-        case 32: MVS_BF16_NT(32); break;
-        default: MVS_BF16_NT(64); break;
+        case 8: MVS_BF16_NT(8, false); break;
+        case 16: MVS_BF16_NT(16, false); break;
+        case 32: if (ks) { MVS_BF16_NT(32, true); } else { MVS_BF16_NT(32, false); } break;
+        default: if (ks) { MVS_BF16_NT(64, true); } else { MVS_BF16_NT(64, false); } break;
     }
 #undef MVS_BF16_NT
 #undef MVS_BF16_GO
@@ -764,7 +805,7 @@ static int bf16_conv3d_impl(const void* x, const void* wpacked, const float* sca
     MVS_REQUIRE(items < ((int64_t)1 << 30), "mvs_bf16_conv3d: too many rows");
     a.items = (int)items;
     a.stats_part = stats_part;
-    a.stats_rows = block_rows ? (int)((items + 3) / 4) : 0;
+    a.stats_rows = block_rows ? (int)(conv_ksplit(Cin, (int)items, taps) ? items : (items + 3) / 4) : 0;      // one row per BLOCK
     hipStream_t s = MVS_STREAM(stream);
     const int nt = nt_of(Cout);
     int rc;
@@ -1118,7 +1159,7 @@ __global__ __launch_bounds__(256) void bf16_bn_rows_finalize_kernel(const float*
 extern "C" int64_t mvs_bf16_conv3d_bn_fwd_workspace_bytes(int B, int Cout, int Do, int Ho, int Wo) {
     if (!chan_ok(Cout) || B < 1 || Do < 1 || Ho < 1 || Wo < 1) return -1;
     const int64_t items = (int64_t)B * Do * Ho * ((Wo + 63) / 64);
-    return ((items + 3) / 4) * 2 * Cout * (int64_t)sizeof(float);
+    return items * 2 * Cout * (int64_t)sizeof(float);      // one row per block: up to one block per work item (the K-split form)
 }
 
 // y = raw conv(x) (kept: the BatchNorm backward needs it), z = [relu](BatchNorm_train(y)) [+ residual]; stats4 = [scale | shift | mean |
@@ -1141,7 +1182,8 @@ extern "C" int mvs_bf16_conv3d_bn_fwd(const void* x, const void* wpacked, void* 
                                   reinterpret_cast<float*>(workspace), groups, nullptr, stream, true, taps))
         return rc;
     hipStream_t s = MVS_STREAM(stream);
-    const int nrows = (int)((ips * B + 3) / 4), rps = B == 1 ? nrows : (int)(ips / 4);
+    const bool ks = conv_ksplit(Cin, (int)(ips * B), taps);                  // one work item per block then: four times the rows
+    const int nrows = ks ? (int)(ips * B) : (int)((ips * B + 3) / 4), rps = B == 1 ? nrows : (int)(ks ? ips : ips / 4);
     const int64_t R = (int64_t)B * Do * Ho * Wo;
     hipLaunchKernelGGL(bf16_bn_rows_finalize_kernel, dim3(Cout), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), nrows, rps, B, groups,
                        Cout, gamma, beta, running_mean, running_var, momentum, eps, (double)(R / groups), stats4,
