@@ -122,14 +122,24 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
         }
         return;
     }
-    const int wchunk = item % a.nwchunks;
-    const int oh = (item / a.nwchunks) % a.Ho;
-    const int od = (item / (a.nwchunks * a.Ho)) % a.Do;
-    const int b = item / (a.nwchunks * a.Ho * a.Do);
+    // Transposed convolution (GATHER = 1), column stride 2: a work item is the 64 output voxels of ONE column parity of a 128-column chunk
+    // of a row (item's lowest bit = the parity), so that which taps exist is the same for all of its voxels - row / depth parities are a
+    // row's anyway.  The K loop then walks only the existing taps (1 / 2 per strided axis: 6.75 of 27 on average at stride (1,2,2), 3.4 at
+    // (2,2,2)) instead of multiplying structural zeros for the others.
+    constexpr int WSTEP = (GATHER == 1 && SHW == 2) ? 2 : 1;                    // output-column step between a lane's neighbours
+    const int pw = WSTEP == 2 ? (item & 1) : 0, item_ = WSTEP == 2 ? (item >> 1) : item;
+    const int wchunk = item_ % a.nwchunks;
+    const int oh = (item_ / a.nwchunks) % a.Ho;
+    const int od = (item_ / (a.nwchunks * a.Ho)) % a.Do;
+    const int b = item_ / (a.nwchunks * a.Ho * a.Do);
     const int j = lane & 15, kb = lane >> 4;
-    const int ow0 = wchunk * 64;
+    const int ow0 = wchunk * 64 * WSTEP + pw;
+    // existing taps per axis for this item's parities: stride 1 -> k = 0, 1, 2; stride 2 -> parity 0: k = 1, parity 1: k = 0, 2
+    const int nkd = (GATHER == 1 && SD == 2) ? ((od & 1) ? 2 : 1) : 3, nkh = (GATHER == 1 && SHW == 2) ? ((oh & 1) ? 2 : 1) : 3,
+              nkw = (GATHER == 1 && SHW == 2) ? (pw ? 2 : 1) : 3;
+    const int nsteps = GATHER == 1 ? (nkd * nkh * nkw * KQ + 3) / 4 : STEPS;
     const rsrc_t xr = make_rsrc(a.x + (size_t)b * a.Di * a.Hi * a.Wi * CIN, (unsigned)((size_t)a.Di * a.Hi * a.Wi * CIN * 2));
-    const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wp) + lane;
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wp) + (GATHER == 1 ? j : lane);
 
     f32x4 acc[NT][VT];
 #pragma unroll
@@ -138,11 +148,25 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
         for (int vt = 0; vt < VT; ++vt) acc[nt][vt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll 2
-    for (int step = KSPLIT ? wave : 0; step < STEPS; step += KSPLIT ? 4 : 1) {
-        const int t = 4 * step + kb;
-        const int tap = t / KQ, cq = t % KQ;
-        const int kd = TAPS == 9 ? 1 : tap / 9, kh = TAPS == 9 ? tap / 3 : (tap / 3) % 3, kw = tap % 3;
+    for (int step = KSPLIT ? wave : 0; step < nsteps; step += KSPLIT ? 4 : 1) {
+        int t = 4 * step + kb;                              // K block of this lane group: (tap, channel octet)
+        int tap = t / KQ;
+        const int cq = t % KQ;
         bool rowok = t < NKB;
+        int kd, kh, kw;
+        if (GATHER == 1) {
+            // compact index over the EXISTING taps -> the tap itself; the weight fragment of K block (tap, cq) sits in the packed image at
+            // step (tap*KQ + cq) / 4, lane group (tap*KQ + cq) % 4 - read from there whatever lane group multiplies it
+            rowok = tap < nkd * nkh * nkw;
+            const int ikd = tap / (nkh * nkw), ikh = (tap / nkw) % nkh, ikw = tap % nkw;
+            kd = SD == 2 ? (nkd == 2 ? 2 * ikd : 1) : ikd;
+            kh = SHW == 2 ? (nkh == 2 ? 2 * ikh : 1) : ikh;
+            kw = SHW == 2 ? (nkw == 2 ? 2 * ikw : 1) : ikw;
+            tap = min((kd * 3 + kh) * 3 + kw, 26);
+            t = tap * KQ + cq;
+        } else {
+            kd = TAPS == 9 ? 1 : tap / 9, kh = TAPS == 9 ? tap / 3 : (tap / 3) % 3, kw = tap % 3;
+        }
         int id, ih;
         if (GATHER == 0) {
             id = od * SD - 1 + kd;
@@ -158,7 +182,7 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
         bf16x8 xb[VT];
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt) {
-            const int ow = ow0 + vt * 16 + j;
+            const int ow = ow0 + (vt * 16 + j) * WSTEP;
             int iw;
             bool v = rowok;
             if (GATHER == 0) {
@@ -173,7 +197,8 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const bf16x8 wa = wp[(size_t)(step * NT + nt) * 64];
+            const bf16x8 wa = GATHER == 1 ? (rowok ? wp[(size_t)((t >> 2) * NT + nt) * 64 + (t & 3) * 16] : bf16x8{})
+                                          : wp[(size_t)(step * NT + nt) * 64];
 #pragma unroll
             for (int vt = 0; vt < VT; ++vt) acc[nt][vt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[vt], acc[nt][vt], 0, 0, 0);
         }
@@ -212,7 +237,7 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
         for (int r = 0; r < 4; ++r) ssum[nt][r] = ssq[nt][r] = 0.0f;
 #pragma unroll
     for (int vt = 0; vt < VT; ++vt) {
-        const int ow = ow0 + vt * 16 + j;
+        const int ow = ow0 + (vt * 16 + j) * WSTEP;
         if (ow >= a.Wo) continue;
         const size_t vox = (((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
 #pragma unroll
@@ -773,7 +798,7 @@ extern "C" int mvs_bf16_conv3d_taps(const void* x, const void* wpacked, void* y,
 // mvs_bf16_conv3d_stats_workspace_bytes (one partial row per work item, then the fixed-order reduce).
 extern "C" int64_t mvs_bf16_conv3d_stats_workspace_bytes(int B, int Cout, int Do, int Ho, int Wo) {
     if (!chan_ok(Cout) || B < 1 || Do < 1 || Ho < 1 || Wo < 1) return -1;
-    return (int64_t)B * Do * Ho * ((Wo + 63) / 64) * 2 * Cout * (int64_t)sizeof(float);
+    return (int64_t)B * Do * Ho * ((Wo + 127) / 128) * 2 * 2 * Cout * (int64_t)sizeof(float);      // >= the work items of either form
 }
 
 extern "C" int mvs_bf16_conv3d_stats(const void* x, const void* wpacked, void* y, int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather,
@@ -800,8 +825,10 @@ static int bf16_conv3d_impl(const void* x, const void* wpacked, const float* sca
     a.B = B, a.Di = Di, a.Hi = Hi, a.Wi = Wi, a.Cout = Cout;
     if (gather == 0) a.Do = (Di - 1) / sd + 1, a.Ho = (Hi - 1) / shw + 1, a.Wo = (Wi - 1) / shw + 1;
     else a.Do = Di * sd, a.Ho = Hi * shw, a.Wo = Wi * shw;
-    a.nwchunks = (a.Wo + 63) / 64;
-    const int64_t items = (int64_t)B * a.Do * a.Ho * a.nwchunks;
+    // work items: 64 output voxels of a row; the transposed form with column stride 2 takes the two column parities of a 128-voxel chunk as two items
+    const bool wpar = gather == 1 && shw == 2;
+    a.nwchunks = wpar ? (a.Wo + 127) / 128 : (a.Wo + 63) / 64;
+    const int64_t items = (int64_t)B * a.Do * a.Ho * a.nwchunks * (wpar ? 2 : 1);
     MVS_REQUIRE(items < ((int64_t)1 << 30), "mvs_bf16_conv3d: too many rows");
     a.items = (int)items;
     a.stats_part = stats_part;
@@ -825,7 +852,7 @@ static int bf16_conv3d_impl(const void* x, const void* wpacked, const float* sca
     }
     if (rc != MVS_OK || !stats_part || block_rows) return rc;
     // work items are sample-major, so the rows of sample b are [b*bps, (b+1)*bps): the grouped fixed-order reduce applies as is
-    mvs::launch_partials_reduce_grouped(stats_part, a.Do * a.Ho * a.nwchunks, B, groups, Cout, sums, s);
+    mvs::launch_partials_reduce_grouped(stats_part, (int)(items / B), B, groups, Cout, sums, s);
     return mvs::finish_launch("mvs_bf16_conv3d_stats");
 }
 
@@ -1158,7 +1185,7 @@ __global__ __launch_bounds__(256) void bf16_bn_rows_finalize_kernel(const float*
 
 extern "C" int64_t mvs_bf16_conv3d_bn_fwd_workspace_bytes(int B, int Cout, int Do, int Ho, int Wo) {
     if (!chan_ok(Cout) || B < 1 || Do < 1 || Ho < 1 || Wo < 1) return -1;
-    const int64_t items = (int64_t)B * Do * Ho * ((Wo + 63) / 64);
+    const int64_t items = (int64_t)B * Do * Ho * ((Wo + 127) / 128) * 2;           // >= the work items of either form (see bf16_conv3d_impl)
     return items * 2 * Cout * (int64_t)sizeof(float);      // one row per block: up to one block per work item (the K-split form)
 }
 
@@ -1175,7 +1202,7 @@ extern "C" int mvs_bf16_conv3d_bn_fwd(const void* x, const void* wpacked, void* 
     int Do, Ho, Wo;
     if (gather == 0) Do = (Di - 1) / sd + 1, Ho = (Hi - 1) / shw + 1, Wo = (Wi - 1) / shw + 1;
     else Do = Di * sd, Ho = Hi * shw, Wo = Wi * shw;
-    const int64_t ips = (int64_t)Do * Ho * ((Wo + 63) / 64);                // work items per sample
+    const int64_t ips = (gather == 1 && shw == 2) ? (int64_t)Do * Ho * ((Wo + 127) / 128) * 2 : (int64_t)Do * Ho * ((Wo + 63) / 64);   // work items per sample
     MVS_REQUIRE(B == 1 || ips % 4 == 0, "mvs_bf16_conv3d_bn_fwd: %lld work items per sample are not a multiple of 4 (block rows would straddle samples)",
                 (long long)ips);
     if (int rc = bf16_conv3d_impl(x, wpacked, nullptr, nullptr, nullptr, y, B, Cin, Cout, Di, Hi, Wi, gather, sd, shw, 0,
