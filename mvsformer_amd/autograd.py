@@ -598,23 +598,34 @@ class LayerBf16Fn(torch.autograd.Function):
         mom = bn.momentum if groups > 1 else (_momentum(bn) if track else 0.0)
         nbt = bn.num_batches_tracked if track and bn.num_batches_tracked is not None else None       # incremented by the kernel
         res = residual.contiguous() if residual is not None else None
-        y, z, scale, shift, mean, invstd = ops.bf16_conv3d_bn_fwd(x, wf, cin_map, cout, gather, stride, res, relu, g, b, rm, rv, mom, bn.eps,
-                                                                  groups, nbt, taps)
-        gfull = g if g is not None else scale.new_ones(cout)
+        y, z, st = ops.bf16_conv3d_bn_fwd(x, wf, cin_map, cout, gather, stride, res, relu, g, b, rm, rv, mom, bn.eps, groups, nbt, taps)
+        gfull = g if g is not None else st.new_ones(cout)
         if groups > 1:
             gfull = gfull.repeat(groups)
-        ctx.save_for_backward(x, wb, y, scale, shift, mean, invstd, gfull)
+        ctx.save_for_backward(x, wb, y, st, gfull)
         ctx.cfg = (relu, gather, tuple(stride), groups, cin, cin_map, cout, residual is not None, taps)
+        # The producer of x, if it is a layer of this kind whose output feeds only this one: its BatchNorm's backward sums can be taken in
+        # the epilogue of OUR data gradient (which IS its incoming gradient) instead of by a pass of their own.  The tag rides on the
+        # tensor object; a tensor that also feeds a skip connection has it removed by the network (module.py), and a gradient that was
+        # accumulated from two consumers arrives as a new tensor without the answer attached - the plain reduce runs then.
+        ctx.prev_bn = getattr(x, "_mvs_bn", None) if need_dx and _fused_layers() else None
+        z._mvs_bn = (y, st, relu, groups)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x, wb, y, scale, shift, mean, invstd, gfull = ctx.saved_tensors
+        x, wb, y, st, gfull = ctx.saved_tensors
+        scale, shift, mean, invstd = st[0], st[1], st[2], st[3]
         relu, gather, (sd, shw), groups, cin, cin_map, cout, has_res, taps = ctx.cfg
         dz = dz.contiguous()
-        # (an in-launch completion of the reduce - last block to arrive adds the partial rows - was built and measured: a thousand
+        # the two sums of the BatchNorm backward: taken by the consumer's data-gradient convolution if it knew us (see forward), else here.
+        # (An in-launch completion of the reduce - last block to arrive adds the partial rows - was built and measured: a thousand
         #  same-address agent-scope atomics cost 15-25 us per call, three times the launch they replace; NOTEBOOK.md)
-        sums = ops.bf16_bn_bwd_reduce(dz, y, scale, shift, mean, invstd, relu, groups)
+        tag = getattr(dz, "_mvs_bn_sums", None)
+        if tag is not None and tag[0] == y.data_ptr() and tag[1] == dz.data_ptr():
+            sums = tag[2]
+        else:
+            sums = ops.bf16_bn_bwd_reduce(dz, y, scale, shift, mean, invstd, relu, groups)
         dy = ops.bf16_bn_bwd_apply(dz, y, scale, shift, mean, invstd, gfull, sums, float(y.numel() // (cout * groups)), relu, None, groups)
         CT = cout * groups
         if groups > 1:                                                        # shared parameters: sum the groups' gradients (one launch)
@@ -624,10 +635,15 @@ class LayerBf16Fn(torch.autograd.Function):
             dbeta, dgamma = sums[:CT], sums[CT:]
         dx = None
         if ctx.needs_input_grad[0]:
-            if gather == 0:     # stride 1: the same conv with channels swapped and taps mirrored; strided: the transposed conv
-                dx = ops.bf16_conv3d(dy, wb, cout, cin_map, 0 if shw == 1 else 1, (1, 1) if shw == 1 else (sd, shw), taps=taps)
-            else:               # transposed conv: strided conv of dY with W read as [out = cin, in = cout]
-                dx = ops.bf16_conv3d(dy, wb, cout, cin, 0, (sd, 2))
+            # stride 1: the same conv with channels swapped and taps mirrored; strided: the transposed conv; transposed conv: the strided
+            # conv of dY with W read as [out = cin, in = cout]
+            g_, st_, cin_ = ((0 if shw == 1 else 1), ((1, 1) if shw == 1 else (sd, shw)), cin_map) if gather == 0 else (0, (sd, 2), cin)
+            prev = ctx.prev_bn
+            if prev is not None and tuple(prev[0].shape) == tuple(x.shape):
+                dx, psums = ops.bf16_conv3d_bnbwd(dy, wb, cout, cin_, g_, st_, prev[0], prev[1], prev[2], prev[3], taps)
+                dx._mvs_bn_sums = (prev[0].data_ptr(), dx.data_ptr(), psums)
+            else:
+                dx = ops.bf16_conv3d(dy, wb, cout, cin_, g_, st_, taps=taps)
             if dx.shape != x.shape:
                 raise ops._lib.MvsHipError("conv backward: input %s does not match the gradient grid %s" % (tuple(x.shape), tuple(dx.shape)))
         dw = None

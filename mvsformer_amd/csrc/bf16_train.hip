@@ -95,7 +95,14 @@ struct ConvArgs {
     float* stats_part;        // optional [items][2*Cout]: per work item, sum and sum of squares of the bf16-ROUNDED outputs per channel
                               // (the batch statistics of the BatchNorm that follows: no separate pass over y)
     int stats_rows;           // > 0: BLOCK rows instead, transposed: stats_part[j * stats_rows + block] for j < 2*Cout (the four waves of
-};                            // a block combined through LDS in a fixed order; mvs_bf16_conv3d_bn_fwd)
+                              // a block combined through LDS in a fixed order; mvs_bf16_conv3d_bn_fwd)
+    // bn_y != null (with stats_rows > 0): the rows are NOT the output's statistics but the two sums of a BatchNorm(+ReLU) BACKWARD whose
+    // incoming gradient this convolution produces (the data gradient of the NEXT layer = dz of the previous one): g = y_out * [relu'(bn_y *
+    // scale + shift)], rows = [sum g | sum g * (bn_y - mean) * invstd] per channel; bn4 = [scale | shift | mean | invstd], each bn_groups*Cout
+    const __bf16* bn_y;
+    const float* bn4;
+    int bn_relu, bn_groups;
+};
 
 // GATHER = 0: Conv3d, input voxel = out*stride - 1 + k.  GATHER = 1: ConvTranspose3d (k=3, padding 1, output_padding stride-1) as a
 // gather: input voxel = (out + 1 - k) / stride where divisible.
@@ -258,7 +265,19 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
             }
             const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
             *reinterpret_cast<bf16x4*>(a.y + vox * a.Cout + co0) = o;
-            if (a.stats_part) {
+            if (a.bn_y) {                                  // BatchNorm backward sums of the layer this gradient belongs to
+                const bf16x4 yv = *reinterpret_cast<const bf16x4*>(a.bn_y + vox * a.Cout + co0);
+                const int CT = a.Cout * a.bn_groups;
+                const float* p4 = a.bn4 + (b % a.bn_groups) * a.Cout + co0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float f = (float)yv[r];
+                    float g = (float)o[r];                 // the ROUNDED gradient: what the apply kernel reads
+                    if (a.bn_relu && !(fmaf(f, p4[r], p4[CT + r]) > 0.0f)) g = 0.0f;
+                    ssum[nt][r] += g;
+                    ssq[nt][r] = fmaf(g, (f - p4[2 * CT + r]) * p4[3 * CT + r], ssq[nt][r]);
+                }
+            } else if (a.stats_part) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float f = (float)o[r];          // what BatchNorm will see
@@ -777,7 +796,8 @@ extern "C" int mvs_bf16_pack_table_run(const void* dev_table, int njobs, int tot
 // gather: 0 = Conv3d (out = (in - 1)/stride + 1), 1 = ConvTranspose3d k3 p1 op(stride-1) (out = in*stride)
 static int bf16_conv3d_impl(const void* x, const void* wpacked, const float* scale, const float* shift, const void* residual, void* y,
                             int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd, int shw, int relu, float* stats_part,
-                            int groups, float* sums, mvs_stream_t stream, bool block_rows = false, int taps = 27);
+                            int groups, float* sums, mvs_stream_t stream, bool block_rows = false, int taps = 27, const void* bn_y = nullptr,
+                            const float* bn4 = nullptr, int bn_relu = 0, int bn_groups = 1);
 
 extern "C" int mvs_bf16_conv3d(const void* x, const void* wpacked, const float* scale, const float* shift, const void* residual, void* y,
                                int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd, int shw, int relu,
@@ -810,7 +830,8 @@ extern "C" int mvs_bf16_conv3d_stats(const void* x, const void* wpacked, void* y
 
 static int bf16_conv3d_impl(const void* x, const void* wpacked, const float* scale, const float* shift, const void* residual, void* y,
                             int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd, int shw, int relu, float* stats_part,
-                            int groups, float* sums, mvs_stream_t stream, bool block_rows, int taps) {
+                            int groups, float* sums, mvs_stream_t stream, bool block_rows, int taps, const void* bn_y, const float* bn4,
+                            int bn_relu, int bn_groups) {
     MVS_REQUIRE(x && wpacked && y, "mvs_bf16_conv3d: null pointer");
     MVS_REQUIRE(taps == 27 || (taps == 9 && gather == 0 && sd == 1 && shw == 1 && Cin <= 16 && Cout <= 16),
                 "mvs_bf16_conv3d: taps = 9 (2-D kernel) is built for stride-1 convolutions of up to 16 channels");
@@ -831,6 +852,7 @@ static int bf16_conv3d_impl(const void* x, const void* wpacked, const float* sca
     const int64_t items = (int64_t)B * a.Do * a.Ho * a.nwchunks * (wpar ? 2 : 1);
     MVS_REQUIRE(items < ((int64_t)1 << 30), "mvs_bf16_conv3d: too many rows");
     a.items = (int)items;
+    a.bn_y = reinterpret_cast<const __bf16*>(bn_y), a.bn4 = bn4, a.bn_relu = bn_relu, a.bn_groups = bn_groups;
     a.stats_part = stats_part;
     a.stats_rows = block_rows ? (int)(conv_ksplit(Cin, (int)items, taps) ? items : (items + 3) / 4) : 0;      // one row per BLOCK
     hipStream_t s = MVS_STREAM(stream);
@@ -1182,6 +1204,49 @@ __global__ __launch_bounds__(256) void bf16_bn_rows_finalize_kernel(const float*
 }
 
 }  // namespace
+
+namespace {
+// part = [2C][nrows] transposed block rows (rows of sample b = [b*rps, (b+1)*rps), sample b in group b % groups) -> sums
+// [sum (groups*C) | second sum (groups*C)], fixed order: one block per (group, row kind j), its threads stride over the group's rows
+__global__ __launch_bounds__(256) void bf16_rows_reduce_kernel(const float* __restrict__ part, int nrows, int rps, int nsamples, int groups, int C,
+                                                               float* __restrict__ sums) {
+    __shared__ float red[4];
+    const int q = blockIdx.x / (2 * C), j = blockIdx.x % (2 * C);
+    const int per = (nsamples / groups) * rps;
+    const float* p = part + (size_t)j * nrows;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < per; i += 256) s += p[(q + (i / rps) * groups) * rps + (i % rps)];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[(j >= C ? groups * C : 0) + q * C + (j % C)] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+}  // namespace
+
+// Raw convolution (no epilogue arithmetic) whose OUTPUT is the gradient dz arriving at a BatchNorm(+ReLU) layer - the data gradient of the layer
+// after it - with that BatchNorm's two backward sums taken in the convolution's epilogue: sums [2*groups*Cout] = [sum g | sum g*xhat],
+// g = dz * [bn_y*scale + shift > 0 or !relu], exactly what mvs_bf16_bn_bwd_reduce(dz, bn_y, ...) returns, without the pass over dz and bn_y.
+// bn4 = the forward's stats4 ([scale | shift | mean | invstd], each groups*Cout); workspace = mvs_bf16_conv3d_bn_fwd_workspace_bytes.
+extern "C" int mvs_bf16_conv3d_bnbwd(const void* x, const void* wpacked, void* y, int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd,
+                                     int shw, int taps, const void* bn_y, const float* bn4, int relu, int groups, float* sums, void* workspace,
+                                     mvs_stream_t stream) {
+    MVS_REQUIRE(bn_y && bn4 && sums && workspace && groups >= 1 && B % groups == 0, "mvs_bf16_conv3d_bnbwd: bad arguments (B=%d groups=%d)", B, groups);
+    MVS_REQUIRE((sd == 1 || sd == 2) && (shw == 1 || shw == 2) && (gather == 0 || gather == 1), "mvs_bf16_conv3d_bnbwd: bad stride / gather");
+    int Do, Ho, Wo;
+    if (gather == 0) Do = (Di - 1) / sd + 1, Ho = (Hi - 1) / shw + 1, Wo = (Wi - 1) / shw + 1;
+    else Do = Di * sd, Ho = Hi * shw, Wo = Wi * shw;
+    const int64_t ips = (gather == 1 && shw == 2) ? (int64_t)Do * Ho * ((Wo + 127) / 128) * 2 : (int64_t)Do * Ho * ((Wo + 63) / 64);
+    const bool ks = conv_ksplit(Cin, (int)(ips * B), taps);
+    MVS_REQUIRE(B == 1 || ks || ips % 4 == 0, "mvs_bf16_conv3d_bnbwd: %lld work items per sample are not a multiple of 4", (long long)ips);
+    if (int rc = bf16_conv3d_impl(x, wpacked, nullptr, nullptr, nullptr, y, B, Cin, Cout, Di, Hi, Wi, gather, sd, shw, 0,
+                                  reinterpret_cast<float*>(workspace), groups, nullptr, stream, true, taps, bn_y, bn4, relu, groups))
+        return rc;
+    const int nrows = ks ? (int)(ips * B) : (int)((ips * B + 3) / 4), rps = B == 1 ? nrows : (int)(ks ? ips : ips / 4);
+    hipLaunchKernelGGL(bf16_rows_reduce_kernel, dim3(groups * 2 * Cout), dim3(256), 0, MVS_STREAM(stream), reinterpret_cast<const float*>(workspace),
+                       nrows, rps, B, groups, Cout, sums);
+    return mvs::finish_launch("mvs_bf16_conv3d_bnbwd");
+}
 
 extern "C" int64_t mvs_bf16_conv3d_bn_fwd_workspace_bytes(int B, int Cout, int Do, int Ho, int Wo) {
     if (!chan_ok(Cout) || B < 1 || Do < 1 || Ho < 1 || Wo < 1) return -1;

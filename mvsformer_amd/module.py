@@ -65,6 +65,14 @@ def autocast_bf16() -> bool:
         return False
 
 
+def _multi_use(t):
+    """A training-layer output that feeds more than one consumer (a skip connection) or a consumer of another kind (the head): its
+    BatchNorm's backward sums cannot be taken by ONE consumer's data gradient (autograd.LayerBf16Fn) - drop the tag that offers it."""
+    if hasattr(t, "_mvs_bn"):
+        del t._mvs_bn
+    return t
+
+
 def _train_conv_bn_act(x, conv, bn, relu, residual, transposed_sd=None):
     """Training-mode layer: raw (transposed) conv -> batch-stat BN -> ReLU (+ residual), all autograd-tracked HIP ops.
     bf16 channel-last input (``[B,D,H,W,C]``) selects the bf16 kernels, fp32 ``[B,C,D,H,W]`` the fp32 ones."""
@@ -329,12 +337,12 @@ class CostRegNet(nn.Module):
         if self.training and autocast_bf16():
             from . import autograd as ag
             x = ag.ToBf16Fn.apply(x)                     # fp32 cost volume -> bf16 channel-last; every layer below follows the dtype
-        c2 = self.conv2(self.conv1(x))
-        c4 = self.conv4(self.conv3(c2))
+        c2 = _multi_use(self.conv2(self.conv1(x)))
+        c4 = _multi_use(self.conv4(self.conv3(c2)))
         y = self.conv6(self.conv5(c4))
         y = self.conv7(y, residual=c4)
         y = self.conv9(y, residual=c2)
-        return self.conv11(y, residual=x)
+        return _multi_use(self.conv11(y, residual=x))
 
     def forward(self, x):
         y = self.features(x)
@@ -466,12 +474,12 @@ class CostRegNet3D(nn.Module):
         if self.training and autocast_bf16():
             from . import autograd as ag
             x = ag.ToBf16Fn.apply(x)                     # fp32 cost volume -> bf16 channel-last; every layer below follows the dtype
-        c2 = self.conv2(self.conv1(x))
-        c4 = self.conv4(self.conv3(c2))
+        c2 = _multi_use(self.conv2(self.conv1(x)))
+        c4 = _multi_use(self.conv4(self.conv3(c2)))
         y = self.conv6(self.conv5(c4))
         y = self._up("conv7", y, c4)
         y = self._up("conv9", y, c2)
-        return self._up("conv11", y, x)
+        return _multi_use(self._up("conv11", y, x))
 
     def prob_params(self):
         return _f32c(self.prob.weight).reshape(-1), _f32c(self.prob.bias).reshape(-1)

@@ -1177,6 +1177,31 @@ def bf16_conv3d(x, wpacked, cin, cout, gather: int, stride, scale=None, shift=No
     return y
 
 
+def bf16_conv3d_bnbwd(x, wpacked, cin, cout, gather: int, stride, bn_y, bn4, relu, groups: int = 1, taps: int = 27):
+    """Raw convolution whose output is the gradient arriving at a BatchNorm(+ReLU) layer (the data gradient of the layer after it) + that
+    BatchNorm's backward sums from the convolution's epilogue -> ``(dz, sums [2*groups*cout])``; ``bn_y`` = the BatchNorm's input,
+    ``bn4 [4, groups*cout]`` = the forward's (scale, shift, mean, invstd)."""
+    _chk16(x, "x"), _chk16(wpacked, "packed weights"), _chk16(bn_y, "bn_y"), _chk(bn4, "bn4")
+    B, Di, Hi, Wi, C = x.shape
+    assert C == cin
+    sd, shw = stride
+    if gather == 0:
+        Do, Ho, Wo = (Di - 1) // sd + 1, (Hi - 1) // shw + 1, (Wi - 1) // shw + 1
+    else:
+        Do, Ho, Wo = Di * sd, Hi * shw, Wi * shw
+    y = torch.empty(B, Do, Ho, Wo, cout, device=x.device, dtype=torch.bfloat16)
+    if tuple(bn_y.shape) != tuple(y.shape) or bn4.shape != (4, groups * cout) or B % groups:
+        raise _lib.MvsHipError("bf16_conv3d_bnbwd: BatchNorm input %s / statistics %s do not match the gradient %s (groups %d)" % (
+            tuple(bn_y.shape), tuple(bn4.shape), tuple(y.shape), groups))
+    sums = torch.empty(2 * groups * cout, device=x.device, dtype=torch.float32)
+    ws = _reduce_ws("mvs_bf16_conv3d_bn_fwd_workspace_bytes", x.device, B, cout, Do, Ho, Wo)
+    flops = 2.0 * taps * cin * cout * B * (Do * Ho * Wo if gather == 0 else Di * Hi * Wi)
+    tag = ("bf16_conv_kernel<%d,%d,g%d,s%d%d%s>" % (cin, cout, gather, sd, shw, ",2d" if taps == 9 else ""), "flops", flops)
+    _call("mvs_bf16_conv3d_bnbwd", tag, _ptr(x), _ptr(wpacked), _ptr(y), B, cin, cout, Di, Hi, Wi, int(gather), sd, shw, int(taps), _ptr(bn_y),
+          _ptr(bn4), int(relu), int(groups), _ptr(sums), _ptr(ws), _stream())
+    return y, sums
+
+
 def bf16_conv3d_stats(x, wpacked, cin, cout, gather: int, stride, groups: int = 1):
     """Raw convolution + the batch statistics of its bf16-rounded output in one pass -> ``(y, sums [2*groups*cout])``: the sums are
     what :func:`bf16_bn_stats` ``(y, groups)`` would return, without the extra pass over ``y``."""
@@ -1303,7 +1328,7 @@ def bf16_bn_bwd_reduce(dy, x, scale, shift, mean, invstd, relu, groups: int = 1)
 def bf16_conv3d_bn_fwd(x, wpacked, cin, cout, gather: int, stride, residual, relu, gamma, beta, running_mean, running_var, momentum, eps,
                        groups: int = 1, num_batches_tracked=None, taps: int = 27):
     """conv -> batch-statistics BatchNorm -> [ReLU] [+ residual] of one bf16 channel-last training layer in one call (three launches, the
-    statistics ride the convolution's epilogue) -> ``(y raw conv output, z, scale, shift, mean, invstd)``."""
+    statistics ride the convolution's epilogue) -> ``(y raw conv output, z, stats4 [4, groups*cout] = scale | shift | mean | invstd)``."""
     _chk16(x, "x"), _chk16(wpacked, "packed weights")
     _opt(gamma, "bn.weight"), _opt(beta, "bn.bias"), _opt(running_mean, "bn.running_mean"), _opt(running_var, "bn.running_var")
     B, Di, Hi, Wi, C = x.shape
@@ -1330,7 +1355,7 @@ def bf16_conv3d_bn_fwd(x, wpacked, cin, cout, gather: int, stride, residual, rel
     _call("mvs_bf16_conv3d_bn_fwd", tag, _ptr(x), _ptr(wpacked), _ptr(y), _ptr(z), _ptr(residual), int(relu), B, cin, cout, Di, Hi, Wi,
           int(gather), sd, shw, int(taps), int(groups), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
           _ptr(num_batches_tracked), _ptr(st), _ptr(ws), _stream())
-    return y, z, st[0], st[1], st[2], st[3]
+    return y, z, st
 
 
 def bf16_bn_bwd_apply(dy, x, scale, shift, mean, invstd, gamma, sums, count, relu, count_dev=None, groups: int = 1):
