@@ -353,7 +353,7 @@ __device__ __forceinline__ bf16x8 frag_tr(const unsigned short* p0, const unsign
 constexpr int WG_PW = 16;                                   // patch columns
 
 template <int TA, int TB>                                   // channel tiles per block
-__global__ __launch_bounds__(256, TA * TB == 1 ? 3 : 2) void bf16_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void bf16_wgrad_kernel(const WgradArgs a) {
     constexpr int TT = TA * TB;
     constexpr int NIB = 4;                                  // 16-byte pieces of ONE Bt plane tile per thread, at most
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -669,11 +669,23 @@ __global__ __launch_bounds__(256) void bf16_bn_bwd_apply_kernel(const __bf16* __
                                                                 const float* __restrict__ gamma, const float* __restrict__ sums,
                                                                 double count_host, const float* __restrict__ count_dev, int relu, int C,
                                                                 size_t total8, size_t RS, int groups, __bf16* __restrict__ dx) {
+    // per-channel constants once per BLOCK into LDS (they used to be 56 global loads and 16 fp64 divisions per THREAD: the divisions alone
+    // were most of the kernel): [scale | shift | mean | invstd | gamma*invstd | sum g / n | sum g*xhat / n], each groups*C <= 256 entries
+    __shared__ float P[7][256];
+    const int CT = C * groups;                              // sums = [sum g (groups*C)] [sum g*xhat (groups*C)]
+    if ((int)threadIdx.x < CT) {
+        const int c = threadIdx.x;
+        const double count = resolve_count(count_host, count_dev);
+        const float is = invstd[c];
+        P[0][c] = scale[c], P[1][c] = shift[c], P[2][c] = mean[c], P[3][c] = is;
+        P[4][c] = (gamma ? gamma[c] : 1.0f) * is;
+        P[5][c] = (float)((double)sums[c] / count);
+        P[6][c] = (float)((double)sums[CT + c] / count);
+    }
+    __syncthreads();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total8) return;
-    const double count = resolve_count(count_host, count_dev);
     const int c0 = (int)(i % (C / 8)) * 8 + (groups > 1 ? (int)(((i / (C / 8)) / RS) % groups) * C : 0);
-    const int CT = C * groups;                              // sums = [sum g (groups*C)] [sum g*xhat (groups*C)]
     const bf16x8 xv = reinterpret_cast<const bf16x8*>(x)[i], gv = reinterpret_cast<const bf16x8*>(dy)[i];
     bf16x8 o;
 #pragma unroll
@@ -681,10 +693,8 @@ __global__ __launch_bounds__(256) void bf16_bn_bwd_apply_kernel(const __bf16* __
         const int c = c0 + e;
         const float f = (float)xv[e];
         float g = (float)gv[e];
-        if (relu && !(fmaf(f, scale[c], shift[c]) > 0.0f)) g = 0.0f;
-        const float m1 = (float)((double)sums[c] / count), m2 = (float)((double)sums[CT + c] / count);
-        const float gi = (gamma ? gamma[c] : 1.0f) * invstd[c];
-        o[e] = (__bf16)(gi * (g - m1 - (f - mean[c]) * invstd[c] * m2));
+        if (relu && !(fmaf(f, P[0][c], P[1][c]) > 0.0f)) g = 0.0f;
+        o[e] = (__bf16)(P[4][c] * (g - P[5][c] - (f - P[2][c]) * P[3][c] * P[6][c]));
     }
     reinterpret_cast<bf16x8*>(dx)[i] = o;
 }
@@ -899,10 +909,9 @@ WgradPlan wgrad_plan(int nbatch, int CA, int CB, int Dp, int Hp, int Wp, int shw
     while (p.PH > 2 && (size_t)4 * (p.PH * shw + 2) * (WG_PW * shw + 2) * b_row * 2 > WG_RING_B) p.PH >>= 1;
     p.npr = (Hp + p.PH - 1) / p.PH;
     p.npc = (Wp + WG_PW - 1) / WG_PW;
-    // resident blocks over all channel groups: two per CU, three for the single-tile instance (8 / 16 channels on both sides: 14 KB of
-    // LDS, 139 VGPRs; four would spill) - its depth steps are latency chains (load -> LDS -> barrier -> 28 MFMAs), and more blocks
-    // per CU is what hides them
-    const int target = (p.TA * p.TB == 1 ? 768 : 512) / p.gy;
+    // two resident blocks per CU over all channel groups (three for the single-tile instance was measured: no faster, and every block
+    // writes a slab the reduce kernel reads back)
+    const int target = 512 / p.gy;
     p.nseg = wgrad_nseg(nbatch * p.npr * p.npc, Dp, target);
     p.dseg = (Dp + p.nseg - 1) / p.nseg;
     p.nseg = (Dp + p.dseg - 1) / p.dseg;
@@ -1131,6 +1140,7 @@ extern "C" int mvs_bf16_bn_bwd_apply(const void* dy, const void* x, const float*
     BnShape sh;
     MVS_REQUIRE(dy && x && scale && shift && mean && invstd && sums && dx && bn_shape(C, R, groups, rows_per_sample, &sh),
                 "mvs_bf16_bn_bwd_apply: bad arguments");
+    MVS_REQUIRE((int64_t)C * groups <= 256, "mvs_bf16_bn_bwd_apply: %d channels x %d groups exceed the 256 per-channel constants kept in LDS", C, groups);
     const size_t total8 = (size_t)R * (C / 8);
     hipLaunchKernelGGL(bf16_bn_bwd_apply_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, MVS_STREAM(stream),
                        reinterpret_cast<const __bf16*>(dy), reinterpret_cast<const __bf16*>(x), scale, shift, mean, invstd, gamma, sums, count,
