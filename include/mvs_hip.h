@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 19
+#define MVS_ABI_VERSION 20
 
 typedef void* mvs_stream_t;
 
@@ -347,6 +347,10 @@ int mvs_bf16_bn_bwd_reduce(const void* dy, const void* x, const float* scale, co
 int mvs_bf16_bn_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
                           const float* invstd, const float* gamma, const float* sums, double count, const float* count_dev,
                           int relu, int C, int64_t R, int groups, int64_t rows_per_sample, void* dx, mvs_stream_t stream);
+/* the same + dgb [2*C] = [dbeta | dgamma] of a GROUPED BatchNorm's shared parameters (the groups' sums added in group order) */
+int mvs_bf16_bn_bwd_apply_dgb(const void* dy, const void* x, const float* scale, const float* shift, const float* mean, const float* invstd,
+                              const float* gamma, const float* sums, double count, const float* count_dev, int relu, int C, int64_t R,
+                              int groups, int64_t rows_per_sample, void* dx, float* dgb, mvs_stream_t stream);
 
 /* Round-5 fused forms of the bf16 training layer (fewer graph nodes per step; reference layer: models/module.py:83-165 under
  * trainer/mvsformer_trainer.py:104-106 autocast).

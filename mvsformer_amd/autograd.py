@@ -626,12 +626,12 @@ class LayerBf16Fn(torch.autograd.Function):
             sums = tag[2]
         else:
             sums = ops.bf16_bn_bwd_reduce(dz, y, scale, shift, mean, invstd, relu, groups)
-        dy = ops.bf16_bn_bwd_apply(dz, y, scale, shift, mean, invstd, gfull, sums, float(y.numel() // (cout * groups)), relu, None, groups)
         CT = cout * groups
-        if groups > 1:                                                        # shared parameters: sum the groups' gradients (one launch)
-            both = sums.view(2, groups, -1).sum(1)
-            dbeta, dgamma = both[0], both[1]
+        if groups > 1:                                                        # shared parameters: the groups' gradients summed by the apply kernel
+            dy, dgb = ops.bf16_bn_bwd_apply(dz, y, scale, shift, mean, invstd, gfull, sums, float(y.numel() // CT), relu, None, groups, True)
+            dbeta, dgamma = dgb[:cout], dgb[cout:]
         else:
+            dy = ops.bf16_bn_bwd_apply(dz, y, scale, shift, mean, invstd, gfull, sums, float(y.numel() // CT), relu, None, groups)
             dbeta, dgamma = sums[:CT], sums[CT:]
         dx = None
         if ctx.needs_input_grad[0]:

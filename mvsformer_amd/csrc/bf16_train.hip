@@ -14,6 +14,8 @@
 // train.hip (statistics, and all arithmetic, in fp32).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -642,6 +644,12 @@ __global__ __launch_bounds__(256) void bf16_bn_reduce_kernel(const __bf16* __res
 __global__ __launch_bounds__(256) void bf16_affine_act_kernel(const __bf16* __restrict__ x, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const __bf16* __restrict__ res, int relu, int C,
                                                               size_t total8, size_t RS, int groups, __bf16* __restrict__ y) {
+    __shared__ float P[2][256];                              // scale | shift of the groups*C <= 256 channels, once per block
+    if ((int)threadIdx.x < C * groups) {
+        P[0][threadIdx.x] = scale[threadIdx.x];
+        P[1][threadIdx.x] = shift[threadIdx.x];
+    }
+    __syncthreads();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one channel octet
     if (i >= total8) return;
     const int c0 = (int)(i % (C / 8)) * 8 + (groups > 1 ? (int)(((i / (C / 8)) / RS) % groups) * C : 0);
@@ -651,7 +659,7 @@ __global__ __launch_bounds__(256) void bf16_affine_act_kernel(const __bf16* __re
     bf16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        float v = fmaf((float)xv[e], scale[c0 + e], shift[c0 + e]);
+        float v = fmaf((float)xv[e], P[0][c0 + e], P[1][c0 + e]);
         if (relu) v = fmaxf(v, 0.0f);
         if (res) v += (float)rv[e];
         o[e] = (__bf16)v;
@@ -668,7 +676,8 @@ __global__ __launch_bounds__(256) void bf16_bn_bwd_apply_kernel(const __bf16* __
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ sums,
                                                                 double count_host, const float* __restrict__ count_dev, int relu, int C,
-                                                                size_t total8, size_t RS, int groups, __bf16* __restrict__ dx) {
+                                                                size_t total8, size_t RS, int groups, __bf16* __restrict__ dx,
+                                                                float* __restrict__ dgb) {
     // per-channel constants once per BLOCK into LDS (they used to be 56 global loads and 16 fp64 divisions per THREAD: the divisions alone
     // were most of the kernel): [scale | shift | mean | invstd | gamma*invstd | sum g / n | sum g*xhat / n], each groups*C <= 256 entries
     __shared__ float P[7][256];
@@ -681,6 +690,14 @@ __global__ __launch_bounds__(256) void bf16_bn_bwd_apply_kernel(const __bf16* __
         P[4][c] = (gamma ? gamma[c] : 1.0f) * is;
         P[5][c] = (float)((double)sums[c] / count);
         P[6][c] = (float)((double)sums[CT + c] / count);
+    }
+    // the parameter gradients of a GROUPED BatchNorm (shared affine parameters: the groups' sums added, in group order) by block 0 - it
+    // holds the sums anyway; saves the separate reduction launch: dgb = [dbeta (C) | dgamma (C)]
+    if (dgb && blockIdx.x == 0 && (int)threadIdx.x < 2 * C) {
+        const int kind = threadIdx.x / C, c = threadIdx.x % C;
+        float acc = 0.0f;
+        for (int g = 0; g < groups; ++g) acc += sums[kind * CT + g * C + c];
+        dgb[threadIdx.x] = acc;
     }
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1038,7 +1055,8 @@ extern "C" int mvs_bf16_bn_stats(const void* x, int C, int64_t R, int groups, in
 extern "C" int mvs_bf16_affine_act(const void* x, const float* scale, const float* shift, const void* residual, int relu, int C, int64_t R,
                                    int groups, int64_t rows_per_sample, void* y, mvs_stream_t stream) {
     BnShape sh;
-    MVS_REQUIRE(x && scale && shift && y && bn_shape(C, R, groups, rows_per_sample, &sh), "mvs_bf16_affine_act: bad arguments");
+    MVS_REQUIRE(x && scale && shift && y && bn_shape(C, R, groups, rows_per_sample, &sh) && (int64_t)C * groups <= 256,
+                "mvs_bf16_affine_act: bad arguments (channels x groups <= 256)");
     const size_t total8 = (size_t)R * (C / 8);
     hipLaunchKernelGGL(bf16_affine_act_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, MVS_STREAM(stream),
                        reinterpret_cast<const __bf16*>(x), scale, shift, reinterpret_cast<const __bf16*>(residual), relu, C, total8,
@@ -1116,7 +1134,8 @@ extern "C" int mvs_bf16_bn_train_fwd(const void* x, const void* residual, int re
                                      const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                                      float eps, int64_t* num_batches_tracked, float* stats4, void* y, void* workspace, mvs_stream_t stream) {
     BnShape sh;
-    MVS_REQUIRE(x && stats4 && y && workspace && bn_shape(C, R, groups, rows_per_sample, &sh), "mvs_bf16_bn_train_fwd: bad arguments");
+    MVS_REQUIRE(x && stats4 && y && workspace && bn_shape(C, R, groups, rows_per_sample, &sh) && (int64_t)C * groups <= 256,
+                "mvs_bf16_bn_train_fwd: bad arguments (channels x groups <= 256)");
     MVS_REQUIRE((!running_mean) == (!running_var), "mvs_bf16_bn_train_fwd: running_mean and running_var come together");
     hipStream_t s = MVS_STREAM(stream);
     float* part = reinterpret_cast<float*>(workspace);
@@ -1134,9 +1153,29 @@ extern "C" int mvs_bf16_bn_train_fwd(const void* x, const void* residual, int re
     return mvs::finish_launch("mvs_bf16_bn_train_fwd");
 }
 
+static int bn_bwd_apply_impl(const void* dy, const void* x, const float* scale, const float* shift, const float* mean, const float* invstd,
+                             const float* gamma, const float* sums, double count, const float* count_dev, int relu, int C, int64_t R, int groups,
+                             int64_t rows_per_sample, void* dx, float* dgb, mvs_stream_t stream);
+
 extern "C" int mvs_bf16_bn_bwd_apply(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
                                      const float* invstd, const float* gamma, const float* sums, double count, const float* count_dev,
                                      int relu, int C, int64_t R, int groups, int64_t rows_per_sample, void* dx, mvs_stream_t stream) {
+    return bn_bwd_apply_impl(dy, x, scale, shift, mean, invstd, gamma, sums, count, count_dev, relu, C, R, groups, rows_per_sample, dx, nullptr, stream);
+}
+
+// the same + dgb [2*C] = [dbeta | dgamma] of the shared affine parameters (the groups' sums added in group order), written by the kernel's
+// first block: no separate reduction launch for a grouped BatchNorm's parameter gradients
+extern "C" int mvs_bf16_bn_bwd_apply_dgb(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
+                                         const float* invstd, const float* gamma, const float* sums, double count, const float* count_dev,
+                                         int relu, int C, int64_t R, int groups, int64_t rows_per_sample, void* dx, float* dgb,
+                                         mvs_stream_t stream) {
+    MVS_REQUIRE(dgb, "mvs_bf16_bn_bwd_apply_dgb: null dgb");
+    return bn_bwd_apply_impl(dy, x, scale, shift, mean, invstd, gamma, sums, count, count_dev, relu, C, R, groups, rows_per_sample, dx, dgb, stream);
+}
+
+static int bn_bwd_apply_impl(const void* dy, const void* x, const float* scale, const float* shift, const float* mean, const float* invstd,
+                             const float* gamma, const float* sums, double count, const float* count_dev, int relu, int C, int64_t R, int groups,
+                             int64_t rows_per_sample, void* dx, float* dgb, mvs_stream_t stream) {
     BnShape sh;
     MVS_REQUIRE(dy && x && scale && shift && mean && invstd && sums && dx && bn_shape(C, R, groups, rows_per_sample, &sh),
                 "mvs_bf16_bn_bwd_apply: bad arguments");
@@ -1144,7 +1183,7 @@ extern "C" int mvs_bf16_bn_bwd_apply(const void* dy, const void* x, const float*
     const size_t total8 = (size_t)R * (C / 8);
     hipLaunchKernelGGL(bf16_bn_bwd_apply_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, MVS_STREAM(stream),
                        reinterpret_cast<const __bf16*>(dy), reinterpret_cast<const __bf16*>(x), scale, shift, mean, invstd, gamma, sums, count,
-                       count_dev, relu, C, total8, (size_t)sh.RS, groups, reinterpret_cast<__bf16*>(dx));
+                       count_dev, relu, C, total8, (size_t)sh.RS, groups, reinterpret_cast<__bf16*>(dx), dgb);
     return mvs::finish_launch("mvs_bf16_bn_bwd_apply");
 }
 
@@ -1271,7 +1310,8 @@ extern "C" int mvs_bf16_conv3d_bn_fwd(const void* x, const void* wpacked, void* 
                                       int Cout, int Di, int Hi, int Wi, int gather, int sd, int shw, int taps, int groups, const float* gamma,
                                       const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                       int64_t* num_batches_tracked, float* stats4, void* workspace, mvs_stream_t stream) {
-    MVS_REQUIRE(z && stats4 && workspace && groups >= 1 && B % groups == 0, "mvs_bf16_conv3d_bn_fwd: bad arguments (B=%d groups=%d)", B, groups);
+    MVS_REQUIRE(z && stats4 && workspace && groups >= 1 && B % groups == 0 && (int64_t)Cout * groups <= 256,
+                "mvs_bf16_conv3d_bn_fwd: bad arguments (B=%d groups=%d; channels x groups <= 256)", B, groups);
     MVS_REQUIRE((!running_mean) == (!running_var), "mvs_bf16_conv3d_bn_fwd: running_mean and running_var come together");
     MVS_REQUIRE((sd == 1 || sd == 2) && (shw == 1 || shw == 2) && (gather == 0 || gather == 1), "mvs_bf16_conv3d_bn_fwd: bad stride / gather");
     int Do, Ho, Wo;

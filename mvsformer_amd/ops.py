@@ -1358,10 +1358,17 @@ def bf16_conv3d_bn_fwd(x, wpacked, cin, cout, gather: int, stride, residual, rel
     return y, z, st
 
 
-def bf16_bn_bwd_apply(dy, x, scale, shift, mean, invstd, gamma, sums, count, relu, count_dev=None, groups: int = 1):
+def bf16_bn_bwd_apply(dy, x, scale, shift, mean, invstd, gamma, sums, count, relu, count_dev=None, groups: int = 1, want_dgb: bool = False):
+    """``want_dgb``: also return ``dgb [2*C] = [dbeta | dgamma]`` of a grouped BatchNorm's shared parameters (the groups' sums added by the
+    kernel's first block: no separate reduction launch) -> ``(dx, dgb)``."""
     _chk16(dy, "dy"), _chk16(x, "x"), _chk(sums, "sums"), _opt(gamma, "gamma"), _opt(count_dev, "count_dev")
     C, R, rps = _bf16_bn_shape(x, groups)
     dx = torch.empty_like(x)
+    if want_dgb:
+        dgb = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        _call("mvs_bf16_bn_bwd_apply_dgb", "bf16_bn_bwd_apply", _ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _ptr(gamma),
+              _ptr(sums), float(count), _ptr(count_dev), int(relu), C, R, groups, rps, _ptr(dx), _ptr(dgb), _stream())
+        return dx, dgb
     _call("mvs_bf16_bn_bwd_apply", "bf16_bn_bwd_apply", _ptr(dy), _ptr(x), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _ptr(gamma),
           _ptr(sums), float(count), _ptr(count_dev), int(relu), C, R, groups, rps, _ptr(dx), _stream())
     return dx

@@ -14,7 +14,7 @@ for d in sys.argv[1:]:
             k = re.match(r"([\w:]+(?:<[^(]*>)?)", k).group(1)[:60]
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in acc.items():
-    if not re.search(r"cv_|vis_|conv3d|deconv|head|prob3|wino|fpn|x3_", k):
+    if not re.search(r"cv_|vis_|conv3d|deconv|head|prob3|wino|fpn|x3_|bf16_|gemm", k):
         continue
     print(k)
     for c, v in sorted(cs.items()):
