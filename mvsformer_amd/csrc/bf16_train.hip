@@ -568,14 +568,14 @@ __global__ void bf16_ndhwc_to_f32_ncdhw_kernel(const __bf16* __restrict__ in, fl
 
 // ------------------------------------------------------------------------------------------------ BatchNorm / ReLU / skip, channel-last bf16
 // x is [R rows (voxels), C]; a thread owns one channel octet of a strided set of rows.
-constexpr int ROWS_PER_BLOCK = 2048;
+constexpr int ROWS_PER_BLOCK = 2048;                        // at most; bn_shape picks fewer rows per block for small tensors
 
 template <bool BWD>
 __global__ __launch_bounds__(256) void bf16_bn_reduce_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
-                                                             int C, size_t RS, int groups, float* __restrict__ part) {
-    // grid = (blocks per sample, samples); RS = rows per sample.  Plain BatchNorm: one "sample" of all R rows.  Grouped (the batch
+                                                             int C, size_t RS, int groups, float* __restrict__ part, int rpb) {
+    // grid = (blocks per sample, samples); RS = rows per sample; rpb = rows per block.  Plain BatchNorm: one "sample" of all R rows.  Grouped (the batch
     // holds `groups` independent calls, sample n belongs to group n % groups): parameters of group g live at [g*C, (g+1)*C).
     __shared__ float red[4][2 * 64];
     const int CQ = C / 8;
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void bf16_bn_reduce_kernel(const __bf16* __res
         }
     }
     const size_t s0 = (size_t)blockIdx.y * RS;
-    const size_t r0 = s0 + (size_t)blockIdx.x * ROWS_PER_BLOCK, r1 = min(r0 + ROWS_PER_BLOCK, s0 + RS);
+    const size_t r0 = s0 + (size_t)blockIdx.x * rpb, r1 = min(r0 + (size_t)rpb, s0 + RS);
     for (size_t r = r0 + rsub; r < r1; r += rstep) {
         const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + r * C + cq * 8);
         if (!BWD) {
@@ -1021,7 +1021,7 @@ namespace {
 // Grouped BatchNorm over a channel-last batch (groups independent calls of the same module interleaved in the batch dimension, sample n
 // -> group n % groups: the visibility CNN, applied once per source view by the reference): statistics per (group, channel); every
 // per-channel array is [groups*C], sums are [sum (groups*C)][sum sq (groups*C)] - the layout mvs_bn_finalize_grouped consumes.
-struct BnShape { int64_t RS; int nsamples; unsigned bps; };
+struct BnShape { int64_t RS; int nsamples; unsigned bps; int rpb; };
 bool bn_shape(int C, int64_t R, int groups, int64_t rows_per_sample, BnShape* o) {
     if (!chan_ok(C) || R < 1 || groups < 1) return false;
     if (groups == 1) { o->RS = R; o->nsamples = 1; }
@@ -1029,7 +1029,15 @@ bool bn_shape(int C, int64_t R, int groups, int64_t rows_per_sample, BnShape* o)
         if (rows_per_sample < 1 || R % rows_per_sample || (R / rows_per_sample) % groups || R / rows_per_sample > 65535) return false;
         o->RS = rows_per_sample; o->nsamples = (int)(R / rows_per_sample);
     }
-    o->bps = (unsigned)((o->RS + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+    // rows per block: a multiple of the rows one sweep of the block's 256 threads covers (256 / (C/8)), sized for ~512 blocks in total so that
+    // a 5 MB tensor is not reduced by 20 blocks (a 64-channel level-3 map: 47 us for 41 000 rows), at most ROWS_PER_BLOCK
+    const int rstep = 256 / (C / 8);
+    int64_t rpb = (o->RS * o->nsamples + 511) / 512;
+    rpb = ((rpb + rstep - 1) / rstep) * rstep;
+    if (rpb < 2 * rstep) rpb = 2 * rstep;
+    if (rpb > ROWS_PER_BLOCK) rpb = ROWS_PER_BLOCK;
+    o->rpb = (int)rpb;
+    o->bps = (unsigned)((o->RS + rpb - 1) / rpb);
     return true;
 }
 }  // namespace
@@ -1047,7 +1055,7 @@ extern "C" int mvs_bf16_bn_stats(const void* x, int C, int64_t R, int groups, in
     float* part = reinterpret_cast<float*>(workspace);
     hipLaunchKernelGGL(bf16_bn_reduce_kernel<false>, dim3(sh.bps, sh.nsamples), dim3(256), 0, MVS_STREAM(stream),
                        reinterpret_cast<const __bf16*>(x), (const __bf16*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, 0, C, (size_t)sh.RS, groups, part);
+                       (const float*)nullptr, (const float*)nullptr, 0, C, (size_t)sh.RS, groups, part, sh.rpb);
     mvs::launch_partials_reduce_grouped(part, (int)sh.bps, sh.nsamples, groups, C, sums, MVS_STREAM(stream));
     return mvs::finish_launch("mvs_bf16_bn_stats");
 }
@@ -1073,7 +1081,7 @@ extern "C" int mvs_bf16_bn_bwd_reduce(const void* dy, const void* x, const float
     float* part = reinterpret_cast<float*>(workspace);
     hipLaunchKernelGGL(bf16_bn_reduce_kernel<true>, dim3(sh.bps, sh.nsamples), dim3(256), 0, MVS_STREAM(stream),
                        reinterpret_cast<const __bf16*>(x), reinterpret_cast<const __bf16*>(dy), scale, shift, mean, invstd, relu, C,
-                       (size_t)sh.RS, groups, part);
+                       (size_t)sh.RS, groups, part, sh.rpb);
     mvs::launch_partials_reduce_grouped(part, (int)sh.bps, sh.nsamples, groups, C, sums, MVS_STREAM(stream));
     return mvs::finish_launch("mvs_bf16_bn_bwd_reduce");
 }
@@ -1142,7 +1150,7 @@ extern "C" int mvs_bf16_bn_train_fwd(const void* x, const void* residual, int re
     const int CT = C * groups;
     hipLaunchKernelGGL(bf16_bn_reduce_kernel<false>, dim3(sh.bps, sh.nsamples), dim3(256), 0, s, reinterpret_cast<const __bf16*>(x),
                        (const __bf16*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, C,
-                       (size_t)sh.RS, groups, part);
+                       (size_t)sh.RS, groups, part, sh.rpb);
     hipLaunchKernelGGL(bf16_bn_reduce_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, (int)sh.bps, sh.nsamples, groups, C, gamma, beta,
                        running_mean, running_var, momentum, eps, (double)(R / groups), stats4,
                        reinterpret_cast<long long*>(num_batches_tracked));
