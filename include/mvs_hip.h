@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 20
+#define MVS_ABI_VERSION 21
 
 typedef void* mvs_stream_t;
 
@@ -129,6 +129,10 @@ int mvs_vis_fwd(const float* entropy, const float* params, int N, int H, int W, 
 int mvs_cv_aggregate_fwd(const float* feat, const float* rt, const float* depth, const float* weight,
                          int B, int V, int C, int G, int D, int H, int W,
                          float* volume, float* sim_depth, int flags, mvs_stream_t stream);
+/* the same + volume16: the volume ALSO as bf16 channel-last [B,D,H,W,G] - the layout the bf16 training regularizer reads (no separate
+ * fp32 NCDHW -> bf16 NDHWC pass) */
+int mvs_cv_aggregate_fwd_bf16(const float* feat, const float* rt, const float* depth, const float* weight, int B, int V, int C, int G, int D, int H,
+                              int W, float* volume, void* volume16, float* sim_depth, int flags, mvs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Stored-correlation form of the two sweeps for the coarse cascade stages (C = 32 | 64), same reference lines

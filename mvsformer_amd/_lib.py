@@ -18,7 +18,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVS_HIP_LIB: diagnostics only - another BUILD of the same library (tests/test_hip_multistream.py's variants); never a fallback
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 from ctypes import c_double  # noqa: E402
 
@@ -36,6 +36,7 @@ SIGNATURES = {
     "mvs_cv_entropy_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, I, P]),
     "mvs_vis_fwd": (I, [P, P, I, I, I, P, P]),
     "mvs_cv_aggregate_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, I, P]),
+    "mvs_cv_aggregate_fwd_bf16": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, P, I, P]),
     "mvs_cv_corr_store_bytes": (L, [I, I, I, I, I, I, I]),
     "mvs_cv_corr_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, P]),
     "mvs_cv_merge_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P, P]),

@@ -247,22 +247,27 @@ class AggregateFn(torch.autograd.Function):
     """volume_mean = sum_v w_v * corr(ref, warp(src_v)) / (sum_v w_v + 1e-6); grads to features and to w."""
 
     @staticmethod
-    def forward(ctx, feat, weight, rt, hyp, G, feat_cl=None):
-        """``feat_cl``: the channel-last copy of ``feat`` if the caller already made it (the entropy sweep reads the same one)."""
+    def forward(ctx, feat, weight, rt, hyp, G, feat_cl=None, as_bf16=False):
+        """``feat_cl``: the channel-last copy of ``feat`` if the caller already made it (the entropy sweep reads the same one).
+        ``as_bf16``: return the volume as bf16 channel-last ``[B,D,H,W,G]`` (what the bf16 regularizer reads; written by the same launch,
+        its gradient arrives in the same form and the backward kernel reads it as it is) - the fp32 volume is still kept for the backward."""
         if feat_cl is None:
             feat_cl = ops.to_channels_last(feat.detach().to(torch.float32).contiguous())
         weight = weight.contiguous()
-        vol, _ = ops.cv_aggregate(feat_cl, rt, hyp, weight, G, want_sim_depth=False, exact=True)   # same geometry as the backward kernel
+        if as_bf16:
+            vol, _, vol16 = ops.cv_aggregate(feat_cl, rt, hyp, weight, G, want_sim_depth=False, exact=True, want_bf16=True)
+        else:
+            vol, _ = ops.cv_aggregate(feat_cl, rt, hyp, weight, G, want_sim_depth=False, exact=True)   # same geometry as the backward kernel
         ctx.save_for_backward(feat_cl, rt, hyp, weight, vol)
         ctx.G, ctx.dtype = G, feat.dtype
-        return vol
+        return vol16 if as_bf16 else vol
 
     @staticmethod
     def backward(ctx, gvol):
         feat_cl, rt, hyp, weight, vol = ctx.saved_tensors
         dfeat_cl, dw = ops.cv_aggregate_bwd(feat_cl, rt, hyp, weight, vol, gvol.contiguous(), ctx.G)
         dfeat = ops.to_channels_first(dfeat_cl).to(ctx.dtype) if ctx.needs_input_grad[0] else None
-        return dfeat, (dw if ctx.needs_input_grad[1] else None), None, None, None, None
+        return dfeat, (dw if ctx.needs_input_grad[1] else None), None, None, None, None, None
 
 
 class HeadFn(torch.autograd.Function):

@@ -271,7 +271,9 @@ template <int LPP, bool SIM, bool FAST>
 __global__ __launch_bounds__(64 * NW) void cv_aggregate_kernel(const float* __restrict__ feat, const float* __restrict__ rt_all,
                                                                const float* __restrict__ depth, const float* __restrict__ weight,
                                                                int V, int D, int H, int W, float* __restrict__ volume,
-                                                               float* __restrict__ sim_depth, int gx, int total) {
+                                                               float* __restrict__ sim_depth, int gx, int total, __bf16* __restrict__ vol16) {
+    // vol16 (optional): the same volume ALSO as bf16 channel-last [B,D,H,W,G] - what the bf16 regularizer of the training path reads (the
+    // separate fp32 NCDHW -> bf16 NDHWC pass then never runs)
     constexpr int C = 4 * LPP, CPG = C / G, PPW = 64 / LPP;
     constexpr int NG = (CPG >= 4) ? 1 : 4 / CPG;          // correlation groups whose sums live in this lane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -386,8 +388,11 @@ __global__ __launch_bounds__(64 * NW) void cv_aggregate_kernel(const float* __re
                     if (d < D) {
                         if (active) {
 #pragma unroll
-                            for (int k = 0; k < NG; ++k)
-                                volume[((size_t)(b * G + cq * NG + k) * D + d) * HW + pix] = acc[dd][k] / denom;
+                            for (int k = 0; k < NG; ++k) {
+                                const float v = acc[dd][k] / denom;
+                                volume[((size_t)(b * G + cq * NG + k) * D + d) * HW + pix] = v;
+                                if (vol16) vol16[(((size_t)b * D + d) * HW + pix) * G + cq * NG + k] = (__bf16)v;
+                            }
                         }
                         if (SIM && simtot[dd] > best) { best = simtot[dd]; besti = d; }
                     }
@@ -471,7 +476,9 @@ __global__ __launch_bounds__(64 * NW) void cv_aggregate_kernel(const float* __re
 #pragma unroll
                     for (int k = 0; k < NG; ++k) {
                         const int g = (CPG == 8) ? (cq >> 1) : cq * NG + k;
-                        volume[((size_t)(b * G + g) * D + d) * HW + pix] = acc[dd][k] / denom;
+                        const float v = acc[dd][k] / denom;
+                        volume[((size_t)(b * G + g) * D + d) * HW + pix] = v;
+                        if (vol16) vol16[(((size_t)b * D + d) * HW + pix) * G + g] = (__bf16)v;
                     }
                 }
                 if (SIM && simtot[dd] > best) { best = simtot[dd]; besti = d; }
@@ -861,9 +868,25 @@ extern "C" int mvs_cv_entropy_fwd(const float* feat, const float* rt, const floa
     return mvs::finish_launch("mvs_cv_entropy_fwd");
 }
 
+static int cv_aggregate_impl(const float* feat, const float* rt, const float* depth, const float* weight, int B, int V, int C, int Gin, int D, int H,
+                             int W, float* volume, void* volume16, float* sim_depth, int flags, mvs_stream_t stream);
+
 extern "C" int mvs_cv_aggregate_fwd(const float* feat, const float* rt, const float* depth, const float* weight, int B, int V,
                                     int C, int Gin, int D, int H, int W, float* volume, float* sim_depth, int flags,
                                     mvs_stream_t stream) {
+    return cv_aggregate_impl(feat, rt, depth, weight, B, V, C, Gin, D, H, W, volume, nullptr, sim_depth, flags, stream);
+}
+
+// the same + volume16: the volume ALSO as bf16 channel-last [B,D,H,W,G] (device bf16), the layout the bf16 training regularizer reads
+extern "C" int mvs_cv_aggregate_fwd_bf16(const float* feat, const float* rt, const float* depth, const float* weight, int B, int V, int C, int Gin,
+                                         int D, int H, int W, float* volume, void* volume16, float* sim_depth, int flags, mvs_stream_t stream) {
+    MVS_REQUIRE(volume16, "mvs_cv_aggregate_fwd_bf16: null volume16");
+    return cv_aggregate_impl(feat, rt, depth, weight, B, V, C, Gin, D, H, W, volume, volume16, sim_depth, flags, stream);
+}
+
+static int cv_aggregate_impl(const float* feat, const float* rt, const float* depth, const float* weight, int B, int V, int C, int Gin, int D, int H,
+                             int W, float* volume, void* volume16, float* sim_depth, int flags, mvs_stream_t stream) {
+    __bf16* vol16 = reinterpret_cast<__bf16*>(volume16);
     MVS_REQUIRE(feat && rt && depth && weight && volume, "mvs_cv_aggregate_fwd: null pointer");
     if (int rc = check_shapes("mvs_cv_aggregate_fwd", B, V, C, Gin, D, H, W)) return rc;
     const int LPP = C / 4, PPW = 64 / LPP;
@@ -877,7 +900,7 @@ extern "C" int mvs_cv_aggregate_fwd(const float* feat, const float* rt, const fl
     const bool fast = !(flags & 1);
 #define MVS_LAUNCH_AGG2(L, SIMV, FASTV)                                                                                  \
     hipLaunchKernelGGL((cv_aggregate_kernel<L, SIMV, FASTV>), grid, block, lds, s, feat, rt, depth, weight, V, D, H, W, volume, \
-                       sim_depth, gx, total)
+                       sim_depth, gx, total, vol16)
 #define MVS_LAUNCH_AGG(L)                                                              \
     if (sim_depth) {                                                                   \
         if (fast) MVS_LAUNCH_AGG2(L, true, true); else MVS_LAUNCH_AGG2(L, true, false);   \

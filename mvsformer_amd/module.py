@@ -330,11 +330,14 @@ class CostRegNet(nn.Module):
         """Everything up to (not including) ``prob``; residual adds are fused into the deconv epilogues."""
         if not isinstance(self.inner, nn.Identity):
             raise MvsHipError("CostRegNet: in_channels != base_channels (1x1x1 'inner' conv) is not built")
-        x = x.to(torch.float32)
+        pre16 = self.training and x.dtype == torch.bfloat16       # already bf16 channel-last [B,D,H,W,C] (autograd.AggregateFn as_bf16)
+        if not pre16:
+            x = x.to(torch.float32)
         x = x if x.is_contiguous() else x.contiguous()
-        if x.shape[2] % 8 or x.shape[3] % 8 or x.shape[4] % 8:
-            raise MvsHipError("CostRegNet needs D, H, W divisible by 8 (three stride-2 levels), got %s" % (tuple(x.shape[2:]),))
-        if self.training and autocast_bf16():
+        dhw = x.shape[1:4] if pre16 else x.shape[2:]
+        if dhw[0] % 8 or dhw[1] % 8 or dhw[2] % 8:
+            raise MvsHipError("CostRegNet needs D, H, W divisible by 8 (three stride-2 levels), got %s" % (tuple(dhw),))
+        if self.training and autocast_bf16() and not pre16:
             from . import autograd as ag
             x = ag.ToBf16Fn.apply(x)                     # fp32 cost volume -> bf16 channel-last; every layer below follows the dtype
         c2 = _multi_use(self.conv2(self.conv1(x)))
@@ -467,11 +470,14 @@ class CostRegNet3D(nn.Module):
     def features(self, x: torch.Tensor) -> torch.Tensor:
         if not isinstance(self.inner, nn.Identity):
             raise MvsHipError("CostRegNet3D: in_channels != base_channel (1x1x1 'inner' conv) is not built")
-        x = x.to(torch.float32)
+        pre16 = self.training and x.dtype == torch.bfloat16       # already bf16 channel-last [B,D,H,W,C] (autograd.AggregateFn as_bf16)
+        if not pre16:
+            x = x.to(torch.float32)
         x = x if x.is_contiguous() else x.contiguous()
-        if x.shape[3] % 8 or x.shape[4] % 8:
-            raise MvsHipError("CostRegNet3D needs H, W divisible by 8 (three stride-2 levels), got %s" % (tuple(x.shape[3:]),))
-        if self.training and autocast_bf16():
+        hw = x.shape[2:4] if pre16 else x.shape[3:]
+        if hw[0] % 8 or hw[1] % 8:
+            raise MvsHipError("CostRegNet3D needs H, W divisible by 8 (three stride-2 levels), got %s" % (tuple(hw),))
+        if self.training and autocast_bf16() and not pre16:
             from . import autograd as ag
             x = ag.ToBf16Fn.apply(x)                     # fp32 cost volume -> bf16 channel-last; every layer below follows the dtype
         c2 = _multi_use(self.conv2(self.conv1(x)))

@@ -296,7 +296,8 @@ def vis_x3(entropy: torch.Tensor, params: torch.Tensor, prepared: torch.Tensor) 
 
 
 def cv_aggregate(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, weight: torch.Tensor, G: int,
-                 want_sim_depth: bool, exact: Optional[bool] = None):
+                 want_sim_depth: bool, exact: Optional[bool] = None, want_bf16: bool = False):
+    """``want_bf16``: also return the volume as bf16 channel-last ``[B,D,H,W,G]`` (written by the same launch) -> ``(vol, sim, vol16)``."""
     _chk(feat, "features"), _chk(rt, "rt"), _chk(depth, "depth_values"), _chk(weight, "vis_weight")
     B, V, H, W, C = feat.shape
     D = depth.shape[1]
@@ -304,6 +305,11 @@ def cv_aggregate(feat: torch.Tensor, rt: torch.Tensor, depth: torch.Tensor, weig
     sim = torch.empty(B, H, W, device=feat.device, dtype=torch.float32) if want_sim_depth else None
     tag = ("cv_aggregate_kernel<%d,%s>" % (C // 4, "true" if want_sim_depth else "false"), "bytes",
            4.0 * B * H * W * (V * C + D + G * D))          # 4*H*W*(V*C + D + G*D)
+    if want_bf16:
+        vol16 = torch.empty(B, D, H, W, G, device=feat.device, dtype=torch.bfloat16)
+        _call("mvs_cv_aggregate_fwd_bf16", tag, _ptr(feat), _ptr(rt), _ptr(depth), _ptr(weight), B, V, C, G, D, H, W,
+              _ptr(vol), _ptr(vol16), _ptr(sim), _cv_flags(exact), _stream())
+        return vol, sim, vol16
     _call("mvs_cv_aggregate_fwd", tag, _ptr(feat), _ptr(rt), _ptr(depth), _ptr(weight), B, V, C, G, D, H, W,
           _ptr(vol), _ptr(sim), _cv_flags(exact), _stream())
     return vol, sim
@@ -848,12 +854,18 @@ def conv3d_wgrad(A: torch.Tensor, Bt: torch.Tensor, stride) -> torch.Tensor:
 
 
 def cv_aggregate_bwd(feat_cl, rt, depth, weight, volume, gvolume, G: int, stats: Optional[torch.Tensor] = None):
-    for t, n in ((feat_cl, "features"), (rt, "rt"), (depth, "depth_values"), (weight, "vis_weight"), (volume, "volume"), (gvolume, "grad")):
+    """``gvolume``: fp32 ``[B,G,D,H,W]``, or bf16 channel-last ``[B,D,H,W,G]`` (the bf16 regularizer's first data gradient: converted here)."""
+    for t, n in ((feat_cl, "features"), (rt, "rt"), (depth, "depth_values"), (weight, "vis_weight"), (volume, "volume")):
         _chk(t, n)
     B, V, H, W, C = feat_cl.shape
     D = depth.shape[1]
     dfeat = torch.zeros_like(feat_cl)
     mode = os.environ.get("MVS_CV_BWD", "own")
+    if gvolume.dtype == torch.bfloat16:
+        # (the default scatter kernel reading this form directly was built and measured: its strided 2-byte loads cost it 0.3 ms per step,
+        #  three times what the conversion pass costs - NOTEBOOK.md)
+        gvolume = bf16_to_f32(_chk16(gvolume, "grad"))
+    _chk(gvolume, "grad")
     if mode not in ("own", "lds", "direct"):
         raise _lib.MvsHipError("MVS_CV_BWD=%r: expected 'own', 'lds' or 'direct'" % mode)
     if mode != "direct":

@@ -193,7 +193,8 @@ class StageNet(nn.Module):
         entropy = ops.cv_entropy(feat_cl, rt, hyp, G, exact=True)           # sim_vol.detach() in the reference
         V = features.shape[1]
         weight = ag.vis_train_views(entropy, self.vis)                     # per-view statistics, one batched pass
-        volume = ag.AggregateFn.apply(features, weight, rt, hyp, G, feat_cl)
+        # under autocast the volume leaves the aggregation as bf16 channel-last too (the layout the bf16 regularizer reads) in the same launch
+        volume = ag.AggregateFn.apply(features, weight, rt, hyp, G, feat_cl, autocast_bf16() and ag._fused_layers())
         if type(tmp) == list:
             tmp = tmp[self.stage_idx]
         pre = self.cost_reg(volume).squeeze(1)
