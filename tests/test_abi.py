@@ -177,3 +177,37 @@ def test_store_plan_and_vis_mode_host_logic(monkeypatch):
     monkeypatch.setenv("MVS_VIS", "winograd")
     with pytest.raises(ValueError):
         net._vis_params()
+
+
+def test_small_limit_env_is_parsed_once_and_validated():
+    """MVS_CONV_SMALL_MAX_WORK accepts 'conv,deconv' or one value for both, and rejects anything else at parse time."""
+    from mvsformer_amd import module
+    assert module._parse_small_limit(None) == module.SMALL_MAX_WORK
+    assert module._parse_small_limit("0") == (0, 0)
+    assert module._parse_small_limit("5,7") == (5, 7)
+    for bad in ("a", "1,2,3", "-1", "1,x"):
+        with pytest.raises(ValueError):
+            module._parse_small_limit(bad)
+
+
+def test_pack_table_host_fill_without_a_gpu():
+    """The job table of the one-launch weight packing is filled on the HOST (mvs_bf16_pack_table_fill): block starts accumulate, a weight
+    that does not fit the requested map is refused, 2-D kernels take 9 taps."""
+    import ctypes
+    from mvsformer_amd import _lib
+    lib = _lib.load()
+    n = 3
+    nbytes = lib.mvs_bf16_pack_table_bytes(n)
+    assert nbytes > 0 and lib.mvs_bf16_pack_table_bytes(0) < 0
+    host = (ctypes.c_uint8 * nbytes)()
+    fake = 0x1000                                            # never dereferenced on the host
+    assert lib.mvs_bf16_pack_table_fill(host, n, 0, fake, 16, 8, 0, 16, 8, 27, fake) == 0       # conv 8 -> 16
+    assert lib.mvs_bf16_pack_table_fill(host, n, 1, fake, 16, 1, 0, 16, 8, 9, fake) == 0        # 2-D 1 -> 16 run as 8 -> 16
+    assert lib.mvs_bf16_pack_table_fill(host, n, 2, fake, 1, 8, 0, 8, 8, 27, fake) == 0         # 8 -> 1 run as 8 -> 8
+    starts = (ctypes.c_int32 * (n + 1)).from_buffer(host, nbytes - 4 * (n + 1))
+    want = [0]
+    for cin, cout, taps in ((8, 16, 27), (8, 16, 9), (8, 8, 27)):
+        want.append(want[-1] + (lib.mvs_bf16_packed_elems_taps(cin, cout, taps) // 8 + 255) // 256)
+    assert list(starts) == want
+    assert lib.mvs_bf16_pack_table_fill(host, n, 0, fake, 32, 8, 0, 16, 8, 27, fake) != 0       # 32 rows do not fit a 16-row map
+    assert lib.mvs_bf16_pack_table_fill(host, n, 0, fake, 16, 8, 0, 16, 8, 5, fake) != 0        # taps must be 27 or 9
