@@ -232,6 +232,148 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- attention
+// softmax(Q K^T * scale) V per (image, head) without materializing the N x N matrix (flash form, online softmax), split-form arithmetic:
+//   block = 64 queries (4 wavefronts x 16), loop over tiles of 32 keys: S = Q K^T (Q's split fragments live in registers, K's in LDS),
+//   running row max / sum in the accumulator layout (a lane's four rows 4*kb + r; the 16 lanes of a group hold 16 keys: xor butterflies),
+//   P -> split -> the wavefront's own LDS tile -> A operand of P V (V^T tile [d][key] in LDS as the B operand), O rescaled per row.
+// qkv = [B][N][3C] packed rows (q | k | v, head h at columns h*64), vt = V transposed [B][heads][64][N], out = [B][N][C] (head h at h*64).
+// hd = 64 only (ViT-small / base); scale is applied to Q before the split (exact for 64^-0.5 = 0.125).
+constexpr int AT_KT = 32;                                    // keys per tile
+constexpr int AT_KROW = 64 * 2 + 16, AT_VROW = AT_KT * 2 + 16, AT_PROW = AT_KT * 2 + 16;   // LDS row strides in bytes (16 bytes of padding)
+constexpr int AT_KTERM = AT_KT * AT_KROW, AT_VTERM = 64 * AT_VROW, AT_PTERM = 16 * AT_PROW;
+
+__global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ vt, float* __restrict__ out, int N,
+                                                           int NH, float scale) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * AT_KTERM + 3 * AT_VTERM + 4 * 3 * AT_PTERM];
+    unsigned char* kl = lds;
+    unsigned char* vl = lds + 3 * AT_KTERM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char* pl = lds + 3 * AT_KTERM + 3 * AT_VTERM + wave * 3 * AT_PTERM;
+    const int j = lane & 15, kb = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z, C = NH * 64;
+    const float* qrow = qkv + (size_t)b * N * 3 * C + h * 64;
+    const float* vth = vt + ((size_t)b * NH + h) * 64 * N;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+
+    // Q fragments (A operand of S): lane (i = query q0 + j, kb) holds d = 32*s + 8*kb .. + 7
+    bf16x8 qa[2][3];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        float v[8];
+        const int q = q0 + j;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = q < N ? qrow[(size_t)q * 3 * C + 32 * st + 8 * kb + e] * scale : 0.0f;
+        const mvsx3::Split3 sp = mvsx3::split3(v);
+        qa[st][0] = sp.h, qa[st][1] = sp.m, qa[st][2] = sp.l;
+    }
+    f32x4 acc_o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc_o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrow[4], lrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mrow[r] = -INFINITY, lrow[r] = 0.0f;
+
+    // staging roles: K tile: thread -> (key = tid / 8, 8 d at (tid % 8) * 8); V^T tile: thread -> (d = tid / 4, 8 keys at (tid % 4) * 8)
+    const int kkey = tid >> 3, kd = (tid & 7) * 8, vd = tid >> 2, vk = (tid & 3) * 8;
+    float pk[8], pv[8];
+    auto fetch = [&](int kt) {
+        const int key = kt + kkey;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pk[e] = key < N ? qrow[(size_t)key * 3 * C + C + kd + e] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv[e] = kt + vk + e < N ? vth[(size_t)vd * N + kt + vk + e] : 0.0f;
+    };
+    auto commit = [&]() {
+        const mvsx3::Split3 a = mvsx3::split3(pk), c = mvsx3::split3(pv);
+        unsigned char* d0 = kl + kkey * AT_KROW + kd * 2;
+        *reinterpret_cast<bf16x8*>(d0) = a.h;
+        *reinterpret_cast<bf16x8*>(d0 + AT_KTERM) = a.m;
+        *reinterpret_cast<bf16x8*>(d0 + 2 * AT_KTERM) = a.l;
+        unsigned char* d1 = vl + vd * AT_VROW + vk * 2;
+        *reinterpret_cast<bf16x8*>(d1) = c.h;
+        *reinterpret_cast<bf16x8*>(d1 + AT_VTERM) = c.m;
+        *reinterpret_cast<bf16x8*>(d1 + 2 * AT_VTERM) = c.l;
+    };
+    fetch(0);
+    for (int kt = 0; kt < N; kt += AT_KT) {
+        __syncthreads();                                     // the previous tile's K / V^T fragments are consumed
+        commit();
+        __syncthreads();
+        if (kt + AT_KT < N) fetch(kt + AT_KT);
+        // ---- S = Q K^T for 2 x 16 keys: D[i = query 4*kb + r][j = key]
+        f32x4 sacc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const unsigned char* bp = kl + (nt * 16 + j) * AT_KROW + (32 * st + 8 * kb) * 2;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp), bm = *reinterpret_cast<const bf16x8*>(bp + AT_KTERM),
+                             bl = *reinterpret_cast<const bf16x8*>(bp + 2 * AT_KTERM);
+                c = mvsx3::mfma6(qa[st][0], qa[st][1], qa[st][2], bh, bm, bl, c);
+            }
+            if (kt + nt * 16 + j >= N) c = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            sacc[nt] = c;
+        }
+        // ---- online softmax over the tile's 32 keys, per row r of this lane group
+        float alpha[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mx = fmaxf(sacc[0][r], sacc[1][r]);
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+            const float mnew = fmaxf(mrow[r], mx);
+            const float p0 = __expf(sacc[0][r] - mnew), p1 = __expf(sacc[1][r] - mnew);
+            float sum = p0 + p1;
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+            alpha[r] = __expf(mrow[r] - mnew);
+            lrow[r] = lrow[r] * alpha[r] + sum;
+            mrow[r] = mnew;
+            sacc[0][r] = p0, sacc[1][r] = p1;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc_o[t][r] *= alpha[r];
+        // ---- P (this wavefront's 16 x 32 tile) -> split -> own LDS tile [term][query][key]
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                __bf16 ph, pm, plo;
+                mvsx3::split3_bounded(sacc[nt][r], ph, pm, plo);
+                unsigned char* d = pl + (4 * kb + r) * AT_PROW + (nt * 16 + j) * 2;
+                *reinterpret_cast<__bf16*>(d) = ph;
+                *reinterpret_cast<__bf16*>(d + AT_PTERM) = pm;
+                *reinterpret_cast<__bf16*>(d + 2 * AT_PTERM) = plo;
+            }
+        __builtin_amdgcn_wave_barrier();                     // a wavefront's LDS operations execute in order: its own stores are visible to its loads
+        const unsigned char* ap = pl + j * AT_PROW + kb * 16;
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap), am = *reinterpret_cast<const bf16x8*>(ap + AT_PTERM),
+                     al = *reinterpret_cast<const bf16x8*>(ap + 2 * AT_PTERM);
+        // ---- O += P V: B operand = V^T tile [d = 16*t + j][keys 8*kb .. + 7]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned char* bp = vl + (t * 16 + j) * AT_VROW + kb * 16;
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp), bm = *reinterpret_cast<const bf16x8*>(bp + AT_VTERM),
+                         bl = *reinterpret_cast<const bf16x8*>(bp + 2 * AT_VTERM);
+            acc_o[t] = mvsx3::mfma6(ah, am, al, bh, bm, bl, acc_o[t]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = q0 + 4 * kb + r;
+        if (q >= N) continue;
+        const float inv = 1.0f / lrow[r];
+        float* o = out + ((size_t)b * N + q) * C + h * 64 + j;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t * 16] = acc_o[t][r] * inv;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- LayerNorm
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
                                                         float* __restrict__ y, int rows, int C, float eps) {
@@ -388,6 +530,15 @@ extern "C" int mvs_conv2d_gemm_x3(int mode, const float* A, const float* Bmap, f
     MVS_REQUIRE((int64_t)nb1 * nb2 <= 65535, "mvs_conv2d_gemm_x3: too many batch items x splits (%d x %d)", nb1, nb2);
     hipLaunchKernelGGL(gemm_x3_kernel, dim3((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nb1 * nb2), dim3(256), 0, MVS_STREAM(stream), a);
     return mvs::finish_launch("mvs_conv2d_gemm_x3");
+}
+
+// out [B][N][heads*64] = softmax(scale * Q K^T) V per (image, head), flash form (the N x N matrix is never written); qkv = [B][N][3*heads*64]
+// packed (q | k | v), vt = V transposed [B][heads][64][N].  head dimension 64.
+extern "C" int mvs_attention_x3(const float* qkv, const float* vt, float* out, int B, int N, int heads, int head_dim, float scale, mvs_stream_t stream) {
+    MVS_REQUIRE(qkv && vt && out && B >= 1 && B <= 65535 && N >= 1 && heads >= 1 && heads <= 65535, "mvs_attention_x3: bad shape");
+    MVS_REQUIRE(head_dim == 64, "mvs_attention_x3: head dimension 64 only (got %d)", head_dim);
+    hipLaunchKernelGGL(attention_x3_kernel, dim3((N + 63) / 64, heads, B), dim3(256), 0, MVS_STREAM(stream), qkv, vt, out, N, heads, scale);
+    return mvs::finish_launch("mvs_attention_x3");
 }
 
 extern "C" int mvs_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps, mvs_stream_t stream) {

@@ -1479,6 +1479,17 @@ def gemm_x3(A, B, C, M, N, K, lda, ldb, ldc, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0),
     return C
 
 
+def attention_x3(qkv: torch.Tensor, vt: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """``softmax(scale * Q K^T) V`` per (image, head) in flash form: ``qkv [B,N,3C]`` packed, ``vt [B,heads,64,N]`` = V transposed -> ``[B,N,C]``."""
+    _chk(qkv, "qkv"), _chk(vt, "vt")
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    out = torch.empty(B, N, C, device=qkv.device, dtype=torch.float32)
+    _call("mvs_attention_x3", ("x3_attention", "flops", 4.0 * B * heads * N * N * (C // heads)), _ptr(qkv), _ptr(vt), _ptr(out), B, N, heads,
+          C // heads, float(scale), _stream())
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
     _chk(x, "x"), _chk(gamma, "gamma"), _chk(beta, "beta")
     y = torch.empty_like(x)

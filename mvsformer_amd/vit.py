@@ -11,6 +11,7 @@ multiply and one mean over 6 heads).  ``mvsformer_amd.install(features=True)`` r
 from __future__ import annotations
 
 import math
+import os
 from functools import partial
 
 import torch
@@ -127,20 +128,27 @@ class VisionTransformer(nn.Module):
         ops.gemm_x3(patches, pw, tok, n, C, nc * P * P, nc * P * P, nc * P * P, C, nb1=B, sA=(n * nc * P * P, 0), sC=(N * C, 0), shift=pb, c_off=C)
         t = (tok + self._pos(hp, wp)).contiguous()
         eps = self.norm.eps
-        scores = torch.empty(B, NH, N, N, device=x.device, dtype=torch.float32)
-        att_out = torch.empty(B, N, C, device=x.device, dtype=torch.float32)
+        scores = None
         for i, (n1w, n1b, qw, qb, prw, prb, n2w, n2b, f1w, f1b, f2w, f2b) in enumerate(blocks):
             y = ops.layernorm(t, n1w, n1b, eps)
             qkv = torch.empty(B, N, 3 * C, device=x.device, dtype=torch.float32)
             ops.gemm_x3(y, qw, qkv, B * N, 3 * C, C, C, C, 3 * C, shift=qb)
-            # scores[b, h] = Q . K^T (head slices of the packed qkv rows), softmax(scale * .), out[b, :, h] = P . V
-            ops.gemm_x3(qkv, qkv, scores, N, N, hd, 3 * C, 3 * C, N, nb1=B, nb2=NH, sA=(N * 3 * C, hd), sB=(N * 3 * C, hd), sC=(NH * N * N, N * N),
-                        b_off=C)
-            ops.softmax_rows_(scores, hd ** -0.5)
-            # P . V with V handed over TRANSPOSED ([B, heads, hd, N], one strided copy of 13 MB): the GEMM's B operand is then read along K
-            # like every other one (reading V [N, hd] in place costs 2-byte transposing LDS stores: 0.44 vs 0.28 ms per block, measured)
+            # V handed over TRANSPOSED ([B, heads, hd, N], one strided copy of 13 MB): the attention's / GEMM's B operand is then read along K
             vt = qkv[:, :, 2 * C:].reshape(B, N, NH, hd).permute(0, 2, 3, 1).contiguous()
-            ops.gemm_x3(scores, vt, att_out, N, hd, N, N, N, C, nb1=B, nb2=NH, sA=(NH * N * N, N * N), sB=(NH * hd * N, hd * N), sC=(N * C, hd))
+            last = want_att and i == len(blocks) - 1
+            if hd == 64 and not last and os.environ.get("MVS_VIT_FLASH", "1") != "0":
+                # flash form: softmax(Q K^T / sqrt(hd)) V without the N x N matrix (csrc/vit.hip attention_x3_kernel)
+                att_out = ops.attention_x3(qkv, vt, NH, hd ** -0.5)
+            else:
+                # materialized form (the LAST block's attention matrix is an output: mvsformer_model.py:257 reads its CLS row): scores[b, h] =
+                # Q . K^T (head slices of the packed qkv rows), softmax(scale * .), out[b, :, h] = P . V
+                if scores is None:
+                    scores = torch.empty(B, NH, N, N, device=x.device, dtype=torch.float32)
+                ops.gemm_x3(qkv, qkv, scores, N, N, hd, 3 * C, 3 * C, N, nb1=B, nb2=NH, sA=(N * 3 * C, hd), sB=(N * 3 * C, hd), sC=(NH * N * N, N * N),
+                            b_off=C)
+                ops.softmax_rows_(scores, hd ** -0.5)
+                att_out = torch.empty(B, N, C, device=x.device, dtype=torch.float32)
+                ops.gemm_x3(scores, vt, att_out, N, hd, N, N, N, C, nb1=B, nb2=NH, sA=(NH * N * N, N * N), sB=(NH * hd * N, hd * N), sC=(N * C, hd))
             t2 = torch.empty_like(t)
             ops.gemm_x3(att_out, prw, t2, B * N, C, C, C, C, C, shift=prb, res=t)
             y = ops.layernorm(t2, n2w, n2b, eps)

@@ -101,3 +101,25 @@ def test_layernorm_softmax_bicubic(dev):
     want = F.interpolate(tab[None], scale_factor=(sh, sw), mode="bicubic", align_corners=False)[0]
     assert want.shape[-2:] == (8, 10)
     assert _rel(ops.bicubic_resize(tab.to(dev), 8, 10, 1 / sh, 1 / sw), want) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 50), (2, 6, 197), (1, 3, 1729), (3, 2, 64)])
+def test_attention_x3_flash_vs_fp64(dev, shape):
+    """Flash-form attention (online softmax, no N x N matrix) against softmax(Q K^T / 8) V in fp64, and against the materialized
+    split-form path it replaces in blocks 0..10 (vision_transformer.py:60-76 is the reference's Attention.forward)."""
+    from mvsformer_amd import ops
+    B, NH, N = shape
+    hd, C = 64, NH * 64
+    gen = torch.Generator().manual_seed(N + 3 * B)
+    qkv = torch.randn(B, N, 3 * C, generator=gen) * 1.7
+    q, k, v = (qkv[:, :, i * C:(i + 1) * C].reshape(B, N, NH, hd).permute(0, 2, 1, 3).double() for i in range(3))
+    want = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, C)
+    fp32 = (torch.softmax(q.float() @ k.float().transpose(-1, -2) * hd ** -0.5, -1) @ v.float()).permute(0, 2, 1, 3).reshape(B, N, C)
+    d = qkv.to(dev)
+    vt = d[:, :, 2 * C:].reshape(B, N, NH, hd).permute(0, 2, 3, 1).contiguous()
+    got = ops.attention_x3(d, vt, NH, hd ** -0.5)
+    torch.cuda.synchronize()
+    err, err32 = _rel(got, want), _rel(fp32, want)
+    assert err < 3 * err32 + 5e-7, (err, err32)
+    with pytest.raises(Exception):
+        ops.attention_x3(d[:, :, :96].contiguous(), vt, 1, 0.1)          # head dimension 32: refused loudly, no silent fallback

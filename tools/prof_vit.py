@@ -37,7 +37,5 @@ for t, ms in rows:
 for t, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-20s calls %4d  total %8.3f ms" % (t, n, ms))
 print("sum of launches %.3f ms" % tot)
-# the GEMMs of ONE block in order: qkv, scores, PV, proj, fc1, fc2
-g = [ms for t, ms in rows if t == "x3_gemm"]
-print("patch embed %.3f | block 0: qkv %.3f scores %.3f PV %.3f proj %.3f fc1 %.3f fc2 %.3f | decoder: %s" % (
-    g[0], g[1], g[2], g[3], g[4], g[5], g[6], " ".join("%.3f" % v for v in g[1 + 12 * 6:])))
+# the launches of block 0 in order (flash form: layernorm, qkv GEMM, attention, proj GEMM, layernorm, fc1, fc2)
+print("first launches: " + " | ".join("%s %.3f" % (t, ms) for t, ms in rows[:12]))
