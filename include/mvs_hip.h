@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 22
+#define MVS_ABI_VERSION 23
 
 typedef void* mvs_stream_t;
 
@@ -371,10 +371,11 @@ int mvs_bf16_conv3d_bn_fwd(const void* x, const void* wpacked, void* y, void* z,
 /* mvs_bf16_conv3d_bnbwd: a raw convolution whose output is the gradient dz arriving at a BatchNorm(+ReLU) layer (the data gradient of the
  * layer AFTER it), with that BatchNorm's backward sums [sum g | sum g*xhat] (g = dz * relu'(bn_y*scale + shift)) taken in the epilogue:
  * what mvs_bf16_bn_bwd_reduce(dz, bn_y, ...) returns, without its pass over dz and bn_y.  bn4 = the forward's stats4; workspace as
- * mvs_bf16_conv3d_bn_fwd_workspace_bytes of the output grid. */
+ * mvs_bf16_conv3d_bn_fwd_workspace_bytes of the output grid.  addend (optional, y's shape, bf16): a second gradient of the same tensor (the
+ * tensor also fed a skip connection) added before the rounding and the sums: y = the TOTAL gradient. */
 int mvs_bf16_conv3d_bnbwd(const void* x, const void* wpacked, void* y, int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd,
-                          int shw, int taps, const void* bn_y, const float* bn4, int relu, int groups, float* sums, void* workspace,
-                          mvs_stream_t stream);
+                          int shw, int taps, const void* bn_y, const float* bn4, int relu, int groups, const void* addend, float* sums,
+                          void* workspace, mvs_stream_t stream);
 /* 2-D kernels on the same machinery (`taps` = 27 or 9; 9 = only the centre depth tap exists: the visibility CNN's Conv2d layers run as
  * D = 1 volumes at a third of the matrix work of a zero-embedded 3x3x3 kernel, forward, data gradient and weight gradient):
  *   mvs_bf16_packed_elems_taps / mvs_bf16_pack_table_*: w = [d0][d1][taps]; rows / channels of the Cin -> Cout map beyond d0 / d1 pack as

@@ -18,7 +18,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVS_HIP_LIB: diagnostics only - another BUILD of the same library (tests/test_hip_multistream.py's variants); never a fallback
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 from ctypes import c_double  # noqa: E402
 
@@ -93,7 +93,7 @@ SIGNATURES = {
     "mvs_bf16_bn_bwd_apply_dgb": (I, [P, P, P, P, P, P, P, P, Dbl, P, I, I, L, I, L, P, P, P]),
     "mvs_bf16_conv3d_bn_fwd_workspace_bytes": (L, [I, I, I, I, I]),
     "mvs_bf16_conv3d_bn_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P, F, F, P, P, P, P]),
-    "mvs_bf16_conv3d_bnbwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, P, P, I, I, P, P, P]),
+    "mvs_bf16_conv3d_bnbwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, P, P, I, I, P, P, P, P]),
     "mvs_bf16_packed_elems_taps": (L, [I, I, I]),
     "mvs_bf16_pack_table_bytes": (L, [I]),
     "mvs_bf16_pack_table_fill": (I, [P, I, I, P, I, I, I, I, I, I, P]),

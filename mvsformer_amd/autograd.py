@@ -558,6 +558,24 @@ def _bn_synced(bn) -> bool:
     return isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size(bn.process_group) > 1
 
 
+class SkipLink:
+    """Hand-over of a skip connection's gradient between two :class:`LayerBf16Fn` nodes of one network (CostRegNet's c2 / c4 / input
+    volume: each feeds a strided convolution AND, later, the residual input of a transposed-convolution layer).  Autograd would add the
+    tensor's two gradients with a kernel of its own and the sum would arrive without the BatchNorm sums attached; instead
+
+      * the strided convolution's layer (``take``) ARMS the link in its forward - it promises to add whatever the link holds to its
+        data gradient in the convolution's epilogue (ops.bf16_conv3d with ``residual`` / ops.bf16_conv3d_bnbwd with ``addend``);
+      * the residual layer (``give``), whose backward always runs first (its output depends on the strided layer's), leaves its incoming
+        gradient - which IS the residual's gradient - in the link and returns None for the residual.
+
+    An armed link that is empty when the taker's backward runs is an error (a gradient would be lost), never a silent zero."""
+
+    __slots__ = ("armed", "grad")
+
+    def __init__(self):
+        self.armed, self.grad = False, None
+
+
 class LayerBf16Fn(torch.autograd.Function):
     """One whole training layer on bf16 channel-last activations as ONE autograd node: (transposed) 3x3x3 convolution -> batch-statistics
     BatchNorm (statistics in the convolution's epilogue) -> [ReLU] [+ skip]; backward = BatchNorm backward, data gradient, weight
@@ -572,7 +590,7 @@ class LayerBf16Fn(torch.autograd.Function):
     here; 3x3x3 only)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, residual, bn, relu, gather, stride, groups=1, packed=None):
+    def forward(ctx, x, weight, gamma, beta, residual, bn, relu, gather, stride, groups=1, packed=None, take=None, give=None):
         x = x.contiguous()
         taps = ops._taps_of(weight)
         if gather == 0:
@@ -614,6 +632,11 @@ class LayerBf16Fn(torch.autograd.Function):
         # tensor object; a tensor that also feeds a skip connection has it removed by the network (module.py), and a gradient that was
         # accumulated from two consumers arrives as a new tensor without the answer attached - the plain reduce runs then.
         ctx.prev_bn = getattr(x, "_mvs_bn", None) if need_dx and _fused_layers() else None
+        # skip-connection gradient hand-over (SkipLink): we take x's other gradient into our data gradient / we give the residual's away
+        ctx.take = take if take is not None and need_dx and _fused_layers() else None
+        if ctx.take is not None:
+            ctx.take.armed, ctx.take.grad = True, None
+        ctx.give = give if give is not None and give.armed and residual is not None and ctx.needs_input_grad[4] else None
         z._mvs_bn = (y, st, relu, groups)
         return z
 
@@ -644,11 +667,23 @@ class LayerBf16Fn(torch.autograd.Function):
             # conv of dY with W read as [out = cin, in = cout]
             g_, st_, cin_ = ((0 if shw == 1 else 1), ((1, 1) if shw == 1 else (sd, shw)), cin_map) if gather == 0 else (0, (sd, 2), cin)
             prev = ctx.prev_bn
+            other = None
+            if ctx.take is not None:
+                other, ctx.take.grad, ctx.take.armed = ctx.take.grad, None, False
+                if other is None:
+                    raise ops._lib.MvsHipError("SkipLink: the residual layer's backward has not run before the strided layer's - a gradient "
+                                               "would be lost (MVS_TRAIN_SKIPLINK=0 turns the hand-over off)")
+                if tuple(other.shape) != tuple(x.shape):
+                    raise ops._lib.MvsHipError("SkipLink: gradient %s for a tensor of shape %s" % (tuple(other.shape), tuple(x.shape)))
             if prev is not None and tuple(prev[0].shape) == tuple(x.shape):
-                dx, psums = ops.bf16_conv3d_bnbwd(dy, wb, cout, cin_, g_, st_, prev[0], prev[1], prev[2], prev[3], taps)
+                dx, psums = ops.bf16_conv3d_bnbwd(dy, wb, cout, cin_, g_, st_, prev[0], prev[1], prev[2], prev[3], taps, other)
                 dx._mvs_bn_sums = (prev[0].data_ptr(), dx.data_ptr(), psums)
+            elif other is not None and taps == 27:
+                dx = ops.bf16_conv3d(dy, wb, cout, cin_, g_, st_, residual=other)
             else:
                 dx = ops.bf16_conv3d(dy, wb, cout, cin_, g_, st_, taps=taps)
+                if other is not None:
+                    dx = dx + other
             if dx.shape != x.shape:
                 raise ops._lib.MvsHipError("conv backward: input %s does not match the gradient grid %s" % (tuple(x.shape), tuple(dx.shape)))
         dw = None
@@ -657,8 +692,11 @@ class LayerBf16Fn(torch.autograd.Function):
                 dw = ops.bf16_conv3d_wgrad(dy, x, (sd, shw), taps, cin)
             else:
                 dw = ops.bf16_conv3d_wgrad(x, dy, (sd, 2))
+        dres = dz if has_res else None
+        if ctx.give is not None:                            # the strided layer that also consumed the residual adds it in its epilogue
+            ctx.give.grad, dres = dz, None
         return dx, dw, (dgamma if ctx.needs_input_grad[2] else None), (dbeta if ctx.needs_input_grad[3] else None), \
-            (dz if has_res else None), None, None, None, None, None, None
+            dres, None, None, None, None, None, None, None, None
 
 
 class HeadBf16Fn(torch.autograd.Function):

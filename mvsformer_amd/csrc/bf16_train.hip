@@ -1285,9 +1285,11 @@ __global__ __launch_bounds__(256) void bf16_rows_reduce_kernel(const float* __re
 // after it - with that BatchNorm's two backward sums taken in the convolution's epilogue: sums [2*groups*Cout] = [sum g | sum g*xhat],
 // g = dz * [bn_y*scale + shift > 0 or !relu], exactly what mvs_bf16_bn_bwd_reduce(dz, bn_y, ...) returns, without the pass over dz and bn_y.
 // bn4 = the forward's stats4 ([scale | shift | mean | invstd], each groups*Cout); workspace = mvs_bf16_conv3d_bn_fwd_workspace_bytes.
+// addend (optional, y's shape): a second gradient of the same tensor (it also fed a skip connection), added before the rounding and the
+// sums - the total gradient leaves this launch, no separate sum of the two and no separate reduce.
 extern "C" int mvs_bf16_conv3d_bnbwd(const void* x, const void* wpacked, void* y, int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd,
-                                     int shw, int taps, const void* bn_y, const float* bn4, int relu, int groups, float* sums, void* workspace,
-                                     mvs_stream_t stream) {
+                                     int shw, int taps, const void* bn_y, const float* bn4, int relu, int groups, const void* addend, float* sums,
+                                     void* workspace, mvs_stream_t stream) {
     MVS_REQUIRE(bn_y && bn4 && sums && workspace && groups >= 1 && B % groups == 0, "mvs_bf16_conv3d_bnbwd: bad arguments (B=%d groups=%d)", B, groups);
     MVS_REQUIRE((sd == 1 || sd == 2) && (shw == 1 || shw == 2) && (gather == 0 || gather == 1), "mvs_bf16_conv3d_bnbwd: bad stride / gather");
     int Do, Ho, Wo;
@@ -1296,7 +1298,7 @@ extern "C" int mvs_bf16_conv3d_bnbwd(const void* x, const void* wpacked, void* y
     const int64_t ips = (gather == 1 && shw == 2) ? (int64_t)Do * Ho * ((Wo + 127) / 128) * 2 : (int64_t)Do * Ho * ((Wo + 63) / 64);
     const bool ks = conv_ksplit(Cin, (int)(ips * B), taps);
     MVS_REQUIRE(B == 1 || ks || ips % 4 == 0, "mvs_bf16_conv3d_bnbwd: %lld work items per sample are not a multiple of 4", (long long)ips);
-    if (int rc = bf16_conv3d_impl(x, wpacked, nullptr, nullptr, nullptr, y, B, Cin, Cout, Di, Hi, Wi, gather, sd, shw, 0,
+    if (int rc = bf16_conv3d_impl(x, wpacked, nullptr, nullptr, addend, y, B, Cin, Cout, Di, Hi, Wi, gather, sd, shw, 0,
                                   reinterpret_cast<float*>(workspace), groups, nullptr, stream, true, taps, bn_y, bn4, relu, groups))
         return rc;
     const int nrows = ks ? (int)(ips * B) : (int)((ips * B + 3) / 4), rps = B == 1 ? nrows : (int)(ks ? ips : ips / 4);

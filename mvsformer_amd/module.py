@@ -65,15 +65,24 @@ def autocast_bf16() -> bool:
         return False
 
 
-def _multi_use(t):
+def _multi_use(t, link=None):
     """A training-layer output that feeds more than one consumer (a skip connection) or a consumer of another kind (the head): its
-    BatchNorm's backward sums cannot be taken by ONE consumer's data gradient (autograd.LayerBf16Fn) - drop the tag that offers it."""
-    if hasattr(t, "_mvs_bn"):
+    BatchNorm's backward sums cannot be taken by ONE consumer's data gradient (autograd.LayerBf16Fn) - drop the tag that offers it.
+    With a ``link`` (autograd.SkipLink) the strided consumer's data gradient WILL be the tensor's total gradient: the tag stays."""
+    if link is None and hasattr(t, "_mvs_bn"):
         del t._mvs_bn
     return t
 
 
-def _train_conv_bn_act(x, conv, bn, relu, residual, transposed_sd=None):
+def _skip_links(x, n=3):
+    """``n`` SkipLinks for one forward of a U-Net on the fused bf16 training layers, else Nones (MVS_TRAIN_SKIPLINK=0: autograd adds)."""
+    from . import autograd as ag
+    if x.dtype == torch.bfloat16 and ag._fused_layers() and os.environ.get("MVS_TRAIN_SKIPLINK", "1") != "0":
+        return tuple(ag.SkipLink() for _ in range(n))
+    return (None,) * n
+
+
+def _train_conv_bn_act(x, conv, bn, relu, residual, transposed_sd=None, take=None, give=None):
     """Training-mode layer: raw (transposed) conv -> batch-stat BN -> ReLU (+ residual), all autograd-tracked HIP ops.
     bf16 channel-last input (``[B,D,H,W,C]``) selects the bf16 kernels, fp32 ``[B,C,D,H,W]`` the fp32 ones."""
     from . import autograd as ag
@@ -89,8 +98,10 @@ def _train_conv_bn_act(x, conv, bn, relu, residual, transposed_sd=None):
             # normalize): 8 graph nodes per layer and step instead of 11
             if transposed_sd is None:
                 s = tuple(conv.stride)
-                return ag.LayerBf16Fn.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, bool(relu), 0, (s[0], s[1]), 1, pk)
-            return ag.LayerBf16Fn.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, bool(relu), 1, (transposed_sd, 2), 1, pk)
+                return ag.LayerBf16Fn.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, bool(relu), 0, (s[0], s[1]), 1, pk, take, give)
+            return ag.LayerBf16Fn.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, bool(relu), 1, (transposed_sd, 2), 1, pk, take, give)
+        if take is not None:
+            _multi_use(x)                                    # no hand-over on the unfused chain: the tag (if any) must not promise one
         if transposed_sd is None:
             s = tuple(conv.stride)
             out = ag.ConvBf16Fn.apply(x, conv.weight, (s[0], s[1]), fused, pk)
@@ -199,9 +210,9 @@ class Conv3d(nn.Module):
             self._cache = (key, packed, scale, shift, (s[0], s[1]), wino, x3, small)
         return self._cache[1:]
 
-    def forward(self, x, residual: Optional[torch.Tensor] = None):
+    def forward(self, x, residual: Optional[torch.Tensor] = None, take=None):
         if self.training:
-            return _train_conv_bn_act(x, self.conv, self.bn, self.relu, residual)
+            return _train_conv_bn_act(x, self.conv, self.bn, self.relu, residual, take=take)
         packed, scale, shift, stride, wino, x3, small = self._prepared()
         # (a sample beyond the split-form kernel's 2 GiB buffer window falls through to the 64-bit-addressed fp32-MFMA kernel below)
         if x3 is not None and x.shape[2] * (x.shape[3] // stride[1]) * (x.shape[4] // stride[1]) >= int(os.environ.get("MVS_CONV_X3_MIN_VOXELS", X3_MIN_VOXELS)) \
@@ -228,10 +239,10 @@ class Deconv3d(nn.Module):
         self.relu = relu
         self._cache = None
 
-    def forward(self, x, residual: Optional[torch.Tensor] = None):
+    def forward(self, x, residual: Optional[torch.Tensor] = None, give=None):
         if self.training:
             _prepare_deconv_check(self.conv)
-            return _train_conv_bn_act(x, self.conv, self.bn, self.relu, residual, transposed_sd=self.conv.stride[0])
+            return _train_conv_bn_act(x, self.conv, self.bn, self.relu, residual, transposed_sd=self.conv.stride[0], give=give)
         key = _versions(self)
         if self._cache is None or self._cache[0] != key:
             prepared = _prepare_deconv(self.conv, self.bn)
@@ -340,12 +351,19 @@ class CostRegNet(nn.Module):
         if self.training and autocast_bf16() and not pre16:
             from . import autograd as ag
             x = ag.ToBf16Fn.apply(x)                     # fp32 cost volume -> bf16 channel-last; every layer below follows the dtype
-        c2 = _multi_use(self.conv2(self.conv1(x)))
-        c4 = _multi_use(self.conv4(self.conv3(c2)))
-        y = self.conv6(self.conv5(c4))
-        y = self.conv7(y, residual=c4)
-        y = self.conv9(y, residual=c2)
-        return _multi_use(self.conv11(y, residual=x))
+        if not self.training:
+            c2 = self.conv2(self.conv1(x))
+            c4 = self.conv4(self.conv3(c2))
+            y = self.conv7(self.conv6(self.conv5(c4)), residual=c4)
+            return self.conv11(self.conv9(y, residual=c2), residual=x)
+        # training: each skip tensor's two gradients meet in the strided convolution's data-gradient epilogue (autograd.SkipLink)
+        l0, l2, l4 = _skip_links(x)
+        c2 = _multi_use(self.conv2(self.conv1(x, take=l0)), l2)
+        c4 = _multi_use(self.conv4(self.conv3(c2, take=l2)), l4)
+        y = self.conv6(self.conv5(c4, take=l4))
+        y = self.conv7(y, residual=c4, give=l4)
+        y = self.conv9(y, residual=c2, give=l2)
+        return _multi_use(self.conv11(y, residual=x, give=l0))
 
     def forward(self, x):
         y = self.features(x)
@@ -398,11 +416,11 @@ class CostRegNet3D(nn.Module):
         self.prob = nn.Conv3d(base_channel, 1, 1, stride=1, padding=0)
         self._dcache: Dict[str, tuple] = {}
 
-    def _up(self, name: str, x, residual):
+    def _up(self, name: str, x, residual, give=None):
         seq = getattr(self, name)
         if self.training:
             _prepare_deconv_check(seq[0])
-            return _train_conv_bn_act(x, seq[0], seq[1], True, residual, transposed_sd=seq[0].stride[0])
+            return _train_conv_bn_act(x, seq[0], seq[1], True, residual, transposed_sd=seq[0].stride[0], give=give)
         key = _versions(seq)
         c = self._dcache.get(name)
         if c is None or c[0] != key:
@@ -480,12 +498,13 @@ class CostRegNet3D(nn.Module):
         if self.training and autocast_bf16() and not pre16:
             from . import autograd as ag
             x = ag.ToBf16Fn.apply(x)                     # fp32 cost volume -> bf16 channel-last; every layer below follows the dtype
-        c2 = _multi_use(self.conv2(self.conv1(x)))
-        c4 = _multi_use(self.conv4(self.conv3(c2)))
-        y = self.conv6(self.conv5(c4))
-        y = self._up("conv7", y, c4)
-        y = self._up("conv9", y, c2)
-        return _multi_use(self._up("conv11", y, x))
+        l0, l2, l4 = _skip_links(x) if self.training else (None,) * 3
+        c2 = _multi_use(self.conv2(self.conv1(x, take=l0)), l2)
+        c4 = _multi_use(self.conv4(self.conv3(c2, take=l2)), l4)
+        y = self.conv6(self.conv5(c4, take=l4))
+        y = self._up("conv7", y, c4, l4)
+        y = self._up("conv9", y, c2, l2)
+        return _multi_use(self._up("conv11", y, x, l0))
 
     def prob_params(self):
         return _f32c(self.prob.weight).reshape(-1), _f32c(self.prob.bias).reshape(-1)

@@ -1189,10 +1189,11 @@ def bf16_conv3d(x, wpacked, cin, cout, gather: int, stride, scale=None, shift=No
     return y
 
 
-def bf16_conv3d_bnbwd(x, wpacked, cin, cout, gather: int, stride, bn_y, bn4, relu, groups: int = 1, taps: int = 27):
+def bf16_conv3d_bnbwd(x, wpacked, cin, cout, gather: int, stride, bn_y, bn4, relu, groups: int = 1, taps: int = 27, addend=None):
     """Raw convolution whose output is the gradient arriving at a BatchNorm(+ReLU) layer (the data gradient of the layer after it) + that
     BatchNorm's backward sums from the convolution's epilogue -> ``(dz, sums [2*groups*cout])``; ``bn_y`` = the BatchNorm's input,
-    ``bn4 [4, groups*cout]`` = the forward's (scale, shift, mean, invstd)."""
+    ``bn4 [4, groups*cout]`` = the forward's (scale, shift, mean, invstd).  ``addend``: the tensor's other gradient (it also fed a skip
+    connection), added before the rounding and the sums."""
     _chk16(x, "x"), _chk16(wpacked, "packed weights"), _chk16(bn_y, "bn_y"), _chk(bn4, "bn4")
     B, Di, Hi, Wi, C = x.shape
     assert C == cin
@@ -1205,12 +1206,16 @@ def bf16_conv3d_bnbwd(x, wpacked, cin, cout, gather: int, stride, bn_y, bn4, rel
     if tuple(bn_y.shape) != tuple(y.shape) or bn4.shape != (4, groups * cout) or B % groups:
         raise _lib.MvsHipError("bf16_conv3d_bnbwd: BatchNorm input %s / statistics %s do not match the gradient %s (groups %d)" % (
             tuple(bn_y.shape), tuple(bn4.shape), tuple(y.shape), groups))
+    if addend is not None:
+        _chk16(addend, "addend")
+        if tuple(addend.shape) != tuple(y.shape):
+            raise _lib.MvsHipError("bf16_conv3d_bnbwd: addend %s does not match the gradient %s" % (tuple(addend.shape), tuple(y.shape)))
     sums = torch.empty(2 * groups * cout, device=x.device, dtype=torch.float32)
     ws = _reduce_ws("mvs_bf16_conv3d_bn_fwd_workspace_bytes", x.device, B, cout, Do, Ho, Wo)
     flops = 2.0 * taps * cin * cout * B * (Do * Ho * Wo if gather == 0 else Di * Hi * Wi)
     tag = ("bf16_conv_kernel<%d,%d,g%d,s%d%d%s>" % (cin, cout, gather, sd, shw, ",2d" if taps == 9 else ""), "flops", flops)
     _call("mvs_bf16_conv3d_bnbwd", tag, _ptr(x), _ptr(wpacked), _ptr(y), B, cin, cout, Di, Hi, Wi, int(gather), sd, shw, int(taps), _ptr(bn_y),
-          _ptr(bn4), int(relu), int(groups), _ptr(sums), _ptr(ws), _stream())
+          _ptr(bn4), int(relu), int(groups), _ptr(addend), _ptr(sums), _ptr(ws), _stream())
     return y, sums
 
 
