@@ -36,8 +36,9 @@ def parse(argv=None):
                          "master weights fp32 (what the reference's autocast training does); f32: everything fp32")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the whole step (forward + loss + backward + AdamW) as ONE hipGraph (mvsformer_amd/graphs.py): host cost per "
-                         "step 13-22 ms (box dependent) -> 0.6 ms, so the step runs at the GPU's pace (13.2 ms) whatever the host does; "
-                         "auto = on for a single rank (eager fallback if capture fails), off under DistributedDataParallel")
+                         "step 13-22 ms (box dependent) -> 0.4 ms, so the step runs at the GPU's pace whatever the host does; auto = on, with an "
+                         "eager fallback if the capture fails.  Under DistributedDataParallel + SyncBatchNorm the RCCL all-reduces are "
+                         "captured with the kernels (DDP constructed, warmed up for 12 iterations and captured on one side stream)")
     return ap.parse_args(argv)
 
 
@@ -52,16 +53,25 @@ def measure(args, top=12):
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")       # the watchdog's event queries are not capturable
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     import mvsformer_amd as m
     from mvsformer_amd import synth
     torch.manual_seed(0)
     net = m.CascadeMVS(dict(ndepths=[32, 16, 8, 8])).to(dev).train()
     model = net
+    # the whole step - SyncBatchNorm's and the reducer's RCCL all-reduces included - is captured under DDP too ("auto"; --graph off = eager)
+    use_graph = args.graph in ("on", "auto")
+    ddp_stream = None
     if ddp:
         net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
-        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local])
-    use_graph = args.graph == "on" or (args.graph == "auto" and not ddp)
+        if use_graph:                                        # whole-step capture under DDP: construct, warm up and capture on ONE side stream
+            ddp_stream = torch.cuda.Stream()
+            ddp_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ddp_stream):
+                model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local])
+        else:
+            model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local])
     # torch.optim.AdamW as the reference trainer builds it (train.py:98), in its FUSED form: one multi-tensor kernel for all ~190
     # parameter tensors (the default capturable form spends 304 elementwise launches and 1.1 ms of a 12.9 ms step on bias corrections)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=use_graph, fused=True)
@@ -88,7 +98,9 @@ def measure(args, top=12):
     if use_graph:
         try:
             from mvsformer_amd.graphs import CapturedStep
-            step = CapturedStep(eager_step, warmup=3, keep_graph=True)
+            # under DDP: the reducer's logger times its first 10 iterations with events (not capturable) and rebuilds its buckets after the
+            # first one - torch's whole-network-capture recipe is >= 11 eager iterations first
+            step = CapturedStep(eager_step, warmup=12 if ddp else 3, keep_graph=True, stream=ddp_stream)
         except Exception as e:                               # report, fall back to eager launches
             if args.graph == "on":
                 raise

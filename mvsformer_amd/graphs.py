@@ -22,11 +22,13 @@ class CapturedStep:
     """``step_fn()`` (no arguments, returns a tensor or a tuple of tensors) captured into a hipGraph after ``warmup`` eager runs on a
     side stream (lazy initialisation - weight-pack caches, hipFuncSetAttribute, allocator growth - must not happen during capture)."""
 
-    def __init__(self, step_fn: Callable[[], object], warmup: int = 3, keep_graph: bool = False):
-        """``keep_graph``: keep the captured hipGraph_t beside the executable one, so :meth:`node_counts` can walk it."""
+    def __init__(self, step_fn: Callable[[], object], warmup: int = 3, keep_graph: bool = False, stream=None):
+        """``keep_graph``: keep the captured hipGraph_t beside the executable one, so :meth:`node_counts` can walk it.  ``stream``: the
+        side stream to warm up AND capture on (DistributedDataParallel wants the stream it was constructed on: its reducer's
+        AccumulateGrad hooks remember it)."""
         if not torch.cuda.is_available():
             raise RuntimeError("CapturedStep needs a GPU")
-        side = torch.cuda.Stream()
+        side = stream if stream is not None else torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
@@ -35,7 +37,7 @@ class CapturedStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph(keep_graph=True) if keep_graph else torch.cuda.CUDAGraph()
         self._kept = keep_graph
-        with torch.cuda.graph(self.graph):
+        with (torch.cuda.graph(self.graph, stream=stream) if stream is not None else torch.cuda.graph(self.graph)):
             self.outputs = step_fn()
 
     def node_counts(self):

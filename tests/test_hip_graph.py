@@ -51,6 +51,67 @@ def test_captured_training_step_matches_eager():
             assert torch.equal(v, after_g[k]), k
 
 
+def test_captured_ddp_syncbn_step_matches_eager():
+    """The whole step under DistributedDataParallel + SyncBatchNorm over RCCL (train.py:138-139) captured into ONE hipGraph - the
+    SyncBatchNorm all-reduces of forward and backward and the reducer's bucket all-reduce are recorded with the kernels - and replayed:
+    same loss and same updated state as the eager DDP step from the same state.  One rank (the box has one GPU; the collectives are real
+    RCCL calls on a world of one).  Recipe of torch's whole-network capture: construct DDP, warm up (>= 11 iterations: the reducer's
+    logger times its first ten with events and rebuilds its buckets after the first) and capture on ONE side stream."""
+    import os
+    import torch.distributed as dist
+    import mvsformer_amd as m
+    from mvsformer_amd import synth
+    from mvsformer_amd.graphs import CapturedStep
+    from mvsformer_amd.losses import ce_loss_stage4
+    dev = torch.device("cuda:0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29547"
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        feats, proj, dv, scene = synth.make_inputs(3, 128, 192, seed=4, device=dev)
+        gts = {"stage%d" % (i + 1): synth.plane_depth(scene, s, device=dev)[None] for i, s in enumerate(synth.STAGE_SCALES)}
+        masks = {k: torch.ones_like(v) for k, v in gts.items()}
+        torch.manual_seed(0)
+        net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m.CascadeMVS(dict(ndepths=[8, 8, 4, 4]))).to(dev).train()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[0])
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = model(feats, proj, dv, tmp=[5.0, 5.0, 5.0, 1.0])
+            loss = sum(ce_loss_stage4(out, gts, masks, dlossw=[1, 1, 1, 1]).values())
+            loss.backward()
+            opt.step()
+            return loss
+
+        graphed = CapturedStep(step, warmup=12, keep_graph=True, stream=side)
+        counts = graphed.node_counts()
+        assert counts is None or counts["kernel"] > 100, counts
+        state = {k: v.clone() for k, v in net.state_dict().items()}
+        loss_g = graphed().clone()
+        after_g = {k: v.clone() for k, v in net.state_dict().items()}
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                v.copy_(state[k])
+        with torch.cuda.stream(side):
+            loss_e = step().clone()
+        torch.cuda.synchronize()
+        assert abs(loss_e.item() - loss_g.item()) <= 1e-5 * abs(loss_e.item()), (loss_e.item(), loss_g.item())
+        for k, v in net.state_dict().items():
+            if v.dtype.is_floating_point:
+                assert (v - after_g[k]).abs().max().item() <= 1e-6 + 2e-3 * v.abs().max().item(), k
+            else:
+                assert torch.equal(v, after_g[k]), k
+    finally:
+        dist.destroy_process_group()
+
+
 def test_captured_eval_cascade_is_bit_equal():
     """The eval cascade (no host synchronization once the weight caches are built) captured into a hipGraph: replays on new inputs
     (copied in place into the captured tensors) reproduce the eager outputs bit for bit."""
