@@ -37,7 +37,9 @@ class CapturedStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph(keep_graph=True) if keep_graph else torch.cuda.CUDAGraph()
         self._kept = keep_graph
-        with (torch.cuda.graph(self.graph, stream=stream) if stream is not None else torch.cuda.graph(self.graph)):
+        # with a caller's stream (DDP): thread-local capture mode - the process group's watchdog thread polls events of earlier
+        # collectives while we capture, which the default (global) mode turns into a capture error
+        with (torch.cuda.graph(self.graph, stream=stream, capture_error_mode="thread_local") if stream is not None else torch.cuda.graph(self.graph)):
             self.outputs = step_fn()
 
     def node_counts(self):
