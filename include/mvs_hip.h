@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 23
+#define MVS_ABI_VERSION 24
 
 typedef void* mvs_stream_t;
 
@@ -376,6 +376,18 @@ int mvs_bf16_conv3d_bn_fwd(const void* x, const void* wpacked, void* y, void* z,
 int mvs_bf16_conv3d_bnbwd(const void* x, const void* wpacked, void* y, int B, int Cin, int Cout, int Di, int Hi, int Wi, int gather, int sd,
                           int shw, int taps, const void* bn_y, const float* bn4, int relu, int groups, const void* addend, float* sums,
                           void* workspace, mvs_stream_t stream);
+/* The weight gradients of SEVERAL layers in one call: one grid per kernel instance (all jobs of it side by side) + one fixed-order reduce for
+ * all of them.  A layer alone is a chain of short round trips on a fraction of the chip; a training step's ~50 of them in a row were a
+ * quarter of the step.  jobs = HOST array; per job dW [CA][CBout][taps] = sum A[p][a] * Bt[p*s-1+k][b] exactly as mvs_bf16_conv3d_wgrad_taps
+ * (same kernels, same slab order: bit-identical to the layer-by-layer calls).  workspace >= mvs_bf16_wgrad_group_workspace_bytes(jobs). */
+typedef struct MvsWgradJob {
+    const void* A;            /* [nbatch,Dp,Hp,Wp,CA] bf16 channel-last: the operand on the grid the stride divides */
+    const void* Bt;           /* [nbatch,Db,Hb,Wb,CB] bf16 channel-last */
+    float* dW;                /* [CA][CBout][taps] fp32 */
+    int nbatch, CA, CB, CBout, Dp, Hp, Wp, Db, Hb, Wb, sd, shw, taps, reserved;
+} MvsWgradJob;
+int64_t mvs_bf16_wgrad_group_workspace_bytes(const MvsWgradJob* jobs, int njobs);
+int mvs_bf16_wgrad_group(const MvsWgradJob* jobs, int njobs, void* workspace, int64_t workspace_bytes, mvs_stream_t stream);
 /* 2-D kernels on the same machinery (`taps` = 27 or 9; 9 = only the centre depth tap exists: the visibility CNN's Conv2d layers run as
  * D = 1 volumes at a third of the matrix work of a zero-embedded 3x3x3 kernel, forward, data gradient and weight gradient):
  *   mvs_bf16_packed_elems_taps / mvs_bf16_pack_table_*: w = [d0][d1][taps]; rows / channels of the Cin -> Cout map beyond d0 / d1 pack as

@@ -350,7 +350,7 @@ def vis_train_views(entropy: torch.Tensor, vis: nn.Sequential) -> torch.Tensor:
             pk = packed_of(blk.conv)
             if fused and pk is not None:
                 # the 2-D parameter itself (9 taps of a D = 1 volume), packed this step by the stage's StagePack
-                x16 = LayerBf16Fn.apply(x16, blk.conv.weight, blk.bn.weight, blk.bn.bias, None, blk.bn, True, 0, (1, 1), Vs, pk)
+                x16 = LayerBf16Fn.apply(x16, route_of(blk.conv), blk.bn.weight, blk.bn.bias, None, blk.bn, True, 0, (1, 1), Vs, pk)
                 continue
             cin_pad = 8 if i == 0 else blk.conv.in_channels
             w3 = embed_conv2d_weight(blk.conv.weight, cin_pad)
@@ -401,6 +401,67 @@ class FromBf16Fn(torch.autograd.Function):
         return ops.bf16_from_f32(dy.contiguous())
 
 
+class WgradQueue:
+    """Weight-gradient jobs of one stage's backward, run TOGETHER when the last of them has been queued (:class:`WgradFlushFn`): one
+    grid per kernel instance with all its layers side by side + one reduce (ops.bf16_wgrad_group) instead of two launches per layer.
+    ``push`` returns the (still unwritten) gradient tensor; the operands stay referenced until the flush."""
+
+    def __init__(self):
+        self.jobs = []
+
+    def push(self, A, Bt, stride, taps: int = 27, cb_out=None):
+        dW = torch.empty(ops.bf16_wgrad_shape(A, Bt, taps, cb_out), device=A.device, dtype=torch.float32)
+        self.jobs.append((A, Bt, dW, (int(stride[0]), int(stride[1])), int(taps), cb_out))
+        return dW
+
+    def flush(self, grads=()):
+        jobs, self.jobs = self.jobs, []
+        if not jobs:
+            return
+        # every queued gradient must arrive here as the tensor we handed out (not a copy autograd made on the way): the fill below
+        # writes through the pointer
+        seen = {g.data_ptr() for g in grads if g is not None}
+        for job in jobs:
+            if job[2].data_ptr() not in seen:
+                raise ops._lib.MvsHipError("WgradQueue: a deferred weight gradient did not reach its flush node as handed out "
+                                           "(MVS_TRAIN_WGRAD_GROUP=0 runs the weight gradients layer by layer)")
+        ops.bf16_wgrad_group(jobs)
+
+
+class WgradFlushFn(torch.autograd.Function):
+    """Identity on a stage's weights that marks where their gradients are COMPLETED: the layers that consume the routed weights return
+    unwritten gradient tensors and queue the work (``weight._mvs_wq``); this node's backward runs when all of them have arrived - the
+    end of the stage's backward - fills them with grouped launches and hands them on to the parameters (AccumulateGrad, DDP's hooks)."""
+
+    @staticmethod
+    def forward(ctx, queue, *weights):
+        ctx.queue = queue
+        return tuple(w.detach() for w in weights)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ctx.queue.flush(grads)
+        return (None,) + tuple(grads)
+
+
+def _wgrad_group_on() -> bool:
+    return os.environ.get("MVS_TRAIN_WGRAD_GROUP", "1") != "0"
+
+
+def route_of(conv):
+    """The weight a training layer should consume: the routed twin a :class:`StagePack` made for this forward (its gradient is completed
+    by the stage's :class:`WgradFlushFn`), else the parameter itself."""
+    r = getattr(conv, "_mvs_wroute", None)
+    return r if r is not None else conv.weight
+
+
+def _wgrad(weight_in, A, Bt, stride, taps: int = 27, cb_out=None):
+    q = getattr(weight_in, "_mvs_wq", None)
+    if q is not None:
+        return q.push(A, Bt, stride, taps, cb_out)
+    return ops.bf16_conv3d_wgrad(A, Bt, stride, taps, cb_out)
+
+
 class ConvBf16Fn(torch.autograd.Function):
     """Raw 3x3x3 convolution on bf16 channel-last activations, fp32 master weight ``[Cout,Cin,3,3,3]`` cast per call."""
 
@@ -425,6 +486,7 @@ class ConvBf16Fn(torch.autograd.Function):
                 wf, wb = ops.bf16_pack(w, 0, cin, cout), None
         ctx.save_for_backward(x, wb)
         ctx.stride, ctx.wshape, ctx.cpad = stride, (cout, cin), cpad
+        ctx.win = weight if getattr(weight, "_mvs_wq", None) is not None else None
         if stats_groups:
             y, sums = ops.bf16_conv3d_stats(x, wf, cin, cpad, 0, stride, stats_groups)
             ctx.mark_non_differentiable(sums)
@@ -448,7 +510,7 @@ class ConvBf16Fn(torch.autograd.Function):
                 raise ops._lib.MvsHipError("conv backward: input %s is not 2x the output grid %s" % (tuple(x.shape), tuple(dy.shape)))
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = ops.bf16_conv3d_wgrad(dy, x, (sd, shw))
+            dw = _wgrad(ctx.win, dy, x, (sd, shw))
             if cpad != cout:
                 dw = dw[:cout]
         return dx, dw, None, None, None, None
@@ -471,6 +533,7 @@ class DeconvBf16Fn(torch.autograd.Function):
                 wf, wb = ops.bf16_pack(w, 1, cin, cout), None
         ctx.save_for_backward(x, wb)
         ctx.sd, ctx.wshape = sd, (cin, cout)
+        ctx.win = weight if getattr(weight, "_mvs_wq", None) is not None else None
         if stats_groups:
             y, sums = ops.bf16_conv3d_stats(x, wf, cin, cout, 1, (sd, 2), stats_groups)
             ctx.mark_non_differentiable(sums)
@@ -485,7 +548,7 @@ class DeconvBf16Fn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:   # strided conv of dY with W read as [out = cin, in = cout]
             dx = ops.bf16_conv3d(dy, wb, cout, cin, 0, (ctx.sd, 2))
-        dw = ops.bf16_conv3d_wgrad(x, dy, (ctx.sd, 2)) if ctx.needs_input_grad[1] else None
+        dw = _wgrad(ctx.win, x, dy, (ctx.sd, 2)) if ctx.needs_input_grad[1] else None
         return dx, dw, None, None, None
 
 
@@ -637,6 +700,7 @@ class LayerBf16Fn(torch.autograd.Function):
         if ctx.take is not None:
             ctx.take.armed, ctx.take.grad = True, None
         ctx.give = give if give is not None and give.armed and residual is not None and ctx.needs_input_grad[4] else None
+        ctx.win = weight if getattr(weight, "_mvs_wq", None) is not None else None
         z._mvs_bn = (y, st, relu, groups)
         return z
 
@@ -689,9 +753,9 @@ class LayerBf16Fn(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             if gather == 0:
-                dw = ops.bf16_conv3d_wgrad(dy, x, (sd, shw), taps, cin)
+                dw = _wgrad(ctx.win, dy, x, (sd, shw), taps, cin)
             else:
-                dw = ops.bf16_conv3d_wgrad(x, dy, (sd, 2))
+                dw = _wgrad(ctx.win, x, dy, (sd, 2))
         dres = dz if has_res else None
         if ctx.give is not None:                            # the strided layer that also consumed the residual adds it in its epilogue
             ctx.give.grad, dres = dz, None
@@ -781,6 +845,21 @@ class StagePack:
         outs = self.table.run()
         for holder, w, i, j in self.slots:
             holder._mvs_packed = (w._version, outs[i], outs[j] if j is not None else None)
+        # the stage's weights routed through ONE flush node: their gradients are computed together at the end of the stage's backward
+        self.unroute()
+        if _wgrad_group_on() and torch.is_grad_enabled():
+            live = [(h, w) for h, w, _, _ in self.slots if w.requires_grad]
+            if live:
+                queue = WgradQueue()
+                for (h, _), r in zip(live, WgradFlushFn.apply(queue, *[w for _, w in live])):
+                    r._mvs_wq = queue
+                    h._mvs_wroute = r
+
+    def unroute(self) -> None:
+        """Drop the routed weights (they belong to ONE forward's autograd graph); :func:`route_of` falls back to the parameters."""
+        for holder, _, _, _ in self.slots:
+            if getattr(holder, "_mvs_wroute", None) is not None:
+                holder._mvs_wroute = None
 
 
 def packed_of(conv):

@@ -14,7 +14,9 @@
 // train.hip (statistics, and all arithmetic, in fp32).
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 
@@ -340,7 +342,22 @@ struct WgradArgs {
     int PH, npr, npc, npatch; // patch rows, patches per column / row of a plane, work items (columns of patches) in total
     int dseg, nseg;           // depths per work item, depth segments per column
     int tap0, ntaps;          // taps [tap0, tap0 + ntaps) of the 27: all of them, or (9, 9) = the centre depth tap (a 2-D kernel); the
-};                            // slabs are [CA][CB][ntaps]
+                              // slabs are [CA][CB][ntaps]
+    int nbx;                  // blocks (= slabs) of this job along x; its channel groups (blockIdx.y of a launch of its own) follow
+};
+
+// Jobs of one launch: the weight gradients of SEVERAL layers (all those of a training step that share the <TA, TB> instance) run as one
+// grid - block b belongs to job j with start[j] <= b < start[j+1], inside it (b - start[j]) % nbx is the slab and / nbx the channel
+// group.  A layer alone is a chain of short round trips on a fraction of the chip (40 us against 4 us of matrix work); fifty of them
+// in a row were a quarter of the training step.  Side by side they fill it.  The struct travels as the kernel argument (by value:
+// captured with the launch by a hipGraph, no device table to keep alive).
+constexpr int WG_GROUP = 24;
+struct WgradGroup {
+    int njobs;
+    int start[WG_GROUP + 1];
+    WgradArgs job[WG_GROUP];
+};
+static_assert(sizeof(WgradGroup) <= 3800, "kernel arguments are limited to 4 KB");
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ s16x4 lds_tr16(const unsigned short* p) {
@@ -355,7 +372,7 @@ __device__ __forceinline__ bf16x8 frag_tr(const unsigned short* p0, const unsign
 constexpr int WG_PW = 16;                                   // patch columns
 
 template <int TA, int TB>                                   // channel tiles per block
-__global__ __launch_bounds__(256, 2) void bf16_wgrad_kernel(const WgradArgs a) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, const int by) {
     constexpr int TT = TA * TB;
     constexpr int NIB = 4;                                  // 16-byte pieces of ONE Bt plane tile per thread, at most
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -366,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void bf16_wgrad_kernel(const WgradArgs a) {
     const int BH = a.PH * s + 2, BW = WG_PW * s + 2;
     constexpr int CAB = TA * 16, CBB = TB * 16;             // channels of the staged tiles (a CA / CB of 8 stages 8, see *_row)
     const int a_row = min(CAB, a.CA), b_row = min(CBB, a.CB);            // stored channels per voxel
-    const int ca0 = blockIdx.y * CAB;                       // TB covers all of CB
+    const int ca0 = by * CAB;                               // TB covers all of CB
     unsigned short* sA = smem;                              // [PH*16][a_row]
     unsigned short* sB = smem + a.PH * WG_PW * a_row + 64;  // ring of 4 depth planes [slot][BH][BW][b_row] (+ slack: 8-channel tiles)
     const int plane_elems = BH * BW * b_row;
@@ -401,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void bf16_wgrad_kernel(const WgradArgs a) {
     // Work item = a COLUMN of patches: (n, patch row, patch column, depth segment [d0, d1)).  Consecutive depths of A need the Bt
     // planes (dp*sd - 1 .. dp*sd + 1): all but sd of them are already in the ring (slot = plane & 3), so a step stages sd new
     // planes instead of three - the Bt halo tile was 3/4 of the kernel's staging traffic.
-    for (int col = blockIdx.x; col < a.npatch; col += gridDim.x) {
+    for (int col = bx; col < a.npatch; col += a.nbx) {
         int r = col;
         const int seg = r % a.nseg;
         r /= a.nseg;
@@ -496,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void bf16_wgrad_kernel(const WgradArgs a) {
         }
     }
     // D[i = a (4*kb + r)][j = b] -> this block's slab
-    float* slab = a.part + (size_t)blockIdx.x * a.CA * a.CB * a.ntaps;
+    float* slab = a.part + (size_t)bx * a.CA * a.CB * a.ntaps;
 #pragma unroll
     for (int q = 0; q < NTAP; ++q) {
         const int tap = wave + 4 * q;                       // slab index: relative to tap0
@@ -513,14 +530,39 @@ __global__ __launch_bounds__(256, 2) void bf16_wgrad_kernel(const WgradArgs a) {
     }
 }
 
+template <int TA, int TB>
+__global__ __launch_bounds__(256, 2) void bf16_wgrad_kernel(const WgradGroup g) {
+    int j = 0;
+    while (j + 1 < g.njobs && (int)blockIdx.x >= g.start[j + 1]) ++j;       // block-uniform
+    const int local = (int)blockIdx.x - g.start[j];
+    const int nbx = g.job[j].nbx;
+    wgrad_body<TA, TB>(g.job[j], local % nbx, local / nbx);
+}
+
 // dW[i] = sum over slabs, in a fixed order: 64 outputs per block (coalesced), the four waves take every fourth slab each
 // row_in / row_out: elements per A channel in the slabs (CB*taps) and in dW (CBout*taps, CBout <= CB: a padded operand's extra
 // channels are dropped here instead of by a strided view of the result)
-__global__ __launch_bounds__(256) void bf16_wgrad_reduce_kernel(const float* __restrict__ part, int chunks, int n, float* __restrict__ dW,
-                                                                int row_in, int row_out) {
+struct WgradReduceJob {
+    const float* part;
+    float* dW;
+    int chunks, n, row_in, row_out;
+};
+constexpr int WG_RGROUP = 64;
+struct WgradReduceGroup {
+    int njobs;
+    int start[WG_RGROUP + 1];
+    WgradReduceJob job[WG_RGROUP];
+};
+static_assert(sizeof(WgradReduceGroup) <= 3800, "kernel arguments are limited to 4 KB");
+
+__global__ __launch_bounds__(256) void bf16_wgrad_reduce_kernel(const WgradReduceGroup g) {
     __shared__ float red[4][64];
+    int j = 0;
+    while (j + 1 < g.njobs && (int)blockIdx.x >= g.start[j + 1]) ++j;       // block-uniform
+    const float* __restrict__ part = g.job[j].part;
+    const int chunks = g.job[j].chunks, n = g.job[j].n, row_in = g.job[j].row_in, row_out = g.job[j].row_out;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + lane;
+    const int i = ((int)blockIdx.x - g.start[j]) * 64 + lane;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     if (i < n) {
         int c = wave;
@@ -535,7 +577,7 @@ __global__ __launch_bounds__(256) void bf16_wgrad_reduce_kernel(const float* __r
     red[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (wave == 0 && i < n && (i % row_in) < row_out)
-        dW[(size_t)(i / row_in) * row_out + (i % row_in)] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        g.job[j].dW[(size_t)(i / row_in) * row_out + (i % row_in)] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // ------------------------------------------------------------------------------------------------ layout / precision converters
@@ -950,38 +992,118 @@ extern "C" int64_t mvs_bf16_conv3d_wgrad_workspace_bytes(int nbatch, int CA, int
     return (int64_t)wgrad_plan(nbatch, CA, CB, Dp, Hp, Wp, 1).blocks * CA * CB * 27 * (int64_t)sizeof(float);
 }
 
+// ---- the weight gradients of several layers as one grid per kernel instance + one reduce (MvsWgradJob, include/mvs_hip.h) ----
+namespace {
+constexpr int64_t WG_ALIGN = 256;
+int64_t wgrad_slab_bytes(const MvsWgradJob& j, const WgradPlan& p) {
+    const int64_t b = (int64_t)p.blocks * j.CA * j.CB * j.taps * (int64_t)sizeof(float);
+    return (b + WG_ALIGN - 1) / WG_ALIGN * WG_ALIGN;
+}
+int wgrad_job_check(const MvsWgradJob& j, WgradPlan& p) {
+    MVS_REQUIRE(j.A && j.Bt && j.dW, "mvs_bf16_wgrad_group: null pointer");
+    MVS_REQUIRE(chan_ok(j.CA) && chan_ok(j.CB) && j.nbatch >= 1 && j.CBout >= 1 && j.CBout <= j.CB,
+                "mvs_bf16_wgrad_group: channels must be 8/16/32/64 (CA=%d CB=%d)", j.CA, j.CB);
+    MVS_REQUIRE((j.sd == 1 || j.sd == 2) && (j.shw == 1 || j.shw == 2) && (j.taps == 27 || j.taps == 9), "mvs_bf16_wgrad_group: bad stride / taps");
+    MVS_REQUIRE(j.Dp >= 1 && j.Hp >= 1 && j.Wp >= 1 && j.Db >= 1 && j.Hb >= 1 && j.Wb >= 1, "mvs_bf16_wgrad_group: bad grid");
+    MVS_REQUIRE((int64_t)j.Dp * j.Hp * j.Wp * j.CA * 2 < ((int64_t)1 << 31) && (int64_t)j.Db * j.Hb * j.Wb * j.CB * 2 < ((int64_t)1 << 31),
+                "mvs_bf16_wgrad_group: one sample exceeds the 2 GiB buffer range");
+    p = wgrad_plan(j.nbatch, j.CA, j.CB, j.Dp, j.Hp, j.Wp, j.shw);
+    const int b_row = j.CB < p.TB * 16 ? j.CB : p.TB * 16;
+    const int itemsB = (p.PH * j.shw + 2) * (WG_PW * j.shw + 2) * (b_row / 8);      // one plane tile
+    MVS_REQUIRE(itemsB <= 4 * 256 && p.lds <= 64 * 1024, "mvs_bf16_wgrad_group: Bt halo tile of %d pieces / %zu bytes does not fit (CB=%d stride %d)",
+                itemsB, p.lds, j.CB, j.shw);
+    return MVS_OK;
+}
+template <int TA, int TB>
+void wgrad_launch(const WgradGroup& g, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((bf16_wgrad_kernel<TA, TB>), dim3(g.start[g.njobs]), dim3(256), lds, s, g);
+}
+}  // namespace
+
+extern "C" int64_t mvs_bf16_wgrad_group_workspace_bytes(const MvsWgradJob* jobs, int njobs) {
+    if (!jobs || njobs < 1) return -1;
+    int64_t total = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const MvsWgradJob& j = jobs[i];
+        if (!chan_ok(j.CA) || !chan_ok(j.CB) || j.nbatch < 1 || j.Dp < 1 || j.Hp < 1 || j.Wp < 1 || (j.shw != 1 && j.shw != 2) || (j.taps != 27 && j.taps != 9))
+            return -1;
+        total += wgrad_slab_bytes(j, wgrad_plan(j.nbatch, j.CA, j.CB, j.Dp, j.Hp, j.Wp, j.shw));
+    }
+    return total;
+}
+
+extern "C" int mvs_bf16_wgrad_group(const MvsWgradJob* jobs, int njobs, void* workspace, int64_t workspace_bytes, mvs_stream_t stream) {
+    MVS_REQUIRE(jobs && njobs >= 1 && njobs <= 4096 && workspace, "mvs_bf16_wgrad_group: bad arguments (njobs=%d)", njobs);
+    std::vector<WgradPlan> plan(njobs);
+    std::vector<int64_t> off(njobs);
+    int64_t total = 0;
+    for (int i = 0; i < njobs; ++i) {
+        if (int rc = wgrad_job_check(jobs[i], plan[i])) return rc;
+        off[i] = total;
+        total += wgrad_slab_bytes(jobs[i], plan[i]);
+    }
+    MVS_REQUIRE(total <= workspace_bytes, "mvs_bf16_wgrad_group: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)total);
+    hipStream_t s = MVS_STREAM(stream);
+    // one launch per kernel instance (and per WG_GROUP jobs of it), the longest blocks first: a block's length ~ columns per block x depths
+    static const int inst[6][2] = {{1, 1}, {1, 2}, {2, 1}, {2, 2}, {1, 4}, {4, 1}};
+    for (int k = 0; k < 6; ++k) {
+        std::vector<int> ids;
+        for (int i = 0; i < njobs; ++i)
+            if (plan[i].TA == inst[k][0] && plan[i].TB == inst[k][1]) ids.push_back(i);
+        auto cost = [&](int i) { return (double)((plan[i].npatch + plan[i].blocks - 1) / plan[i].blocks) * plan[i].dseg * plan[i].PH * jobs[i].taps; };
+        std::stable_sort(ids.begin(), ids.end(), [&](int x, int y) { return cost(x) > cost(y); });
+        for (size_t first = 0; first < ids.size(); first += WG_GROUP) {
+            WgradGroup g{};
+            size_t lds = 0;
+            g.njobs = (int)std::min<size_t>(WG_GROUP, ids.size() - first);
+            for (int q = 0; q < g.njobs; ++q) {
+                const int i = ids[first + q];
+                const MvsWgradJob& j = jobs[i];
+                const WgradPlan& p = plan[i];
+                WgradArgs& a = g.job[q];
+                a.A = reinterpret_cast<const __bf16*>(j.A), a.Bt = reinterpret_cast<const __bf16*>(j.Bt);
+                a.part = reinterpret_cast<float*>(static_cast<char*>(workspace) + off[i]);
+                a.nb = j.nbatch, a.CA = j.CA, a.CB = j.CB, a.Dp = j.Dp, a.Hp = j.Hp, a.Wp = j.Wp, a.Db = j.Db, a.Hb = j.Hb, a.Wb = j.Wb, a.sd = j.sd, a.shw = j.shw;
+                a.PH = p.PH, a.npr = p.npr, a.npc = p.npc, a.npatch = p.npatch, a.dseg = p.dseg, a.nseg = p.nseg;
+                a.tap0 = j.taps == 9 ? 9 : 0, a.ntaps = j.taps, a.nbx = p.blocks;
+                g.start[q + 1] = g.start[q] + p.blocks * p.gy;
+                lds = std::max(lds, p.lds);
+            }
+            if (k == 0) wgrad_launch<1, 1>(g, lds, s);
+            else if (k == 1) wgrad_launch<1, 2>(g, lds, s);
+            else if (k == 2) wgrad_launch<2, 1>(g, lds, s);
+            else if (k == 3) wgrad_launch<2, 2>(g, lds, s);
+            else if (k == 4) wgrad_launch<1, 4>(g, lds, s);
+            else wgrad_launch<4, 1>(g, lds, s);
+            if (int rc = mvs::finish_launch("mvs_bf16_wgrad_group")) return rc;
+        }
+    }
+    for (int first = 0; first < njobs; first += WG_RGROUP) {
+        WgradReduceGroup g{};
+        g.njobs = std::min(WG_RGROUP, njobs - first);
+        for (int q = 0; q < g.njobs; ++q) {
+            const int i = first + q;
+            const MvsWgradJob& j = jobs[i];
+            const int n = j.CA * j.CB * j.taps;
+            g.job[q] = WgradReduceJob{reinterpret_cast<const float*>(static_cast<char*>(workspace) + off[i]), j.dW, plan[i].blocks, n, j.CB * j.taps,
+                                      j.CBout * j.taps};
+            g.start[q + 1] = g.start[q] + (n + 63) / 64;
+        }
+        hipLaunchKernelGGL(bf16_wgrad_reduce_kernel, dim3(g.start[g.njobs]), dim3(256), 0, s, g);
+        if (int rc = mvs::finish_launch("mvs_bf16_wgrad_group")) return rc;
+    }
+    return MVS_OK;
+}
+
 // taps = 27: dW [CA][CBout][27]; taps = 9: the centre depth tap only, dW [CA][CBout][9] (a 2-D kernel's gradient).  CBout <= CB drops the
-// padding channels of Bt (the visibility CNN's 1-channel input lives in an 8-channel tensor).
+// padding channels of Bt (the visibility CNN's 1-channel input lives in an 8-channel tensor).  One layer = a group of one.
 extern "C" int mvs_bf16_conv3d_wgrad_taps(const void* A, const void* Bt, float* dW, void* workspace, int nbatch, int CA, int CB, int CBout,
                                           int Dp, int Hp, int Wp, int Db, int Hb, int Wb, int sd, int shw, int taps, mvs_stream_t stream) {
     MVS_REQUIRE(A && Bt && dW && workspace, "mvs_bf16_conv3d_wgrad: null pointer");
-    MVS_REQUIRE(chan_ok(CA) && chan_ok(CB) && nbatch >= 1 && CBout >= 1 && CBout <= CB, "mvs_bf16_conv3d_wgrad: channels must be 8/16/32/64 (CA=%d CB=%d)", CA, CB);
-    MVS_REQUIRE((sd == 1 || sd == 2) && (shw == 1 || shw == 2) && (taps == 27 || taps == 9), "mvs_bf16_conv3d_wgrad: bad stride / taps");
-    MVS_REQUIRE((int64_t)Dp * Hp * Wp * CA * 2 < ((int64_t)1 << 31) && (int64_t)Db * Hb * Wb * CB * 2 < ((int64_t)1 << 31),
-                "mvs_bf16_conv3d_wgrad: one sample exceeds the 2 GiB buffer range");
-    const WgradPlan p = wgrad_plan(nbatch, CA, CB, Dp, Hp, Wp, shw);
-    const int b_row = CB < p.TB * 16 ? CB : p.TB * 16;
-    const int itemsB = (p.PH * shw + 2) * (WG_PW * shw + 2) * (b_row / 8);          // one plane tile
-    MVS_REQUIRE(itemsB <= 4 * 256 && p.lds <= 64 * 1024, "mvs_bf16_conv3d_wgrad: Bt halo tile of %d pieces / %zu bytes does not fit (CB=%d stride %d)",
-                itemsB, p.lds, CB, shw);
-    WgradArgs a{};
-    a.A = reinterpret_cast<const __bf16*>(A), a.Bt = reinterpret_cast<const __bf16*>(Bt), a.part = reinterpret_cast<float*>(workspace);
-    a.nb = nbatch, a.CA = CA, a.CB = CB, a.Dp = Dp, a.Hp = Hp, a.Wp = Wp, a.Db = Db, a.Hb = Hb, a.Wb = Wb, a.sd = sd, a.shw = shw;
-    a.PH = p.PH, a.npr = p.npr, a.npc = p.npc, a.npatch = p.npatch, a.dseg = p.dseg, a.nseg = p.nseg;
-    a.tap0 = taps == 9 ? 9 : 0, a.ntaps = taps;
-    hipStream_t s = MVS_STREAM(stream);
-    const dim3 grid(p.blocks, p.gy);
-    if (p.TA == 1 && p.TB == 1) hipLaunchKernelGGL((bf16_wgrad_kernel<1, 1>), grid, dim3(256), p.lds, s, a);
-    else if (p.TA == 1 && p.TB == 2) hipLaunchKernelGGL((bf16_wgrad_kernel<1, 2>), grid, dim3(256), p.lds, s, a);
-    else if (p.TA == 2 && p.TB == 1) hipLaunchKernelGGL((bf16_wgrad_kernel<2, 1>), grid, dim3(256), p.lds, s, a);
-    else if (p.TA == 2 && p.TB == 2) hipLaunchKernelGGL((bf16_wgrad_kernel<2, 2>), grid, dim3(256), p.lds, s, a);
-    else if (p.TA == 1 && p.TB == 4) hipLaunchKernelGGL((bf16_wgrad_kernel<1, 4>), grid, dim3(256), p.lds, s, a);
-    else if (p.TA == 4 && p.TB == 1) hipLaunchKernelGGL((bf16_wgrad_kernel<4, 1>), grid, dim3(256), p.lds, s, a);
-    else MVS_REQUIRE(false, "mvs_bf16_conv3d_wgrad: no kernel for %d x %d channel tiles", p.TA, p.TB);
-    if (int rc = mvs::finish_launch("mvs_bf16_conv3d_wgrad")) return rc;
-    const int n = CA * CB * taps;
-    hipLaunchKernelGGL(bf16_wgrad_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, s, a.part, p.blocks, n, dW, CB * taps, CBout * taps);
-    return mvs::finish_launch("mvs_bf16_conv3d_wgrad");
+    MVS_REQUIRE(chan_ok(CA) && chan_ok(CB) && nbatch >= 1, "mvs_bf16_conv3d_wgrad: channels must be 8/16/32/64 (CA=%d CB=%d)", CA, CB);
+    const MvsWgradJob job{A, Bt, dW, nbatch, CA, CB, CBout, Dp, Hp, Wp, Db, Hb, Wb, sd, shw, taps, 0};
+    // the caller's workspace is mvs_bf16_conv3d_wgrad_workspace_bytes (sized for 27 taps): at least what the one job needs
+    return mvs_bf16_wgrad_group(&job, 1, workspace, mvs_bf16_conv3d_wgrad_workspace_bytes(nbatch, CA, CB, Dp, Hp, Wp), stream);
 }
 
 extern "C" int mvs_bf16_conv3d_wgrad(const void* A, const void* Bt, float* dW, void* workspace, int nbatch, int CA, int CB, int Dp, int Hp,

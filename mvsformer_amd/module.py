@@ -98,15 +98,15 @@ def _train_conv_bn_act(x, conv, bn, relu, residual, transposed_sd=None, take=Non
             # normalize): 8 graph nodes per layer and step instead of 11
             if transposed_sd is None:
                 s = tuple(conv.stride)
-                return ag.LayerBf16Fn.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, bool(relu), 0, (s[0], s[1]), 1, pk, take, give)
-            return ag.LayerBf16Fn.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, bool(relu), 1, (transposed_sd, 2), 1, pk, take, give)
+                return ag.LayerBf16Fn.apply(x, ag.route_of(conv), bn.weight, bn.bias, residual, bn, bool(relu), 0, (s[0], s[1]), 1, pk, take, give)
+            return ag.LayerBf16Fn.apply(x, ag.route_of(conv), bn.weight, bn.bias, residual, bn, bool(relu), 1, (transposed_sd, 2), 1, pk, take, give)
         if take is not None:
             _multi_use(x)                                    # no hand-over on the unfused chain: the tag (if any) must not promise one
         if transposed_sd is None:
             s = tuple(conv.stride)
-            out = ag.ConvBf16Fn.apply(x, conv.weight, (s[0], s[1]), fused, pk)
+            out = ag.ConvBf16Fn.apply(x, ag.route_of(conv), (s[0], s[1]), fused, pk)
         else:
-            out = ag.DeconvBf16Fn.apply(x, conv.weight, transposed_sd, fused, pk)
+            out = ag.DeconvBf16Fn.apply(x, ag.route_of(conv), transposed_sd, fused, pk)
         y, sums = out if fused else (out, None)
         return ag.BnActBf16Fn.apply(y, bn.weight, bn.bias, residual, bn, bool(relu), 1, sums)
     if transposed_sd is None:
@@ -375,7 +375,7 @@ class CostRegNet(nn.Module):
                 if pk is not None and ag._fused_layers():
                     # the 8 -> 1 parameter packed as an 8 -> 8 map by the stage's StagePack (no padded copy of the weight), channel 0 of
                     # the result straight to fp32
-                    y = ag.Select0Bf16Fn.apply(ag.ConvBf16Fn.apply(y, self.prob.weight, (1, 1), 0, pk, 8)).unsqueeze(1)
+                    y = ag.Select0Bf16Fn.apply(ag.ConvBf16Fn.apply(y, ag.route_of(self.prob), (1, 1), 0, pk, 8)).unsqueeze(1)
                 else:
                     w8 = torch.nn.functional.pad(self.prob.weight, (0, 0, 0, 0, 0, 0, 0, 0, 0, 7))
                     if y.dtype == torch.bfloat16:        # autocast: the logits come out of a half-precision conv, then fp32

@@ -8,6 +8,7 @@ launch stream to get per-kernel durations live.
 from __future__ import annotations
 
 import contextlib
+import ctypes
 import os
 from collections import defaultdict
 from typing import Dict, List, Optional, Tuple
@@ -1260,6 +1261,40 @@ def bf16_conv3d_wgrad(A: torch.Tensor, Bt: torch.Tensor, stride, taps: int = 27,
     _call("mvs_bf16_conv3d_wgrad_taps", tag, _ptr(A), _ptr(Bt), _ptr(dW), _ptr(ws), N, CA, CB, cb_out, Dp, Hp, Wp, Db, Hb, Wb, stride[0],
           stride[1], int(taps), _stream())
     return dW
+
+
+def bf16_wgrad_shape(A: torch.Tensor, Bt: torch.Tensor, taps: int = 27, cb_out: Optional[int] = None):
+    cb = Bt.shape[-1] if cb_out is None else int(cb_out)
+    return (A.shape[-1], cb, 3, 3, 3) if taps == 27 else (A.shape[-1], cb, 3, 3)
+
+
+def bf16_wgrad_group(jobs) -> None:
+    """The weight gradients of several layers in one call (``mvs_bf16_wgrad_group``): one grid per kernel instance with all its jobs side
+    by side + one reduce.  ``jobs``: ``(A, Bt, dW, stride, taps, cb_out)`` as :func:`bf16_conv3d_wgrad` takes them, ``dW`` the fp32
+    tensor of :func:`bf16_wgrad_shape` to fill.  Bit-identical to the layer-by-layer calls."""
+    if not jobs:
+        return
+    arr = (_lib.WgradJob * len(jobs))()
+    flops = 0.0
+    for k, (A, Bt, dW, stride, taps, cb_out) in enumerate(jobs):
+        _chk16(A, "A"), _chk16(Bt, "Bt"), _chk(dW, "dW")
+        N, Dp, Hp, Wp, CA = A.shape
+        _, Db, Hb, Wb, CB = Bt.shape
+        cb = CB if cb_out is None else int(cb_out)
+        if tuple(dW.shape) != bf16_wgrad_shape(A, Bt, taps, cb):
+            raise _lib.MvsHipError("bf16_wgrad_group: dW %s for operands %s x %s" % (tuple(dW.shape), tuple(A.shape), tuple(Bt.shape)))
+        j = arr[k]
+        j.A, j.Bt, j.dW = _ptr(A), _ptr(Bt), _ptr(dW)
+        j.nbatch, j.CA, j.CB, j.CBout, j.Dp, j.Hp, j.Wp, j.Db, j.Hb, j.Wb = N, CA, CB, cb, Dp, Hp, Wp, Db, Hb, Wb
+        j.sd, j.shw, j.taps, j.reserved = int(stride[0]), int(stride[1]), int(taps), 0
+        flops += 2.0 * taps * CA * CB * N * Dp * Hp * Wp
+    ptr = ctypes.cast(arr, ctypes.c_void_p)
+    nws = _lib.load().mvs_bf16_wgrad_group_workspace_bytes(ptr, len(jobs))
+    if nws <= 0:
+        raise _lib.MvsHipError("bf16_wgrad_group: a job's channels / stride / taps are not built")
+    dev = jobs[0][0].device
+    ws = torch.empty(nws, device=dev, dtype=torch.uint8)
+    _call("mvs_bf16_wgrad_group", ("bf16_wgrad_kernel", "flops", flops), ptr, len(jobs), _ptr(ws), int(nws), _stream())
 
 
 def bf16_head_fwd(x: torch.Tensor, w: Optional[torch.Tensor], bias: Optional[torch.Tensor], sigmoid: bool) -> torch.Tensor:

@@ -186,6 +186,15 @@ class StageNet(nn.Module):
             if self._train_pack is None or not self._train_pack.valid():
                 self._train_pack = ag.StagePack(self)
             self._train_pack.run()
+            try:
+                return self._forward_train_body(features, proj_matrices, depth_values, tmp, G)
+            finally:
+                self._train_pack.unroute()                      # the routed weights belong to this forward's graph only
+        return self._forward_train_body(features, proj_matrices, depth_values, tmp, G)
+
+    def _forward_train_body(self, features, proj_matrices, depth_values, tmp, G):
+        from . import autograd as ag
+        from .module import autocast_bf16
         proj = proj_matrices.detach().to(torch.float32).contiguous()
         hyp = depth_values.detach().to(torch.float32).contiguous()
         rt = ops.proj_prepare(proj)
