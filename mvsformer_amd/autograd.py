@@ -841,25 +841,39 @@ class StagePack:
     def valid(self) -> bool:
         return self.table.valid()
 
-    def run(self) -> None:
+    def run(self, route: bool = True) -> None:
+        """``route``: also route this stage's weights through a flush node of its own (False: the caller - the cascade - has routed the
+        weights of all its stages through one, :func:`route_weights`)."""
         outs = self.table.run()
         for holder, w, i, j in self.slots:
             holder._mvs_packed = (w._version, outs[i], outs[j] if j is not None else None)
-        # the stage's weights routed through ONE flush node: their gradients are computed together at the end of the stage's backward
-        self.unroute()
-        if _wgrad_group_on() and torch.is_grad_enabled():
-            live = [(h, w) for h, w, _, _ in self.slots if w.requires_grad]
-            if live:
-                queue = WgradQueue()
-                for (h, _), r in zip(live, WgradFlushFn.apply(queue, *[w for _, w in live])):
-                    r._mvs_wq = queue
-                    h._mvs_wroute = r
+        if route:
+            self.unroute()
+            route_weights([self])
+
+    def live(self):
+        return [(h, w) for h, w, _, _ in self.slots if w.requires_grad]
 
     def unroute(self) -> None:
         """Drop the routed weights (they belong to ONE forward's autograd graph); :func:`route_of` falls back to the parameters."""
         for holder, _, _, _ in self.slots:
             if getattr(holder, "_mvs_wroute", None) is not None:
                 holder._mvs_wroute = None
+
+
+def route_weights(packs) -> bool:
+    """Route the weights of the given :class:`StagePack` s through ONE :class:`WgradFlushFn`: their gradients are computed together
+    (ops.bf16_wgrad_group) when the last of them has been queued - the end of the stage's / the cascade's backward."""
+    if not (_wgrad_group_on() and torch.is_grad_enabled()):
+        return False
+    live = [hw for p in packs for hw in p.live()]
+    if not live:
+        return False
+    queue = WgradQueue()
+    for (h, _), r in zip(live, WgradFlushFn.apply(queue, *[w for _, w in live])):
+        r._mvs_wq = queue
+        h._mvs_wroute = r
+    return True
 
 
 def packed_of(conv):

@@ -39,7 +39,23 @@ class CascadeMVS(nn.Module):
         if not self.training:
             with torch.no_grad():
                 return self._forward(features, proj_matrices, depth_values, tmp)
-        return self._forward(features, proj_matrices, depth_values, tmp)
+        # bf16 training: the weights of ALL stages routed through one flush node - the ~50 weight gradients of the step run together at the
+        # end of the backward (autograd.route_weights; MVS_TRAIN_WGRAD_SCOPE=stage keeps one group per stage)
+        from . import autograd as ag
+        from .module import autocast_bf16
+        stages = list(self.fusions)
+        shared = autocast_bf16() and ag._fused_layers() and os.environ.get("MVS_TRAIN_WGRAD_SCOPE", "cascade") != "stage" \
+            and ag.route_weights([st.train_pack() for st in stages])
+        if not shared:
+            return self._forward(features, proj_matrices, depth_values, tmp)
+        for st in stages:
+            st._routed_by_cascade = True
+        try:
+            return self._forward(features, proj_matrices, depth_values, tmp)
+        finally:
+            for st in stages:
+                st._routed_by_cascade = False
+                st.train_pack().unroute()                       # the routed weights belong to this forward's graph only
 
     def _forward(self, features, proj_matrices, depth_values, tmp):
         n = len(self.ndepths)

@@ -761,9 +761,11 @@ __global__ __launch_bounds__(256) void bf16_bn_bwd_apply_kernel(const __bf16* __
 bool chan_ok(int c) { return c == 8 || c == 16 || c == 32 || c == 64; }
 
 // K split over a block's wavefronts (see bf16_conv_kernel): 32 / 64 input channels (27 / 54 steps per wavefront) while the launch has
-// fewer work items than ~8 per CU - above that there are enough wavefronts per SIMD to hide a step's latency behind other items' steps
+// at most ~3 work items per CU.  Every block streams the whole packed weight image (221 KB at 64 -> 64) from L2, and with one 64-voxel item
+// per block that traffic is what bounds a larger launch: measured per call (tools/exp_small_conv.py, 64 -> 64 stride 1), split / not split:
+// 256 items 14 / 37 us, 512 items 28 / 39 us, 1024 items 53 / 41 us (32 -> 64 stride (1,2,2): 11 / 21, 21 / 22, 41 / 24 us).
 bool conv_ksplit(int cin, int items, int taps) {
-    static const int lim = [] { const char* e = getenv("MVS_BF16_KSPLIT_ITEMS"); return e ? atoi(e) : 2048; }();
+    static const int lim = [] { const char* e = getenv("MVS_BF16_KSPLIT_ITEMS"); return e ? atoi(e) : 768; }();
     return taps == 27 && cin >= 32 && items <= lim;
 }
 

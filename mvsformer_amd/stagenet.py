@@ -72,6 +72,7 @@ class StageNet(nn.Module):
             self.cost_reg = CostRegNet(in_channels, args["base_ch"])
         self._vis_cache = None
         self._train_pack = None
+        self._routed_by_cascade = False
 
     def _vis_params(self):
         """-> (parameter block, the 3x3 layers' weights prepared for the selected kernel or None for the all-VALU form)."""
@@ -177,19 +178,26 @@ class StageNet(nn.Module):
         """Window of conf_regression for the regression head (mvsformer_model.py:139-146); 0 = plain max probability."""
         return 4 if self.ndepth >= 32 else 3 if self.ndepth == 16 else 2 if self.ndepth == 8 else 0
 
+    def train_pack(self):
+        """This stage's :class:`autograd.StagePack` (bf16 weight layouts of a training step in one launch + weight-gradient routing)."""
+        from . import autograd as ag
+        if self._train_pack is None or not self._train_pack.valid():
+            self._train_pack = ag.StagePack(self)
+        return self._train_pack
+
     def _forward_train(self, features, proj_matrices, depth_values, tmp, G):
         """Training branch (reference mvsformer_model.py:62-125 with ``self.training``): no similarity branch, batch-statistics
         BatchNorm everywhere, depth = hypothesis at the arg-max probability; gradients via :mod:`mvsformer_amd.autograd`."""
         from . import autograd as ag
         from .module import autocast_bf16
         if autocast_bf16() and ag._fused_layers():              # every bf16 weight layout of this stage's step in one launch
-            if self._train_pack is None or not self._train_pack.valid():
-                self._train_pack = ag.StagePack(self)
-            self._train_pack.run()
+            pack = self.train_pack()
+            pack.run(route=not self._routed_by_cascade)
             try:
                 return self._forward_train_body(features, proj_matrices, depth_values, tmp, G)
             finally:
-                self._train_pack.unroute()                      # the routed weights belong to this forward's graph only
+                if not self._routed_by_cascade:
+                    pack.unroute()                              # the routed weights belong to this forward's graph only
         return self._forward_train_body(features, proj_matrices, depth_values, tmp, G)
 
     def _forward_train_body(self, features, proj_matrices, depth_values, tmp, G):
