@@ -958,7 +958,11 @@ int wgrad_nseg(int columns, int Dp, int target) {            // depth segments p
     if (nseg > cap) nseg = cap;
     return nseg < 1 ? 1 : nseg;
 }
-WgradPlan wgrad_plan(int nbatch, int CA, int CB, int Dp, int Hp, int Wp, int shw) {
+// grouped: a job of a GROUP launch - the jobs fill the chip together, so each takes fewer blocks (= slabs the reduce reads back) than a
+// launch of its own needs: 256 for the single-tile instance, 128 for the others (measured on config 3's step, kernel time per step of
+// the instances <1,1> / <2,2> / <1,4> / <2,1> at 512: 0.46 / 0.30 / 0.16 / 0.13 ms, at 256: 0.41 / 0.23 / 0.10 / 0.10, at 128: 0.42 / 0.15 /
+// 0.11 / <0.09, at 64: 0.71 / 0.13 / 0.15 / 0.11; block counts proportional to the jobs' patch x depth steps were slower than either).
+WgradPlan wgrad_plan(int nbatch, int CA, int CB, int Dp, int Hp, int Wp, int shw, bool grouped = false) {
     WgradPlan p;
     const int nA = (CA + 15) / 16, nB = (CB + 15) / 16;
     p.TB = nB;                                               // one block sees all of CB (nB <= 4)
@@ -972,7 +976,8 @@ WgradPlan wgrad_plan(int nbatch, int CA, int CB, int Dp, int Hp, int Wp, int shw
     p.npc = (Wp + WG_PW - 1) / WG_PW;
     // two resident blocks per CU over all channel groups (three for the single-tile instance was measured: no faster, and every block
     // writes a slab the reduce kernel reads back)
-    const int target = 512 / p.gy;
+    static const int gblocks = [] { const char* e = getenv("MVS_WGRAD_GROUP_BLOCKS"); return e ? atoi(e) : 0; }();       // diagnostics
+    const int target = (grouped ? (gblocks > 0 ? gblocks : p.TA * p.TB == 1 ? 256 : 128) : 512) / p.gy;
     p.nseg = wgrad_nseg(nbatch * p.npr * p.npc, Dp, target);
     p.dseg = (Dp + p.nseg - 1) / p.nseg;
     p.nseg = (Dp + p.dseg - 1) / p.dseg;
@@ -1001,7 +1006,7 @@ int64_t wgrad_slab_bytes(const MvsWgradJob& j, const WgradPlan& p) {
     const int64_t b = (int64_t)p.blocks * j.CA * j.CB * j.taps * (int64_t)sizeof(float);
     return (b + WG_ALIGN - 1) / WG_ALIGN * WG_ALIGN;
 }
-int wgrad_job_check(const MvsWgradJob& j, WgradPlan& p) {
+int wgrad_job_check(const MvsWgradJob& j, WgradPlan& p, bool grouped) {
     MVS_REQUIRE(j.A && j.Bt && j.dW, "mvs_bf16_wgrad_group: null pointer");
     MVS_REQUIRE(chan_ok(j.CA) && chan_ok(j.CB) && j.nbatch >= 1 && j.CBout >= 1 && j.CBout <= j.CB,
                 "mvs_bf16_wgrad_group: channels must be 8/16/32/64 (CA=%d CB=%d)", j.CA, j.CB);
@@ -1009,7 +1014,7 @@ int wgrad_job_check(const MvsWgradJob& j, WgradPlan& p) {
     MVS_REQUIRE(j.Dp >= 1 && j.Hp >= 1 && j.Wp >= 1 && j.Db >= 1 && j.Hb >= 1 && j.Wb >= 1, "mvs_bf16_wgrad_group: bad grid");
     MVS_REQUIRE((int64_t)j.Dp * j.Hp * j.Wp * j.CA * 2 < ((int64_t)1 << 31) && (int64_t)j.Db * j.Hb * j.Wb * j.CB * 2 < ((int64_t)1 << 31),
                 "mvs_bf16_wgrad_group: one sample exceeds the 2 GiB buffer range");
-    p = wgrad_plan(j.nbatch, j.CA, j.CB, j.Dp, j.Hp, j.Wp, j.shw);
+    p = wgrad_plan(j.nbatch, j.CA, j.CB, j.Dp, j.Hp, j.Wp, j.shw, grouped);
     const int b_row = j.CB < p.TB * 16 ? j.CB : p.TB * 16;
     const int itemsB = (p.PH * j.shw + 2) * (WG_PW * j.shw + 2) * (b_row / 8);      // one plane tile
     MVS_REQUIRE(itemsB <= 4 * 256 && p.lds <= 64 * 1024, "mvs_bf16_wgrad_group: Bt halo tile of %d pieces / %zu bytes does not fit (CB=%d stride %d)",
@@ -1029,7 +1034,7 @@ extern "C" int64_t mvs_bf16_wgrad_group_workspace_bytes(const MvsWgradJob* jobs,
         const MvsWgradJob& j = jobs[i];
         if (!chan_ok(j.CA) || !chan_ok(j.CB) || j.nbatch < 1 || j.Dp < 1 || j.Hp < 1 || j.Wp < 1 || (j.shw != 1 && j.shw != 2) || (j.taps != 27 && j.taps != 9))
             return -1;
-        total += wgrad_slab_bytes(j, wgrad_plan(j.nbatch, j.CA, j.CB, j.Dp, j.Hp, j.Wp, j.shw));
+        total += wgrad_slab_bytes(j, wgrad_plan(j.nbatch, j.CA, j.CB, j.Dp, j.Hp, j.Wp, j.shw, njobs > 1));
     }
     return total;
 }
@@ -1040,7 +1045,7 @@ extern "C" int mvs_bf16_wgrad_group(const MvsWgradJob* jobs, int njobs, void* wo
     std::vector<int64_t> off(njobs);
     int64_t total = 0;
     for (int i = 0; i < njobs; ++i) {
-        if (int rc = wgrad_job_check(jobs[i], plan[i])) return rc;
+        if (int rc = wgrad_job_check(jobs[i], plan[i], njobs > 1)) return rc;
         off[i] = total;
         total += wgrad_slab_bytes(jobs[i], plan[i]);
     }

@@ -51,12 +51,9 @@ def test_captured_training_step_matches_eager():
             assert torch.equal(v, after_g[k]), k
 
 
-def test_captured_ddp_syncbn_step_matches_eager():
-    """The whole step under DistributedDataParallel + SyncBatchNorm over RCCL (train.py:138-139) captured into ONE hipGraph - the
-    SyncBatchNorm all-reduces of forward and backward and the reducer's bucket all-reduce are recorded with the kernels - and replayed:
-    same loss and same updated state as the eager DDP step from the same state.  One rank (the box has one GPU; the collectives are real
-    RCCL calls on a world of one).  Recipe of torch's whole-network capture: construct DDP, warm up (>= 11 iterations: the reducer's
-    logger times its first ten with events and rebuilds its buckets after the first) and capture on ONE side stream."""
+def _captured_ddp_worker(rank, port, out):
+    """Runs in a process of its own: the capture shares the process with RCCL's watchdog / heartbeat threads, and a process group is
+    per process anyway (one rank = one process = one GPU)."""
     import os
     import torch.distributed as dist
     import mvsformer_amd as m
@@ -64,8 +61,8 @@ def test_captured_ddp_syncbn_step_matches_eager():
     from mvsformer_amd.graphs import CapturedStep
     from mvsformer_amd.losses import ce_loss_stage4
     dev = torch.device("cuda:0")
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ["MASTER_PORT"] = "29547"
+    torch.cuda.set_device(dev)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
@@ -77,21 +74,20 @@ def test_captured_ddp_syncbn_step_matches_eager():
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[0])
+            model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[0], gradient_as_bucket_view=True, broadcast_buffers=False)
         opt = torch.optim.SGD(model.parameters(), lr=1e-2)
 
         def step():
             opt.zero_grad(set_to_none=True)
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                out = model(feats, proj, dv, tmp=[5.0, 5.0, 5.0, 1.0])
-            loss = sum(ce_loss_stage4(out, gts, masks, dlossw=[1, 1, 1, 1]).values())
+                o = model(feats, proj, dv, tmp=[5.0, 5.0, 5.0, 1.0])
+            loss = sum(ce_loss_stage4(o, gts, masks, dlossw=[1, 1, 1, 1]).values())
             loss.backward()
             opt.step()
             return loss
 
         graphed = CapturedStep(step, warmup=12, keep_graph=True, stream=side)
         counts = graphed.node_counts()
-        assert counts is None or counts["kernel"] > 100, counts
         state = {k: v.clone() for k, v in net.state_dict().items()}
         loss_g = graphed().clone()
         after_g = {k: v.clone() for k, v in net.state_dict().items()}
@@ -102,14 +98,35 @@ def test_captured_ddp_syncbn_step_matches_eager():
         with torch.cuda.stream(side):
             loss_e = step().clone()
         torch.cuda.synchronize()
-        assert abs(loss_e.item() - loss_g.item()) <= 1e-5 * abs(loss_e.item()), (loss_e.item(), loss_g.item())
+        worst = []
         for k, v in net.state_dict().items():
             if v.dtype.is_floating_point:
-                assert (v - after_g[k]).abs().max().item() <= 1e-6 + 2e-3 * v.abs().max().item(), k
-            else:
-                assert torch.equal(v, after_g[k]), k
+                worst.append(((v - after_g[k]).abs().max().item() / (1e-6 + v.abs().max().item()), k))
+            elif not torch.equal(v, after_g[k]):
+                worst.append((float("inf"), k))
+        out["result"] = (counts, loss_g.item(), loss_e.item(), max(worst))
     finally:
         dist.destroy_process_group()
+
+
+def test_captured_ddp_syncbn_step_matches_eager():
+    """The whole step under DistributedDataParallel + SyncBatchNorm over RCCL (train.py:138-139) captured into ONE hipGraph - the
+    SyncBatchNorm all-reduces of forward and backward and the reducer's bucket all-reduce are recorded with the kernels - and replayed:
+    same loss and same updated state as the eager DDP step from the same state.  One rank (the box has one GPU; the collectives are real
+    RCCL calls on a world of one).  Recipe of torch's whole-network capture: construct DDP, warm up (>= 11 iterations: the reducer's
+    logger times its first ten with events and rebuilds its buckets after the first) and capture on ONE side stream."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = mp.Manager().dict()
+    mp.spawn(_captured_ddp_worker, args=(port, out), nprocs=1, join=True)
+    counts, loss_g, loss_e, (err, name) = out["result"]
+    assert counts is None or counts["kernel"] > 100, counts
+    assert abs(loss_e - loss_g) <= 1e-5 * abs(loss_e), (loss_e, loss_g)
+    assert err <= 2e-3, (err, name)
 
 
 def test_captured_eval_cascade_is_bit_equal():
