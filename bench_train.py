@@ -86,6 +86,8 @@ def measure(args, top=12):
 
     def step():
         opt.zero_grad(set_to_none=True)
+        for v in feats.values():                             # the inputs' gradients go to the feature networks: consumed, not accumulated
+            v.grad = None
         with amp():
             out = model(feats, proj, dv, tmp=[5.0, 5.0, 5.0, 1.0])
         # the reference's loss for depth_type='ce' (trainer/mvsformer_trainer.py:119-120), fused HIP kernel per stage

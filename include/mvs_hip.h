@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 24
+#define MVS_ABI_VERSION 25
 
 typedef void* mvs_stream_t;
 
@@ -361,7 +361,8 @@ int mvs_bf16_bn_bwd_apply_dgb(const void* dy, const void* x, const float* scale,
  *   mvs_bf16_conv3d_bn_fwd: y = raw conv(x) (kept for the backward), z = [relu](BatchNorm_train(y)) [+ residual]; the batch statistics of
  *       the bf16-rounded y are taken in the convolution's epilogue as one row per BLOCK (workspace =
  *       mvs_bf16_conv3d_bn_fwd_workspace_bytes of the OUTPUT grid), a one-block-per-channel kernel adds the rows in a fixed order and
- *       writes stats4 = [scale | shift | mean | invstd] (each groups*Cout) + the running statistics, a third launch normalizes.
+ *       writes stats4 = [scale | shift | mean | invstd | gamma] (FIVE rows of groups*Cout; the fifth is the affine weight replicated per
+ *       group, 1 without one - the operand of the backward's apply kernel) + the running statistics, a third launch normalizes.
  *       groups > 1: sample b belongs to group b % groups (the visibility CNN, one call per source view in the reference). */
 int64_t mvs_bf16_conv3d_bn_fwd_workspace_bytes(int B, int Cout, int Do, int Ho, int Wo);
 int mvs_bf16_conv3d_bn_fwd(const void* x, const void* wpacked, void* y, void* z, const void* residual, int relu, int B, int Cin, int Cout,

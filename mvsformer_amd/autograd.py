@@ -685,10 +685,7 @@ class LayerBf16Fn(torch.autograd.Function):
         nbt = bn.num_batches_tracked if track and bn.num_batches_tracked is not None else None       # incremented by the kernel
         res = residual.contiguous() if residual is not None else None
         y, z, st = ops.bf16_conv3d_bn_fwd(x, wf, cin_map, cout, gather, stride, res, relu, g, b, rm, rv, mom, bn.eps, groups, nbt, taps)
-        gfull = g if g is not None else st.new_ones(cout)
-        if groups > 1:
-            gfull = gfull.repeat(groups)
-        ctx.save_for_backward(x, wb, y, st, gfull)
+        ctx.save_for_backward(x, wb, y, st)                  # st[4] = the affine weight per (group, channel), written by the finalize kernel
         ctx.cfg = (relu, gather, tuple(stride), groups, cin, cin_map, cout, residual is not None, taps)
         # The producer of x, if it is a layer of this kind whose output feeds only this one: its BatchNorm's backward sums can be taken in
         # the epilogue of OUR data gradient (which IS its incoming gradient) instead of by a pass of their own.  The tag rides on the
@@ -706,8 +703,8 @@ class LayerBf16Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz):
-        x, wb, y, st, gfull = ctx.saved_tensors
-        scale, shift, mean, invstd = st[0], st[1], st[2], st[3]
+        x, wb, y, st = ctx.saved_tensors
+        scale, shift, mean, invstd, gfull = st[0], st[1], st[2], st[3], st[4]
         relu, gather, (sd, shw), groups, cin, cin_map, cout, has_res, taps = ctx.cfg
         dz = dz.contiguous()
         # the two sums of the BatchNorm backward: taken by the consumer's data-gradient convolution if it knew us (see forward), else here.

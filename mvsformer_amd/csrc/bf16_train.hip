@@ -1252,6 +1252,7 @@ __global__ __launch_bounds__(256) void bf16_bn_reduce_finalize_kernel(const floa
             out4[CT + cc] = bt - (float)mean * g * invstd;   // shift
             out4[2 * CT + cc] = (float)mean;
             out4[3 * CT + cc] = invstd;
+            out4[4 * CT + cc] = g;                          // the affine weight per (group, channel): what the backward's apply kernel reads
         }
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
         rm = (1.0f - momentum) * rm + momentum * (float)mean;
@@ -1378,6 +1379,7 @@ __global__ __launch_bounds__(256) void bf16_bn_rows_finalize_kernel(const float*
             out4[CT + cc] = bt - (float)mean * g * invstd;
             out4[2 * CT + cc] = (float)mean;
             out4[3 * CT + cc] = invstd;
+            out4[4 * CT + cc] = g;                          // the affine weight per (group, channel): what the backward's apply kernel reads
         }
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
         rm = (1.0f - momentum) * rm + momentum * (float)mean;
@@ -1443,7 +1445,7 @@ extern "C" int64_t mvs_bf16_conv3d_bn_fwd_workspace_bytes(int B, int Cout, int D
 }
 
 // y = raw conv(x) (kept: the BatchNorm backward needs it), z = [relu](BatchNorm_train(y)) [+ residual]; stats4 = [scale | shift | mean |
-// invstd], each groups*Cout.  groups > 1: sample b belongs to group b % groups, and the work items of one sample (Do*Ho*ceil(Wo/64))
+// invstd | gamma], FIVE rows of groups*Cout (the fifth = the affine weight replicated per group, 1 without one: the backward's operand).  groups > 1: sample b belongs to group b % groups, and the work items of one sample (Do*Ho*ceil(Wo/64))
 // must be a multiple of 4 so that a block never straddles two samples.
 extern "C" int mvs_bf16_conv3d_bn_fwd(const void* x, const void* wpacked, void* y, void* z, const void* residual, int relu, int B, int Cin,
                                       int Cout, int Di, int Hi, int Wi, int gather, int sd, int shw, int taps, int groups, const float* gamma,

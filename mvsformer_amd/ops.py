@@ -1204,7 +1204,7 @@ def bf16_conv3d_bnbwd(x, wpacked, cin, cout, gather: int, stride, bn_y, bn4, rel
     else:
         Do, Ho, Wo = Di * sd, Hi * shw, Wi * shw
     y = torch.empty(B, Do, Ho, Wo, cout, device=x.device, dtype=torch.bfloat16)
-    if tuple(bn_y.shape) != tuple(y.shape) or bn4.shape != (4, groups * cout) or B % groups:
+    if tuple(bn_y.shape) != tuple(y.shape) or bn4.dim() != 2 or bn4.shape[0] < 4 or bn4.shape[1] != groups * cout or B % groups:
         raise _lib.MvsHipError("bf16_conv3d_bnbwd: BatchNorm input %s / statistics %s do not match the gradient %s (groups %d)" % (
             tuple(bn_y.shape), tuple(bn4.shape), tuple(y.shape), groups))
     if addend is not None:
@@ -1380,7 +1380,7 @@ def bf16_bn_bwd_reduce(dy, x, scale, shift, mean, invstd, relu, groups: int = 1)
 def bf16_conv3d_bn_fwd(x, wpacked, cin, cout, gather: int, stride, residual, relu, gamma, beta, running_mean, running_var, momentum, eps,
                        groups: int = 1, num_batches_tracked=None, taps: int = 27):
     """conv -> batch-statistics BatchNorm -> [ReLU] [+ residual] of one bf16 channel-last training layer in one call (three launches, the
-    statistics ride the convolution's epilogue) -> ``(y raw conv output, z, stats4 [4, groups*cout] = scale | shift | mean | invstd)``."""
+    statistics ride the convolution's epilogue) -> ``(y raw conv output, z, stats [5, groups*cout] = scale | shift | mean | invstd | gamma per (group, channel))``."""
     _chk16(x, "x"), _chk16(wpacked, "packed weights")
     _opt(gamma, "bn.weight"), _opt(beta, "bn.bias"), _opt(running_mean, "bn.running_mean"), _opt(running_var, "bn.running_var")
     B, Di, Hi, Wi, C = x.shape
@@ -1400,7 +1400,7 @@ def bf16_conv3d_bn_fwd(x, wpacked, cin, cout, gather: int, stride, residual, rel
             raise _lib.MvsHipError("residual shape %s != output %s" % (tuple(residual.shape), tuple(y.shape)))
     if num_batches_tracked is not None:
         _chk(num_batches_tracked, "bn.num_batches_tracked", dtype=torch.int64)
-    st = torch.empty(4, groups * cout, device=x.device, dtype=torch.float32)
+    st = torch.empty(5, groups * cout, device=x.device, dtype=torch.float32)
     ws = _reduce_ws("mvs_bf16_conv3d_bn_fwd_workspace_bytes", x.device, B, cout, Do, Ho, Wo)
     flops = 2.0 * taps * cin * cout * B * (Do * Ho * Wo if gather == 0 else Di * Hi * Wi)
     tag = ("bf16_conv_bn_fwd<%d,%d,g%d,s%d%d%s>" % (cin, cout, gather, sd, shw, ",2d" if taps == 9 else ""), "flops", flops)
