@@ -606,7 +606,7 @@ int mvs_ce_loss_bwd_scale(const float* grad_unscaled, float* grad, int64_t numel
  *       a_mode 1: A is the implicit im2col of a 3x3 / pad-1 convolution over a channel-last map [H][W][Cp] (M = H*W, K = 9*Cp, k = tap*Cp + c);
  *       a_mode 2: the 2x2 taps of output-parity class b2 (ph = b2 / 2, pw = b2 % 2; nb2 = 4) of a ConvTranspose2d(kernel 4, stride 2,
  *       padding 1) over [H][W][Cp] (M = H*W input pixels, K = 4*Cp; class output (y, x) is output pixel (2y + ph, 2x + pw)).  Cp % 8 == 0.
- *       epi(v) = act(v*scale[n] + shift[n]) * mul + res   (scale / shift / mul / res may be NULL; act 0 none, 1 GELU(erf), 2 Swish;
+ *       epi(v) = act(v*scale[n] + shift[n]) * mul + res   (scale / shift / mul / res may be NULL; act 0 none, 1 GELU(erf), 2 Swish, 3 ReLU;
  *       mul and res are C-shaped with C's strides).
  *   mvs_layernorm: y = (x - mean) * rsqrt(var + eps) * gamma + beta over rows of C <= 1024 features.
  *   mvs_softmax_rows: y = softmax(scale * x) over rows of N <= 8192 (in place allowed).

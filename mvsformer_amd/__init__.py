@@ -12,7 +12,7 @@ from . import synth  # noqa: F401
 
 __all__ = ["synth", "StageNet", "DepthNet", "CostRegNet", "CostRegNet3D", "CascadeMVS", "homo_warping_3D_with_mask",
            "homo_warping_3D", "homo_warping", "depth_regression", "conf_regression", "init_inverse_range",
-           "schedule_inverse_range", "install", "fusion", "FPNDecoder", "FPNEncoder", "vit_small", "VisionTransformer",
+           "schedule_inverse_range", "install", "fusion", "FPNDecoder", "FPNDecoderV2", "FPNEncoder", "vit_small", "VisionTransformer",
            "VITDecoderStage4Single"]
 
 
@@ -30,7 +30,7 @@ def __getattr__(name):
     if name in ("CascadeMVS", "randomize_bn_"):
         from . import cascade
         return getattr(cascade, name)
-    if name in ("FPNDecoder", "FPNEncoder"):
+    if name in ("FPNDecoder", "FPNDecoderV2", "FPNEncoder"):
         from . import fpn
         return getattr(fpn, name)
     if name in ("vit_small", "VisionTransformer", "VITDecoderStage4Single"):

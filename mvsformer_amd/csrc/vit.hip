@@ -224,6 +224,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmArgs a) {
             v = fmaf(v, sc, sh);
             if (a.act == 1) v = gelu_erf(v);
             else if (a.act == 2) v = v / (1.0f + __expf(-v));
+            else if (a.act == 3) v = fmaxf(v, 0.0f);
             const size_t o = (size_t)m * a.ldc + n;
             if (a.mul) v *= a.mul[eoff + o];
             if (a.res) v += a.res[eoff + o];
@@ -485,7 +486,7 @@ extern "C" int mvs_gemm_x3(const float* A, const float* B, float* C, int M, int 
                            float alpha, const float* scale, const float* shift, int act, const float* mul, const float* res,
                            mvs_stream_t stream) {
     MVS_REQUIRE(A && B && C && M >= 1 && N >= 1 && K >= 1 && nb1 >= 1 && nb2 >= 1, "mvs_gemm_x3: bad shape M=%d N=%d K=%d", M, N, K);
-    MVS_REQUIRE((int64_t)nb1 * nb2 <= 65535 && (b_kn == 0 || b_kn == 1) && act >= 0 && act <= 2, "mvs_gemm_x3: bad batch / flags");
+    MVS_REQUIRE((int64_t)nb1 * nb2 <= 65535 && (b_kn == 0 || b_kn == 1) && act >= 0 && act <= 3, "mvs_gemm_x3: bad batch / flags");
     MVS_REQUIRE(a_mode == 0 || ((a_mode == 1 || a_mode == 2) && H >= 1 && W >= 1 && Cp >= 8 && Cp % 8 == 0 && M == H * W &&
                                 K == (a_mode == 1 ? 9 : 4) * Cp && (a_mode == 1 || nb2 == 4)),
                 "mvs_gemm_x3: implicit convolution needs M = H*W, K = taps*Cp, Cp a multiple of 8 (and nb2 = 4 parity classes for the transposed form)");

@@ -91,6 +91,9 @@ def _train_layer(x, conv: nn.Conv2d, bn, act: int):
     return y if bn is None else BnActFn.apply(y, bn.weight, bn.bias, None, bn, act)
 
 
+ACT_SWISH_GEMM, ACT_RELU_GEMM = 2, 3      # activation codes of mvs_gemm_x3's epilogue (include/mvs_hip.h)
+
+
 class Swish(nn.Module):
     """Parameterless placeholder (models/module.py:200-206) so that ``nn.Sequential`` indices match the reference's keys; the
     activation itself runs in the kernels' epilogues."""
@@ -158,6 +161,81 @@ class FPNDecoder(nn.Module):
                 w_in, b_in, packed, scale, shift = levels[i]
                 intra, out = ops.fpn_level(intra, lateral.float().contiguous(), w_in, b_in, packed, scale, shift, want_intra=(i < 2))
                 outs.append(out)
+        return [o.permute(0, 3, 1, 2) for o in outs]
+
+
+class FPNDecoderV2(nn.Module):
+    """models/module.py:273-302 (the decoder of ``TwinMVSNet``): four 3x3 Conv + BatchNorm + Swish outputs, the upper three reading the
+    concatenation [decoder map | transformer map], joined by ConvTranspose2d(4, 2, 1) + BatchNorm + ReLU upsamplings with the encoder
+    maps added.  Eval mode on the split-form implicit GEMMs of csrc/vit.hip (``mvs_gemm_x3``: 3x3 convolution = A rows gathered from the
+    channel-last map, the transposed convolution = four output-parity classes of 2x2 taps; BatchNorm folded, activation in the epilogue):
+    fp32-equivalent.  ``forward(conv01, conv11, conv21, conv31, vit1, vit2, vit3) -> [out1 (1/8), out2 (1/4), out3 (1/2), out4 (full)]``,
+    logical NCHW over channel-last memory.  Training mode is not built (Twins itself cannot be pinned here: models/gvt.py needs timm)."""
+
+    def __init__(self, feat_chs):
+        super().__init__()
+        c = list(feat_chs)
+        if any(ch % 8 for ch in c) or len(c) != 4:
+            raise _lib.MvsHipError("FPNDecoderV2: four channel counts, multiples of 8 (got %s)" % (c,))
+        self.out1 = nn.Sequential(nn.Conv2d(c[3] * 2, c[3], kernel_size=3, padding=1), nn.BatchNorm2d(c[3]), Swish())
+        self.upsample1 = nn.Sequential(nn.ConvTranspose2d(c[3], c[2], kernel_size=4, stride=2, padding=1), nn.BatchNorm2d(c[2]), nn.ReLU(True))
+        self.out2 = nn.Sequential(nn.Conv2d(c[2] * 2, c[2], kernel_size=3, padding=1), nn.BatchNorm2d(c[2]), Swish())
+        self.upsample2 = nn.Sequential(nn.ConvTranspose2d(c[2], c[1], kernel_size=4, stride=2, padding=1), nn.BatchNorm2d(c[1]), nn.ReLU(True))
+        self.out3 = nn.Sequential(nn.Conv2d(c[1] * 2, c[1], kernel_size=3, padding=1), nn.BatchNorm2d(c[1]), Swish())
+        self.upsample3 = nn.Sequential(nn.ConvTranspose2d(c[1], c[0], kernel_size=4, stride=2, padding=1), nn.BatchNorm2d(c[0]), nn.ReLU(True))
+        self.out4 = nn.Sequential(nn.Conv2d(c[0], c[0], kernel_size=3, padding=1), nn.BatchNorm2d(c[0]), Swish())
+        self._cache = None
+
+    def _prepared(self):
+        from .vit import _conv3_matrix, _convT_matrices, _fold
+        key = _versions(self)
+        if self._cache is None or self._cache[0] != key:
+            prep = {}
+            for k in (1, 2, 3, 4):
+                seq = getattr(self, "out%d" % k)
+                prep["out%d" % k] = (_conv3_matrix(seq[0].weight, seq[0].in_channels), _fold(seq[0], seq[1]))
+            for k in (1, 2, 3):
+                seq = getattr(self, "upsample%d" % k)
+                prep["up%d" % k] = (_convT_matrices(seq[0].weight), _fold(seq[0], seq[1]))
+            _publish_cache()
+            self._cache = (key, prep)
+        return self._cache[1]
+
+    @staticmethod
+    def _conv3(x_cl, wm, fold):
+        """3x3 convolution (padding 1) + folded BatchNorm + Swish on a channel-last map ``[B,h,w,C]`` -> ``[B,h,w,Cout]``."""
+        B, h, w, C = x_cl.shape
+        cout = wm.shape[0]
+        out = torch.empty(B, h, w, cout, device=x_cl.device, dtype=torch.float32)
+        ops.gemm_x3(x_cl, wm, out, h * w, cout, 9 * C, 0, 9 * C, cout, nb1=B, sA=(h * w * C, 0), sC=(h * w * cout, 0), a_mode=1, H=h, W=w, Cp=C,
+                    scale=fold[0], shift=fold[1], act=ACT_SWISH_GEMM)
+        return out
+
+    def forward(self, conv01, conv11, conv21, conv31, vit1, vit2, vit3):
+        if self.training:
+            raise _lib.MvsHipError("FPNDecoderV2: only eval mode is built on the HIP path")
+        from .vit import VITDecoderStage4Single
+        p = self._prepared()
+
+        def cl(t):                                            # logical NCHW -> channel-last memory (free when it already is)
+            return t.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous()
+
+        with torch.no_grad():
+            outs = []
+            x = torch.cat([cl(conv31), cl(vit1)], dim=-1)
+            for k, (skip, vit) in enumerate(((conv21, vit2), (conv11, vit3), (conv01, None)), start=1):
+                out = self._conv3(x, *p["out%d" % k])
+                outs.append(out)
+                up = VITDecoderStage4Single._up(out, p["up%d" % k][0], p["up%d" % k][1], ACT_RELU_GEMM)      # [B,2h,2w,C/2]
+                s = cl(skip)
+                if vit is None:
+                    x = up.add_(s)
+                else:                                         # [up + skip | vit] written straight into the next convolution's input
+                    C = up.shape[-1]
+                    x = torch.empty(up.shape[:-1] + (2 * C,), device=up.device, dtype=torch.float32)
+                    torch.add(up, s, out=x[..., :C])
+                    x[..., C:] = cl(vit)
+            outs.append(self._conv3(x, *p["out4"]))
         return [o.permute(0, 3, 1, 2) for o in outs]
 
 

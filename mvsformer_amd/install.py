@@ -29,7 +29,8 @@ _SYMBOLS = {
     "homo_warping_3D_with_mask": _w.homo_warping_3D_with_mask,
 }
 # the rows before the path: eval-only on the HIP path, so they are rebound only on request
-_FEATURE_SYMBOLS = {"FPNDecoder": _f.FPNDecoder, "FPNEncoder": _f.FPNEncoder, "VITDecoderStage4Single": _v.VITDecoderStage4Single}
+_FEATURE_SYMBOLS = {"FPNDecoder": _f.FPNDecoder, "FPNDecoderV2": _f.FPNDecoderV2, "FPNEncoder": _f.FPNEncoder,
+                    "VITDecoderStage4Single": _v.VITDecoderStage4Single}
 # DINOMVSNet builds its backbone as ``vits.__dict__[vit_arch](...)`` (mvsformer_model.py:180): the factory is rebound in that module
 _VIT_MODULE, _VIT_FACTORIES = "models.vision_transformer", {"vit_small": _v.vit_small}
 

@@ -22,6 +22,7 @@ float16-exact values to halve the files):
   cascade_v3.npz, cascade_v5.npz   4-stage inverse-depth cascade, 64x64, tmp=[5,5,5,1]
   train_costregnet.npz, train_costregnet3d.npz   train-mode StageNet (B=2): forward, loss=sum(pre*R), all gradients
   fpn_decoder.npz          FPNDecoder (the step before the path), eval BatchNorm: state_dict, encoder outputs, the 4 feature maps
+  fpn_decoder_v2.npz       FPNDecoderV2 (TwinMVSNet's decoder), eval BatchNorm: state_dict (conv weights float16-exact), 7 input maps, 4 outputs
   fpn_encoder.npz          FPNEncoder, eval BatchNorm: state_dict (conv weights float16-exact), image, the 4 encoder outputs
 """
 import json
@@ -561,6 +562,39 @@ def gen_fpn_decoder():
 
 if __name__ == "__main__" and os.environ.get("GEN_FPN", "1") == "1":
     gen_fpn_decoder()
+
+
+def gen_fpn_decoder_v2():
+    """FPNDecoderV2 (models/module.py:273-302, TwinMVSNet's decoder), eval mode: seeded default init with the convolution weights rounded
+    to float16-exact values (both sides use exactly these) + randomized BatchNorm; encoder maps as gen_fpn_decoder (coarsest 5x6: partial
+    tiles at every level), transformer maps vit1..3 at 1/8, 1/4, 1/2 with 64 / 32 / 16 channels."""
+    from models.module import FPNDecoderV2
+    from oracle import ref_fpn
+    torch.manual_seed(17)
+    dec = FPNDecoderV2([8, 16, 32, 64])
+    ref_fpn.randomize_bn(dec, 18)
+    with torch.no_grad():
+        for name, p in dec.named_parameters():
+            if name.endswith("0.weight"):
+                p.copy_(f16exact(p))
+    dec.eval()
+    conv01, conv11, conv21, conv31 = ref_fpn.make_case(19, 1, 5, 6)
+    g = torch.Generator().manual_seed(20)
+    vit1, vit2, vit3 = (torch.randn(1, c, 5 * s, 6 * s, generator=g) for c, s in ((64, 1), (32, 2), (16, 4)))
+    with torch.no_grad():
+        outs = dec(conv01, conv11, conv21, conv31, vit1, vit2, vit3)
+    arrs = {}
+    for k, v in dec.state_dict().items():
+        if v.dtype.is_floating_point:
+            arrs["sd." + k] = np32(v).astype(np.float16) if k.endswith("0.weight") else np32(v)
+    arrs.update(conv01=np32(conv01), conv11=np32(conv11), conv21=np32(conv21), conv31=np32(conv31), vit1=np32(vit1), vit2=np32(vit2),
+                vit3=np32(vit3))
+    arrs.update({"out%d" % (i + 1): np32(o) for i, o in enumerate(outs)})
+    save("fpn_decoder_v2.npz", **arrs)
+
+
+if __name__ == "__main__" and os.environ.get("GEN_FPN_V2", "1") == "1":
+    gen_fpn_decoder_v2()
 
 
 def gen_fpn_encoder():

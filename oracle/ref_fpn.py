@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE — CPU oracle for the FPN decoder and encoder (the steps that hand features to the path).
 
-Restates reference models/module.py:242-270 (``FPNDecoder``: lateral 1x1 convolutions, bilinear x2 upsampling with
+Restates reference models/module.py:273-302 (``FPNDecoderV2``, pinned by tests/golden/fpn_decoder_v2.npz) and models/module.py:242-270 (``FPNDecoder``: lateral 1x1 convolutions, bilinear x2 upsampling with
 align_corners=True, 3x3 output convolutions followed by BatchNorm2d and Swish, module.py:200-206) as a function of the
 module's ``state_dict``, eval-mode BatchNorm, and models/module.py:208-240 (``FPNEncoder``) likewise.  Pinned by
 tests/golden/fpn_decoder.npz and fpn_encoder.npz (outputs of the real modules, made by oracle/gen_golden.py).  Never imported by the product path.
@@ -37,6 +37,20 @@ def fpn_decoder_forward(sd, conv01, conv11, conv21, conv31):
             F.conv2d(lateral, sd["inner%d.weight" % k], sd["inner%d.bias" % k])
         outs.append(_out(intra, sd, "out%d" % k, 1))
     return outs
+
+
+def fpn_decoder_v2_forward(sd, conv01, conv11, conv21, conv31, vit1, vit2, vit3):
+    """module.py:291-302 (``FPNDecoderV2.forward``) -> [out1 (1/8), out2 (1/4), out3 (1/2), out4 (full)]; eval-mode BatchNorm.
+    out_k = Swish(BN(conv3x3(.))) (module.py:276,280,284,288), upsample_k = ReLU(BN(ConvTranspose2d(4, 2, 1)(.))) (module.py:277-286)."""
+    def up(x, name):
+        y = F.conv_transpose2d(x, sd[name + ".0.weight"], sd[name + ".0.bias"], stride=2, padding=1)
+        return F.relu(_bn_eval(y, sd, name + ".1"))
+
+    out1 = _out(torch.cat([conv31, vit1], dim=1), sd, "out1", 1)
+    out2 = _out(torch.cat([up(out1, "upsample1") + conv21, vit2], dim=1), sd, "out2", 1)
+    out3 = _out(torch.cat([up(out2, "upsample2") + conv11, vit3], dim=1), sd, "out3", 1)
+    out4 = _out(up(out3, "upsample3") + conv01, sd, "out4", 1)
+    return [out1, out2, out3, out4]
 
 
 def make_case(seed, N, h, w, feat_chs=(8, 16, 32, 64)):

@@ -240,3 +240,66 @@ def test_fpn_training_mode_vs_reference_gradients():
             if b.dtype.is_floating_point:
                 assert rel(b, g["%s.buf.%s" % (tag, k)]) < 2e-5, (tag, k)
     print("worst parameter gradient", worst)
+
+
+# ------------------------------------------------------------------------------------------ FPNDecoderV2 (models/module.py:273-302)
+V2_INPUTS = ("conv01", "conv11", "conv21", "conv31", "vit1", "vit2", "vit3")
+
+
+def build_decoder_v2(sd=None, seed=0):
+    from mvsformer_amd import FPNDecoderV2
+    from oracle import ref_fpn
+    torch.manual_seed(seed)
+    dec = FPNDecoderV2([8, 16, 32, 64])
+    if sd is None:
+        ref_fpn.randomize_bn(dec, seed + 1)
+    else:
+        missing, unexpected = dec.load_state_dict(sd, strict=False)
+        assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+    return dec.eval()
+
+
+def v2_case(seed, N, h, w):
+    from oracle import ref_fpn
+    g = torch.Generator().manual_seed(seed + 100)
+    return ref_fpn.make_case(seed, N, h, w) + tuple(torch.randn(N, c, h * s, w * s, generator=g) for c, s in ((64, 1), (32, 2), (16, 4)))
+
+
+def test_fpn_decoder_v2_is_checkpoint_compatible_and_eval_only():
+    """CPU: the reference's parameter names (the golden state_dict loads strictly up to num_batches_tracked); training mode raises."""
+    g = load_golden("fpn_decoder_v2.npz")
+    dec = build_decoder_v2({k[3:]: t(v.astype(np.float32)) for k, v in g.items() if k.startswith("sd.")})
+    assert sorted(k for k in dec.state_dict() if not k.endswith("num_batches_tracked")) == sorted(k[3:] for k in g if k.startswith("sd."))
+    from mvsformer_amd._lib import MvsHipError
+    with pytest.raises(MvsHipError):
+        dec.train()(*[t(g[k]) for k in V2_INPUTS])
+
+
+@pytest.mark.gpu
+def test_fpn_decoder_v2_vs_golden():
+    """Against the outputs of the reference's own FPNDecoderV2 (oracle/gen_golden.py::gen_fpn_decoder_v2): split-form GEMMs are
+    fp32-equivalent, four layers deep -> 2e-5 of each map's scale."""
+    g = load_golden("fpn_decoder_v2.npz")
+    dev = torch.device("cuda:0")
+    dec = build_decoder_v2({k[3:]: t(v.astype(np.float32)) for k, v in g.items() if k.startswith("sd.")}).to(dev)
+    outs = dec(*[t(g[k], dev) for k in V2_INPUTS])
+    assert len(outs) == 4
+    for i, o in enumerate(outs, start=1):
+        assert tuple(o.shape) == g["out%d" % i].shape
+        assert o.permute(0, 2, 3, 1).is_contiguous()            # channel-last memory, the reference's logical shape
+        assert scale_err(o.cpu(), g["out%d" % i]) < TOL, (i, scale_err(o.cpu(), g["out%d" % i]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,h,w", [(2, 7, 9), (1, 1, 1), (3, 2, 17)])
+def test_fpn_decoder_v2_vs_oracle(N, h, w):
+    """Other shapes (ragged tiles, several images, the 1x1 coarsest level) against the CPU oracle (oracle/ref_fpn.py)."""
+    from oracle import ref_fpn
+    dec = build_decoder_v2(seed=3)
+    ins = v2_case(4, N, h, w)
+    want = ref_fpn.fpn_decoder_v2_forward({k: v.detach() for k, v in dec.state_dict().items()}, *ins)
+    dec = dec.to("cuda:0")
+    outs = dec(*[f.to("cuda:0") for f in ins])
+    for i, (o, ww) in enumerate(zip(outs, want)):
+        assert o.shape == ww.shape
+        assert scale_err(o.cpu(), ww) < TOL, (i, scale_err(o.cpu(), ww))

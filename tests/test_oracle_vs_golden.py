@@ -231,6 +231,17 @@ def test_fpn_decoder_oracle_vs_reference():
         assert max_abs(o, g["out%d" % i]) < TOL * max(1.0, float(np.abs(g["out%d" % i]).max())), i
 
 
+def test_fpn_decoder_v2_oracle_vs_reference():
+    """oracle/ref_fpn.py against the real FPNDecoderV2 (models/module.py:273-302; tests/golden/fpn_decoder_v2.npz), eval BatchNorm."""
+    from oracle import ref_fpn
+    g = load_golden("fpn_decoder_v2.npz")
+    sd = {k[3:]: t(v.astype(np.float32)) for k, v in g.items() if k.startswith("sd.")}
+    outs = ref_fpn.fpn_decoder_v2_forward(sd, *[t(g[k]) for k in ("conv01", "conv11", "conv21", "conv31", "vit1", "vit2", "vit3")])
+    assert [tuple(o.shape) for o in outs] == [(1, 64, 5, 6), (1, 32, 10, 12), (1, 16, 20, 24), (1, 8, 40, 48)]
+    for i, o in enumerate(outs, start=1):
+        assert max_abs(o, g["out%d" % i]) < TOL * max(1.0, float(np.abs(g["out%d" % i]).max())), i
+
+
 def fpn_encoder_golden():
     g = load_golden("fpn_encoder.npz")
     return g, {k[3:]: t(v) for k, v in g.items() if k.startswith("sd.")}
