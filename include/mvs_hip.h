@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 25
+#define MVS_ABI_VERSION 26
 
 typedef void* mvs_stream_t;
 
@@ -594,6 +594,15 @@ int64_t mvs_ce_loss_acc_floats(int B, int64_t HW);
 int mvs_ce_loss_fwd(const float* logits, const float* depth_values, const float* depth_gt, const float* mask, int B, int D, int64_t HW,
                     int inverse_depth, float weight, float* grad_unscaled, float* acc, float* loss, uint8_t* valid, int* gt_index,
                     mvs_stream_t stream);
+/* models/losses.py:353-408 (mixup_ce_loss_stage4), one stage: loss = weight * sum(mask * (w_l*CE(logits[:-1], idx) + w_r*CE(logits[1:], idx)))
+ * / (sum(mask) + 1e-6); acc / grad_unscaled / loss as mvs_ce_loss_fwd (acc[1] holds the denominator: mvs_ce_loss_bwd_scale applies it). */
+int mvs_mixup_ce_loss_fwd(const float* logits, const float* depth_values, const float* depth_gt, const float* mask, int B, int D, int64_t HW,
+                          int inverse_depth, float weight, float* grad_unscaled, float* acc, float* loss, mvs_stream_t stream);
+/* models/losses.py:51-85 (reg_loss_stage4), one stage: weight * mean over {mask > 0.5 [and gt in range if depth_values != NULL]} of
+ * smooth_l1(depth/interval[b] - gt/interval[b]); depth, gt, mask [B][HW], depth_values [B][D][HW] or NULL (mask_out_range=False),
+ * grad_unscaled [B][HW] = d(sum)/d depth (may be NULL), acc >= mvs_ce_loss_acc_floats(B, HW) floats. */
+int mvs_reg_loss_fwd(const float* depth, const float* depth_gt, const float* mask, const float* depth_values, const float* interval, int B, int D,
+                     int64_t HW, int inverse_depth, float weight, float* grad_unscaled, float* acc, float* loss, mvs_stream_t stream);
 int mvs_ce_loss_bwd_scale(const float* grad_unscaled, float* grad, int64_t numel, const float* acc, const float* grad_out, float weight,
                           mvs_stream_t stream);
 

@@ -80,8 +80,120 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
             (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
-// acc[0..1] = the rows (acc + 2) added in a fixed order; loss = weight * acc[0] / acc[1]
-__global__ __launch_bounds__(256) void ce_finalize_kernel(float* __restrict__ acc, int nrows, float weight, float* __restrict__ loss) {
+// models/losses.py:353-408 (mixup_ce_loss_stage4), one stage: the ground truth lies between hypotheses idx and idx + 1 (flipped order);
+// loss = w_l * CE(logits[:-1], idx) + w_r * CE(logits[1:], idx) with w_l = clamp(|gt - dv[idx]| / |dv[idx+1] - dv[idx]|, 0, 1), w_r = 1 - w_l,
+// summed over pixels TIMES the float mask (in range [dv[0], dv[D-1]] and mask > 0.5) and divided by (sum(mask) + 1e-6).  One lane = one
+// pixel: a walk finds idx and the two log-sum-exps (over D-1 logits each), a second writes the unnormalized gradient
+// mask * (w_l * (softmax_left - onehot_idx) + w_r * (softmax_right - onehot_{idx+1})) in the ORIGINAL depth order.
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void mixup_ce_loss_kernel(const float* __restrict__ logits, const float* __restrict__ hyp,
+                                                            const float* __restrict__ gt, const float* __restrict__ mask, int D, size_t HW,
+                                                            float* __restrict__ grad, float* __restrict__ rows) {
+    __shared__ float red[2][4];
+    const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    float lsum = 0.0f, cnt = 0.0f;
+    if (pix < HW) {
+        const float* lg = logits + (size_t)b * D * HW + pix;
+        const float* hv = hyp + (size_t)b * D * HW + pix;
+        const float g = gt[(size_t)b * HW + pix];
+        auto at = [&](const float* p, int j) { return p[(size_t)(INVERSE ? D - 1 - j : j) * HW]; };
+        const float lo = at(hv, 0), hi = at(hv, D - 1);
+        int idx = 0;
+        float ml = -INFINITY, sl = 0.0f, mr = -INFINITY, sr = 0.0f;
+        for (int j = 0; j < D; ++j) {
+            if (j >= 1) idx += (at(hv, j) <= g) ? 1 : 0;
+            const float l = at(lg, j);
+            if (j < D - 1) {
+                const float mn = fmaxf(ml, l);
+                sl = sl * expf(ml - mn) + expf(l - mn);
+                ml = mn;
+            }
+            if (j >= 1) {
+                const float mn = fmaxf(mr, l);
+                sr = sr * expf(mr - mn) + expf(l - mn);
+                mr = mn;
+            }
+        }
+        idx = min(idx, D - 2);
+        const float left = at(hv, idx), itv = fabsf(at(hv, idx + 1) - left);
+        const float x = fabsf(g - left) / itv;
+        const float wl = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x), wr = 1.0f - wl;      // torch.clamp: a NaN stays a NaN
+        const float outl = g < lo ? 1.0f : 0.0f, outr = g > hi ? 1.0f : 0.0f;
+        const float fm = (1.0f - fminf(outl + outr, 1.0f)) * (mask[(size_t)b * HW + pix] > 0.5f ? 1.0f : 0.0f);
+        const float lsel = ml + logf(sl), lser = mr + logf(sr);
+        lsum = (lsel - at(lg, idx)) * wl * fm + (lser - at(lg, idx + 1)) * wr * fm;
+        cnt = fm;
+        if (grad) {
+            float* gr = grad + (size_t)b * D * HW + pix;
+            for (int d = 0; d < D; ++d) {
+                const int j = INVERSE ? D - 1 - d : d;       // position in the flipped column
+                const float l = lg[(size_t)d * HW];
+                float v = 0.0f;
+                if (j < D - 1) v += wl * fm * (expf(l - lsel) - (j == idx ? 1.0f : 0.0f));
+                if (j >= 1) v += wr * fm * (expf(l - lser) - (j == idx + 1 ? 1.0f : 0.0f));
+                gr[(size_t)d * HW] = v;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lsum += __shfl_down(lsum, o, 64);
+        cnt += __shfl_down(cnt, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = lsum;
+        red[1][threadIdx.x >> 6] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        rows[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + threadIdx.x] =
+            (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// models/losses.py:51-85 (reg_loss_stage4), one stage: smooth-L1 (beta = 1) of depth / interval against gt / interval, mean over the pixels
+// with mask > 0.5 [and, mask_out_range: gt inside the hypothesis column widened by half an interval at both ends, losses.py:62-74].
+// grad = d(sum of the selected terms) / d depth; the 1 / N of the mean is applied by mvs_ce_loss_bwd_scale.
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void reg_loss_kernel(const float* __restrict__ depth, const float* __restrict__ gt, const float* __restrict__ mask,
+                                                       const float* __restrict__ hyp /*null: no range mask*/, const float* __restrict__ interval,
+                                                       int D, size_t HW, float* __restrict__ grad, float* __restrict__ rows) {
+    __shared__ float red[2][4];
+    const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    float lsum = 0.0f, cnt = 0.0f;
+    if (pix < HW) {
+        const float itv = interval[b];
+        const float gv = gt[(size_t)b * HW + pix];
+        bool valid = mask[(size_t)b * HW + pix] > 0.5f;
+        if (hyp) {
+            const float* hv = hyp + (size_t)b * D * HW + pix;
+            auto at = [&](int j) { return hv[(size_t)(INVERSE ? D - 1 - j : j) * HW]; };
+            const float lo = at(0) - fabsf(at(1) - at(0)) / 2.0f, hi = at(D - 1) + fabsf(at(D - 1) - at(D - 2)) / 2.0f;
+            valid = valid && !(gv < lo) && !(gv > hi);
+        }
+        const float x = depth[(size_t)b * HW + pix] / itv - gv / itv, ax = fabsf(x);
+        if (valid) {
+            lsum = ax < 1.0f ? 0.5f * x * x : ax - 0.5f;
+            cnt = 1.0f;
+        }
+        if (grad) grad[(size_t)b * HW + pix] = valid ? (ax < 1.0f ? x : (x > 0.0f ? 1.0f : -1.0f)) / itv : 0.0f;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lsum += __shfl_down(lsum, o, 64);
+        cnt += __shfl_down(cnt, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = lsum;
+        red[1][threadIdx.x >> 6] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        rows[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + threadIdx.x] =
+            (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// acc[0..1] = the rows (acc + 2) added in a fixed order, acc[1] + eps = the denominator; loss = weight * acc[0] / acc[1]
+__global__ __launch_bounds__(256) void ce_finalize_kernel(float* __restrict__ acc, int nrows, float weight, float eps, float* __restrict__ loss) {
     __shared__ float red[2][4];
     const float* rows = acc + 2;
     float s = 0.0f, c = 0.0f;
@@ -101,9 +213,10 @@ __global__ __launch_bounds__(256) void ce_finalize_kernel(float* __restrict__ ac
     if (threadIdx.x == 0) {
         s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
         c = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        c += eps;                                     // 0 for the means over a selection, 1e-6 for mixup_ce's sum(mask) + 1e-6
         acc[0] = s;
         acc[1] = c;
-        loss[0] = weight * (s / c);                   // N = 0 -> 0/0 = NaN, as F.cross_entropy on an empty selection
+        loss[0] = weight * (s / c);                   // N = 0, eps = 0 -> 0/0 = NaN, as F.cross_entropy on an empty selection
     }
 }
 
@@ -134,8 +247,37 @@ extern "C" int mvs_ce_loss_fwd(const float* logits, const float* depth_values, c
     else
         hipLaunchKernelGGL(ce_loss_kernel<false>, grid, dim3(256), 0, s, logits, depth_values, depth_gt, mask, D, (size_t)HW,
                            grad_unscaled, acc2, valid, gt_index);
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, acc, (int)(grid.x * grid.y), weight, loss);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, acc, (int)(grid.x * grid.y), weight, 0.0f, loss);
     return mvs::finish_launch("mvs_ce_loss_fwd");
+}
+
+extern "C" int mvs_mixup_ce_loss_fwd(const float* logits, const float* depth_values, const float* depth_gt, const float* mask, int B, int D,
+                                     int64_t HW, int inverse_depth, float weight, float* grad_unscaled, float* acc, float* loss, mvs_stream_t stream) {
+    MVS_REQUIRE(logits && depth_values && depth_gt && mask && acc && loss, "mvs_mixup_ce_loss_fwd: null pointer");
+    MVS_REQUIRE(B >= 1 && B <= 65535 && D >= 2 && HW >= 1, "mvs_mixup_ce_loss_fwd: bad shape B=%d D=%d (>= 2) HW=%lld", B, D, (long long)HW);
+    hipStream_t s = MVS_STREAM(stream);
+    dim3 grid((unsigned)mvs::ceil_div((long long)HW, 256LL), B);
+    if (inverse_depth)
+        hipLaunchKernelGGL(mixup_ce_loss_kernel<true>, grid, dim3(256), 0, s, logits, depth_values, depth_gt, mask, D, (size_t)HW, grad_unscaled, acc + 2);
+    else
+        hipLaunchKernelGGL(mixup_ce_loss_kernel<false>, grid, dim3(256), 0, s, logits, depth_values, depth_gt, mask, D, (size_t)HW, grad_unscaled, acc + 2);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, acc, (int)(grid.x * grid.y), weight, 1e-6f, loss);
+    return mvs::finish_launch("mvs_mixup_ce_loss_fwd");
+}
+
+extern "C" int mvs_reg_loss_fwd(const float* depth, const float* depth_gt, const float* mask, const float* depth_values, const float* interval,
+                                int B, int D, int64_t HW, int inverse_depth, float weight, float* grad_unscaled, float* acc, float* loss,
+                                mvs_stream_t stream) {
+    MVS_REQUIRE(depth && depth_gt && mask && interval && acc && loss, "mvs_reg_loss_fwd: null pointer");
+    MVS_REQUIRE(B >= 1 && B <= 65535 && HW >= 1 && (!depth_values || D >= 2), "mvs_reg_loss_fwd: bad shape B=%d D=%d HW=%lld", B, D, (long long)HW);
+    hipStream_t s = MVS_STREAM(stream);
+    dim3 grid((unsigned)mvs::ceil_div((long long)HW, 256LL), B);
+    if (inverse_depth)
+        hipLaunchKernelGGL(reg_loss_kernel<true>, grid, dim3(256), 0, s, depth, depth_gt, mask, depth_values, interval, D, (size_t)HW, grad_unscaled, acc + 2);
+    else
+        hipLaunchKernelGGL(reg_loss_kernel<false>, grid, dim3(256), 0, s, depth, depth_gt, mask, depth_values, interval, D, (size_t)HW, grad_unscaled, acc + 2);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, acc, (int)(grid.x * grid.y), weight, 0.0f, loss);
+    return mvs::finish_launch("mvs_reg_loss_fwd");
 }
 
 extern "C" int mvs_ce_loss_bwd_scale(const float* grad_unscaled, float* grad, int64_t numel, const float* acc, const float* grad_out,

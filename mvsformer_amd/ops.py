@@ -1044,6 +1044,41 @@ def ce_loss(logits, depth_values, depth_gt, mask, inverse_depth: bool, weight: f
     return loss, acc, grad
 
 
+def mixup_ce_loss(logits, depth_values, depth_gt, mask, inverse_depth: bool, weight: float = 1.0, want_grad: bool = True):
+    """models/losses.py:353-408 for one stage -> ``(loss [], acc, grad_unscaled [B,D,H,W] or None)``; ``acc[1]`` = sum(mask) + 1e-6."""
+    _chk(logits, "prob_volume_pre"), _chk(depth_values, "depth_values"), _chk(depth_gt, "depth_gt"), _chk(mask, "mask")
+    B, D, H, W = logits.shape
+    if depth_values.shape != logits.shape or depth_gt.shape != (B, H, W) or mask.shape != (B, H, W):
+        raise _lib.MvsHipError("mixup_ce_loss: shapes %s %s %s %s" % (tuple(logits.shape), tuple(depth_values.shape), tuple(depth_gt.shape),
+                                                                     tuple(mask.shape)))
+    dev = logits.device
+    acc = torch.empty(_lib.load().mvs_ce_loss_acc_floats(B, H * W), device=dev, dtype=torch.float32)
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    grad = torch.empty_like(logits) if want_grad else None
+    algo = 4.0 * B * H * W * (2 * D + 2 + (D if want_grad else 0))
+    _call("mvs_mixup_ce_loss_fwd", ("mixup_ce_loss", "bytes", algo), _ptr(logits), _ptr(depth_values), _ptr(depth_gt), _ptr(mask), B, D, H * W,
+          int(inverse_depth), float(weight), _ptr(grad), _ptr(acc), _ptr(loss), _stream())
+    return loss, acc, grad
+
+
+def reg_loss(depth, depth_gt, mask, interval, depth_values=None, inverse_depth: bool = True, weight: float = 1.0, want_grad: bool = True):
+    """models/losses.py:51-85 for one stage: ``depth``, ``depth_gt``, ``mask`` ``[B,H,W]``, ``interval [B]``, ``depth_values [B,D,H,W]`` only
+    with ``mask_out_range`` -> ``(loss [], acc, grad_unscaled [B,H,W] or None)``."""
+    _chk(depth, "depth"), _chk(depth_gt, "depth_gt"), _chk(mask, "mask"), _chk(interval, "depth_interval"), _opt(depth_values, "depth_values")
+    B, H, W = depth.shape
+    D = depth_values.shape[1] if depth_values is not None else 0
+    if depth_gt.shape != (B, H, W) or mask.shape != (B, H, W) or interval.numel() != B or \
+            (depth_values is not None and (depth_values.shape[0] != B or tuple(depth_values.shape[2:]) != (H, W))):
+        raise _lib.MvsHipError("reg_loss: shapes %s %s %s %s" % (tuple(depth.shape), tuple(depth_gt.shape), tuple(mask.shape), tuple(interval.shape)))
+    dev = depth.device
+    acc = torch.empty(_lib.load().mvs_ce_loss_acc_floats(B, H * W), device=dev, dtype=torch.float32)
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    grad = torch.empty_like(depth) if want_grad else None
+    _call("mvs_reg_loss_fwd", "reg_loss", _ptr(depth), _ptr(depth_gt), _ptr(mask), _ptr(depth_values), _ptr(interval), B, D, H * W,
+          int(inverse_depth), float(weight), _ptr(grad), _ptr(acc), _ptr(loss), _stream())
+    return loss, acc, grad
+
+
 def ce_loss_bwd_scale(grad, acc, gout, weight: float) -> torch.Tensor:
     """-> ``grad * weight * gout / count`` as a NEW tensor (the saved unscaled gradient stays intact for a second backward)."""
     _chk(grad, "grad"), _chk(acc, "acc"), _chk(gout, "grad_out")

@@ -541,6 +541,47 @@ if __name__ == "__main__" and os.environ.get("GEN_LOSS", "1") == "1":
     gen_ce_loss()
 
 
+def gen_other_losses():
+    """other_losses.npz: models/losses.py mixup_ce_loss_stage4 and reg_loss_stage4 (mask_out_range False and True) values and gradients on
+    the SAME seeded cases as ce_loss.npz (oracle/ref_losses.make_loss_case, seeds 3 / 4: the inputs are read from that file by the
+    tests); the regression head's depth = sum(softmax(logits) * depth_values) and the per-sample depth interval are stored."""
+    from models.losses import mixup_ce_loss_stage4, reg_loss_stage4
+    from oracle import ref_losses
+    out = {}
+    w = [1.0, 0.5, 2.0, 1.0]
+    for tag, inverse in (("inv", True), ("fwd", False)):
+        inputs, gts, masks = ref_losses.make_loss_case(seed=3 if inverse else 4, inverse_depth=inverse)
+        for k in inputs:
+            inputs[k]["prob_volume_pre"].requires_grad_(True)
+        losses = mixup_ce_loss_stage4(inputs, gts, masks, dlossw=w, inverse_depth=inverse)
+        sum(losses.values()).backward()
+        for k in inputs:
+            out["%s_%s_mixup_loss" % (tag, k)] = np.float64(losses[k].item())
+            out["%s_%s_mixup_grad" % (tag, k)] = np32(inputs[k]["prob_volume_pre"].grad)
+            print(tag, k, "mixup %.5f" % losses[k].item())
+        itv = torch.tensor([2.5, 3.5])
+        out[tag + "_interval"] = np32(itv)
+        for rng in (False, True):
+            reg_in = {}
+            for k in inputs:
+                d = (torch.softmax(inputs[k]["prob_volume_pre"].detach(), 1) * inputs[k]["depth_values"]).sum(1)
+                d = d + 2.0 * torch.randn(d.shape, generator=torch.Generator().manual_seed(5))      # both branches of the smooth L1
+                reg_in[k] = dict(depth=d.clone().requires_grad_(True), depth_values=inputs[k]["depth_values"])
+            losses = reg_loss_stage4(reg_in, gts, masks, w, itv, mask_out_range=rng, inverse_depth=inverse)
+            sum(losses.values()).backward()
+            for k in inputs:
+                out["%s_%s_reg_depth" % (tag, k)] = np32(reg_in[k]["depth"])
+                out["%s_%s_reg%d_loss" % (tag, k, int(rng))] = np.float64(losses[k].item())
+                out["%s_%s_reg%d_grad" % (tag, k, int(rng))] = np32(reg_in[k]["depth"].grad)
+                print(tag, k, "reg range=%d %.5f" % (rng, losses[k].item()))
+    out["dlossw"] = np.asarray(w, np.float32)
+    save("other_losses.npz", **out)
+
+
+if __name__ == "__main__" and os.environ.get("GEN_LOSS2", "1") == "1":
+    gen_other_losses()
+
+
 # ---------------------------------------------------------------------------------------------
 def gen_fpn_decoder():
     """FPNDecoder (models/module.py:242-270), eval mode, default-initialized weights under a seed + randomized BatchNorm.

@@ -1,7 +1,7 @@
-"""TEST INFRASTRUCTURE — CPU oracle for the training loss: restates reference
-models/losses.py:304-350 (ce_loss_stage4, focal=False) for one stage, in the order of operations the reference uses.
-Pinned by tests/golden/ce_loss.npz (values and gradients produced by the real function).  Never imported by the
-product path."""
+"""TEST INFRASTRUCTURE — CPU oracle for the training losses: restates reference
+models/losses.py:304-350 (ce_loss_stage4, focal=False), :353-408 (mixup_ce_loss_stage4) and :51-85 (reg_loss_stage4) for one stage,
+in the order of operations the reference uses.  Pinned by tests/golden/ce_loss.npz and other_losses.npz (values and gradients produced
+by the real functions).  Never imported by the product path."""
 import torch
 import torch.nn.functional as F
 
@@ -28,6 +28,50 @@ def ce_loss_stage(prob_volume_pre, depth_values, depth_gt, mask, inverse_depth=T
 def ce_loss_stage4(inputs, depth_gt_ms, mask_ms, dlossw, inverse_depth=True):
     return {k: ce_loss_stage(inputs[k]["prob_volume_pre"].float(), inputs[k]["depth_values"], depth_gt_ms[k], mask_ms[k], inverse_depth,
                              1.0 if dlossw is None else dlossw[int(k[-1]) - 1]) for k in ("stage1", "stage2", "stage3", "stage4")}
+
+
+def mixup_ce_loss_stage(prob_volume_pre, depth_values, depth_gt, mask, inverse_depth=True, weight=1.0):
+    """losses.py:358-399 for one stage."""
+    gt = depth_gt.unsqueeze(1)
+    maskf = (mask > 0.5).float()
+    dv = torch.flip(depth_values, dims=[1]) if inverse_depth else depth_values
+    logits = torch.flip(prob_volume_pre, dims=[1]) if inverse_depth else prob_volume_pre
+    outside = torch.clamp((gt < dv[:, 0:1]).float() + (gt > dv[:, -1:]).float(), 0, 1)
+    final = (1 - outside).squeeze(1) * maskf
+    index = (dv[:, 1:] <= gt.expand_as(dv[:, :-1])).float().sum(dim=1, keepdim=True).long()
+    index = torch.clamp_max(index, dv.shape[1] - 2).squeeze(1)
+    left = torch.gather(dv[:, :-1], 1, index.unsqueeze(1))
+    itv = torch.gather((dv[:, 1:] - dv[:, :-1]).abs(), 1, index.unsqueeze(1))
+    wl = torch.clamp((gt - left).abs() / itv, 0, 1).squeeze(1)
+    wr = 1 - wl
+    ll = F.cross_entropy(logits[:, :-1], index, reduction="none")
+    lr = F.cross_entropy(logits[:, 1:], index, reduction="none")
+    den = final.sum() + 1e-6
+    return weight * ((ll * wl * final).sum() / den + (lr * wr * final).sum() / den)
+
+
+def mixup_ce_loss_stage4(inputs, depth_gt_ms, mask_ms, dlossw, inverse_depth=True):
+    return {k: mixup_ce_loss_stage(inputs[k]["prob_volume_pre"].float(), inputs[k]["depth_values"], depth_gt_ms[k], mask_ms[k], inverse_depth,
+                                   1.0 if dlossw is None else dlossw[int(k[-1]) - 1]) for k in ("stage1", "stage2", "stage3", "stage4")}
+
+
+def reg_loss_stage(depth, depth_values, depth_gt, mask, interval, mask_out_range=False, inverse_depth=True, weight=1.0):
+    """losses.py:56-84 for one stage; ``interval [B]``."""
+    itv = interval.reshape(-1, 1, 1)
+    sel = mask > 0.5
+    if mask_out_range:
+        dv = torch.flip(depth_values, dims=[1]) if inverse_depth else depth_values
+        half = (dv[:, 1:] - dv[:, :-1]).abs() / 2
+        half = torch.cat([half, half[:, -1:]], dim=1)
+        lo, hi = dv[:, 0] - half[:, 0], dv[:, -1] + half[:, -1]
+        outside = torch.clamp((depth_gt < lo).float() + (depth_gt > hi).float(), 0, 1)
+        sel = sel & (1 - outside).bool()
+    return weight * F.smooth_l1_loss((depth / itv)[sel], (depth_gt / itv)[sel], reduction="mean")
+
+
+def reg_loss_stage4(inputs, depth_gt_ms, mask_ms, dlossw, depth_interval, mask_out_range=False, inverse_depth=True):
+    return {k: reg_loss_stage(inputs[k]["depth"], inputs[k]["depth_values"], depth_gt_ms[k], mask_ms[k], depth_interval, mask_out_range,
+                              inverse_depth, 1.0 if dlossw is None else dlossw[int(k[-1]) - 1]) for k in ("stage1", "stage2", "stage3", "stage4")}
 
 
 def make_loss_case(seed=0, B=2, sizes=((32, 8, 12), (16, 16, 24), (8, 24, 32), (4, 40, 56)), inverse_depth=True):

@@ -215,6 +215,40 @@ def test_ce_loss_oracle_vs_reference(tag, inverse):
         assert max_abs(inputs[k]["prob_volume_pre"].grad, g["%s_%s_grad" % (tag, k)]) < 1e-8
 
 
+def _loss_inputs(tag):
+    g = load_golden("ce_loss.npz")
+    inputs, gts, masks = {}, {}, {}
+    for k in ("stage1", "stage2", "stage3", "stage4"):
+        inputs[k] = dict(depth_values=t(g["%s_%s_depth_values" % (tag, k)]), prob_volume_pre=t(g["%s_%s_logits" % (tag, k)]))
+        gts[k], masks[k] = t(g["%s_%s_gt" % (tag, k)]), t(g["%s_%s_mask" % (tag, k)])
+    return inputs, gts, masks
+
+
+@pytest.mark.parametrize("tag,inverse", [("inv", True), ("fwd", False)])
+def test_mixup_ce_and_reg_loss_oracle_vs_reference(tag, inverse):
+    """oracle/ref_losses.py against models/losses.py mixup_ce_loss_stage4 / reg_loss_stage4 (tests/golden/other_losses.npz; inputs of ce_loss.npz)."""
+    from oracle import ref_losses
+    g = load_golden("other_losses.npz")
+    w = [float(x) for x in g["dlossw"]]
+    inputs, gts, masks = _loss_inputs(tag)
+    for k in inputs:
+        inputs[k]["prob_volume_pre"].requires_grad_(True)
+    losses = ref_losses.mixup_ce_loss_stage4(inputs, gts, masks, w, inverse_depth=inverse)
+    sum(losses.values()).backward()
+    for k in inputs:
+        assert abs(losses[k].item() - float(g["%s_%s_mixup_loss" % (tag, k)])) < 2e-6
+        assert max_abs(inputs[k]["prob_volume_pre"].grad, g["%s_%s_mixup_grad" % (tag, k)]) < 1e-8
+    itv = t(g[tag + "_interval"])
+    for rng in (0, 1):
+        reg_in = {k: dict(depth=t(g["%s_%s_reg_depth" % (tag, k)]).requires_grad_(True), depth_values=inputs[k]["depth_values"]) for k in inputs}
+        losses = ref_losses.reg_loss_stage4(reg_in, gts, masks, w, itv, mask_out_range=bool(rng), inverse_depth=inverse)
+        sum(losses.values()).backward()
+        for k in inputs:
+            want = float(g["%s_%s_reg%d_loss" % (tag, k, rng)])
+            assert abs(losses[k].item() - want) < 2e-6 * max(1.0, want)
+            assert max_abs(reg_in[k]["depth"].grad, g["%s_%s_reg%d_grad" % (tag, k, rng)]) < 1e-8
+
+
 def fpn_golden():
     g = load_golden("fpn_decoder.npz")
     sd = {k[3:]: t(v) for k, v in g.items() if k.startswith("sd.")}
