@@ -12,7 +12,10 @@
 //   mvs_softmax_rows   y = softmax(scale * x) over rows of up to 8192 elements, one block per row
 //   mvs_bicubic_resize ATen's upsample_bicubic2d (align_corners = False, A = -0.75, clamped taps) with explicit scale factors - the image
 //                      resize of mvsformer_model.py:246-247 and the position-table resize of vision_transformer.py:394-416
+#include <stdlib.h>
+
 #include "common.h"
+#include "geometry.h"
 #include "split3.h"
 
 namespace {
@@ -99,40 +102,49 @@ __device__ __forceinline__ void load_a8(const GemmArgs& a, const float* __restri
     }
 }
 
-__device__ __forceinline__ void store_split(unsigned char* tile, int row, int kseg, const float (&v)[8]) {
+__device__ __forceinline__ void store_split(unsigned char* tile, int term_bytes, int row, int kseg, const float (&v)[8]) {
     const mvsx3::Split3 s = mvsx3::split3(v);
     unsigned char* d = tile + row * ROWB + kseg * 2;
     *reinterpret_cast<bf16x8*>(d) = s.h;
-    *reinterpret_cast<bf16x8*>(d + TERMB) = s.m;
-    *reinterpret_cast<bf16x8*>(d + 2 * TERMB) = s.l;
+    *reinterpret_cast<bf16x8*>(d + term_bytes) = s.m;
+    *reinterpret_cast<bf16x8*>(d + 2 * term_bytes) = s.l;
 }
 
+// RT = row tiles of 16 per wavefront: the block's tile is (64 * RT) x 64.  RT = 2 (the large GEMMs: M >= 2048) reads every B fragment
+// for two row tiles - 18 fragment reads per 48 MFMAs instead of 15 per 24 - and halves the barriers per MFMA.
+template <int RT>
 __global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[6 * TERMB];          // A terms h|m|l, then B terms h|m|l
+    constexpr int TERMA = RT * TERMB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * TERMA + 3 * TERMB];          // A terms h|m|l, then B terms h|m|l
     unsigned char* tA = lds;
-    unsigned char* tB = lds + 3 * TERMB;
+    unsigned char* tB = lds + 3 * TERMA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b1 = blockIdx.z / a.nb2, b2 = blockIdx.z % a.nb2;
     const float* Ab = a.A + b1 * a.sA1 + b2 * a.sA2;
     const float* Bb = a.B + b1 * a.sB1 + b2 * a.sB2;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.y * (BM * RT), n0 = blockIdx.x * BN;
     const int j = lane & 15, kb = lane >> 4;
 
-    f32x4 acc[4];
+    f32x4 acc[RT][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // staging roles: A (and B stored [n][k]): thread -> (row = tid / 4, 8 k at (tid % 4) * 8); B stored [k][n]: thread -> (k = tid / 8, 8 n)
     const int srow = tid >> 2, skseg = (tid & 3) * 8;
     const int tk = tid >> 3, tn = (tid & 7) * 8;
-    float pa[8], pb[8];
+    float pa[RT][8], pb[8];
     const int k_begin = a.ksplit > 0 ? b2 * a.ksplit : 0, k_end = a.ksplit > 0 ? min(a.K, k_begin + a.ksplit) : a.K;
     auto fetch = [&](int k0) {
-        load_a8(a, Ab, m0 + srow, k0 + skseg, b2, pa);
-        if (a.ksplit > 0) {                                  // a split's last tile may run past its range
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (k0 + skseg + e >= k_end) pa[e] = 0.0f;
+        for (int rt = 0; rt < RT; ++rt) {
+            load_a8(a, Ab, m0 + rt * 64 + srow, k0 + skseg, b2, pa[rt]);
+            if (a.ksplit > 0) {                              // a split's last tile may run past its range
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (k0 + skseg + e >= k_end) pa[rt][e] = 0.0f;
+            }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) pb[e] = 0.0f;
@@ -175,9 +187,10 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmArgs a) {
         }
     };
     auto commit = [&]() {
-        store_split(tA, srow, skseg, pa);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) store_split(tA, TERMA, rt * 64 + srow, skseg, pa[rt]);
         if (a.b_mode == 3 || (a.b_mode == 0 && a.b_kn == 0)) {
-            store_split(tB, srow, skseg, pb);
+            store_split(tB, TERMB, srow, skseg, pb);
         } else {                                             // transposed into [n][k]: 2-byte stores
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -197,15 +210,20 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmArgs a) {
         commit();
         __syncthreads();
         if (k0 + BK < k_end) fetch(k0 + BK);                 // the next tile's loads travel under this step's MFMAs
-        const unsigned char* ap = tA + (wave * 16 + j) * ROWB + kb * 16;
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap), am = *reinterpret_cast<const bf16x8*>(ap + TERMB),
-                     al = *reinterpret_cast<const bf16x8*>(ap + 2 * TERMB);
+        bf16x8 ah[RT], am[RT], al[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const unsigned char* ap = tA + (rt * 64 + wave * 16 + j) * ROWB + kb * 16;
+            ah[rt] = *reinterpret_cast<const bf16x8*>(ap), am[rt] = *reinterpret_cast<const bf16x8*>(ap + TERMA),
+            al[rt] = *reinterpret_cast<const bf16x8*>(ap + 2 * TERMA);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const unsigned char* bp = tB + (t * 16 + j) * ROWB + kb * 16;
             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp), bm = *reinterpret_cast<const bf16x8*>(bp + TERMB),
                          bl = *reinterpret_cast<const bf16x8*>(bp + 2 * TERMB);
-            acc[t] = mvsx3::mfma6(ah, am, al, bh, bm, bl, acc[t]);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt][t] = mvsx3::mfma6(ah[rt], am[rt], al[rt], bh, bm, bl, acc[rt][t]);
         }
     }
     // D[i = 4*kb + r (row of the wave's 16)][j = column of the tile]
@@ -217,10 +235,143 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmArgs a) {
         if (n >= a.N) continue;
         const float sc = a.scale ? a.scale[n] : 1.0f, sh = a.shift ? a.shift[n] : 0.0f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wave * 16 + kb * 4 + r;
+        for (int rr = 0; rr < 4 * RT; ++rr) {
+            const int rt = rr >> 2, r = rr & 3;
+            const int m = m0 + rt * 64 + wave * 16 + kb * 4 + r;
             if (m >= a.M) continue;
-            float v = acc[t][r] * a.alpha;
+            float v = acc[rt][t][r] * a.alpha;
+            v = fmaf(v, sc, sh);
+            if (a.act == 1) v = gelu_erf(v);
+            else if (a.act == 2) v = v / (1.0f + __expf(-v));
+            else if (a.act == 3) v = fmaxf(v, 0.0f);
+            const size_t o = (size_t)m * a.ldc + n;
+            if (a.mul) v *= a.mul[eoff + o];
+            if (a.res) v += a.res[eoff + o];
+            Cb[o] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- plain GEMM, pipelined
+// The plain case (A [M][K] and B [N][K] row-major, K a multiple of 32, rows 16-byte aligned: the transformer's linear layers) with TWO
+// tiles of global loads in flight.  The general kernel above prefetches one tile ahead and its loads branch (alignment / range / mode),
+// so every wait is a full drain and a K step pays most of a global round trip: 18 % of the split-form rate.  Here every load is a
+// 16-byte buffer load whose out-of-range cases (rows beyond M / N, tiles beyond K) are OFFSETS beyond the descriptor - no branches, a
+// fixed number of loads per tile, so the wait before a tile's commit leaves the next tile's loads flying.
+__device__ __forceinline__ f32x4 buf_load4(mvs::rsrc_t r, unsigned voff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, 0, 0));
+}
+
+template <int RT>
+__global__ __launch_bounds__(256) void gemm_x3_fast_kernel(const GemmArgs a) {
+    using mvs::rsrc_t;
+    constexpr int TERMA = RT * TERMB;
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * TERMA + 3 * TERMB];
+    unsigned char* tA = lds;
+    unsigned char* tB = lds + 3 * TERMA;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b1 = blockIdx.z / a.nb2, b2 = blockIdx.z % a.nb2;
+    const float* Ab = a.A + b1 * a.sA1 + b2 * a.sA2;
+    const float* Bb = a.B + b1 * a.sB1 + b2 * a.sB2;
+    const int m0 = blockIdx.y * (BM * RT), n0 = blockIdx.x * BN;
+    const int j = lane & 15, kb = lane >> 4;
+    const rsrc_t ra = mvs::make_rsrc(Ab, (unsigned)((size_t)a.M * a.lda * 4)), rb = mvs::make_rsrc(Bb, (unsigned)((size_t)a.N * a.ldb * 4));
+    const int srow = tid >> 2, skseg = (tid & 3) * 8;
+    unsigned offA[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int m = m0 + rt * 64 + srow;
+        offA[rt] = m < a.M ? (unsigned)(((size_t)m * a.lda + skseg) * 4) : OOB;
+    }
+    const unsigned offB = n0 + srow < a.N ? (unsigned)(((size_t)(n0 + srow) * a.ldb + skseg) * 4) : OOB;
+
+    f32x4 acc[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 pa[2][RT][2], pb[2][2];                            // two tiles of loads: [set][row tile][half of the 8 k]
+    auto fetch = [&](int set, int k0) {                      // `set` is a literal at every call: the sets stay in registers
+        const unsigned kofs = k0 < a.K ? (unsigned)k0 * 4u : OOB;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const unsigned o = (offA[rt] | kofs) & OOB ? OOB : offA[rt] + kofs;
+            pa[set][rt][0] = buf_load4(ra, o);
+            pa[set][rt][1] = buf_load4(ra, o == OOB ? OOB : o + 16u);
+        }
+        const unsigned o = (offB | kofs) & OOB ? OOB : offB + kofs;
+        pb[set][0] = buf_load4(rb, o);
+        pb[set][1] = buf_load4(rb, o == OOB ? OOB : o + 16u);
+    };
+    auto commit = [&](int set) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const float v[8] = {pa[set][rt][0][0], pa[set][rt][0][1], pa[set][rt][0][2], pa[set][rt][0][3],
+                                pa[set][rt][1][0], pa[set][rt][1][1], pa[set][rt][1][2], pa[set][rt][1][3]};
+            store_split(tA, TERMA, rt * 64 + srow, skseg, v);
+        }
+        const float v[8] = {pb[set][0][0], pb[set][0][1], pb[set][0][2], pb[set][0][3], pb[set][1][0], pb[set][1][1], pb[set][1][2], pb[set][1][3]};
+        store_split(tB, TERMB, srow, skseg, v);
+    };
+    auto mfmas = [&]() {
+        bf16x8 ah[RT], am[RT], al[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const unsigned char* ap = tA + (rt * 64 + wave * 16 + j) * ROWB + kb * 16;
+            ah[rt] = *reinterpret_cast<const bf16x8*>(ap), am[rt] = *reinterpret_cast<const bf16x8*>(ap + TERMA),
+            al[rt] = *reinterpret_cast<const bf16x8*>(ap + 2 * TERMA);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned char* bp = tB + (t * 16 + j) * ROWB + kb * 16;
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp), bm = *reinterpret_cast<const bf16x8*>(bp + TERMB),
+                         bl = *reinterpret_cast<const bf16x8*>(bp + 2 * TERMB);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt][t] = mvsx3::mfma6(ah[rt], am[rt], al[rt], bh, bm, bl, acc[rt][t]);
+        }
+    };
+    // sched_barrier: the machine scheduler otherwise sinks a tile's loads below the MFMAs towards their use (one tile ahead at best, and
+    // the wait at the loop head becomes a full drain); pinned in program order the waits are counted - vmcnt(loads of the younger tile)
+    fetch(0, 0);
+    __builtin_amdgcn_sched_barrier(0);                       // (tile 0's loads first: the loop head waits for the OLDER tile only)
+    fetch(1, BK);
+    __builtin_amdgcn_sched_barrier(0);
+    int k0 = 0;
+    for (; k0 + 2 * BK <= a.K; k0 += 2 * BK) {               // pairs of tiles (no exit between the halves: the wait counts stay exact)
+        __syncthreads();                                     // the previous tile's fragment reads are done
+        commit(0);
+        __syncthreads();
+        fetch(0, k0 + 2 * BK);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas();
+        __syncthreads();
+        commit(1);
+        __syncthreads();
+        fetch(1, k0 + 3 * BK);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas();
+    }
+    if (k0 < a.K) {                                          // an odd tile count: the last tile sits in set 0
+        __syncthreads();
+        commit(0);
+        __syncthreads();
+        mfmas();
+    }
+    float* Cb = a.C + b1 * a.sC1 + b2 * a.sC2;
+    const size_t eoff = (size_t)(b1 * a.sC1 + b2 * a.sC2);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int n = n0 + t * 16 + j;
+        if (n >= a.N) continue;
+        const float sc = a.scale ? a.scale[n] : 1.0f, sh = a.shift ? a.shift[n] : 0.0f;
+#pragma unroll
+        for (int rr = 0; rr < 4 * RT; ++rr) {
+            const int rt = rr >> 2, r = rr & 3;
+            const int m = m0 + rt * 64 + wave * 16 + kb * 4 + r;
+            if (m >= a.M) continue;
+            float v = acc[rt][t][r] * a.alpha;
             v = fmaf(v, sc, sh);
             if (a.act == 1) v = gelu_erf(v);
             else if (a.act == 2) v = v / (1.0f + __expf(-v));
@@ -481,6 +632,23 @@ __global__ __launch_bounds__(256) void bicubic_kernel(const float* __restrict__ 
 }
 }  // namespace
 
+namespace {
+void launch_gemm(const GemmArgs& a, int nbatch, hipStream_t s) {
+    static const int big = [] { const char* e = getenv("MVS_GEMM_BIG_M"); return e ? atoi(e) : 2048; }();     // rows from which the 128-row tile is used
+    static const bool fast_on = [] { const char* e = getenv("MVS_GEMM_FAST"); return !e || atoi(e) != 0; }();
+    const bool aligned = a.K % 32 == 0 && a.lda % 4 == 0 && a.ldb % 4 == 0 && a.sA1 % 4 == 0 && a.sA2 % 4 == 0 && a.sB1 % 4 == 0 && a.sB2 % 4 == 0 &&
+                         (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0 &&
+                         (int64_t)a.M * a.lda * 4 < ((int64_t)1 << 31) && (int64_t)a.N * a.ldb * 4 < ((int64_t)1 << 31);
+    if (fast_on && a.a_mode == 0 && a.b_mode == 0 && a.b_kn == 0 && a.ksplit == 0 && aligned) {        // the linear layers: pipelined kernel
+        if (a.M >= big) hipLaunchKernelGGL(gemm_x3_fast_kernel<2>, dim3((a.N + BN - 1) / BN, (a.M + 2 * BM - 1) / (2 * BM), nbatch), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(gemm_x3_fast_kernel<1>, dim3((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nbatch), dim3(256), 0, s, a);
+        return;
+    }
+    if (a.M >= big) hipLaunchKernelGGL(gemm_x3_kernel<2>, dim3((a.N + BN - 1) / BN, (a.M + 2 * BM - 1) / (2 * BM), nbatch), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gemm_x3_kernel<1>, dim3((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nbatch), dim3(256), 0, s, a);
+}
+}  // namespace
+
 extern "C" int mvs_gemm_x3(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int nb1, int nb2,
                            int64_t sA1, int64_t sA2, int64_t sB1, int64_t sB2, int64_t sC1, int64_t sC2, int b_kn, int a_mode, int H, int W, int Cp,
                            float alpha, const float* scale, const float* shift, int act, const float* mul, const float* res,
@@ -495,7 +663,7 @@ extern "C" int mvs_gemm_x3(const float* A, const float* B, float* C, int M, int 
     a.sA1 = sA1, a.sA2 = sA2, a.sB1 = sB1, a.sB2 = sB2, a.sC1 = sC1, a.sC2 = sC2;
     a.M = M, a.N = N, a.K = K, a.lda = lda, a.ldb = ldb, a.ldc = ldc, a.nb2 = nb2, a.b_kn = b_kn, a.a_mode = a_mode, a.H = H, a.W = W, a.Cp = Cp;
     a.act = act, a.alpha = alpha;
-    hipLaunchKernelGGL(gemm_x3_kernel, dim3((N + BN - 1) / BN, (M + BM - 1) / BM, nb1 * nb2), dim3(256), 0, MVS_STREAM(stream), a);
+    launch_gemm(a, nb1 * nb2, MVS_STREAM(stream));
     return mvs::finish_launch("mvs_gemm_x3");
 }
 
@@ -529,7 +697,7 @@ extern "C" int mvs_conv2d_gemm_x3(int mode, const float* A, const float* Bmap, f
         a.sC2 = (long long)a.M * a.N, a.sC1 = a.sC2 * nb2;
     }
     MVS_REQUIRE((int64_t)nb1 * nb2 <= 65535, "mvs_conv2d_gemm_x3: too many batch items x splits (%d x %d)", nb1, nb2);
-    hipLaunchKernelGGL(gemm_x3_kernel, dim3((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, nb1 * nb2), dim3(256), 0, MVS_STREAM(stream), a);
+    launch_gemm(a, nb1 * nb2, MVS_STREAM(stream));
     return mvs::finish_launch("mvs_conv2d_gemm_x3");
 }
 
