@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 26
+#define MVS_ABI_VERSION 27
 
 typedef void* mvs_stream_t;
 
@@ -626,8 +626,10 @@ int mvs_gemm_x3(const float* A, const float* B, float* C, int M, int N, int K, i
                 int64_t sA2, int64_t sB1, int64_t sB2, int64_t sC1, int64_t sC2, int b_kn, int a_mode, int H, int W, int Cp, float alpha,
                 const float* scale, const float* shift, int act, const float* mul, const float* res, mvs_stream_t stream);
 /* out [B][N][heads*64] = softmax(scale * Q K^T) V per (image, head) in flash form (online softmax; the N x N matrix is never written), split-form
- * arithmetic; qkv = [B][N][3*heads*64] packed rows (q | k | v), vt = V transposed [B][heads][64][N]; head_dim = 64 */
-int mvs_attention_x3(const float* qkv, const float* vt, float* out, int B, int N, int heads, int head_dim, float scale, mvs_stream_t stream);
+ * arithmetic; qkv = [B][N][3*heads*64] packed rows (q | k | v), vt = V transposed [B][heads][64][ldv] with row stride ldv >= N floats, a
+ * multiple of 4 (16-byte aligned rows: the kernel reads them with 16-byte buffer loads, two key tiles ahead), padding finite; head_dim = 64 */
+int mvs_attention_x3(const float* qkv, const float* vt, float* out, int B, int N, int heads, int head_dim, int ldv, float scale,
+                     mvs_stream_t stream);
 int mvs_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int C, float eps, mvs_stream_t stream);
 int mvs_softmax_rows(const float* x, float* y, int64_t rows, int N, float scale, mvs_stream_t stream);
 int mvs_bicubic_resize(const float* in, float* out, int planes, int H, int W, int Ho, int Wo, float rscale_h, float rscale_w,

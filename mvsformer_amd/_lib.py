@@ -18,7 +18,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVS_HIP_LIB: diagnostics only - another BUILD of the same library (tests/test_hip_multistream.py's variants); never a fallback
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 from ctypes import c_double  # noqa: E402
 
@@ -135,7 +135,7 @@ SIGNATURES = {
     "mvs_ce_loss_acc_floats": (L, [I, L]),
     "mvs_bf16_embed_ch0": (I, [P, P, L, P]),
     "mvs_gemm_x3": (I, [P, P, P, I, I, I, I, I, I, I, I, L, L, L, L, L, L, I, I, I, I, I, F, P, P, I, P, P, P]),
-    "mvs_attention_x3": (I, [P, P, P, I, I, I, I, F, P]),
+    "mvs_attention_x3": (I, [P, P, P, I, I, I, I, I, F, P]),
     "mvs_layernorm": (I, [P, P, P, P, L, I, F, P]),
     "mvs_conv2d_gemm_x3": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "mvs_partials_reduce": (I, [P, I, I, P, P]),

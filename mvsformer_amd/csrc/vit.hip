@@ -392,11 +392,19 @@ __global__ __launch_bounds__(256) void gemm_x3_fast_kernel(const GemmArgs a) {
 // qkv = [B][N][3C] packed rows (q | k | v, head h at columns h*64), vt = V transposed [B][heads][64][N], out = [B][N][C] (head h at h*64).
 // hd = 64 only (ViT-small / base); scale is applied to Q before the split (exact for 64^-0.5 = 0.125).
 constexpr int AT_KT = 32;                                    // keys per tile
-constexpr int AT_KROW = 64 * 2 + 16, AT_VROW = AT_KT * 2 + 16, AT_PROW = AT_KT * 2 + 16;   // LDS row strides in bytes (16 bytes of padding)
+// LDS tiles WITHOUT row padding (36 KB per block: FOUR blocks per CU - 840 blocks of the half-size ViT input then run as one round of 1024
+// slots instead of a full round of 768 and a nearly empty second one); bank conflicts of the 16-byte fragment reads (16 lanes = 16 rows,
+// same chunk) are avoided by storing 16-byte chunk c of row r at chunk c ^ f(r):
+//   K tile  [32 keys][64 d]  bf16, 128-byte rows (8 chunks):  f(r) = (r >> 1) & 7   (two rows per 256 bytes of banks)
+//   V^T     [64 d][32 keys]  bf16,  64-byte rows (4 chunks):  f(r) = (r >> 2) & 3   (four rows per 256 bytes)
+//   P       [16 q][32 keys]  bf16,  64-byte rows, per wavefront: as V^T
+constexpr int AT_KROW = 64 * 2, AT_VROW = AT_KT * 2, AT_PROW = AT_KT * 2;
 constexpr int AT_KTERM = AT_KT * AT_KROW, AT_VTERM = 64 * AT_VROW, AT_PTERM = 16 * AT_PROW;
+__device__ __forceinline__ int at_koff(int row, int chunk) { return row * AT_KROW + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int at_voff(int row, int chunk) { return row * AT_VROW + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-__global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ vt, float* __restrict__ out, int N,
-                                                           int NH, float scale) {
+__global__ __launch_bounds__(256, 4) void attention_x3_kernel(const float* __restrict__ qkv, const float* __restrict__ vt, float* __restrict__ out, int N,
+                                                           int NH, int ldv, float scale) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * AT_KTERM + 3 * AT_VTERM + 4 * 3 * AT_PTERM];
     unsigned char* kl = lds;
     unsigned char* vl = lds + 3 * AT_KTERM;
@@ -405,7 +413,6 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
     const int j = lane & 15, kb = lane >> 4;
     const int h = blockIdx.y, b = blockIdx.z, C = NH * 64;
     const float* qrow = qkv + (size_t)b * N * 3 * C + h * 64;
-    const float* vth = vt + ((size_t)b * NH + h) * 64 * N;
     const int q0 = blockIdx.x * 64 + wave * 16;
 
     // Q fragments (A operand of S): lane (i = query q0 + j, kb) holds d = 32*s + 8*kb .. + 7
@@ -426,41 +433,45 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) mrow[r] = -INFINITY, lrow[r] = 0.0f;
 
-    // staging roles: K tile: thread -> (key = tid / 8, 8 d at (tid % 8) * 8); V^T tile: thread -> (d = tid / 4, 8 keys at (tid % 4) * 8)
+    // staging roles: K tile: thread -> (key = tid / 8, 8 d at (tid % 8) * 8); V^T tile: thread -> (d = tid / 4, 8 keys at (tid % 4) * 8).
+    // All loads are 16-byte BUFFER loads (keys beyond N / tiles beyond the last: offsets beyond the descriptor -> zeros): no branches, a
+    // fixed number of loads per tile, so TWO tiles of loads can be in flight with counted waits (the scheduler's order is pinned below).
     const int kkey = tid >> 3, kd = (tid & 7) * 8, vd = tid >> 2, vk = (tid & 3) * 8;
-    float pk[8], pv[8];
-    auto fetch = [&](int kt) {
-        const int key = kt + kkey;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pk[e] = key < N ? qrow[(size_t)key * 3 * C + C + kd + e] : 0.0f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pv[e] = kt + vk + e < N ? vth[(size_t)vd * N + kt + vk + e] : 0.0f;
+    constexpr unsigned OOB = 0x80000000u;
+    const mvs::rsrc_t rk = mvs::make_rsrc(qrow, (unsigned)((size_t)N * 3 * C * 4));
+    const mvs::rsrc_t rv = mvs::make_rsrc(vt + ((size_t)b * NH + h) * 64 * ldv, (unsigned)((size_t)64 * ldv * 4));
+    const unsigned kbase = (unsigned)(((size_t)kkey * 3 * C + C + kd) * 4), vbase = (unsigned)(((size_t)vd * ldv + vk) * 4);
+    f32x4 pk[1][2], pv[1][2];
+    auto fetch = [&](int set, int kt) {                      // `set` is a literal at every call
+        const unsigned ko = kt + kkey < N ? kbase + (unsigned)((size_t)kt * 3 * C * 4) : OOB;
+        const unsigned vo = kt < N ? vbase + (unsigned)kt * 4u : OOB;
+        pk[set][0] = buf_load4(rk, ko);
+        pk[set][1] = buf_load4(rk, ko == OOB ? OOB : ko + 16u);
+        pv[set][0] = buf_load4(rv, vo);
+        pv[set][1] = buf_load4(rv, vo == OOB ? OOB : vo + 16u);
     };
-    auto commit = [&]() {
-        const mvsx3::Split3 a = mvsx3::split3(pk), c = mvsx3::split3(pv);
-        unsigned char* d0 = kl + kkey * AT_KROW + kd * 2;
+    auto commit = [&](int set) {
+        const float kv[8] = {pk[set][0][0], pk[set][0][1], pk[set][0][2], pk[set][0][3], pk[set][1][0], pk[set][1][1], pk[set][1][2], pk[set][1][3]};
+        const float vv[8] = {pv[set][0][0], pv[set][0][1], pv[set][0][2], pv[set][0][3], pv[set][1][0], pv[set][1][1], pv[set][1][2], pv[set][1][3]};
+        const mvsx3::Split3 a = mvsx3::split3(kv), c = mvsx3::split3(vv);
+        unsigned char* d0 = kl + at_koff(kkey, kd >> 3);
         *reinterpret_cast<bf16x8*>(d0) = a.h;
         *reinterpret_cast<bf16x8*>(d0 + AT_KTERM) = a.m;
         *reinterpret_cast<bf16x8*>(d0 + 2 * AT_KTERM) = a.l;
-        unsigned char* d1 = vl + vd * AT_VROW + vk * 2;
+        unsigned char* d1 = vl + at_voff(vd, vk >> 3);
         *reinterpret_cast<bf16x8*>(d1) = c.h;
         *reinterpret_cast<bf16x8*>(d1 + AT_VTERM) = c.m;
         *reinterpret_cast<bf16x8*>(d1 + 2 * AT_VTERM) = c.l;
     };
-    fetch(0);
-    for (int kt = 0; kt < N; kt += AT_KT) {
-        __syncthreads();                                     // the previous tile's K / V^T fragments are consumed
-        commit();
-        __syncthreads();
-        if (kt + AT_KT < N) fetch(kt + AT_KT);
-        // ---- S = Q K^T for 2 x 16 keys: D[i = query 4*kb + r][j = key]
+    auto tile = [&](int kt) {
+    // ---- S = Q K^T for 2 x 16 keys: D[i = query 4*kb + r][j = key]
         f32x4 sacc[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                const unsigned char* bp = kl + (nt * 16 + j) * AT_KROW + (32 * st + 8 * kb) * 2;
+                const unsigned char* bp = kl + at_koff(nt * 16 + j, 4 * st + kb);
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp), bm = *reinterpret_cast<const bf16x8*>(bp + AT_KTERM),
                              bl = *reinterpret_cast<const bf16x8*>(bp + 2 * AT_KTERM);
                 c = mvsx3::mfma6(qa[st][0], qa[st][1], qa[st][2], bh, bm, bl, c);
@@ -496,24 +507,36 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
             for (int r = 0; r < 4; ++r) {
                 __bf16 ph, pm, plo;
                 mvsx3::split3_bounded(sacc[nt][r], ph, pm, plo);
-                unsigned char* d = pl + (4 * kb + r) * AT_PROW + (nt * 16 + j) * 2;
+                unsigned char* d = pl + at_voff(4 * kb + r, (nt * 16 + j) >> 3) + ((nt * 16 + j) & 7) * 2;
                 *reinterpret_cast<__bf16*>(d) = ph;
                 *reinterpret_cast<__bf16*>(d + AT_PTERM) = pm;
                 *reinterpret_cast<__bf16*>(d + 2 * AT_PTERM) = plo;
             }
         __builtin_amdgcn_wave_barrier();                     // a wavefront's LDS operations execute in order: its own stores are visible to its loads
-        const unsigned char* ap = pl + j * AT_PROW + kb * 16;
+        const unsigned char* ap = pl + at_voff(j, kb);
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap), am = *reinterpret_cast<const bf16x8*>(ap + AT_PTERM),
                      al = *reinterpret_cast<const bf16x8*>(ap + 2 * AT_PTERM);
         // ---- O += P V: B operand = V^T tile [d = 16*t + j][keys 8*kb .. + 7]
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const unsigned char* bp = vl + (t * 16 + j) * AT_VROW + kb * 16;
+            const unsigned char* bp = vl + at_voff(t * 16 + j, kb);
             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp), bm = *reinterpret_cast<const bf16x8*>(bp + AT_VTERM),
                          bl = *reinterpret_cast<const bf16x8*>(bp + 2 * AT_VTERM);
             acc_o[t] = mvsx3::mfma6(ah, am, al, bh, bm, bl, acc_o[t]);
         }
         __builtin_amdgcn_wave_barrier();
+    };
+    // one tile of loads ahead (two were built: the counted waits work - vmcnt(4) with the younger tile flying - but the tile is bound by its
+    // dependent chain S -> row max / sum butterflies -> P -> LDS -> P V, not by the loads: 3.59 -> 3.53 ms, and the second register set
+    // costs the fourth block per CU)
+    fetch(0, 0);
+    for (int kt = 0; kt < N; kt += AT_KT) {
+        __syncthreads();                                     // the previous tile's K / V^T fragments are consumed
+        commit(0);
+        __syncthreads();
+        fetch(0, kt + AT_KT);
+        __builtin_amdgcn_sched_barrier(0);
+        tile(kt);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -702,11 +725,16 @@ extern "C" int mvs_conv2d_gemm_x3(int mode, const float* A, const float* Bmap, f
 }
 
 // out [B][N][heads*64] = softmax(scale * Q K^T) V per (image, head), flash form (the N x N matrix is never written); qkv = [B][N][3*heads*64]
-// packed (q | k | v), vt = V transposed [B][heads][64][N].  head dimension 64.
-extern "C" int mvs_attention_x3(const float* qkv, const float* vt, float* out, int B, int N, int heads, int head_dim, float scale, mvs_stream_t stream) {
+// packed (q | k | v), vt = V transposed [B][heads][64][ldv] (row stride ldv >= N floats, a multiple of 4; the padding must be finite).
+// head dimension 64.
+extern "C" int mvs_attention_x3(const float* qkv, const float* vt, float* out, int B, int N, int heads, int head_dim, int ldv, float scale,
+                                mvs_stream_t stream) {
     MVS_REQUIRE(qkv && vt && out && B >= 1 && B <= 65535 && N >= 1 && heads >= 1 && heads <= 65535, "mvs_attention_x3: bad shape");
     MVS_REQUIRE(head_dim == 64, "mvs_attention_x3: head dimension 64 only (got %d)", head_dim);
-    hipLaunchKernelGGL(attention_x3_kernel, dim3((N + 63) / 64, heads, B), dim3(256), 0, MVS_STREAM(stream), qkv, vt, out, N, heads, scale);
+    MVS_REQUIRE(ldv >= N && ldv % 4 == 0 && (reinterpret_cast<uintptr_t>(vt) & 15) == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0,
+                "mvs_attention_x3: V^T rows must be 16-byte aligned (row stride %d floats, a multiple of 4, >= N = %d; padding finite)", ldv, N);
+    MVS_REQUIRE((int64_t)N * 3 * heads * 64 * 4 < ((int64_t)1 << 31) && (int64_t)64 * ldv * 4 < ((int64_t)1 << 31), "mvs_attention_x3: one image exceeds the 2 GiB buffer range");
+    hipLaunchKernelGGL(attention_x3_kernel, dim3((N + 63) / 64, heads, B), dim3(256), 0, MVS_STREAM(stream), qkv, vt, out, N, heads, ldv, scale);
     return mvs::finish_launch("mvs_attention_x3");
 }
 

@@ -1555,13 +1555,29 @@ def gemm_x3(A, B, C, M, N, K, lda, ldb, ldc, nb1=1, nb2=1, sA=(0, 0), sB=(0, 0),
 
 
 def attention_x3(qkv: torch.Tensor, vt: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
-    """``softmax(scale * Q K^T) V`` per (image, head) in flash form: ``qkv [B,N,3C]`` packed, ``vt [B,heads,64,N]`` = V transposed -> ``[B,N,C]``."""
+    """``softmax(scale * Q K^T) V`` per (image, head) in flash form: ``qkv [B,N,3C]`` packed, ``vt [B,heads,64,ldv]`` = V transposed with a
+    row stride ``ldv >= N`` that is a multiple of 4 (zero / finite padding; :func:`attention_vt` makes it) -> ``[B,N,C]``."""
     _chk(qkv, "qkv"), _chk(vt, "vt")
     B, N, C3 = qkv.shape
     C = C3 // 3
+    if vt.dim() != 4 or vt.shape[0] != B or vt.shape[1] != heads or vt.shape[2] * heads != C or not vt.is_contiguous():
+        raise _lib.MvsHipError("attention_x3: vt %s for qkv %s, %d heads" % (tuple(vt.shape), tuple(qkv.shape), heads))
     out = torch.empty(B, N, C, device=qkv.device, dtype=torch.float32)
     _call("mvs_attention_x3", ("x3_attention", "flops", 4.0 * B * heads * N * N * (C // heads)), _ptr(qkv), _ptr(vt), _ptr(out), B, N, heads,
-          C // heads, float(scale), _stream())
+          C // heads, int(vt.shape[3]), float(scale), _stream())
+    return out
+
+
+def attention_vt(qkv: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """V of packed ``qkv [B,N,3C]`` transposed to ``[B,heads,hd,ldv]``, ``ldv`` = N rounded up to a multiple of 4 with zero padding (the B
+    operand of ``P V`` is then read along the keys, 16 bytes at a time).  ``out``: a buffer of that shape to reuse (its padding is kept)."""
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    hd = C // heads
+    ldv = (N + 3) // 4 * 4
+    if out is None:
+        out = torch.zeros(B, heads, hd, ldv, device=qkv.device, dtype=torch.float32)
+    out[..., :N].copy_(qkv[:, :, 2 * C:].reshape(B, N, heads, hd).permute(0, 2, 3, 1))
     return out
 
 

@@ -128,20 +128,21 @@ class VisionTransformer(nn.Module):
         ops.gemm_x3(patches, pw, tok, n, C, nc * P * P, nc * P * P, nc * P * P, C, nb1=B, sA=(n * nc * P * P, 0), sC=(N * C, 0), shift=pb, c_off=C)
         t = (tok + self._pos(hp, wp)).contiguous()
         eps = self.norm.eps
-        scores = None
+        scores, vt_pad = None, None
         for i, (n1w, n1b, qw, qb, prw, prb, n2w, n2b, f1w, f1b, f2w, f2b) in enumerate(blocks):
             y = ops.layernorm(t, n1w, n1b, eps)
             qkv = torch.empty(B, N, 3 * C, device=x.device, dtype=torch.float32)
             ops.gemm_x3(y, qw, qkv, B * N, 3 * C, C, C, C, 3 * C, shift=qb)
-            # V handed over TRANSPOSED ([B, heads, hd, N], one strided copy of 13 MB): the attention's / GEMM's B operand is then read along K
-            vt = qkv[:, :, 2 * C:].reshape(B, N, NH, hd).permute(0, 2, 3, 1).contiguous()
             last = want_att and i == len(blocks) - 1
             if hd == 64 and not last and os.environ.get("MVS_VIT_FLASH", "1") != "0":
-                # flash form: softmax(Q K^T / sqrt(hd)) V without the N x N matrix (csrc/vit.hip attention_x3_kernel)
-                att_out = ops.attention_x3(qkv, vt, NH, hd ** -0.5)
+                # flash form: softmax(Q K^T / sqrt(hd)) V without the N x N matrix (csrc/vit.hip attention_x3_kernel); V handed over
+                # TRANSPOSED with 16-byte aligned rows ([B, heads, hd, N rounded up to 4], one strided copy into a buffer reused by all blocks)
+                vt_pad = ops.attention_vt(qkv, NH, vt_pad)
+                att_out = ops.attention_x3(qkv, vt_pad, NH, hd ** -0.5)
             else:
                 # materialized form (the LAST block's attention matrix is an output: mvsformer_model.py:257 reads its CLS row): scores[b, h] =
                 # Q . K^T (head slices of the packed qkv rows), softmax(scale * .), out[b, :, h] = P . V
+                vt = qkv[:, :, 2 * C:].reshape(B, N, NH, hd).permute(0, 2, 3, 1).contiguous()     # the GEMM's B operand, read along K
                 if scores is None:
                     scores = torch.empty(B, NH, N, N, device=x.device, dtype=torch.float32)
                 ops.gemm_x3(qkv, qkv, scores, N, N, hd, 3 * C, 3 * C, N, nb1=B, nb2=NH, sA=(N * 3 * C, hd), sB=(N * 3 * C, hd), sC=(NH * N * N, N * N),

@@ -116,10 +116,11 @@ def test_attention_x3_flash_vs_fp64(dev, shape):
     want = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, C)
     fp32 = (torch.softmax(q.float() @ k.float().transpose(-1, -2) * hd ** -0.5, -1) @ v.float()).permute(0, 2, 1, 3).reshape(B, N, C)
     d = qkv.to(dev)
-    vt = d[:, :, 2 * C:].reshape(B, N, NH, hd).permute(0, 2, 3, 1).contiguous()
+    vt = ops.attention_vt(d, NH)
+    assert vt.shape == (B, NH, hd, (N + 3) // 4 * 4)
     got = ops.attention_x3(d, vt, NH, hd ** -0.5)
     torch.cuda.synchronize()
     err, err32 = _rel(got, want), _rel(fp32, want)
     assert err < 3 * err32 + 5e-7, (err, err32)
     with pytest.raises(Exception):
-        ops.attention_x3(d[:, :, :96].contiguous(), vt, 1, 0.1)          # head dimension 32: refused loudly, no silent fallback
+        ops.attention_x3(d[:, :, :96].contiguous(), vt[:, :1, :32].contiguous(), 1, 0.1)      # head dimension 32: refused loudly, no silent fallback
