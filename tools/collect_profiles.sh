@@ -36,6 +36,10 @@ DBT=$(find gpurun_out/prof_train_${ROUND} -name "*.db" | head -1)
 NK=$(python -c "import json; print(json.load(open('gpurun_out/train_under_rocprof.json'))['launches_per_step']['kernel']*5)")
 python tools/rocpd_stats.py $DBT $NK > gpurun_out/${ROUND}_train_kernel_stats.csv 2>> gpurun_out/rocpd_stats.err
 rm -rf gpurun_out/prof_train_${ROUND}
+# the same step under DistributedDataParallel + SyncBatchNorm over RCCL (one rank), captured whole; the ViT branch's per-kernel table
+python bench_train.py --force-ddp --steps 30 --warmup 3 > gpurun_out/${ROUND}_bench_train_ddp.json 2> gpurun_out/${ROUND}_bench_train_ddp.err
+python tools/prof_vit.py > gpurun_out/${ROUND}_prof_vit.txt 2>&1
+python tools/exp_small_conv.py > gpurun_out/${ROUND}_bf16_small_conv.txt 2>&1
 python bench.py --steps 200 --warmup 10 > gpurun_out/${ROUND}_final_bench.json 2> gpurun_out/${ROUND}_final_bench.err
 tail -c 400 gpurun_out/${ROUND}_final_bench.err
 ls -la gpurun_out | tail -20
