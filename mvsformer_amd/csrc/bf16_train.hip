@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
     bool ok;
     xcd_item(KSPLIT ? a.items : (a.items + 3) / 4, logical, ok);
     if (!ok) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform FOR THE COMPILER: the buffer descriptor below depends on it (a divergent one is a waterfall loop per load)
     __shared__ float sred[4][2 * 64];                      // block rows of the statistics (stats_rows > 0 only)
     __shared__ f32x4 kred[KSPLIT ? 3 * NT * 4 * 64 : 1];   // KSPLIT: the partial tiles of wavefronts 1..3
     const int item = KSPLIT ? logical : logical * 4 + wave;

@@ -262,6 +262,12 @@ __device__ __forceinline__ f32x4 buf_load4(mvs::rsrc_t r, unsigned voff_bytes) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, 0, 0));
 }
 
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
+
 template <int RT>
 __global__ __launch_bounds__(256) void gemm_x3_fast_kernel(const GemmArgs a) {
     using mvs::rsrc_t;
@@ -276,7 +282,9 @@ __global__ __launch_bounds__(256) void gemm_x3_fast_kernel(const GemmArgs a) {
     const float* Bb = a.B + b1 * a.sB1 + b2 * a.sB2;
     const int m0 = blockIdx.y * (BM * RT), n0 = blockIdx.x * BN;
     const int j = lane & 15, kb = lane >> 4;
-    const rsrc_t ra = mvs::make_rsrc(Ab, (unsigned)((size_t)a.M * a.lda * 4)), rb = mvs::make_rsrc(Bb, (unsigned)((size_t)a.N * a.ldb * 4));
+    // (the batch item's base address is block-uniform, but its 64-bit arithmetic may be done on the vector ALU: a descriptor word that lives
+    //  in a vector register turns EVERY buffer load into a readfirstlane waterfall loop - seen in the RT = 2 instance; pin them scalar)
+    const rsrc_t ra = mvs::make_rsrc(uniform_ptr(Ab), (unsigned)((size_t)a.M * a.lda * 4)), rb = mvs::make_rsrc(uniform_ptr(Bb), (unsigned)((size_t)a.N * a.ldb * 4));
     const int srow = tid >> 2, skseg = (tid & 3) * 8;
     unsigned offA[RT];
 #pragma unroll
