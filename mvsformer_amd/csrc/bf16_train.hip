@@ -158,17 +158,21 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt) acc[nt][vt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 2
-    for (int step = KSPLIT ? wave : 0; step < nsteps; step += KSPLIT ? 4 : 1) {
+    // K loop, software-pipelined one step deep: the operands of step s + 1 (VT activation fragments straight from global memory through
+    // the buffer descriptor + NT weight fragments) are in flight under the MFMAs of step s.  Two register sets with literal indices, the
+    // load order pinned (sched_barrier: the scheduler otherwise sinks the loads below the MFMAs towards their use) and no exit between
+    // the loop's halves, so the compiler's waits are counted (the younger step's loads stay in flight) - NOTEBOOK.md, late round 5.
+    bf16x8 xs[2][VT], ws[2][NT];
+    auto load_step = [&](int set, int step) {
         int t = 4 * step + kb;                              // K block of this lane group: (tap, channel octet)
         int tap = t / KQ;
         const int cq = t % KQ;
-        bool rowok = t < NKB;
+        bool rowok = t < NKB && step < nsteps;
         int kd, kh, kw;
         if (GATHER == 1) {
             // compact index over the EXISTING taps -> the tap itself; the weight fragment of K block (tap, cq) sits in the packed image at
             // step (tap*KQ + cq) / 4, lane group (tap*KQ + cq) % 4 - read from there whatever lane group multiplies it
-            rowok = tap < nkd * nkh * nkw;
+            rowok = rowok && tap < nkd * nkh * nkw;
             const int ikd = tap / (nkh * nkw), ikh = (tap / nkw) % nkh, ikw = tap % nkw;
             kd = SD == 2 ? (nkd == 2 ? 2 * ikd : 1) : ikd;
             kh = SHW == 2 ? (nkh == 2 ? 2 * ikh : 1) : ikh;
@@ -190,7 +194,6 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
         }
         rowok = rowok && (unsigned)id < (unsigned)a.Di && (unsigned)ih < (unsigned)a.Hi;
         const unsigned rowbase = (unsigned)((id * a.Hi + ih) * a.Wi) * (unsigned)(CIN * 2) + (unsigned)(cq * 16);
-        bf16x8 xb[VT];
 #pragma unroll
         for (int vt = 0; vt < VT; ++vt) {
             const int ow = ow0 + (vt * 16 + j) * WSTEP;
@@ -204,15 +207,32 @@ __global__ __launch_bounds__(256) void bf16_conv_kernel(const ConvArgs a) {
                 iw = nw / SHW;
             }
             v = v && (unsigned)iw < (unsigned)a.Wi;
-            xb[vt] = ld8(xr, v ? rowbase + (unsigned)iw * (unsigned)(CIN * 2) : OOB);
+            xs[set][vt] = ld8(xr, v ? rowbase + (unsigned)iw * (unsigned)(CIN * 2) : OOB);
         }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const bf16x8 wa = GATHER == 1 ? (rowok ? wp[(size_t)((t >> 2) * NT + nt) * 64 + (t & 3) * 16] : bf16x8{})
-                                          : wp[(size_t)(step * NT + nt) * 64];
+        for (int nt = 0; nt < NT; ++nt)                      // (a step beyond the last reads the last step's fragment: inside the packed image)
+            ws[set][nt] = GATHER == 1 ? wp[(size_t)((min(t, NKB - 1) >> 2) * NT + nt) * 64 + (t & 3) * 16] : wp[(size_t)(min(step, STEPS - 1) * NT + nt) * 64];
+    };
+    auto mma = [&](int set) {
 #pragma unroll
-            for (int vt = 0; vt < VT; ++vt) acc[nt][vt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[vt], acc[nt][vt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int vt = 0; vt < VT; ++vt) acc[nt][vt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws[set][nt], xs[set][vt], acc[nt][vt], 0, 0, 0);
+    };
+    {
+        constexpr int DS = KSPLIT ? 4 : 1;
+        int step = KSPLIT ? wave : 0;
+        load_step(0, step);
+        __builtin_amdgcn_sched_barrier(0);
+        for (; step + DS < nsteps; step += 2 * DS) {         // pairs of steps
+            load_step(1, step + DS);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0);
+            load_step(0, step + 2 * DS);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1);
         }
+        if (step < nsteps) mma(0);                           // an odd count: the last step sits in set 0
     }
     if (KSPLIT) {                                          // partial tiles of wavefronts 1..3 -> wavefront 0, added in that order
         if (wave > 0) {
