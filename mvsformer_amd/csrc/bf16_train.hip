@@ -987,7 +987,8 @@ WgradPlan wgrad_plan(int nbatch, int CA, int CB, int Dp, int Hp, int Wp, int shw
     const int nA = (CA + 15) / 16, nB = (CB + 15) / 16;
     p.TB = nB;                                               // one block sees all of CB (nB <= 4)
     p.TA = nA < 4 / nB ? nA : 4 / nB;
-    if (p.TA < 1) p.TA = 1;
+    if (p.TA > 2) p.TA = 2;                                  // the A tile is staged as two 16-byte pieces per thread: 32 channels at most
+    if (p.TA < 1) p.TA = 1;                                  // (64 x <=16 channels - no layer of the networks - runs as two channel groups)
     p.gy = (nA + p.TA - 1) / p.TA;
     const int b_row = CB < p.TB * 16 ? CB : p.TB * 16, a_row = CA < p.TA * 16 ? CA : p.TA * 16;
     p.PH = 8;
@@ -1072,8 +1073,8 @@ extern "C" int mvs_bf16_wgrad_group(const MvsWgradJob* jobs, int njobs, void* wo
     MVS_REQUIRE(total <= workspace_bytes, "mvs_bf16_wgrad_group: workspace of %lld bytes, %lld needed", (long long)workspace_bytes, (long long)total);
     hipStream_t s = MVS_STREAM(stream);
     // one launch per kernel instance (and per WG_GROUP jobs of it), the longest blocks first: a block's length ~ columns per block x depths
-    static const int inst[6][2] = {{1, 1}, {1, 2}, {2, 1}, {2, 2}, {1, 4}, {4, 1}};
-    for (int k = 0; k < 6; ++k) {
+    static const int inst[5][2] = {{1, 1}, {1, 2}, {2, 1}, {2, 2}, {1, 4}};
+    for (int k = 0; k < 5; ++k) {
         std::vector<int> ids;
         for (int i = 0; i < njobs; ++i)
             if (plan[i].TA == inst[k][0] && plan[i].TB == inst[k][1]) ids.push_back(i);
@@ -1100,8 +1101,7 @@ extern "C" int mvs_bf16_wgrad_group(const MvsWgradJob* jobs, int njobs, void* wo
             else if (k == 1) wgrad_launch<1, 2>(g, lds, s);
             else if (k == 2) wgrad_launch<2, 1>(g, lds, s);
             else if (k == 3) wgrad_launch<2, 2>(g, lds, s);
-            else if (k == 4) wgrad_launch<1, 4>(g, lds, s);
-            else wgrad_launch<4, 1>(g, lds, s);
+            else wgrad_launch<1, 4>(g, lds, s);
             if (int rc = mvs::finish_launch("mvs_bf16_wgrad_group")) return rc;
         }
     }

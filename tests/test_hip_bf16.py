@@ -444,3 +444,84 @@ def test_cascade_bf16_vs_cpu_autocast_all_stage_geometries(dev):
         l2, mx, agree = report["fp32/stage%d" % (i + 1)]
         assert l2 < CASCADE_BF16["logits_l2"] and mx < CASCADE_BF16["logits_max"] and agree >= CASCADE_BF16["depth_agree"], report
     assert abs(loss_hip - l32) / l32 < CASCADE_BF16["loss_fp32"] and abs(loss_hip - l16) / l16 < CASCADE_BF16["loss_autocast"], report
+
+
+def test_wgrad_group_equals_layer_by_layer(dev):
+    """ops.bf16_wgrad_group (all jobs of a kernel instance in one grid + one reduce) against ops.bf16_conv3d_wgrad per layer: same kernels,
+    another number of partial slabs per job -> equal up to the fp32 summation order.  Jobs cover every kernel instance (channel tiles
+    1x1, 1x2, 2x1, 2x2, 1x4, 4x1), both strides, a 2-D (9-tap) job with dropped padding channels, and a job alone (a group of one)."""
+    from mvsformer_amd import ops
+    g = torch.Generator().manual_seed(3)
+
+    def act(n, d, h, w, c):
+        return torch.randn(n, d, h, w, c, generator=g).to(torch.bfloat16).to(dev)
+
+    jobs = []
+    for ca, cb, stride, (n, dp, hp, wp), taps, cb_out in [
+            (8, 8, (1, 1), (1, 3, 9, 20), 27, None), (16, 32, (1, 1), (2, 2, 8, 24), 27, None), (32, 16, (2, 2), (1, 2, 6, 10), 27, None),
+            (32, 32, (1, 1), (1, 2, 6, 18), 27, None), (16, 64, (1, 1), (1, 2, 5, 12), 27, None), (64, 8, (1, 1), (1, 1, 7, 16), 27, None), (64, 32, (1, 2), (1, 2, 5, 12), 27, None),
+            (16, 8, (1, 1), (4, 1, 12, 40), 9, 1), (64, 64, (1, 1), (1, 2, 4, 8), 27, None)]:
+        A = act(n, dp, hp, wp, ca)
+        db, hb, wb = ((dp - 1) * stride[0] + 1, (hp - 1) * stride[1] + 1, (wp - 1) * stride[1] + 1) if stride != (1, 1) else (dp, hp, wp)
+        if stride != (1, 1):                                  # Bt lives on the finer grid (even sizes, as the layers have them)
+            db, hb, wb = dp * stride[0], hp * stride[1], wp * stride[1]
+        Bt = act(n, db, hb, wb, cb)
+        jobs.append((A, Bt, stride, taps, cb_out))
+    want = [ops.bf16_conv3d_wgrad(A, Bt, st, taps, cbo) for A, Bt, st, taps, cbo in jobs]
+    outs = [torch.empty(ops.bf16_wgrad_shape(A, Bt, taps, cbo), device=dev) for A, Bt, st, taps, cbo in jobs]
+    ops.bf16_wgrad_group([(A, Bt, o, st, taps, cbo) for (A, Bt, st, taps, cbo), o in zip(jobs, outs)])
+    torch.cuda.synchronize()
+    for k, (o, w) in enumerate(zip(outs, want)):
+        assert o.shape == w.shape
+        relclose(o, w, 2e-5, "job %d" % k)
+    one = torch.empty_like(outs[0])
+    ops.bf16_wgrad_group([jobs[0][:2] + (one,) + jobs[0][2:]])
+    assert torch.equal(one, want[0])                          # a group of one IS the layer-by-layer call
+
+
+@pytest.mark.parametrize("C,ndepth,H,W,V", [(32, 16, 32, 48, 3), (8, 8, 40, 56, 4)])
+def test_skiplink_and_grouped_wgrad_do_not_change_gradients(dev, C, ndepth, H, W, V, monkeypatch):
+    """A StageNet training step (both regularizer kinds) with the round's two autograd-level fusions - a skip tensor's two gradients meeting
+    in the strided layer's data-gradient epilogue (autograd.SkipLink) and the weight gradients deferred to grouped launches
+    (WgradFlushFn) - against the same step with both switched off (autograd adds the skip gradients, every layer runs its own weight
+    gradient).  Same kernels; what differs is one bf16 rounding per skip sum (the fused form rounds the sum once, autograd's add rounds
+    both terms' sum of rounded values) and the fp32 summation order of the slabs: per-tensor relative L2 error at the bf16 rounding level."""
+    import mvsformer_amd as m
+    from mvsformer_amd import synth
+    from oracle import ref_torch
+    scale = {64: 8, 32: 4, 16: 2, 8: 1}[C]
+    torch.manual_seed(C + ndepth)
+    net = m.StageNet(dict(base_ch=8, fusion_type="cnn", depth_type="ce"), ndepth, 0).to(dev).train()
+    scene = synth.make_scene(V, H * scale, W * scale, seed=W)
+    feat = synth.render_features(scene, scale, C, batch=2).to(dev)
+    proj = synth.proj_matrices(scene, (scale,), 2)["stage1"].to(dev)
+    hyp = ref_torch.init_inverse_range(synth.depth_range(2), ndepth, H, W).to(dev)
+    R = torch.randn(2, ndepth, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    grads = []
+    for skip, group in (("1", "1"), ("0", "0")):
+        monkeypatch.setenv("MVS_TRAIN_SKIPLINK", skip)
+        monkeypatch.setenv("MVS_TRAIN_WGRAD_GROUP", group)
+        net.load_state_dict(state)                            # the running statistics moved in the first pass
+        net.zero_grad(set_to_none=True)
+        fg = feat.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            got = net(fg, proj, hyp, tmp=5.0)
+        (got["prob_volume_pre"] * R).sum().backward()
+        assert all(getattr(mod, "_mvs_wroute", None) is None for mod in net.modules())      # routed weights do not outlive the forward
+        grads.append(({n: p.grad.double().clone() for n, p in net.named_parameters()}, fg.grad.double().clone(), got["prob_volume_pre"].detach().clone()))
+    (ga, xa, pa), (gb, xb, pb) = grads
+    assert torch.equal(pa, pb)                                # the forward is the same launches
+    # bf16 has 8 significand bits (2^-9 = 2e-3 per rounding); a few differently rounded skip sums upstream of a tensor: 2e-2 of its norm
+    assert ((xa - xb).norm() / xb.norm()).item() < 2e-2
+    va, vb = [], []
+    for n in ga:
+        assert ga[n].shape == gb[n].shape
+        if n.startswith("vis."):                              # d loss / d w_v is a difference of nearly equal terms: the regularizer's input-gradient
+            va.append(ga[n].flatten())                        # noise arrives amplified ~10x (see test_stage_train_bf16_vs_fp32_oracle): direction
+            vb.append(gb[n].flatten())
+            continue
+        rel = ((ga[n] - gb[n]).norm() / (gb[n].norm() + 1e-30)).item()
+        assert rel < 2e-2, (n, rel)
+    a, b = torch.cat(va), torch.cat(vb)
+    assert (a @ b / (a.norm() * b.norm() + 1e-30)).item() > 0.995
