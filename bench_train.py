@@ -34,6 +34,7 @@ def parse(argv=None):
                     help="bf16 (BASELINE configs[2]): forward under torch.autocast(bfloat16) - the regularizer runs on bf16 channel-last "
                          "activations and v_mfma_f32_16x16x32_bf16, the cost volume, BatchNorm statistics, head and loss stay fp32, "
                          "master weights fp32 (what the reference's autocast training does); f32: everything fp32")
+    ap.add_argument("--optimizer", choices=["hip", "torch"], default="hip", help="AdamW implementation: mvsformer_amd.optim.FusedAdamW or torch.optim.AdamW(fused=True)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the whole step (forward + loss + backward + AdamW) as ONE hipGraph (mvsformer_amd/graphs.py): host cost per "
                          "step 13-22 ms (box dependent) -> 0.4 ms, so the step runs at the GPU's pace whatever the host does; auto = on, with an "
@@ -72,9 +73,14 @@ def measure(args, top=12):
                 model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local], gradient_as_bucket_view=True, broadcast_buffers=False)
         else:
             model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local], gradient_as_bucket_view=True, broadcast_buffers=False)
-    # torch.optim.AdamW as the reference trainer builds it (train.py:98), in its FUSED form: one multi-tensor kernel for all ~190
-    # parameter tensors (the default capturable form spends 304 elementwise launches and 1.1 ms of a 12.9 ms step on bias corrections)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=use_graph, fused=True)
+    # AdamW as the reference trainer builds it (train.py:98), as mvsformer_amd.optim.FusedAdamW: the same update in three launches of 2048-value
+    # blocks (--optimizer torch: torch.optim.AdamW(fused=True, capturable=True), five launches of 40 us - one block per tensor chunk; its
+    # default capturable form spends 304 elementwise launches and 1.1 ms of the step on bias corrections)
+    if args.optimizer == "hip":
+        from mvsformer_amd.optim import FusedAdamW
+        opt = FusedAdamW(model.parameters(), lr=1e-4)
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=use_graph, fused=True)
     feats, proj, dv, scene = synth.make_inputs(args.views, args.height, args.width, seed=rank, device=dev)
     feats = {k: v.requires_grad_(True) for k, v in feats.items()}
     from mvsformer_amd.losses import ce_loss_stage4

@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 27
+#define MVS_ABI_VERSION 28
 
 typedef void* mvs_stream_t;
 
@@ -651,6 +651,19 @@ int mvs_conv2d_gemm_x3(int mode, const float* A, const float* Bmap, float* C, in
 int mvs_partials_reduce(const float* part, int nparts, int n, float* out, mvs_stream_t stream);   /* out[j] = sum_p part[p*n + j], fixed order */
 int mvs_upsample2x_add(const float* x, const float* lateral, float* y, int planes, int h, int w, mvs_stream_t stream);
 int mvs_upsample2x_bwd(const float* dy, float* dx, int planes, int h, int w, mvs_stream_t stream);
+
+/* ---- AdamW over many parameter tensors in a few launches (the optimizer of the reference's trainer: train.py:98 torch.optim.AdamW) ----
+ * p <- p*(1 - lr*wd);  m <- b1*m + (1-b1)*g;  v <- b2*v + (1-b2)*g*g;  p <- p - lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  t = step[0] + 1;
+ * then step[0] += 1 (a device scalar: the call is capturable).  tensors = HOST array; all tensors fp32, contiguous, on the stream's device. */
+typedef struct MvsAdamTensor {
+    float* p;                 /* parameter, updated in place */
+    const float* g;           /* its gradient */
+    float* m;                 /* exp_avg */
+    float* v;                 /* exp_avg_sq */
+    int64_t n;                /* elements */
+} MvsAdamTensor;
+int mvs_adamw_step(const MvsAdamTensor* tensors, int ntensors, float lr, float beta1, float beta2, float eps, float weight_decay, int maximize,
+                   float* step, mvs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -18,13 +18,18 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVS_HIP_LIB: diagnostics only - another BUILD of the same library (tests/test_hip_multistream.py's variants); never a fallback
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 from ctypes import c_double  # noqa: E402
 
 P, I, F, L, Dbl = c_void_p, c_int, c_float, c_int64, c_double
 
 # name -> (restype, argtypes); mirrors include/mvs_hip.h one to one (tests/test_abi.py cross-checks the header)
+class AdamTensor(ctypes.Structure):
+    """``MvsAdamTensor`` of include/mvs_hip.h."""
+    _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("n", ctypes.c_int64)]
+
+
 class WgradJob(ctypes.Structure):
     """``MvsWgradJob`` of include/mvs_hip.h."""
     _fields_ = [("A", ctypes.c_void_p), ("Bt", ctypes.c_void_p), ("dW", ctypes.c_void_p)] + \
@@ -105,6 +110,7 @@ SIGNATURES = {
     "mvs_bf16_pack_table_fill": (I, [P, I, I, P, I, I, I, I, I, I, P]),
     "mvs_bf16_pack_table_run": (I, [P, I, I, P]),
     "mvs_bf16_conv3d_taps": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "mvs_adamw_step": (I, [P, I, F, F, F, F, F, I, P, P]),
     "mvs_bf16_wgrad_group_workspace_bytes": (L, [P, I]),
     "mvs_bf16_wgrad_group": (I, [P, I, P, L, P]),
     "mvs_bf16_conv3d_wgrad_taps": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),

@@ -1,0 +1,56 @@
+"""AdamW on the HIP path: ``torch.optim.AdamW``'s update (the reference's optimizer, train.py:98) for all parameter tensors of a group in
+a few launches of ``mvs_adamw_step`` (csrc/optim.hip) instead of ATen's multi-tensor kernel.
+
+Same constructor arguments and ``state_dict`` layout as ``torch.optim.AdamW`` where they apply (``exp_avg``, ``exp_avg_sq`` per
+parameter; the step count is ONE device scalar per group, advanced by the kernel, so ``step()`` is capturable in a hipGraph as it is).
+fp32 contiguous GPU parameters only; ``amsgrad`` and sparse gradients are not built; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib, ops
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, maximize=False):
+        if amsgrad:
+            raise _lib.MvsHipError("FusedAdamW: amsgrad is not built")
+        if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
+            raise ValueError("FusedAdamW: lr %r, betas %r, eps %r, weight_decay %r" % (lr, betas, eps, weight_decay))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, maximize=maximize))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            todo = [p for p in group["params"] if p.grad is not None]
+            if not todo:
+                continue
+            dev = todo[0].device
+            if "step" not in group:
+                group["step"] = torch.zeros((), device=dev, dtype=torch.float32)
+            arr = (_lib.AdamTensor * len(todo))()
+            for k, p in enumerate(todo):
+                g = p.grad
+                if p.dtype != torch.float32 or g.dtype != torch.float32 or not p.is_cuda or p.device != dev or g.is_sparse:
+                    raise _lib.MvsHipError("FusedAdamW: fp32 dense GPU parameters of one device (got %s / %s on %s)" % (p.dtype, g.dtype, p.device))
+                if not p.is_contiguous():
+                    raise _lib.MvsHipError("FusedAdamW: a parameter is not contiguous")
+                if not g.is_contiguous():
+                    g = p.grad = g.contiguous()
+                st = self.state[p]
+                if not st:
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                t = arr[k]
+                t.p, t.g, t.m, t.v, t.n = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+            b1, b2 = group["betas"]
+            ops._call("mvs_adamw_step", "adamw", ctypes.cast(arr, ctypes.c_void_p), len(todo), float(group["lr"]), float(b1), float(b2),
+                      float(group["eps"]), float(group["weight_decay"]), int(bool(group["maximize"])), group["step"].data_ptr(), ops._stream())
+        return loss
