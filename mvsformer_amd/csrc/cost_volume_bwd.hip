@@ -411,6 +411,7 @@ __global__ __launch_bounds__(64 * OW_NW) void cv_aggregate_bwd_own_kernel(const 
     constexpr int CPG = C / G, NOCT = C / 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int WX = 1 << wx_log2, NCELL = WX * WY;
+    const unsigned omask = (1u << (31 - __builtin_clz((unsigned)NCELL))) - 1u;      // tag slots of the footprint origins: a power of two <= NCELL
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t per_wave = (size_t)NCELL * 32 + 64 * 36 + (size_t)OW_QCAP * 20 + (size_t)NCELL * 2;
@@ -545,12 +546,19 @@ __global__ __launch_bounds__(64 * OW_NW) void cv_aggregate_bwd_own_kernel(const 
                         cr[i] = coef[i] * wv * r[i];
                     }
                     const int rx = (int)(short)(xy & 0xFFFF), ry = xy >> 16;
+                    // The four taps of a pixel are the 2 x 2 cells at its footprint origin (rx, ry), and all lanes handle tap k in the same
+                    // instruction: two lanes meet in a cell of tap k exactly when their ORIGINS coincide - whatever k.  So ONE election per
+                    // (pixel, plane) on a tag slot of the origin serializes such lanes for all four taps (round 5: it was one election per
+                    // tap - four tag write / read-back round trips instead of one on a kernel that is bound by exactly those).  Different
+                    // origins that share a slot (the origin may lie one cell outside the window: the slot is its hash) only wait a round.
+                    int cellk[4];
+                    bool inw[4];
+                    bool any_in = false;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const bool want = active && w[k] != 0.0f;             // taps outside the image carry weight 0
                         const int txx = rx + (k & 1), tyy = ry + (k >> 1);
                         const bool inwin = want && (unsigned)txx < (unsigned)WX && (unsigned)tyy < (unsigned)WY;
-                        const f32x4 add = {w[k] * cr[0], w[k] * cr[1], w[k] * cr[2], w[k] * cr[3]};
                         const bool miss = want && !inwin;
                         const unsigned long long mm = __builtin_amdgcn_ballot_w64(miss);
                         if (mm != 0) {                                        // wave-uniform
@@ -559,7 +567,7 @@ __global__ __launch_bounds__(64 * OW_NW) void cv_aggregate_bwd_own_kernel(const 
                             if (miss) {
                                 const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0u));
                                 qoff[slot] = o[k] * (unsigned)C + (unsigned)cq * 4u;
-                                qval[slot] = add;
+                                qval[slot] = f32x4{w[k] * cr[0], w[k] * cr[1], w[k] * cr[2], w[k] * cr[3]};
                             }
                             qn += nm;
                         }
@@ -567,21 +575,29 @@ __global__ __launch_bounds__(64 * OW_NW) void cv_aggregate_bwd_own_kernel(const 
                             if (want) atomicAdd(stats, 1u);
                             if (miss) atomicAdd(stats + 1, 1u);
                         }
-                        const int cell = inwin ? (tyy << wx_log2) + txx : 0;
+                        cellk[k] = inwin ? (tyy << wx_log2) + txx : 0;
+                        inw[k] = inwin;
+                        any_in = any_in || inwin;
                         if (inwin) {
-                            clo = min(clo, cell);
-                            chi = max(chi, cell);
+                            clo = min(clo, cellk[k]);
+                            chi = max(chi, cellk[k]);
                         }
-                        bool pending = inwin;
-                        while (__builtin_amdgcn_ballot_w64(pending) != 0) {    // wave-uniform; one round unless two lanes share a cell
-                            if (pending) tags[cq * NCELL + cell] = (unsigned char)lane;
-                            const bool mine = pending && tags[cq * NCELL + cell] == (unsigned char)lane;
-                            if (mine) {
-                                f32x4 v = win[cell * 2 + cq];
-                                v += add;
-                                win[cell * 2 + cq] = v;
-                                pending = false;
-                            }
+                    }
+                    const int oslot = cq * NCELL + (int)(((unsigned)(ry + 1) * (unsigned)(WX + 1) + (unsigned)(rx + 1)) & omask);
+                    bool pending = any_in;
+                    while (__builtin_amdgcn_ballot_w64(pending) != 0) {        // wave-uniform; one round unless two lanes share an origin slot
+                        if (pending) tags[oslot] = (unsigned char)lane;
+                        const bool mine = pending && tags[oslot] == (unsigned char)lane;
+                        if (mine) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (inw[k]) {
+                                    f32x4 v = win[cellk[k] * 2 + cq];
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) v[i] += w[k] * cr[i];
+                                    win[cellk[k] * 2 + cq] = v;
+                                }
+                            pending = false;
                         }
                     }
                 }
