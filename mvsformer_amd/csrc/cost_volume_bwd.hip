@@ -589,6 +589,8 @@ __global__ __launch_bounds__(64 * OW_NW) void cv_aggregate_bwd_own_kernel(const 
                         if (pending) tags[oslot] = (unsigned char)lane;
                         const bool mine = pending && tags[oslot] == (unsigned char)lane;
                         if (mine) {
+                            // tap by tap, each a read-modify-write of its own: lane A's tap 1 cell IS lane B's tap 0 cell when their origins are
+                            // neighbours - reading all four cells first and writing them afterwards loses one of the two updates (tried: wrong)
 #pragma unroll
                             for (int k = 0; k < 4; ++k)
                                 if (inw[k]) {
