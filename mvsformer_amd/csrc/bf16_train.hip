@@ -505,7 +505,11 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bx, con
                 int arow[2], acol[2];
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
-                    const int v = 8 * kb + 4 * rr + vsub;
+                    // K position (8*kb + 4*rr + e) -> voxel of the 2 x 16 patch rows: any bijection serves (A and Bt fragments share it).  This one
+                    // lets the two lane groups that share an LDS pass (kb = 0, 1 / 2, 3) read NEIGHBOURING runs of 4 voxels - 8 voxels x 32
+                    // bytes = every bank once for 16-channel tiles - where 8*kb + 4*rr + e put them 8 voxels = 256 bytes apart, on the same
+                    // banks (SQ_LDS_BANK_CONFLICT 35 % of the LDS cycles of the single-tile instance, profiles/r05_pmc_train_final.txt)
+                    const int v = 16 * (kb >> 1) + 8 * rr + 4 * (kb & 1) + vsub;
                     arow[rr] = 2 * ks + (v >> 4);
                     acol[rr] = v & 15;
                 }
