@@ -211,3 +211,58 @@ def test_pack_table_host_fill_without_a_gpu():
     assert list(starts) == want
     assert lib.mvs_bf16_pack_table_fill(host, n, 0, fake, 32, 8, 0, 16, 8, 27, fake) != 0       # 32 rows do not fit a 16-row map
     assert lib.mvs_bf16_pack_table_fill(host, n, 0, fake, 16, 8, 0, 16, 8, 5, fake) != 0        # taps must be 27 or 9
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """The by-value job structs of the C ABI (``MvsWgradJob``, ``MvsAdamTensor``) as the C compiler lays them out against the ctypes twins
+    in mvsformer_amd/_lib.py: sizes and every field offset (the header is plain C: gcc compiles it as such)."""
+    import ctypes
+    import shutil
+    import subprocess
+    from mvsformer_amd import _lib
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    structs = {"MvsWgradJob": _lib.WgradJob, "MvsAdamTensor": _lib.AdamTensor}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mvs_hip.h"', 'int main(void) {']
+    for cname, ct in structs.items():
+        lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for f, _ in ct._fields_:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (cname, f))
+        lines.append('printf("\\n");')
+    lines += ['return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call([cc, "-std=c99", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split("\n")
+    for line in out:
+        if not line.strip():
+            continue
+        parts = line.split()
+        ct = structs[parts[0]]
+        want = [int(v) for v in parts[1:]]
+        got = [ctypes.sizeof(ct)] + [getattr(ct, f).offset for f, _ in ct._fields_]
+        assert got == want, (parts[0], got, want)
+
+
+def test_fused_adamw_and_queues_have_no_cpu_path():
+    """Host-side contracts that need no GPU: FusedAdamW refuses CPU parameters (no fallback), amsgrad is refused at construction; an armed
+    SkipLink that is never filled is an error by construction (checked in LayerBf16Fn.backward), and an empty WgradQueue flushes to nothing."""
+    from mvsformer_amd import autograd as ag
+    from mvsformer_amd._lib import MvsHipError
+    from mvsformer_amd.optim import FusedAdamW
+    p = torch.nn.Parameter(torch.ones(3))
+    with pytest.raises(MvsHipError):
+        FusedAdamW([p], amsgrad=True)
+    opt = FusedAdamW([p], lr=1e-3)
+    p.grad = torch.ones(3)
+    with pytest.raises(MvsHipError):
+        opt.step()
+    opt.zero_grad(set_to_none=True)
+    opt.step()                                                  # nothing to do: no gradient, no launch
+    link = ag.SkipLink()
+    assert link.armed is False and link.grad is None
+    q = ag.WgradQueue()
+    q.flush(())                                                 # no jobs: no call into the library
+    assert q.jobs == []
