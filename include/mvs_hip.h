@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 28
+#define MVS_ABI_VERSION 29
 
 typedef void* mvs_stream_t;
 
@@ -340,7 +340,8 @@ int mvs_bf16_bn_stats(const void* x, int C, int64_t R, int groups, int64_t rows_
 int mvs_bf16_affine_act(const void* x, const float* scale, const float* shift, const void* residual, int relu, int C, int64_t R,
                         int groups, int64_t rows_per_sample, void* y, mvs_stream_t stream);
 /* training-mode BatchNorm forward in one call / three launches when no cross-rank reduction sits between statistics and finalize:
- * = mvs_bf16_bn_stats + mvs_bn_finalize(_grouped) + mvs_bf16_affine_act; stats4 = [scale | shift | mean | invstd], each groups*C */
+ * = mvs_bf16_bn_stats + mvs_bn_finalize(_grouped) + mvs_bf16_affine_act; stats4 = [scale | shift | mean | invstd | gamma]: FIVE rows of
+ * groups*C floats (the fifth = the affine weight per (group, channel), 1 without one: ABI 25) */
 int mvs_bf16_bn_train_fwd(const void* x, const void* residual, int relu, int C, int64_t R, int groups, int64_t rows_per_sample,
                           const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                           int64_t* num_batches_tracked /* NULL, or nn.BatchNorm's counter: += groups */, float* stats4, void* y,

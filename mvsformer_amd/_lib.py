@@ -18,7 +18,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVS_HIP_LIB: diagnostics only - another BUILD of the same library (tests/test_hip_multistream.py's variants); never a fallback
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 from ctypes import c_double  # noqa: E402
 

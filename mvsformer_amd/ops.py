@@ -1384,7 +1384,7 @@ def bf16_bn_train_fwd(x, residual, relu, gamma, beta, running_mean, running_var,
         _chk(num_batches_tracked, "bn.num_batches_tracked", dtype=torch.int64)
     C, R, rps = _bf16_bn_shape(x, groups)
     y = torch.empty_like(x)
-    st = torch.empty(4, groups * C, device=x.device, dtype=torch.float32)
+    st = torch.empty(5, groups * C, device=x.device, dtype=torch.float32)      # scale | shift | mean | invstd | gamma per (group, channel)
     ws = _reduce_ws("mvs_bf16_bn_reduce_workspace_bytes", x.device, C, R, groups, rps)
     _call("mvs_bf16_bn_train_fwd", "bf16_bn_train_fwd", _ptr(x), _ptr(residual), int(relu), C, R, groups, rps, _ptr(gamma), _ptr(beta),
           _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), _ptr(num_batches_tracked), _ptr(st), _ptr(y), _ptr(ws), _stream())
