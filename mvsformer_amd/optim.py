@@ -4,6 +4,10 @@ a few launches of ``mvs_adamw_step`` (csrc/optim.hip) instead of ATen's multi-te
 Same constructor arguments and ``state_dict`` layout as ``torch.optim.AdamW`` where they apply (``exp_avg``, ``exp_avg_sq`` per
 parameter; the step count is ONE device scalar per group, advanced by the kernel, so ``step()`` is capturable in a hipGraph as it is).
 fp32 contiguous GPU parameters only; ``amsgrad`` and sparse gradients are not built; there is no CPU path.
+
+Under hipGraph capture the scalar hyper-parameters (``lr``, betas, ``eps``, ``weight_decay``) travel as kernel arguments and are captured
+BY VALUE: a learning-rate schedule needs a re-capture when the rate changes (or the eager ``step()``); the step count, which the bias
+corrections depend on, is read from the device and does advance in a replay.
 """
 from __future__ import annotations
 
