@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 29
+#define MVS_ABI_VERSION 30
 
 typedef void* mvs_stream_t;
 
@@ -635,6 +635,38 @@ int mvs_layernorm(const float* x, const float* gamma, const float* beta, float* 
 int mvs_softmax_rows(const float* x, float* y, int64_t rows, int N, float scale, mvs_stream_t stream);
 int mvs_bicubic_resize(const float* in, float* out, int planes, int H, int W, int Ho, int Wo, float rscale_h, float rscale_w,
                        mvs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * The transformer blocks on PRE-SPLIT ("packed") operands (csrc/vit_packed.hip; models/vision_transformer.py:123-154,194-214): every matrix
+ * operand is stored already split into the three bf16 terms of "Arithmetic" above and already in MFMA fragment order, so the main loops move
+ * it with LDS-DMA and contain no conversion.  Same arithmetic as mvs_gemm_x3 / mvs_attention_x3 (six v_mfma_f32_16x16x32_bf16 per K = 32
+ * step, fp32 accumulation), fp32-equivalent.
+ *   packed X [R][K] (K % 32 == 0, rows_alloc % 16 == 0 rows allocated): piece (rt = r/16, ks = k/32, term t) = 1 KiB of 64 lanes x 8 bf16 at
+ *   byte ((rt * K/32 + ks) * 3 + t) * 1024, lane = ((k%32)/8)*16 + r%16, element k%8; mvs_x3p_bytes(rows_alloc, K) bytes in all.
+ *   mvs_x3p_pack / mvs_x3p_unpack: fp32 [R][K] (rows ld apart) <-> packed (rows >= R packed as zeros; unpack is exact: h + m + l).
+ *   mvs_layernorm_x3p: LayerNorm (vision_transformer.py:199,207 norm1 / norm2) of rows laid out [images][Np] (Np % 16 == 0), written packed;
+ *       rows t >= N of an image are padding: zeros.  32 <= C <= 512, C % 32 == 0.
+ *   mvs_gemm_x3p: out = epi(A . B^T) with A [M][K] and B [N][K] packed (the nn.Linear layers: attn.proj, mlp.fc1, mlp.fc2);
+ *       epi(v) = act(v*scale[n] + shift[n]) + res (act 0 none, 1 GELU(erf)); written as fp32 C [M][ldc] and / or packed Op [M][N]
+ *       (the next GEMM's A operand; Op needs a_rows_alloc rows allocated).  N % 4 == 0.
+ *   mvs_gemm_x3p_qkv: attn.qkv (vision_transformer.py:139): rows = [images][Np] tokens, columns q | k | v of `heads` heads of 64; writes
+ *       Qp = (q + bias) * qscale and Kp packed [image][head][Np rows][64], and Vtp = V^T packed [image][head][64 rows][Np] with the 32 keys of
+ *       a k step permuted (element e of chunk c <-> key (e < 4 ? 4c + e : 16 + 4c + e - 4)): the order mvs_attention_x3p's accumulators
+ *       produce P in.  C = heads * 64, C % 128 == 0, Np % 32 == 0.
+ *   mvs_attention_x3p: softmax(Q K^T) V per (image, head), flash form, keys >= N masked; output packed [images * Np][heads * 64].
+ *   mvs_cls_attention_x3p: att [image][head][N] = softmax(q_cls . K^T): the one attention row the model reads (mvsformer_model.py:257).
+ * ------------------------------------------------------------------------------------------------------- */
+int64_t mvs_x3p_bytes(int64_t rows_alloc, int K);
+int mvs_x3p_pack(const float* x, void* out, int64_t R, int K, int ld, int64_t rows_alloc, mvs_stream_t stream);
+int mvs_x3p_unpack(const void* in, float* x, int64_t R, int K, int ld, int64_t rows_alloc, mvs_stream_t stream);
+int mvs_layernorm_x3p(const float* x, const float* gamma, const float* beta, void* out, int64_t rows, int C, int Np, int N, float eps,
+                      mvs_stream_t stream);
+int mvs_gemm_x3p(const void* Ap, const void* Bp, int M, int N, int K, int64_t a_rows_alloc, int64_t b_rows_alloc, float* C, int ldc,
+                 const float* scale, const float* shift, int act, const float* res, void* Op, mvs_stream_t stream);
+int mvs_gemm_x3p_qkv(const void* Ap, const void* Bp, int images, int Np, int C, int heads, int64_t a_rows_alloc, int64_t b_rows_alloc,
+                     const float* bias, float qscale, void* Qp, void* Kp, void* Vtp, mvs_stream_t stream);
+int mvs_attention_x3p(const void* Qp, const void* Kp, const void* Vtp, void* Op, int images, int N, int Np, int heads, mvs_stream_t stream);
+int mvs_cls_attention_x3p(const void* Qp, const void* Kp, float* att, int images, int N, int Np, int heads, mvs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * training mode of the FPN encoder / decoder (models/module.py:208-270 under train(); csrc/vit.hip, csrc/fpn_train.hip).

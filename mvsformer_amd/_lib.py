@@ -18,7 +18,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVS_HIP_LIB: diagnostics only - another BUILD of the same library (tests/test_hip_multistream.py's variants); never a fallback
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 from ctypes import c_double  # noqa: E402
 
@@ -149,6 +149,14 @@ SIGNATURES = {
     "mvs_upsample2x_bwd": (I, [P, P, I, I, I, P]),
     "mvs_softmax_rows": (I, [P, P, L, I, F, P]),
     "mvs_bicubic_resize": (I, [P, P, I, I, I, I, I, F, F, P]),
+    "mvs_x3p_bytes": (L, [L, I]),
+    "mvs_x3p_pack": (I, [P, P, L, I, I, L, P]),
+    "mvs_x3p_unpack": (I, [P, P, L, I, I, L, P]),
+    "mvs_layernorm_x3p": (I, [P, P, P, P, L, I, I, I, F, P]),
+    "mvs_gemm_x3p": (I, [P, P, I, I, I, L, L, P, I, P, P, I, P, P, P]),
+    "mvs_gemm_x3p_qkv": (I, [P, P, I, I, I, I, L, L, P, F, P, P, P, P]),
+    "mvs_attention_x3p": (I, [P, P, P, P, I, I, I, I, P]),
+    "mvs_cls_attention_x3p": (I, [P, P, P, I, I, I, I, P]),
     "mvs_conv3d_wino_supported": (I, [I, I, I, I, I]),
     "mvs_conv3d_wino_packed_floats": (L, [I, I]),
     "mvs_conv3d_wino_pack_weights": (I, [P, I, I, P, P]),

@@ -1,0 +1,646 @@
+// The transformer blocks of the DINO ViT branch (models/vision_transformer.py:123-154,194-214) on PRE-SPLIT operands.
+//
+// vit.hip's GEMM splits both operands into (h, m, l) bf16 terms on the way into LDS, in EVERY block: each of the ~136 row blocks re-splits the
+// same constant weight tile, each of the 6-24 column blocks re-splits the same activation tile ("weak" 2).  Here every matrix
+// operand lives in memory already split and already in MFMA fragment order ("packed"):
+//
+//     packed X [R rows][K]:  piece (rt = r / 16, ks = k / 32, term) = 1 KiB = 64 lanes x 8 bf16, lane = ((k % 32) / 8) * 16 + r % 16, element k % 8
+//                            at byte ((rt * K/32 + ks) * 3 + term) * 1024          (term 0 = h, 1 = m, 2 = l of split3.h: x = h + m + l exactly)
+//
+// so one piece IS the A- or B-operand fragment of v_mfma_f32_16x16x32_bf16 for 16 rows x 32 k, lane-linear: it moves global -> LDS by LDS-DMA
+// (buffer_load ... lds, no registers, no VALU) and LDS -> registers by one conflict-free ds_read_b128.  Weights are packed once
+// (mvs_x3p_pack at _prepared() time); activations are packed by their PRODUCER: LayerNorm (mvs_layernorm_x3p), the GEMM epilogue
+// (fc1 -> GELU -> packed; qkv -> packed Q (pre-scaled), K and V^T per head) and the attention epilogue.  The main loops contain no
+// conversion and no split: LDS-DMA, ds_read_b128 and six MFMAs per fragment pair.
+//
+//   mvs_x3p_pack          fp32 [R][K] -> packed (weights; tests)
+//   mvs_layernorm_x3p     LayerNorm rows -> packed (the A operand of qkv / fc1)
+//   mvs_gemm_x3p          C = epi(A . B^T), A [M][K] and B [N][K] packed; 128 x 128 x 32 tiles, two LDS stages filled by LDS-DMA one
+//                         K step ahead; epilogue: scale / shift, GELU, residual -> fp32 C and / or packed output, or the qkv form
+//   mvs_attention_x3p     flash attention on packed Q / K / V^T -> packed [M][C]; S^T = K Q^T so that a lane's accumulators ARE its
+//                         fragment of P^T (no LDS round trip of P), online softmax with two cross-lane steps per tile
+//   mvs_cls_attention_x3p the CLS row of softmax(Q K^T) per head from the packed operands (mvsformer_model.py:257 reads only that row)
+#include "common.h"
+#include "split3.h"
+
+namespace {
+using mvsx3::bf16x8;
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int PIECE = 1024;                                  // bytes of one fragment (16 rows x 32 k, one term)
+constexpr int KSTEP = 3 * PIECE;                             // the three terms of one (row tile, k step)
+
+__device__ __forceinline__ rsrc_t rsrc_of(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+// LDS-DMA: lane l moves 16 bytes from src + voff(l) + soff to lds_dst + 16 l (in a __device__ helper on purpose: with the builtin directly
+// in a __global__ template body hipcc drops the kernel's host stub, tools/probe/gather_probe.hip)
+__device__ __forceinline__ void dma16(rsrc_t src, unsigned char* lds_dst, unsigned voff_bytes, unsigned soff_bytes) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_ptr_t)lds_dst, 16, voff_bytes, soff_bytes, 0, 0);
+}
+__device__ __forceinline__ bf16x8 ldfrag(rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0));
+}
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// four fp32 values -> three 8-byte words (4 bf16 each): the h, m, l terms
+__device__ __forceinline__ void split4(const float (&v)[4], u32x2& h, u32x2& m, u32x2& l) {
+    unsigned a, b, c;
+    mvsx3::split3_pair<true>(v[0], v[1], a, b, c);
+    h[0] = a, m[0] = b, l[0] = c;
+    mvsx3::split3_pair<true>(v[2], v[3], a, b, c);
+    h[1] = a, m[1] = b, l[1] = c;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- pack
+// one thread = (row tile, k step, lane): 8 values -> 3 x 16 bytes; rows >= R and k >= K are zeros
+__global__ __launch_bounds__(256) void x3p_pack_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, int R, int K, int ld, int RT, int KS) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)RT * KS * 64) return;
+    const int lane = (int)(idx & 63), ks = (int)((idx >> 6) % KS), rt = (int)((idx >> 6) / KS);
+    const int r = rt * 16 + (lane & 15), k0 = ks * 32 + (lane >> 4) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (r < R && k0 + e < K) ? x[(size_t)r * ld + k0 + e] : 0.0f;
+    const mvsx3::Split3 s = mvsx3::split3(v);
+    unsigned char* d = out + ((size_t)rt * KS + ks) * KSTEP + lane * 16;
+    *reinterpret_cast<bf16x8*>(d) = s.h;
+    *reinterpret_cast<bf16x8*>(d + PIECE) = s.m;
+    *reinterpret_cast<bf16x8*>(d + 2 * PIECE) = s.l;
+}
+
+// packed -> fp32 (h + m + l is exact): tests and the CLS row
+__global__ __launch_bounds__(256) void x3p_unpack_kernel(const unsigned char* __restrict__ in, float* __restrict__ x, int R, int K, int ld, int RT, int KS) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)RT * KS * 64) return;
+    const int lane = (int)(idx & 63), ks = (int)((idx >> 6) % KS), rt = (int)((idx >> 6) / KS);
+    const int r = rt * 16 + (lane & 15), k0 = ks * 32 + (lane >> 4) * 8;
+    if (r >= R) return;
+    const unsigned char* s = in + ((size_t)rt * KS + ks) * KSTEP + lane * 16;
+    const bf16x8 h = *reinterpret_cast<const bf16x8*>(s), m = *reinterpret_cast<const bf16x8*>(s + PIECE), l = *reinterpret_cast<const bf16x8*>(s + 2 * PIECE);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (k0 + e < K) x[(size_t)r * ld + k0 + e] = ((float)h[e] + (float)m[e]) + (float)l[e];
+}
+
+// ---------------------------------------------------------------------------------------------------------------- LayerNorm -> packed
+// One wavefront per row, lane l holds features 8 l .. 8 l + 7 (C <= 512, a multiple of 32): statistics as vit.hip's layernorm_kernel
+// (mean, then the centered sum of squares), output split and written as the row's 16-byte chunks of C / 32 pieces.  Rows are laid out
+// [images][Np]: rows t >= N of an image are padding and written as zeros (finite keys / values for the attention's masked tail).
+__global__ __launch_bounds__(256) void layernorm_x3p_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                            unsigned char* __restrict__ out, int rows, int C, int Np, int N, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const bool active = lane * 8 < C;
+    const bool pad = (row % Np) >= N;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+    if (active && !pad) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(x + (size_t)row * C + lane * 8), hi = *reinterpret_cast<const f32x4*>(x + (size_t)row * C + lane * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = lo[e], v[4 + e] = hi[e];
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[e];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    const float mean = s / (float)C;
+    float q = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float d = active ? v[e] - mean : 0.0f;
+        q = fmaf(d, d, q);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    if (!active) return;
+    float y[8];
+    if (pad) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = 0.0f;
+    } else {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(g + lane * 8), g1 = *reinterpret_cast<const f32x4*>(g + lane * 8 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + lane * 8), b1 = *reinterpret_cast<const f32x4*>(b + lane * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y[e] = fmaf((v[e] - mean) * rstd, g0[e], b0[e]);
+            y[4 + e] = fmaf((v[4 + e] - mean) * rstd, g1[e], b1[e]);
+        }
+    }
+    const mvsx3::Split3 sp = mvsx3::split3(y);
+    const int KS = C >> 5, ks = lane >> 2, kb = lane & 3;
+    unsigned char* d = out + ((size_t)(row >> 4) * KS + ks) * KSTEP + (kb * 16 + (row & 15)) * 16;
+    *reinterpret_cast<bf16x8*>(d) = sp.h;
+    *reinterpret_cast<bf16x8*>(d + PIECE) = sp.m;
+    *reinterpret_cast<bf16x8*>(d + 2 * PIECE) = sp.l;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- GEMM
+struct PGemmArgs {
+    const void* Ap;           // packed activations [Mp][K], Mp = art * 16 rows allocated (>= the 128-row tiles the grid touches, or zero-filled by the range check)
+    const void* Bp;           // packed weights [Npad][K]
+    int M, N, K;              // logical sizes: rows m >= M and columns n >= N are not stored
+    int art, brt;             // row tiles allocated in Ap / Bp
+    int nbm, nbn;             // 128-row / 128-column blocks
+    float* C;                 // optional fp32 output [M][ldc]
+    int ldc;
+    const float* scale;       // [N] or null
+    const float* shift;       // [N] or null
+    const float* res;         // [M][ldc] or null
+    int act;                  // 0 none, 1 GELU (erf)
+    void* Op;                 // optional packed output [Mp][N] (K' = N): the A operand of the next GEMM
+    // the qkv form (MODE 1): columns [0, Cd) = q, [Cd, 2 Cd) = k, [2 Cd, 3 Cd) = v, heads of 64 columns; rows = [images][Np]
+    void* Qp;                 // [image][head][Np / 16][2][3] pieces: q * qscale
+    void* Kp;                 // the same for k
+    void* Vp;                 // V^T [image][head][4 row tiles of d][Np / 32][3] pieces, keys of a 32-step in the order pi (see attention)
+    int Cd, NH, Np;
+    float qscale;
+};
+
+constexpr int GT = 128;                                      // block tile (rows and columns)
+constexpr int GSTAGE = 2 * 8 * KSTEP;                        // one LDS stage: 8 row tiles of each operand x 3 terms = 48 KiB
+
+// MODE 0: fp32 C and / or plain packed output.  MODE 1: the qkv form.
+// The MFMA's first operand supplies the accumulator's ROW index i (a lane holds four consecutive i), the second the column j (lane & 15).
+// T1 = the operand in the first slot, T2 = the second.  Default T1 = weights (i = n), T2 = activations (j = m): a lane holds FOUR
+// CONSECUTIVE n of ONE row m - 16-byte fp32 stores, 8-byte packed stores (half a lane's 8-k chunk of the next GEMM's A operand).
+// The v columns of the qkv form swap the slots (i = token, j = d): four consecutive TOKENS of one d, which is what V^T's pieces want.
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_x3p_kernel(const PGemmArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * GSTAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware order: block id -> XCD id % 8; the column blocks of one row block run on ONE XCD back to back (its A panel stays in that L2)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int mb = (slot / a.nbn) * 8 + xcd, nb = slot % a.nbn;
+    if (mb >= a.nbm) return;
+    const int KS = a.K >> 5;
+    const bool vsec = MODE == 1 && nb * GT >= 2 * a.Cd;
+    // descriptors (block-uniform, scalar)
+    const rsrc_t rA = rsrc_of(a.Ap, (unsigned)((size_t)a.art * KS * KSTEP)), rB = rsrc_of(a.Bp, (unsigned)((size_t)a.brt * KS * KSTEP));
+    // LDS-DMA roles: wavefronts 0, 1 fill T1's eight row tiles (four each), 2, 3 fill T2's; 12 pieces per wavefront per K step
+    const bool fillA = ((wave >> 1) == 0) == vsec;           // this wavefront fills from the activations
+    const rsrc_t rsrc = fillA ? rA : rB;
+    const int rt0 = (fillA ? mb : nb) * 8 + (wave & 1) * 4;  // first of its four row tiles
+    const unsigned voff = lane * 16;
+    unsigned char* const fill_dst = lds + ((wave >> 1) * 8 + (wave & 1) * 4) * KSTEP;
+    auto fill = [&](int stage, int ks) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned soff = (unsigned)(((rt0 + r) * KS + ks) * KSTEP);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) dma16(rsrc, fill_dst + stage * GSTAGE + (r * 3 + t) * PIECE, voff, soff + t * PIECE);
+        }
+    };
+    const int wi = wave >> 1, wj = wave & 1;                 // the wavefront's 64 x 64 quadrant: i tiles wi*4.., j tiles wj*4..
+    const unsigned char* const f1 = lds + (wi * 4) * KSTEP + lane * 16;
+    const unsigned char* const f2 = lds + (8 + wj * 4) * KSTEP + lane * 16;
+
+    f32x4 acc[4][4];                                          // [j tile][i tile]
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[jt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int stage) {
+        bf16x8 t1[4][3], t2[4][3];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) t1[it][t] = *reinterpret_cast<const bf16x8*>(f1 + stage * GSTAGE + (it * 3 + t) * PIECE);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) t2[jt][t] = *reinterpret_cast<const bf16x8*>(f2 + stage * GSTAGE + (jt * 3 + t) * PIECE);
+        // smallest products first (split3.h's mfma6 order), each term pair swept over the 16 accumulators: no two consecutive MFMAs share one
+#define X3P_SWEEP(TA, TB)                                                                                                              \
+    _Pragma("unroll") for (int jt = 0; jt < 4; ++jt) _Pragma("unroll") for (int it = 0; it < 4; ++it) acc[jt][it] =                    \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(t1[it][TA], t2[jt][TB], acc[jt][it], 0, 0, 0);
+        X3P_SWEEP(1, 1)
+        X3P_SWEEP(0, 2)
+        X3P_SWEEP(2, 0)
+        X3P_SWEEP(0, 1)
+        X3P_SWEEP(1, 0)
+        X3P_SWEEP(0, 0)
+#undef X3P_SWEEP
+    };
+
+    fill(0, 0);
+    int ks = 0;
+    for (; ks + 2 <= KS; ks += 2) {                          // two K steps per trip: the stage index is a literal
+        __syncthreads();                                     // stage 0 has landed (the barrier drains the LDS-DMA queue); stage 1's readers are done
+        fill(1, ks + 1);
+        compute(0);
+        __syncthreads();
+        if (ks + 2 < KS) fill(0, ks + 2);
+        compute(1);
+    }
+    if (ks < KS) {
+        __syncthreads();
+        compute(0);
+    }
+
+    // ---- epilogue: lane (jl = lane & 15, kb = lane >> 4) holds acc[jt][it][r] = D[i = i0 + it*16 + 4 kb + r][j = j0 + jt*16 + jl]
+    const int jl = lane & 15, kb = lane >> 4;
+    if (!vsec) {
+        const int n0 = nb * GT + wi * 64, m0 = mb * GT + wj * 64;      // i = n, j = m
+        int img = 0, tok0 = 0, head = 0, sec = 0;
+        if (MODE == 1) {
+            sec = n0 / a.Cd;
+            head = (n0 - sec * a.Cd) >> 6;
+        }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const int m = m0 + jt * 16 + jl;
+            if (m >= a.M) continue;
+            if (MODE == 1) {
+                img = (m0 + jt * 16) / a.Np;
+                tok0 = (m0 + jt * 16) - img * a.Np;               // first token of this 16-row tile (Np % 16 == 0: the tile stays in one image)
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int n = n0 + it * 16 + 4 * kb;
+                if (n >= a.N) continue;
+                float v[4];
+                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+                if (a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = fmaf(acc[jt][it][r], sc[r], sh[r]);
+                    if (MODE == 0 && a.act == 1) v[r] = gelu_erf(v[r]);
+                }
+                if (MODE == 0) {
+                    const size_t o = (size_t)m * a.ldc + n;
+                    if (a.res) {
+                        const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + o);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                    }
+                    if (a.C) *reinterpret_cast<f32x4*>(a.C + o) = f32x4{v[0], v[1], v[2], v[3]};
+                    if (a.Op) {
+                        u32x2 h, mm, l;
+                        split4(v, h, mm, l);
+                        const int KSo = a.N >> 5;
+                        unsigned char* d = reinterpret_cast<unsigned char*>(a.Op) + ((size_t)(m >> 4) * KSo + (n >> 5)) * KSTEP +
+                                           ((((n >> 3) & 3) * 16 + jl) * 16) + ((n >> 2) & 1) * 8;
+                        *reinterpret_cast<u32x2*>(d) = h;
+                        *reinterpret_cast<u32x2*>(d + PIECE) = mm;
+                        *reinterpret_cast<u32x2*>(d + 2 * PIECE) = l;
+                    }
+                } else {                                      // q (scaled) or k of head `head`: packed [image][head][token tile][2 k steps]
+                    if (sec == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] *= a.qscale;
+                    }
+                    u32x2 h, mm, l;
+                    split4(v, h, mm, l);
+                    const int dd = it * 16 + 4 * kb;           // first of the lane's four head dimensions
+                    unsigned char* base = reinterpret_cast<unsigned char*>(sec == 0 ? a.Qp : a.Kp);
+                    unsigned char* d = base + ((((size_t)img * a.NH + head) * (a.Np >> 4) + (tok0 >> 4)) * 2 + (dd >> 5)) * KSTEP +
+                                       ((((dd >> 3) & 3) * 16 + jl) * 16) + ((dd >> 2) & 1) * 8;
+                    *reinterpret_cast<u32x2*>(d) = h;
+                    *reinterpret_cast<u32x2*>(d + PIECE) = mm;
+                    *reinterpret_cast<u32x2*>(d + 2 * PIECE) = l;
+                }
+            }
+        }
+    } else {
+        // v columns, slots swapped: i = token (m), j = d (n).  acc[jt][it]: d = jt*16 + jl of head `head`, tokens m0 + it*16 + 4 kb + r.
+        // V^T piece (d tile jt, key step of 32 tokens): lane (kb, jl) element e <-> key pi(kb, e) = (e < 4 ? 4 kb + e : 16 + 4 kb + e - 4) of the
+        // step - exactly the four tokens this lane holds in the step's first (e < 4) and second (e >= 4) 16-token tile: one 16-byte store.
+        const int m0 = mb * GT + wi * 64, n0 = nb * GT + wj * 64;
+        const int head = (n0 - 2 * a.Cd) >> 6;
+        const int KSV = a.Np >> 5;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                // the 64 tokens = two key steps
+            const int ms = m0 + half * 32;
+            if (ms >= a.M) continue;                          // (M = images * Np is a multiple of 32: a step is all rows or none)
+            const int img = ms / a.Np, step = (ms - img * a.Np) >> 5;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                const int n = n0 + jt * 16 + jl;
+                const float sc = a.scale ? a.scale[n] : 1.0f, sh = a.shift ? a.shift[n] : 0.0f;
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[jt][2 * half][r], sc, sh), v[4 + r] = fmaf(acc[jt][2 * half + 1][r], sc, sh);
+                const mvsx3::Split3 sp = mvsx3::split3(v);
+                unsigned char* d = reinterpret_cast<unsigned char*>(a.Vp) + ((((size_t)img * a.NH + head) * 4 + jt) * KSV + step) * KSTEP + lane * 16;
+                *reinterpret_cast<bf16x8*>(d) = sp.h;
+                *reinterpret_cast<bf16x8*>(d + PIECE) = sp.m;
+                *reinterpret_cast<bf16x8*>(d + 2 * PIECE) = sp.l;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- attention
+// softmax(Q K^T) V per (image, head) in flash form on the packed operands of the qkv GEMM (Q already scaled).  A block owns 128 queries
+// (4 wavefronts x 2 query tiles of 16) and walks the keys in steps of 32; K and V^T steps (12 + 12 pieces = 24 KiB) arrive by LDS-DMA one
+// step ahead (two stages).  Per step and query tile:
+//   S^T [key][query] = K Q^T      first slot = K fragment (i = key), second = Q fragment (j = query): a lane holds keys 4 kb + r of both
+//                                 16-key tiles for ONE query (lane & 15) - eight values
+//   online softmax                row max = the lane's 8 values, then two cross-lane steps (lanes j, j+16, j+32, j+48 share a query);
+//                                 the row SUM stays a per-lane partial until the end
+//   P^T fragment                  = those eight values, split: element e of lane (kb, j) is key pi(kb, e) - the order V^T was packed in,
+//                                 so the fragment never leaves the lane's registers
+//   O^T [d][query] += V^T P^T     first slot = V^T fragment (i = d), second = P^T (j = query)
+// Output: packed [image * Np + token][heads * 64] (the A operand of the projection GEMM): a lane holds four consecutive d of one token.
+constexpr int ASTAGE = 24 * PIECE;
+
+__device__ __forceinline__ float xmax16(float x) { return fmaxf(x, __shfl_xor(x, 16, 64)); }
+__device__ __forceinline__ float xmax32(float x) { return fmaxf(x, __shfl_xor(x, 32, 64)); }
+
+__global__ __launch_bounds__(256, 2) void attention_x3p_kernel(const void* __restrict__ Qp, const void* __restrict__ Kp, const void* __restrict__ Vp,
+                                                               void* __restrict__ Op, int N, int Np, int NH) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * ASTAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int head = blockIdx.y, img = blockIdx.z;
+    const int RT = Np >> 4, KSV = Np >> 5;
+    const size_t bh = (size_t)img * NH + head;
+    const unsigned char* kbase = reinterpret_cast<const unsigned char*>(Kp) + bh * RT * 2 * KSTEP;
+    const unsigned char* vbase = reinterpret_cast<const unsigned char*>(Vp) + bh * 4 * KSV * KSTEP;
+    const rsrc_t rq = rsrc_of(reinterpret_cast<const unsigned char*>(Qp) + bh * RT * 2 * KSTEP, (unsigned)((size_t)RT * 2 * KSTEP));
+    const rsrc_t rk = rsrc_of(kbase, (unsigned)((size_t)RT * 2 * KSTEP)), rv = rsrc_of(vbase, (unsigned)((size_t)4 * KSV * KSTEP));
+    const unsigned voff = lane * 16;
+    const int qt0 = blockIdx.x * 8 + wave * 2;                // the wavefront's two query tiles (tiles >= RT read zeros, store nothing)
+
+    bf16x8 qf[2][2][3];                                       // [query tile][k step of d][term]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) qf[qt][s][t] = ldfrag(rq, voff, (unsigned)(((qt0 + qt) * 2 + s) * KSTEP + t * PIECE));
+
+    f32x4 o[2][4];                                            // [query tile][d tile]
+    float mrow[2], lrow[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        mrow[qt] = -INFINITY, lrow[qt] = 0.0f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // LDS-DMA roles: per step, K = 12 contiguous pieces (2 key tiles x 2 d steps x 3 terms): wavefront w moves pieces 3w .. 3w+2;
+    // V^T: d tile w's three terms.  Stage = [K 12][V 12].
+    auto fill = [&](int stage, int kt) {
+        unsigned char* dk = lds + stage * ASTAGE + wave * KSTEP;
+        const unsigned ko = (unsigned)((kt * 4 + wave) * KSTEP), vo = (unsigned)((wave * KSV + kt) * KSTEP);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) dma16(rk, dk + t * PIECE, voff, ko + t * PIECE);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) dma16(rv, dk + 12 * PIECE + t * PIECE, voff, vo + t * PIECE);
+    };
+    const int kb = lane >> 4;
+    auto step = [&](int stage, int kt) {
+        const unsigned char* sk = lds + stage * ASTAGE + lane * 16;
+        const unsigned char* sv = sk + 12 * PIECE;
+        f32x4 s[2][2];                                        // [query tile][key tile]
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) s[qt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) {
+                const unsigned char* p = sk + (nt * 2 + ds) * KSTEP;
+                const bf16x8 kh = *reinterpret_cast<const bf16x8*>(p), km = *reinterpret_cast<const bf16x8*>(p + PIECE),
+                             kl = *reinterpret_cast<const bf16x8*>(p + 2 * PIECE);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) s[qt][nt] = mvsx3::mfma6(kh, km, kl, qf[qt][ds][0], qf[qt][ds][1], qf[qt][ds][2], s[qt][nt]);
+            }
+        if (kt * 32 + 32 > N) {                               // the tail step: keys >= N are padding
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kt * 32 + nt * 16 + 4 * kb + r >= N) s[qt][nt][r] = -INFINITY;
+        }
+        bf16x8 ph[2], pm[2], pl[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = fmaxf(fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), fmaxf(s[qt][0][2], s[qt][0][3])),
+                             fmaxf(fmaxf(s[qt][1][0], s[qt][1][1]), fmaxf(s[qt][1][2], s[qt][1][3])));
+            mx = xmax32(xmax16(mx));
+            const float mnew = fmaxf(mrow[qt], mx);
+            const float alpha = __expf(mrow[qt] - mnew);
+            mrow[qt] = mnew;
+            float p[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = __expf(s[qt][0][r] - mnew), p[4 + r] = __expf(s[qt][1][r] - mnew);
+            lrow[qt] = fmaf(lrow[qt], alpha, ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {    // the running max moved for some query of the wavefront
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+            }
+            u32x4 h, m, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned a, b, c;
+                mvsx3::split3_pair<false>(p[2 * e], p[2 * e + 1], a, b, c);
+                h[e] = a, m[e] = b, l[e] = c;
+            }
+            ph[qt] = __builtin_bit_cast(bf16x8, h), pm[qt] = __builtin_bit_cast(bf16x8, m), pl[qt] = __builtin_bit_cast(bf16x8, l);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const unsigned char* p = sv + dt * KSTEP;
+            const bf16x8 vh = *reinterpret_cast<const bf16x8*>(p), vm = *reinterpret_cast<const bf16x8*>(p + PIECE),
+                         vl = *reinterpret_cast<const bf16x8*>(p + 2 * PIECE);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) o[qt][dt] = mvsx3::mfma6(vh, vm, vl, ph[qt], pm[qt], pl[qt], o[qt][dt]);
+        }
+    };
+    const int KT = (N + 31) >> 5;
+    fill(0, 0);
+    int kt = 0;
+    for (; kt + 2 <= KT; kt += 2) {
+        __syncthreads();
+        fill(1, kt + 1);
+        step(0, kt);
+        __syncthreads();
+        if (kt + 2 < KT) fill(0, kt + 2);
+        step(1, kt + 1);
+    }
+    if (kt < KT) {
+        __syncthreads();
+        step(0, kt);
+    }
+    // ---- output: o[qt][dt][r] = O[token (qt0 + qt)*16 + jl][d = dt*16 + 4 kb + r] / row sum
+    const int jl = lane & 15;
+    const int KSo = (NH * 64) >> 5;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        if (qt0 + qt >= RT) continue;
+        float l = lrow[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const size_t rt = (size_t)img * RT + qt0 + qt;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const float v[4] = {o[qt][dt][0] * inv, o[qt][dt][1] * inv, o[qt][dt][2] * inv, o[qt][dt][3] * inv};
+            u32x2 h, m, lo;
+            split4(v, h, m, lo);
+            const int n = head * 64 + dt * 16 + 4 * kb;
+            unsigned char* d = reinterpret_cast<unsigned char*>(Op) + (rt * KSo + (n >> 5)) * KSTEP + ((((n >> 3) & 3) * 16 + jl) * 16) + ((n >> 2) & 1) * 8;
+            *reinterpret_cast<u32x2*>(d) = h;
+            *reinterpret_cast<u32x2*>(d + PIECE) = m;
+            *reinterpret_cast<u32x2*>(d + 2 * PIECE) = lo;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- CLS row
+// att[image][head][key] = softmax_key(q_cls . k_key) over keys < N (q already scaled), from the packed Q / K (h + m + l is exact): one block
+// per (image, head), fp32 FMA chains.  The only attention values MVSFormer reads (mvsformer_model.py:257: vit_att[:, :, 0, 1:]).
+__global__ __launch_bounds__(256) void cls_attention_kernel(const unsigned char* __restrict__ Qp, const unsigned char* __restrict__ Kp, float* __restrict__ att,
+                                                            int N, int Np, int NH) {
+    __shared__ float q[64];
+    __shared__ float red[4];
+    __shared__ float sc[8192];                                 // the row's scores (N <= 8192)
+    const int head = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const int RT = Np >> 4;
+    const size_t bh = (size_t)img * NH + head;
+    const unsigned char* qb = Qp + bh * RT * 2 * KSTEP;
+    const unsigned char* kbp = Kp + bh * RT * 2 * KSTEP;
+    auto elem = [](const unsigned char* base, int row, int d) {
+        const unsigned char* p = base + ((size_t)(row >> 4) * 2 + (d >> 5)) * KSTEP + ((((d >> 3) & 3) * 16 + (row & 15)) * 16) + (d & 7) * 2;
+        return ((float)*reinterpret_cast<const __bf16*>(p) + (float)*reinterpret_cast<const __bf16*>(p + PIECE)) +
+               (float)*reinterpret_cast<const __bf16*>(p + 2 * PIECE);
+    };
+    if (tid < 64) q[tid] = elem(qb, 0, tid);
+    __syncthreads();
+    float mx = -INFINITY;
+#pragma unroll 1
+    for (int key = tid; key < N; key += 256) {
+        float acc = 0.0f;
+#pragma unroll 1
+        for (int c = 0; c < 8; ++c) {                          // 16-byte chunk c of the key's row: d = 8 c .. 8 c + 7
+            const unsigned char* p = kbp + ((size_t)(key >> 4) * 2 + (c >> 2)) * KSTEP + (((c & 3) * 16 + (key & 15)) * 16);
+            const bf16x8 h = *reinterpret_cast<const bf16x8*>(p), m = *reinterpret_cast<const bf16x8*>(p + PIECE),
+                         l = *reinterpret_cast<const bf16x8*>(p + 2 * PIECE);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf(q[c * 8 + e], ((float)h[e] + (float)m[e]) + (float)l[e], acc);
+        }
+        sc[key] = acc;
+        mx = fmaxf(mx, acc);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.0f;
+#pragma unroll 1
+    for (int key = tid; key < N; key += 256) {                 // (a thread re-reads only its own scores)
+        const float e = __expf(sc[key] - mx);
+        sc[key] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+#pragma unroll 1
+    for (int key = tid; key < N; key += 256) att[bh * N + key] = sc[key] * inv;
+}
+}  // namespace
+
+extern "C" int64_t mvs_x3p_bytes(int64_t rows, int K) {
+    if (rows < 1 || K < 1) return 0;
+    return ((rows + 15) / 16) * ((K + 31) / 32) * (int64_t)KSTEP;
+}
+
+extern "C" int mvs_x3p_pack(const float* x, void* out, int64_t R, int K, int ld, int64_t rows_alloc, mvs_stream_t stream) {
+    MVS_REQUIRE(x && out && R >= 1 && K >= 1 && ld >= K && rows_alloc >= R && rows_alloc % 16 == 0 && K % 32 == 0,
+                "mvs_x3p_pack: K (%d) must be a multiple of 32, rows_alloc a multiple of 16 >= R", K);
+    const int RT = (int)(rows_alloc / 16), KS = K / 32;
+    MVS_REQUIRE((int64_t)RT * KS * KSTEP < ((int64_t)1 << 32), "mvs_x3p_pack: packed operand exceeds 4 GiB");
+    const long long n = (long long)RT * KS * 64;
+    hipLaunchKernelGGL(x3p_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, MVS_STREAM(stream), x, reinterpret_cast<unsigned char*>(out), (int)R, K, ld, RT, KS);
+    return mvs::finish_launch("mvs_x3p_pack");
+}
+
+extern "C" int mvs_x3p_unpack(const void* in, float* x, int64_t R, int K, int ld, int64_t rows_alloc, mvs_stream_t stream) {
+    MVS_REQUIRE(x && in && R >= 1 && K >= 1 && ld >= K && rows_alloc >= R && rows_alloc % 16 == 0 && K % 32 == 0, "mvs_x3p_unpack: bad shape");
+    const int RT = (int)(rows_alloc / 16), KS = K / 32;
+    const long long n = (long long)RT * KS * 64;
+    hipLaunchKernelGGL(x3p_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, MVS_STREAM(stream), reinterpret_cast<const unsigned char*>(in), x, (int)R, K, ld, RT, KS);
+    return mvs::finish_launch("mvs_x3p_unpack");
+}
+
+extern "C" int mvs_layernorm_x3p(const float* x, const float* gamma, const float* beta, void* out, int64_t rows, int C, int Np, int N, float eps,
+                                 mvs_stream_t stream) {
+    MVS_REQUIRE(x && gamma && beta && out && rows >= 1 && rows < ((int64_t)1 << 31) && C >= 32 && C <= 512 && C % 32 == 0,
+                "mvs_layernorm_x3p: 32 <= C <= 512, a multiple of 32 (got %d)", C);
+    MVS_REQUIRE(Np >= 16 && Np % 16 == 0 && N >= 1 && N <= Np && rows % Np == 0, "mvs_layernorm_x3p: rows = images * Np, Np %% 16 == 0, N <= Np");
+    hipLaunchKernelGGL(layernorm_x3p_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, MVS_STREAM(stream), x, gamma, beta,
+                       reinterpret_cast<unsigned char*>(out), (int)rows, C, Np, N, eps);
+    return mvs::finish_launch("mvs_layernorm_x3p");
+}
+
+namespace {
+int launch_pgemm(PGemmArgs& a, int mode, int64_t a_rows_alloc, int64_t b_rows_alloc, hipStream_t s) {
+    a.art = (int)(a_rows_alloc / 16), a.brt = (int)(b_rows_alloc / 16);
+    a.nbm = (a.M + GT - 1) / GT, a.nbn = (a.N + GT - 1) / GT;
+    const int KS = a.K / 32;
+    MVS_REQUIRE((int64_t)a.art * KS * KSTEP < ((int64_t)1 << 32) && (int64_t)a.brt * KS * KSTEP < ((int64_t)1 << 32), "mvs_gemm_x3p: a packed operand exceeds 4 GiB");
+    const unsigned grid = (unsigned)(((a.nbm + 7) / 8) * 8 * a.nbn);
+    if (mode == 0) hipLaunchKernelGGL(gemm_x3p_kernel<0>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gemm_x3p_kernel<1>, dim3(grid), dim3(256), 0, s, a);
+    return mvs::finish_launch("mvs_gemm_x3p");
+}
+}  // namespace
+
+extern "C" int mvs_gemm_x3p(const void* Ap, const void* Bp, int M, int N, int K, int64_t a_rows_alloc, int64_t b_rows_alloc, float* C, int ldc,
+                            const float* scale, const float* shift, int act, const float* res, void* Op, mvs_stream_t stream) {
+    MVS_REQUIRE(Ap && Bp && M >= 1 && N >= 1 && K >= 32 && K % 32 == 0 && N % 4 == 0, "mvs_gemm_x3p: K (%d) %% 32 == 0 and N (%d) %% 4 == 0 required", K, N);
+    MVS_REQUIRE(a_rows_alloc % 16 == 0 && b_rows_alloc % 16 == 0 && a_rows_alloc >= M && b_rows_alloc >= N, "mvs_gemm_x3p: packed operands hold fewer rows than M / N");
+    MVS_REQUIRE((C || Op) && (!C || ldc >= N) && (!res || C) && act >= 0 && act <= 1 && (!Op || N % 32 == 0) && (!C || ldc % 4 == 0),
+                "mvs_gemm_x3p: needs C and / or a packed output (N %% 32 == 0), res only with C, ldc %% 4 == 0, act 0 / 1");
+    PGemmArgs a{};
+    a.Ap = Ap, a.Bp = Bp, a.M = M, a.N = N, a.K = K, a.C = C, a.ldc = ldc, a.scale = scale, a.shift = shift, a.act = act, a.res = res, a.Op = Op;
+    return launch_pgemm(a, 0, a_rows_alloc, b_rows_alloc, MVS_STREAM(stream));
+}
+
+extern "C" int mvs_gemm_x3p_qkv(const void* Ap, const void* Bp, int images, int Np, int C, int heads, int64_t a_rows_alloc, int64_t b_rows_alloc,
+                                const float* bias, float qscale, void* Qp, void* Kp, void* Vtp, mvs_stream_t stream) {
+    MVS_REQUIRE(Ap && Bp && Qp && Kp && Vtp && images >= 1 && Np >= 32 && Np % 32 == 0 && heads >= 1 && C == heads * 64 && C % 128 == 0,
+                "mvs_gemm_x3p_qkv: head dimension 64, C %% 128 == 0, Np %% 32 == 0 (got C=%d heads=%d Np=%d)", C, heads, Np);
+    MVS_REQUIRE(a_rows_alloc % 16 == 0 && b_rows_alloc % 16 == 0 && a_rows_alloc >= (int64_t)images * Np && b_rows_alloc >= 3 * C, "mvs_gemm_x3p_qkv: packed operands too small");
+    PGemmArgs a{};
+    a.Ap = Ap, a.Bp = Bp, a.M = images * Np, a.N = 3 * C, a.K = C, a.shift = bias, a.Qp = Qp, a.Kp = Kp, a.Vp = Vtp, a.Cd = C, a.NH = heads, a.Np = Np,
+    a.qscale = qscale;
+    return launch_pgemm(a, 1, a_rows_alloc, b_rows_alloc, MVS_STREAM(stream));
+}
+
+extern "C" int mvs_attention_x3p(const void* Qp, const void* Kp, const void* Vtp, void* Op, int images, int N, int Np, int heads, mvs_stream_t stream) {
+    MVS_REQUIRE(Qp && Kp && Vtp && Op && images >= 1 && images <= 65535 && heads >= 1 && heads <= 65535 && N >= 1 && Np >= N && Np % 32 == 0 && (heads * 64) % 32 == 0,
+                "mvs_attention_x3p: Np %% 32 == 0, N <= Np");
+    MVS_REQUIRE((int64_t)Np * 8 * KSTEP < ((int64_t)1 << 32), "mvs_attention_x3p: one head exceeds the buffer range");
+    hipLaunchKernelGGL(attention_x3p_kernel, dim3((Np / 16 + 7) / 8, heads, images), dim3(256), 0, MVS_STREAM(stream), Qp, Kp, Vtp, Op, N, Np, heads);
+    return mvs::finish_launch("mvs_attention_x3p");
+}
+
+extern "C" int mvs_cls_attention_x3p(const void* Qp, const void* Kp, float* att, int images, int N, int Np, int heads, mvs_stream_t stream) {
+    MVS_REQUIRE(Qp && Kp && att && images >= 1 && images <= 65535 && heads >= 1 && N >= 1 && N <= 8192 && Np >= N && Np % 16 == 0, "mvs_cls_attention_x3p: N <= 8192, Np %% 16 == 0");
+    hipLaunchKernelGGL(cls_attention_kernel, dim3(heads, images), dim3(256), 0, MVS_STREAM(stream), reinterpret_cast<const unsigned char*>(Qp),
+                       reinterpret_cast<const unsigned char*>(Kp), att, N, Np, heads);
+    return mvs::finish_launch("mvs_cls_attention_x3p");
+}

@@ -1605,6 +1605,103 @@ def bicubic_resize(x: torch.Tensor, Ho: int, Wo: int, rscale_h: float, rscale_w:
 
 
 # ------------------------------------------------------------------ FPN training mode (csrc/vit.hip mvs_conv2d_gemm_x3, csrc/fpn_train.hip)
+# ----------------------------------------------------------------------------------------------- pre-split ("packed") operands (csrc/vit_packed.hip)
+class Packed:
+    """A matrix ``[rows][K]`` stored split into the three bf16 terms and in MFMA fragment order (include/mvs_hip.h, ``mvs_x3p_*``):
+    ``buf`` is the raw device buffer, ``rows`` the logical rows, ``rows_alloc`` (a multiple of 16) the rows it holds."""
+    __slots__ = ("buf", "rows", "K", "rows_alloc")
+
+    def __init__(self, rows: int, K: int, device, rows_alloc: Optional[int] = None, zero: bool = False):
+        if K % 32:
+            raise _lib.MvsHipError("Packed: K = %d is not a multiple of 32" % K)
+        self.rows, self.K = int(rows), int(K)
+        self.rows_alloc = int(rows_alloc) if rows_alloc is not None else (self.rows + 127) // 128 * 128
+        n = int(_lib.load().mvs_x3p_bytes(self.rows_alloc, self.K))
+        self.buf = (torch.zeros if zero else torch.empty)(n, device=device, dtype=torch.uint8)
+
+    def ptr(self):
+        return self.buf.data_ptr()
+
+
+def x3p_pack(x: torch.Tensor, rows_alloc: Optional[int] = None) -> Packed:
+    """fp32 ``[R, K]`` -> :class:`Packed` (rows beyond R zero)."""
+    _chk(x, "x")
+    R, K = x.shape
+    out = Packed(R, K, x.device, rows_alloc)
+    _call("mvs_x3p_pack", "x3p_pack", _ptr(x), out.ptr(), R, K, K, out.rows_alloc, _stream())
+    return out
+
+
+def x3p_unpack(p: Packed) -> torch.Tensor:
+    x = torch.empty(p.rows, p.K, device=p.buf.device, dtype=torch.float32)
+    _call("mvs_x3p_unpack", "x3p_unpack", p.ptr(), _ptr(x), p.rows, p.K, p.K, p.rows_alloc, _stream())
+    return x
+
+
+def layernorm_x3p(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, Np: int, N: int, out: Optional[Packed] = None) -> Packed:
+    """LayerNorm of rows ``[images*Np, C]`` written packed (rows ``t >= N`` of an image: zeros)."""
+    _chk(x, "x"), _chk(gamma, "gamma"), _chk(beta, "beta")
+    rows, C = x.shape
+    if out is None:
+        out = Packed(rows, C, x.device)
+    _call("mvs_layernorm_x3p", "layernorm_x3p", _ptr(x), _ptr(gamma), _ptr(beta), out.ptr(), rows, C, Np, N, float(eps), _stream())
+    return out
+
+
+def gemm_x3p(A: Packed, B: Packed, N: int, C: Optional[torch.Tensor] = None, scale=None, shift=None, act: int = 0, res=None,
+             out: Optional[Packed] = None) -> None:
+    """``epi(A . B^T)`` on packed operands -> fp32 ``C [M, N]`` (contiguous rows) and / or packed ``out [M][N]``."""
+    if A.K != B.K or B.rows < N:
+        raise _lib.MvsHipError("gemm_x3p: A [%d][%d] x B [%d][%d], N = %d" % (A.rows, A.K, B.rows, B.K, N))
+    if C is not None:
+        _chk(C, "C")
+    _opt(scale, "scale"), _opt(shift, "shift"), _opt(res, "res")
+    if out is not None and (out.K != N or out.rows_alloc < A.rows):
+        raise _lib.MvsHipError("gemm_x3p: packed output [%d][%d] for M = %d, N = %d" % (out.rows_alloc, out.K, A.rows, N))
+    _call("mvs_gemm_x3p", ("x3p_gemm", "flops", 2.0 * A.rows * N * A.K), A.ptr(), B.ptr(), A.rows, N, A.K, A.rows_alloc, B.rows_alloc, _ptr(C),
+          C.shape[-1] if C is not None else 0, _ptr(scale), _ptr(shift), int(act), _ptr(res), out.ptr() if out is not None else None, _stream())
+
+
+class QkvPacked:
+    """Q (pre-scaled), K packed ``[image][head][Np][64]`` and V^T packed ``[image][head][64][Np]`` (keys permuted per 32-step)."""
+    __slots__ = ("q", "k", "vt", "images", "heads", "Np")
+
+    def __init__(self, images: int, heads: int, Np: int, device):
+        self.images, self.heads, self.Np = images, heads, Np
+        n = images * heads * (Np // 16) * 2 * 3072
+        self.q = torch.empty(n, device=device, dtype=torch.uint8)
+        self.k = torch.empty(n, device=device, dtype=torch.uint8)
+        self.vt = torch.empty(n, device=device, dtype=torch.uint8)
+
+
+def gemm_x3p_qkv(A: Packed, W: Packed, bias: Optional[torch.Tensor], images: int, Np: int, heads: int, qscale: float, out: Optional[QkvPacked] = None) -> QkvPacked:
+    C = heads * 64
+    if A.K != C or W.K != C or A.rows != images * Np:
+        raise _lib.MvsHipError("gemm_x3p_qkv: A [%d][%d], W [%d][%d] for %d images x %d rows, %d heads" % (A.rows, A.K, W.rows, W.K, images, Np, heads))
+    _opt(bias, "bias")
+    if out is None:
+        out = QkvPacked(images, heads, Np, A.buf.device)
+    _call("mvs_gemm_x3p_qkv", ("x3p_gemm", "flops", 2.0 * A.rows * 3 * C * C), A.ptr(), W.ptr(), images, Np, C, heads, A.rows_alloc, W.rows_alloc, _ptr(bias),
+          float(qscale), out.q.data_ptr(), out.k.data_ptr(), out.vt.data_ptr(), _stream())
+    return out
+
+
+def attention_x3p(qkv: QkvPacked, N: int, out: Optional[Packed] = None) -> Packed:
+    """Flash attention on the packed operands -> packed ``[images*Np][heads*64]``."""
+    if out is None:
+        out = Packed(qkv.images * qkv.Np, qkv.heads * 64, qkv.q.device)
+    _call("mvs_attention_x3p", ("x3p_attention", "flops", 4.0 * qkv.images * qkv.heads * N * N * 64), qkv.q.data_ptr(), qkv.k.data_ptr(), qkv.vt.data_ptr(),
+          out.ptr(), qkv.images, N, qkv.Np, qkv.heads, _stream())
+    return out
+
+
+def cls_attention_x3p(qkv: QkvPacked, N: int) -> torch.Tensor:
+    """``[images, heads, N]``: the CLS query's attention row per head."""
+    att = torch.empty(qkv.images, qkv.heads, N, device=qkv.q.device, dtype=torch.float32)
+    _call("mvs_cls_attention_x3p", "x3p_cls_attention", qkv.q.data_ptr(), qkv.k.data_ptr(), _ptr(att), qkv.images, N, qkv.Np, qkv.heads, _stream())
+    return att
+
+
 def _conv2d_out(H, W, KS, S, P):
     return (H + 2 * P - KS) // S + 1, (W + 2 * P - KS) // S + 1
 

@@ -106,14 +106,66 @@ class VisionTransformer(nn.Module):
                 blocks.append(tuple(_f(t) for t in (b.norm1.weight, b.norm1.bias, b.attn.qkv.weight, b.attn.qkv.bias, b.attn.proj.weight,
                                                     b.attn.proj.bias, b.norm2.weight, b.norm2.bias, b.mlp.fc1.weight, b.mlp.fc1.bias,
                                                     b.mlp.fc2.weight, b.mlp.fc2.bias)))
+            # the linear layers' weights split once into (h, m, l) bf16 MFMA fragments (csrc/vit_packed.hip): no block of any GEMM splits them again
+            packed = None
+            if self._packed_ok():
+                packed = [tuple(ops.x3p_pack(w) for w in (b[2], b[4], b[8], b[10])) for b in blocks]
             _publish_cache()
-            self._cache = (key, pw, _f(self.patch_embed.proj.bias), blocks, _f(self.norm.weight), _f(self.norm.bias), _f(self.cls_token))
+            self._cache = (key, pw, _f(self.patch_embed.proj.bias), blocks, _f(self.norm.weight), _f(self.norm.bias), _f(self.cls_token), packed)
         return self._cache[1:]
 
-    def _run(self, x: torch.Tensor, want_att: bool):
+    def _packed_ok(self) -> bool:
+        """The pre-split path (csrc/vit_packed.hip) covers heads of 64 with C a multiple of 128 up to 512 (ViT-small)."""
+        C, NH = self.embed_dim, self.num_heads
+        return C == NH * 64 and C % 128 == 0 and C <= 512 and os.environ.get("MVS_VIT_PACKED", "1") != "0"
+
+    def _run_packed(self, x: torch.Tensor, want_cls: bool):
+        """The 12 blocks on pre-split operands: LayerNorm -> packed, qkv GEMM -> packed Q / K / V^T per head, flash attention -> packed,
+        projection (+ residual) -> fp32 tokens, LayerNorm -> packed, fc1 (+ GELU) -> packed, fc2 (+ residual) -> fp32 tokens.  Token rows are
+        laid out [B][Np] with Np = N rounded up to 32 (padding rows stay finite and are masked as keys).  ``want_cls``: also the CLS query's
+        attention row of the last block, ``[B, heads, N]`` - the only part of the attention matrix the model reads (mvsformer_model.py:257)."""
+        pw, pb, blocks, nw, nb, cls, packed = self._prepared()
+        x = x.detach().to(torch.float32)
+        B, nc, h, w = x.shape
+        P, C, NH = self.patch_size, self.embed_dim, self.num_heads
+        hp, wp = h // P, w // P
+        n = hp * wp
+        N = n + 1
+        Np = (N + 31) // 32 * 32
+        M = B * Np
+        dev = x.device
+        patches = x[:, :, :hp * P, :wp * P].reshape(B, nc, hp, P, wp, P).permute(0, 2, 4, 1, 3, 5).reshape(B * n, nc * P * P).contiguous()
+        tok = torch.zeros(B, Np, C, device=dev, dtype=torch.float32)
+        tok[:, 0] = cls[0, 0]
+        ops.gemm_x3(patches, pw, tok, n, C, nc * P * P, nc * P * P, nc * P * P, C, nb1=B, sA=(n * nc * P * P, 0), sC=(Np * C, 0), shift=pb, c_off=C)
+        tok[:, :N] += self._pos(hp, wp)
+        t, t2 = tok.view(M, C), torch.empty(M, C, device=dev, dtype=torch.float32)
+        hidden = blocks[0][8].shape[0]
+        y_p, a_p, h_p = ops.Packed(M, C, dev), ops.Packed(M, C, dev), ops.Packed(M, hidden, dev)
+        qkv_p = ops.QkvPacked(B, NH, Np, dev)
+        eps = self.norm.eps
+        att_cls = None
+        for i, ((n1w, n1b, _, qb, _, prb, n2w, n2b, _, f1b, _, f2b), (wq, wpr, w1, w2)) in enumerate(zip(blocks, packed)):
+            ops.layernorm_x3p(t, n1w, n1b, eps, Np, N, out=y_p)
+            ops.gemm_x3p_qkv(y_p, wq, qb, B, Np, NH, (C // NH) ** -0.5, out=qkv_p)
+            if want_cls and i == len(blocks) - 1:
+                att_cls = ops.cls_attention_x3p(qkv_p, N)
+            ops.attention_x3p(qkv_p, N, out=a_p)
+            ops.gemm_x3p(a_p, wpr, C, C=t2, shift=prb, res=t)
+            ops.layernorm_x3p(t2, n2w, n2b, eps, Np, N, out=y_p)
+            ops.gemm_x3p(y_p, w1, hidden, shift=f1b, act=1, out=h_p)
+            ops.gemm_x3p(h_p, w2, C, C=t, shift=f2b, res=t2)
+        out = ops.layernorm(tok, nw, nb, eps)[:, :N].contiguous()
+        return (out, att_cls) if want_cls else out
+
+    def _run(self, x: torch.Tensor, want_att):
+        """``want_att``: False, True (the last block's whole attention matrix, ``forward_with_last_att``'s contract) or ``"cls"`` (only the CLS
+        query's row ``[B, heads, N]``: what ``vit_branch`` needs)."""
         if self.training:
             raise _lib.MvsHipError("VisionTransformer: only eval mode is built on the HIP path (the reference freezes the ViT: \"fix\": true)")
-        pw, pb, blocks, nw, nb, cls = self._prepared()
+        if want_att is not True and self._packed_ok():
+            return self._run_packed(x, want_att == "cls")
+        pw, pb, blocks, nw, nb, cls = self._prepared()[:6]
         x = x.detach().to(torch.float32)
         B, nc, h, w = x.shape
         P, C, NH = self.patch_size, self.embed_dim, self.num_heads
@@ -157,6 +209,8 @@ class VisionTransformer(nn.Module):
             ops.gemm_x3(y, f1w, hid, B * N, f1w.shape[0], C, C, C, f1w.shape[0], shift=f1b, act=1)
             ops.gemm_x3(hid, f2w, t, B * N, C, f1w.shape[0], f1w.shape[0], f1w.shape[0], C, shift=f2b, res=t2)
         out = ops.layernorm(t, nw, nb, eps)
+        if want_att == "cls":
+            return out, scores[:, :, 0].contiguous()
         return (out, scores) if want_att else out
 
     def forward(self, x, src_epipoles=None):
@@ -165,6 +219,11 @@ class VisionTransformer(nn.Module):
     def forward_with_last_att(self, x):
         """-> (tokens after the final LayerNorm ``[B, 1+hw, C]``, attention of the last block ``[B, heads, 1+hw, 1+hw]``)."""
         return self._run(x, True)
+
+    def forward_with_cls_att(self, x):
+        """-> (tokens ``[B, 1+hw, C]``, the CLS query's attention row of the last block ``[B, heads, 1+hw]``) = what mvsformer_model.py:246-257
+        uses of ``forward_with_last_att`` (``vit_att[:, :, 0, 1:]``) without writing the other 1+hw rows."""
+        return self._run(x, "cls")
 
 
 def vit_small(patch_size=16, **kwargs):
@@ -287,9 +346,9 @@ def vit_branch(vit: VisionTransformer, dec: VITDecoderStage4Single, img: torch.T
     B, _, H, W = img.shape
     vh, vw = int(H * rescale), int(W * rescale)
     x = ops.bicubic_resize(img.detach().to(torch.float32).contiguous(), vh, vw, H / vh, W / vw)
-    tok, att = vit.forward_with_last_att(x)
+    tok, att = vit.forward_with_cls_att(x)
     P = vit.patch_size
     hp, wp = vh // P, vw // P
     feat = tok[:, 1:].reshape(B, hp, wp, vit.embed_dim).permute(0, 3, 1, 2)
-    att_cls = att[:, :, 0, 1:].reshape(B, -1, hp, wp)
-    return {"vit_imgs": x, "vit_feat": tok, "att_cls": att[:, :, 0, 1:], "vit_out": dec(feat, att_cls)}
+    att_cls = att[:, :, 1:].reshape(B, -1, hp, wp)
+    return {"vit_imgs": x, "vit_feat": tok, "att_cls": att[:, :, 1:], "vit_out": dec(feat, att_cls)}

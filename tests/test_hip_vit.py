@@ -124,3 +124,116 @@ def test_attention_x3_flash_vs_fp64(dev, shape):
     assert err < 3 * err32 + 5e-7, (err, err32)
     with pytest.raises(Exception):
         ops.attention_x3(d[:, :, :96].contiguous(), vt[:, :1, :32].contiguous(), 1, 0.1)      # head dimension 32: refused loudly, no silent fallback
+
+
+# ------------------------------------------------------------------------------------------------------------ pre-split ("packed") operands
+def test_x3p_pack_roundtrip_and_layout(dev):
+    """pack -> unpack is EXACT (x = h + m + l), rows beyond R are zeros, and the layout is the documented one (include/mvs_hip.h):
+    piece (rt, ks, term) at ((rt*K/32 + ks)*3 + term) KiB, lane = ((k%32)/8)*16 + r%16, element k%8."""
+    from mvsformer_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(37, 96, generator=gen) * torch.tensor(10.0) ** torch.randint(-20, 20, (37, 1), generator=gen).float()
+    p = ops.x3p_pack(x.to(dev), rows_alloc=48)
+    assert torch.equal(ops.x3p_unpack(p).cpu(), x)
+    raw = p.buf.cpu().view(torch.bfloat16).float().reshape(3, 3, 3, 64, 8)          # [rt][ks][term][lane][8]
+    r, k = 21, 77
+    lane = ((k % 32) // 8) * 16 + r % 16
+    terms = raw[r // 16, k // 32, :, lane, k % 8]
+    h = x[r, k].bfloat16().float()
+    m = (x[r, k] - h).bfloat16().float()
+    assert terms[0] == h and terms[1] == m and terms[2] == (x[r, k] - h - m).bfloat16().float()
+    assert raw[2, :, :, 5:16].abs().max() == 0 and raw[2, :, :, 21:32].abs().max() == 0   # rows 37..47: zeros
+
+
+@pytest.mark.parametrize("shape", [(200, 132, 96, 1), (128, 128, 32, 0), (391, 384, 384, 1), (8645, 64, 160, 0)])
+def test_gemm_x3p_vs_fp64(dev, shape):
+    """The pre-split GEMM (LDS-DMA fed, no split in the main loop) against fp64 with an fp32 product chain's own error as the yardstick -
+    the same contract as test_gemm_x3_vs_fp64 - and bit-equal to the split-on-the-fly kernel's arithmetic is NOT required (the MFMA
+    order within a K step is the same, the tile shapes differ only in who computes what)."""
+    from mvsformer_amd import ops
+    M, N, K, act = shape
+    gen = torch.Generator().manual_seed(M + N)
+    A, B = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen)
+    scale, shift, res = torch.rand(N, generator=gen) + 0.5, torch.randn(N, generator=gen), torch.randn(M, N, generator=gen)
+    Ap, Bp = ops.x3p_pack(A.to(dev)), ops.x3p_pack(B.to(dev))
+    C = torch.full((M, N), float("nan"), device=dev)
+    outp = ops.Packed(M, N, dev, zero=True) if N % 32 == 0 else None
+    ops.gemm_x3p(Ap, Bp, N, C=C, scale=scale.to(dev), shift=shift.to(dev), act=act, res=res.to(dev), out=outp)
+    want = (A.double() @ B.double().t()) * scale.double() + shift.double()
+    want = (F.gelu(want) if act else want) + res.double()
+    v32 = (A @ B.t()) * scale + shift
+    fp32 = (F.gelu(v32) if act else v32) + res
+    err, err32 = _rel(C, want), _rel(fp32, want)
+    assert err < 3 * err32 + 2e-7, (err, err32)
+    if outp is not None:
+        assert torch.equal(ops.x3p_unpack(outp), C)         # the packed copy of the output is the same numbers, exactly
+        only = ops.Packed(M, N, dev, zero=True)
+        ops.gemm_x3p(Ap, Bp, N, scale=scale.to(dev), shift=shift.to(dev), act=act, out=only)     # packed output alone, no residual
+        ops.gemm_x3p(Ap, Bp, N, C=C, scale=scale.to(dev), shift=shift.to(dev), act=act)
+        assert torch.equal(ops.x3p_unpack(only), C)
+
+
+def test_layernorm_x3p(dev):
+    from mvsformer_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    Np, N, C = 64, 37, 384
+    x = torch.randn(2 * Np, C, generator=gen) * 3 + 1
+    g, b = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen)
+    got = ops.x3p_unpack(ops.layernorm_x3p(x.to(dev), g.to(dev), b.to(dev), 1e-6, Np, N)).cpu().reshape(2, Np, C)
+    want = F.layer_norm(x.double(), (C,), g.double(), b.double(), 1e-6).reshape(2, Np, C)
+    assert _rel(got[:, :N], want[:, :N]) < 2e-6
+    assert got[:, N:].abs().max() == 0                     # padding rows: zeros
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 50), (2, 6, 197), (1, 6, 1729), (3, 2, 64)])
+def test_attention_x3p_vs_fp64(dev, shape):
+    """qkv GEMM -> packed Q / K / V^T -> flash attention -> packed output, and the CLS row, against fp64 attention on the fp32 qkv values
+    the GEMM produced (the split-on-the-fly GEMM gives them as fp32)."""
+    from mvsformer_amd import ops
+    B, NH, N = shape
+    hd, C = 64, NH * 64
+    if C % 128:
+        pytest.skip("C %% 128")
+    Np = (N + 31) // 32 * 32
+    gen = torch.Generator().manual_seed(N + 5 * B)
+    x = torch.zeros(B, Np, C)
+    x[:, :N] = torch.randn(B, N, C, generator=gen)
+    W, bias = torch.randn(3 * C, C, generator=gen) * (1.7 / C ** 0.5), torch.randn(3 * C, generator=gen) * 0.3
+    xp, wp = ops.x3p_pack(x.reshape(B * Np, C).to(dev)), ops.x3p_pack(W.to(dev))
+    qkv_p = ops.gemm_x3p_qkv(xp, wp, bias.to(dev), B, Np, NH, hd ** -0.5)
+    qkv = (x.double() @ W.double().t() + bias.double())[:, :N]
+    q, k, v = (qkv[:, :, i * C:(i + 1) * C].reshape(B, N, NH, hd).permute(0, 2, 1, 3) for i in range(3))
+    # packed Q (scaled) and K against the fp64 products
+    RT = Np // 16
+    qraw = ops.Packed(B * NH * Np, 64, dev, rows_alloc=B * NH * Np)
+    qraw.buf = qkv_p.q
+    kraw = ops.Packed(B * NH * Np, 64, dev, rows_alloc=B * NH * Np)
+    kraw.buf = qkv_p.k
+    qg = ops.x3p_unpack(qraw).cpu().reshape(B, NH, Np, 64)[:, :, :N]
+    kg = ops.x3p_unpack(kraw).cpu().reshape(B, NH, Np, 64)[:, :, :N]
+    assert _rel(qg, q * hd ** -0.5) < 2e-6 and _rel(kg, k) < 2e-6
+    att = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1)
+    want = (att @ v).permute(0, 2, 1, 3).reshape(B, N, C)
+    fp32 = (torch.softmax(q.float() @ k.float().transpose(-1, -2) * hd ** -0.5, -1) @ v.float()).permute(0, 2, 1, 3).reshape(B, N, C)
+    got = ops.x3p_unpack(ops.attention_x3p(qkv_p, N)).cpu().reshape(B, Np, C)[:, :N]
+    err, err32 = _rel(got, want), _rel(fp32, want)
+    assert err < 3 * err32 + 5e-7, (err, err32)
+    cls = ops.cls_attention_x3p(qkv_p, N)
+    assert _rel(cls, att[:, :, 0]) < 5e-6
+
+
+def test_vit_packed_path_matches_split_on_the_fly_path(dev, monkeypatch):
+    """The pre-split blocks (default) against the round-5 path (MVS_VIT_PACKED=0: operands split inside every GEMM block, fp32 activations
+    between the layers): same arithmetic family, different tiling -> agreement far inside the 1e-4 the golden test allows."""
+    import mvsformer_amd as m
+    torch.manual_seed(3)
+    net = m.vit_small(patch_size=16, qk_scale="default").to(dev).eval()
+    img = torch.randn(2, 3, 80, 112, device=dev)
+    tok, att = net.forward_with_cls_att(img)
+    full_tok, full_att = net.forward_with_last_att(img)      # the whole attention matrix: the materialized path
+    monkeypatch.setenv("MVS_VIT_PACKED", "0")
+    net._cache = None
+    tok0, att0 = net.forward_with_cls_att(img)
+    assert tok.shape == tok0.shape == (2, 36, 384) and att.shape == att0.shape == (2, 6, 36)
+    assert _rel(tok, tok0.cpu()) < 2e-5 and _rel(att, att0.cpu()) < 2e-5
+    assert _rel(full_tok, tok0.cpu()) < 2e-5 and _rel(full_att[:, :, 0], att0.cpu()) < 2e-5
