@@ -663,6 +663,14 @@ int mvs_layernorm_x3p(const float* x, const float* gamma, const float* beta, voi
                       mvs_stream_t stream);
 int mvs_gemm_x3p(const void* Ap, const void* Bp, int M, int N, int K, int64_t a_rows_alloc, int64_t b_rows_alloc, float* C, int ldc,
                  const float* scale, const float* shift, int act, const float* res, void* Op, mvs_stream_t stream);
+/* Implicit convolutions of the ViT decoder (models/module.py:353-368 VITDecoderStage4Single, :450-466 AttentionFusionSimple) on the same kernel:
+ * Xp = a packed channel-last map [images*H*W pixels][Cp] (Cp % 32 == 0) whose row `zero_row` is all zeros (taps outside the image read it).
+ *   mode 1: 3x3, padding 1: out[pixel][n] = epi(sum_{tap,c} X[pixel + tap][c] * Wp[n][tap*Cp + c]), tap = ky*3 + kx.
+ *   mode 2: ConvTranspose2d(kernel 4, stride 2, padding 1): Wp = four packed matrices [class][w_rows_alloc][4*Cp] (class = ph*2 + pw the output
+ *           parity, k = (th*2 + tw)*Cp + c, taps ky = (1,3) / (0,2) for ph = 0 / 1, kx likewise); output row = image*4HW + (2y+ph)*2W + 2x+pw.
+ * epi(v) = act(v*scale[n] + shift[n]) * mul (act 0 none, 1 GELU(erf), 2 Swish, 3 ReLU; mul [rows][ldc] or NULL); outputs as mvs_gemm_x3p. */
+int mvs_conv_x3p(const void* Xp, int64_t x_rows_alloc, int zero_row, const void* Wp, int64_t w_rows_alloc, int mode, int images, int H, int W, int Cp,
+                 int N, float* C, int ldc, const float* scale, const float* shift, int act, const float* mul, void* Op, mvs_stream_t stream);
 int mvs_gemm_x3p_qkv(const void* Ap, const void* Bp, int images, int Np, int C, int heads, int64_t a_rows_alloc, int64_t b_rows_alloc,
                      const float* bias, float qscale, void* Qp, void* Kp, void* Vtp, mvs_stream_t stream);
 int mvs_attention_x3p(const void* Qp, const void* Kp, const void* Vtp, void* Op, int images, int N, int Np, int heads, mvs_stream_t stream);

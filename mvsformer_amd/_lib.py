@@ -154,6 +154,7 @@ SIGNATURES = {
     "mvs_x3p_unpack": (I, [P, P, L, I, I, L, P]),
     "mvs_layernorm_x3p": (I, [P, P, P, P, L, I, I, I, F, P]),
     "mvs_gemm_x3p": (I, [P, P, I, I, I, L, L, P, I, P, P, I, P, P, P]),
+    "mvs_conv_x3p": (I, [P, L, I, P, L, I, I, I, I, I, I, P, I, P, P, I, P, P, P]),
     "mvs_gemm_x3p_qkv": (I, [P, P, I, I, I, I, L, L, P, F, P, P, P, P]),
     "mvs_attention_x3p": (I, [P, P, P, P, I, I, I, I, P]),
     "mvs_cls_attention_x3p": (I, [P, P, P, I, I, I, I, P]),

@@ -20,6 +20,8 @@
 //   mvs_attention_x3p     flash attention on packed Q / K / V^T -> packed [M][C]; S^T = K Q^T so that a lane's accumulators ARE its
 //                         fragment of P^T (no LDS round trip of P), online softmax with two cross-lane steps per tile
 //   mvs_cls_attention_x3p the CLS row of softmax(Q K^T) per head from the packed operands (mvsformer_model.py:257 reads only that row)
+#include <stdlib.h>
+
 #include "common.h"
 #include "split3.h"
 
@@ -162,19 +164,38 @@ struct PGemmArgs {
     void* Vp;                 // V^T [image][head][4 row tiles of d][Np / 32][3] pieces, keys of a 32-step in the order pi (see attention)
     int Cd, NH, Np;
     float qscale;
+    // implicit convolutions over a packed channel-last map [images * cH * cW pixels][Cp] (MODE 0; models/module.py:353-368,450-466):
+    //   a_mode 1: 3 x 3, padding 1: row m = output pixel, K = 9 * Cp, k = tap * Cp + c (tap = ky * 3 + kx)
+    //   a_mode 2: ConvTranspose2d(kernel 4, stride 2, padding 1), output-parity class blockIdx.y = ph * 2 + pw: row m = INPUT pixel (y, x),
+    //             K = 4 * Cp, k = (th * 2 + tw) * Cp + c, input pixel (y + (ph ? 1 - th : -th), x + (pw ? 1 - tw : -tw)); the class's weights
+    //             are b_class_bytes apart; its output pixel is (2y + ph, 2x + pw): output ROW = image * 4 cH cW + (2y + ph) * 2 cW + 2x + pw
+    // taps outside the image read row `zero_row` of the map (a row of zeros the caller keeps in its padding)
+    int a_mode, cH, cW, Cp, zero_row;
+    long long b_class_bytes;
+    const float* mul;         // [M][ldc] or null: v *= mul after the activation (before res)
 };
 
-constexpr int GT = 128;                                      // block tile (rows and columns)
-constexpr int GSTAGE = 2 * 8 * KSTEP;                        // one LDS stage: 8 row tiles of each operand x 3 terms = 48 KiB
+constexpr int GT = 128;                                      // rows of activations per block (the j side by default)
 
-// MODE 0: fp32 C and / or plain packed output.  MODE 1: the qkv form.
+// MODE 0: fp32 C and / or plain packed output.  MODE 1: the qkv form (TI = 128 only).
 // The MFMA's first operand supplies the accumulator's ROW index i (a lane holds four consecutive i), the second the column j (lane & 15).
-// T1 = the operand in the first slot, T2 = the second.  Default T1 = weights (i = n), T2 = activations (j = m): a lane holds FOUR
-// CONSECUTIVE n of ONE row m - 16-byte fp32 stores, 8-byte packed stores (half a lane's 8-k chunk of the next GEMM's A operand).
-// The v columns of the qkv form swap the slots (i = token, j = d): four consecutive TOKENS of one d, which is what V^T's pieces want.
-template <int MODE>
-__global__ __launch_bounds__(256) void gemm_x3p_kernel(const PGemmArgs a) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * GSTAGE];
+// T1 = the operand in the first slot, T2 = the second.  Default T1 = weights (i = n, TI columns per block), T2 = activations (j = m, 128
+// rows): a lane holds FOUR CONSECUTIVE n of ONE row m - 16-byte fp32 stores, 8-byte packed stores (half a lane's 8-k chunk of the next
+// GEMM's A operand).  The v columns of the qkv form swap the slots (i = token, j = d): four consecutive TOKENS of one d, which is what
+// V^T's pieces want.
+//   TI  columns per block (128 or 64): 128 x 64 blocks have 36 KiB stages -> two blocks per CU, whose epilogues / barriers / LDS-DMA waits
+//       overlap the other block's MFMAs; 128 x 128 blocks move 2/3 of the bytes per MFMA through L2 -> LDS but own their CU
+//   NW  wavefronts (4 or 8): 2 along i x NW/2 along j
+//   NS  LDS stages (2: the barrier of step k drains the LDS-DMA of step k, issued one step earlier; 3: issued TWO steps earlier, counted
+//       vmcnt waits + raw s_barrier so that a step's DMA flies across the previous step's barrier)
+template <int MODE, int TI, int NW, int NS>
+__global__ __launch_bounds__(NW * 64, (TI == 64 || NW == 8) ? 2 : 1) void gemm_x3p_kernel(const PGemmArgs a) {
+    constexpr int RT1 = TI / 16, RTS = RT1 + 8;              // row tiles of T1 / of a stage ([T1 | T2], three terms each)
+    constexpr int STAGE = RTS * KSTEP;
+    constexpr int TPW = RTS / NW;                            // row tiles one wavefront fills per K step
+    constexpr int WJ = NW / 2, JT = 8 / WJ, IT = TI / 32;    // the wavefront's tile: IT i tiles x JT j tiles of 16
+    static_assert(RTS % NW == 0 && (MODE == 0 || TI == 128), "tile / wavefront combination");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware order: block id -> XCD id % 8; the column blocks of one row block run on ONE XCD back to back (its A panel stays in that L2)
@@ -182,46 +203,97 @@ __global__ __launch_bounds__(256) void gemm_x3p_kernel(const PGemmArgs a) {
     const int mb = (slot / a.nbn) * 8 + xcd, nb = slot % a.nbn;
     if (mb >= a.nbm) return;
     const int KS = a.K >> 5;
-    const bool vsec = MODE == 1 && nb * GT >= 2 * a.Cd;
-    // descriptors (block-uniform, scalar)
-    const rsrc_t rA = rsrc_of(a.Ap, (unsigned)((size_t)a.art * KS * KSTEP)), rB = rsrc_of(a.Bp, (unsigned)((size_t)a.brt * KS * KSTEP));
-    // LDS-DMA roles: wavefronts 0, 1 fill T1's eight row tiles (four each), 2, 3 fill T2's; 12 pieces per wavefront per K step
-    const bool fillA = ((wave >> 1) == 0) == vsec;           // this wavefront fills from the activations
-    const rsrc_t rsrc = fillA ? rA : rB;
-    const int rt0 = (fillA ? mb : nb) * 8 + (wave & 1) * 4;  // first of its four row tiles
+    const bool vsec = MODE == 1 && nb * TI >= 2 * a.Cd;
+    const rsrc_t rA = rsrc_of(a.Ap, (unsigned)((size_t)a.art * (MODE == 0 && a.a_mode ? a.Cp >> 5 : KS) * KSTEP));
+    const rsrc_t rB = rsrc_of(reinterpret_cast<const unsigned char*>(a.Bp) + (MODE == 0 ? (size_t)blockIdx.y * a.b_class_bytes : 0), (unsigned)((size_t)a.brt * KS * KSTEP));
+    // LDS-DMA roles: the stage's RTS row tiles are dealt to the wavefronts TPW at a time
     const unsigned voff = lane * 16;
-    unsigned char* const fill_dst = lds + ((wave >> 1) * 8 + (wave & 1) * 4) * KSTEP;
+    // implicit convolution: the pixel (image base row, y, x) of this lane's row in each activation row tile the wavefront fills
+    const int CB = MODE == 0 && a.a_mode ? a.Cp >> 5 : 1;    // k steps per tap
+    int pix_base[TPW], pix_y[TPW], pix_x[TPW];
+    if (MODE == 0 && a.a_mode) {
+#pragma unroll
+        for (int r = 0; r < TPW; ++r) {
+            const int g = wave * TPW + r;
+            const int m = mb * GT + (g - RT1) * 16 + (lane & 15);
+            const int hw = a.cH * a.cW, img = m / hw, rem = m - img * hw;
+            pix_base[r] = g >= RT1 && m < a.M ? img * hw : -1;
+            pix_y[r] = rem / a.cW;
+            pix_x[r] = rem - pix_y[r] * a.cW;
+        }
+    }
     auto fill = [&](int stage, int ks) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const unsigned soff = (unsigned)(((rt0 + r) * KS + ks) * KSTEP);
+        for (int r = 0; r < TPW; ++r) {
+            const int g = wave * TPW + r;                    // row tile of the stage (scalar)
+            const bool first = g < RT1;                      // belongs to T1
+            const bool fromA = first == vsec;                // T1 = weights unless the slots are swapped
+            if (MODE == 0 && a.a_mode && !first) {           // gathered rows of the map: per-lane source rows
+                const int tap = ks / CB, cb = ks - tap * CB;
+                int dy, dx;
+                if (a.a_mode == 1) {
+                    dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+                } else {
+                    const int ph = (int)blockIdx.y >> 1, pw = (int)blockIdx.y & 1, th = tap >> 1, tw = tap & 1;
+                    dy = ph ? 1 - th : -th, dx = pw ? 1 - tw : -tw;
+                }
+                const int iy = pix_y[r] + dy, ix = pix_x[r] + dx;
+                const bool inb = pix_base[r] >= 0 && (unsigned)iy < (unsigned)a.cH && (unsigned)ix < (unsigned)a.cW;
+                const int row = inb ? pix_base[r] + iy * a.cW + ix : a.zero_row;
+                const unsigned vo = (unsigned)((row >> 4) * CB) * (unsigned)KSTEP + (unsigned)(((lane >> 4) << 8) + ((row & 15) << 4));
+                const unsigned soff = (unsigned)(cb * KSTEP);
 #pragma unroll
-            for (int t = 0; t < 3; ++t) dma16(rsrc, fill_dst + stage * GSTAGE + (r * 3 + t) * PIECE, voff, soff + t * PIECE);
+                for (int t = 0; t < 3; ++t) dma16(rA, lds + stage * STAGE + (g * 3 + t) * PIECE, vo, soff + t * PIECE);
+                continue;
+            }
+            const int rt = (fromA ? mb * 8 : nb * RT1) + (first ? g : g - RT1);
+            const unsigned soff = (unsigned)((rt * KS + ks) * KSTEP);
+            const rsrc_t rs = fromA ? rA : rB;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) dma16(rs, lds + stage * STAGE + (g * 3 + t) * PIECE, voff, soff + t * PIECE);
         }
     };
-    const int wi = wave >> 1, wj = wave & 1;                 // the wavefront's 64 x 64 quadrant: i tiles wi*4.., j tiles wj*4..
-    const unsigned char* const f1 = lds + (wi * 4) * KSTEP + lane * 16;
-    const unsigned char* const f2 = lds + (8 + wj * 4) * KSTEP + lane * 16;
+    const int wi = wave / WJ, wj = wave % WJ;
+    const unsigned char* const f1 = lds + (wi * IT) * KSTEP + lane * 16;
+    const unsigned char* const f2 = lds + (RT1 + wj * JT) * KSTEP + lane * 16;
 
-    f32x4 acc[4][4];                                          // [j tile][i tile]
+    f32x4 acc[JT][IT];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+    for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) acc[jt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < IT; ++it) acc[jt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#ifndef X3P_ABLATE
+#define X3P_ABLATE 0                                         // experiment builds only (make exp EXPFLAGS=-DX3P_ABLATE=n): 1 no LDS-DMA in the loop, 2 no MFMAs in the loop,
+#endif                                                       // 3 MFMAs only (no LDS-DMA, barriers, fragment reads in the loop), 4 fragment reads + MFMAs (no LDS-DMA, no barriers)
+#if X3P_ABLATE == 3
+    bf16x8 t1[IT][3], t2[JT][3];
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) t1[it][t] = *reinterpret_cast<const bf16x8*>(f1 + (it * 3 + t) * PIECE);
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) t2[jt][t] = *reinterpret_cast<const bf16x8*>(f2 + (jt * 3 + t) * PIECE);
+#endif
     auto compute = [&](int stage) {
-        bf16x8 t1[4][3], t2[4][3];
+#if X3P_ABLATE != 3
+        bf16x8 t1[IT][3], t2[JT][3];
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
+        for (int it = 0; it < IT; ++it)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) t1[it][t] = *reinterpret_cast<const bf16x8*>(f1 + stage * GSTAGE + (it * 3 + t) * PIECE);
+            for (int t = 0; t < 3; ++t) t1[it][t] = *reinterpret_cast<const bf16x8*>(f1 + stage * STAGE + (it * 3 + t) * PIECE);
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+        for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) t2[jt][t] = *reinterpret_cast<const bf16x8*>(f2 + stage * GSTAGE + (jt * 3 + t) * PIECE);
-        // smallest products first (split3.h's mfma6 order), each term pair swept over the 16 accumulators: no two consecutive MFMAs share one
+            for (int t = 0; t < 3; ++t) t2[jt][t] = *reinterpret_cast<const bf16x8*>(f2 + stage * STAGE + (jt * 3 + t) * PIECE);
+#else
+        asm volatile("" ::: "memory");
+#endif
+        // smallest products first (split3.h's mfma6 order), each term pair swept over all accumulators: no two consecutive MFMAs share one
 #define X3P_SWEEP(TA, TB)                                                                                                              \
-    _Pragma("unroll") for (int jt = 0; jt < 4; ++jt) _Pragma("unroll") for (int it = 0; it < 4; ++it) acc[jt][it] =                    \
+    _Pragma("unroll") for (int jt = 0; jt < JT; ++jt) _Pragma("unroll") for (int it = 0; it < IT; ++it) acc[jt][it] =                  \
         __builtin_amdgcn_mfma_f32_16x16x32_bf16(t1[it][TA], t2[jt][TB], acc[jt][it], 0, 0, 0);
         X3P_SWEEP(1, 1)
         X3P_SWEEP(0, 2)
@@ -232,32 +304,80 @@ __global__ __launch_bounds__(256) void gemm_x3p_kernel(const PGemmArgs a) {
 #undef X3P_SWEEP
     };
 
-    fill(0, 0);
-    int ks = 0;
-    for (; ks + 2 <= KS; ks += 2) {                          // two K steps per trip: the stage index is a literal
-        __syncthreads();                                     // stage 0 has landed (the barrier drains the LDS-DMA queue); stage 1's readers are done
-        fill(1, ks + 1);
-        compute(0);
-        __syncthreads();
-        if (ks + 2 < KS) fill(0, ks + 2);
-        compute(1);
-    }
-    if (ks < KS) {
-        __syncthreads();
-        compute(0);
+    if constexpr (NS == 2) {
+        fill(0, 0);
+        int ks = 0;
+        for (; ks + 2 <= KS; ks += 2) {                      // two K steps per trip: the stage index is a literal
+            if (X3P_ABLATE < 3 || ks == 0) __syncthreads();  // stage 0 has landed (the barrier drains the LDS-DMA queue); stage 1's readers are done
+            if (X3P_ABLATE == 0 || X3P_ABLATE == 2) fill(1, ks + 1);
+            if (X3P_ABLATE != 2 || ks == 0) compute(0);
+            if (X3P_ABLATE < 3) __syncthreads();
+            if ((X3P_ABLATE == 0 || X3P_ABLATE == 2) && ks + 2 < KS) fill(0, ks + 2);
+            if (X3P_ABLATE != 2) compute(1);
+        }
+        if (ks < KS) {
+            __syncthreads();
+            compute(0);
+        }
+    } else {
+        // three stages: step k's pieces are issued during step k-2.  Before step k's barrier a wavefront waits for ITS pieces of step k only
+        // (vmcnt = the pieces of step k+1 it has in flight); the raw s_barrier (no fence: __syncthreads() would drain the queue) then says
+        // everybody's pieces of step k are in LDS and everybody has read step k-1's stage, which step k+2's pieces may now overwrite.
+        constexpr int PW = TPW * 3;                          // LDS-DMA instructions per wavefront per step
+        auto wait_own = [&](bool younger_in_flight) {
+            __builtin_amdgcn_sched_barrier(0);               // (the previous step's MFMAs stay above the waits: hipcc otherwise sinks them across the asm statements and the barrier)
+            if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        fill(0, 0);
+        if (KS > 1) fill(1, 1);
+        int ks = 0;
+        for (; ks + 3 <= KS; ks += 3) {
+            wait_own(ks + 1 < KS);
+            if (ks + 2 < KS) fill(2, ks + 2);
+            compute(0);
+            wait_own(ks + 2 < KS);
+            if (ks + 3 < KS) fill(0, ks + 3);
+            compute(1);
+            wait_own(ks + 3 < KS);
+            if (ks + 4 < KS) fill(1, ks + 4);
+            compute(2);
+        }
+        if (ks < KS) {                                       // one or two steps left: stages 0 (and 1)
+            wait_own(ks + 1 < KS);
+            compute(0);
+            if (ks + 1 < KS) {
+                wait_own(false);
+                compute(1);
+            }
+        }
     }
 
     // ---- epilogue: lane (jl = lane & 15, kb = lane >> 4) holds acc[jt][it][r] = D[i = i0 + it*16 + 4 kb + r][j = j0 + jt*16 + jl]
     const int jl = lane & 15, kb = lane >> 4;
     if (!vsec) {
-        const int n0 = nb * GT + wi * 64, m0 = mb * GT + wj * 64;      // i = n, j = m
+        const int n0 = nb * TI + wi * (TI / 2), m0 = mb * GT + wj * (GT / WJ);      // i = n, j = m
         int img = 0, tok0 = 0, head = 0, sec = 0;
         if (MODE == 1) {
             sec = n0 / a.Cd;
             head = (n0 - sec * a.Cd) >> 6;
         }
+        const bool has_sc = a.scale != nullptr, has_sh = a.shift != nullptr;
+        int orow[JT];                                         // output row of the lane's row m (the transposed convolution interleaves its parity classes)
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
+        for (int jt = 0; jt < JT; ++jt) {
+            const int m = m0 + jt * 16 + jl;
+            orow[jt] = m;
+            if (MODE == 0 && a.a_mode == 2) {
+                const int hw = a.cH * a.cW, img = m / hw, rem = m - img * hw, y = rem / a.cW, x = rem - y * a.cW;
+                orow[jt] = img * 4 * hw + (2 * y + ((int)blockIdx.y >> 1)) * 2 * a.cW + 2 * x + ((int)blockIdx.y & 1);
+            }
+        }
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
             const int m = m0 + jt * 16 + jl;
             if (m >= a.M) continue;
             if (MODE == 1) {
@@ -265,20 +385,29 @@ __global__ __launch_bounds__(256) void gemm_x3p_kernel(const PGemmArgs a) {
                 tok0 = (m0 + jt * 16) - img * a.Np;               // first token of this 16-row tile (Np % 16 == 0: the tile stays in one image)
             }
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
+            for (int it = 0; it < IT; ++it) {
                 const int n = n0 + it * 16 + 4 * kb;
                 if (n >= a.N) continue;
                 float v[4];
                 f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-                if (a.scale) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
-                if (a.shift) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+                if (has_sc) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+                if (has_sh) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     v[r] = fmaf(acc[jt][it][r], sc[r], sh[r]);
-                    if (MODE == 0 && a.act == 1) v[r] = gelu_erf(v[r]);
+                    if (MODE == 0) {
+                        if (a.act == 1) v[r] = gelu_erf(v[r]);
+                        else if (a.act == 2) v[r] = v[r] / (1.0f + __expf(-v[r]));
+                        else if (a.act == 3) v[r] = fmaxf(v[r], 0.0f);
+                    }
                 }
                 if (MODE == 0) {
-                    const size_t o = (size_t)m * a.ldc + n;
+                    const size_t o = (size_t)orow[jt] * a.ldc + n;
+                    if (a.mul) {
+                        const f32x4 mm = *reinterpret_cast<const f32x4*>(a.mul + o);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] *= mm[r];
+                    }
                     if (a.res) {
                         const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + o);
 #pragma unroll
@@ -289,8 +418,8 @@ __global__ __launch_bounds__(256) void gemm_x3p_kernel(const PGemmArgs a) {
                         u32x2 h, mm, l;
                         split4(v, h, mm, l);
                         const int KSo = a.N >> 5;
-                        unsigned char* d = reinterpret_cast<unsigned char*>(a.Op) + ((size_t)(m >> 4) * KSo + (n >> 5)) * KSTEP +
-                                           ((((n >> 3) & 3) * 16 + jl) * 16) + ((n >> 2) & 1) * 8;
+                        unsigned char* d = reinterpret_cast<unsigned char*>(a.Op) + ((size_t)(orow[jt] >> 4) * KSo + (n >> 5)) * KSTEP +
+                                           ((((n >> 3) & 3) * 16 + (orow[jt] & 15)) * 16) + ((n >> 2) & 1) * 8;
                         *reinterpret_cast<u32x2*>(d) = h;
                         *reinterpret_cast<u32x2*>(d + PIECE) = mm;
                         *reinterpret_cast<u32x2*>(d + 2 * PIECE) = l;
@@ -312,12 +441,12 @@ __global__ __launch_bounds__(256) void gemm_x3p_kernel(const PGemmArgs a) {
                 }
             }
         }
-    } else {
-        // v columns, slots swapped: i = token (m), j = d (n).  acc[jt][it]: d = jt*16 + jl of head `head`, tokens m0 + it*16 + 4 kb + r.
-        // V^T piece (d tile jt, key step of 32 tokens): lane (kb, jl) element e <-> key pi(kb, e) = (e < 4 ? 4 kb + e : 16 + 4 kb + e - 4) of the
+    } else if constexpr (MODE == 1) {
+        // v columns, slots swapped: i = token (m), j = d (n).  acc[jt][it]: d = dt0*16 + jt*16 + jl of head `head`, tokens m0 + it*16 + 4 kb + r.
+        // V^T piece (d tile, key step of 32 tokens): lane (kb, jl) element e <-> key pi(kb, e) = (e < 4 ? 4 kb + e : 16 + 4 kb + e - 4) of the
         // step - exactly the four tokens this lane holds in the step's first (e < 4) and second (e >= 4) 16-token tile: one 16-byte store.
-        const int m0 = mb * GT + wi * 64, n0 = nb * GT + wj * 64;
-        const int head = (n0 - 2 * a.Cd) >> 6;
+        const int m0 = mb * GT + wi * 64, n0 = nb * TI + wj * (GT / WJ);
+        const int head = (n0 - 2 * a.Cd) >> 6, dt0 = (n0 & 63) >> 4;
         const int KSV = a.Np >> 5;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {                // the 64 tokens = two key steps
@@ -325,14 +454,14 @@ __global__ __launch_bounds__(256) void gemm_x3p_kernel(const PGemmArgs a) {
             if (ms >= a.M) continue;                          // (M = images * Np is a multiple of 32: a step is all rows or none)
             const int img = ms / a.Np, step = (ms - img * a.Np) >> 5;
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
+            for (int jt = 0; jt < JT; ++jt) {
                 const int n = n0 + jt * 16 + jl;
                 const float sc = a.scale ? a.scale[n] : 1.0f, sh = a.shift ? a.shift[n] : 0.0f;
                 float v[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[jt][2 * half][r], sc, sh), v[4 + r] = fmaf(acc[jt][2 * half + 1][r], sc, sh);
                 const mvsx3::Split3 sp = mvsx3::split3(v);
-                unsigned char* d = reinterpret_cast<unsigned char*>(a.Vp) + ((((size_t)img * a.NH + head) * 4 + jt) * KSV + step) * KSTEP + lane * 16;
+                unsigned char* d = reinterpret_cast<unsigned char*>(a.Vp) + ((((size_t)img * a.NH + head) * 4 + dt0 + jt) * KSV + step) * KSTEP + lane * 16;
                 *reinterpret_cast<bf16x8*>(d) = sp.h;
                 *reinterpret_cast<bf16x8*>(d + PIECE) = sp.m;
                 *reinterpret_cast<bf16x8*>(d + 2 * PIECE) = sp.l;
@@ -596,15 +725,36 @@ extern "C" int mvs_layernorm_x3p(const float* x, const float* gamma, const float
 }
 
 namespace {
+// MVS_X3P_CFG / MVS_X3P_CFG_QKV (diagnostics, read once): "TI,NW,NS" of the plain GEMM / of the qkv form instead of the choice below
+struct PCfg { int ti, nw, ns; };
+PCfg env_cfg(const char* name) {
+    PCfg c{0, 0, 0};
+    if (const char* e = getenv(name)) sscanf(e, "%d,%d,%d", &c.ti, &c.nw, &c.ns);
+    return c;
+}
+template <int MODE, int TI, int NW, int NS>
+void launch_one(const PGemmArgs& a, hipStream_t s) {
+    const unsigned grid = (unsigned)(((a.nbm + 7) / 8) * 8 * a.nbn);
+    hipLaunchKernelGGL((gemm_x3p_kernel<MODE, TI, NW, NS>), dim3(grid, a.a_mode == 2 ? 4 : 1), dim3(NW * 64), 0, s, a);
+}
 int launch_pgemm(PGemmArgs& a, int mode, int64_t a_rows_alloc, int64_t b_rows_alloc, hipStream_t s) {
+    static const PCfg e0 = env_cfg("MVS_X3P_CFG"), e1 = env_cfg("MVS_X3P_CFG_QKV");
     a.art = (int)(a_rows_alloc / 16), a.brt = (int)(b_rows_alloc / 16);
-    a.nbm = (a.M + GT - 1) / GT, a.nbn = (a.N + GT - 1) / GT;
     const int KS = a.K / 32;
     MVS_REQUIRE((int64_t)a.art * KS * KSTEP < ((int64_t)1 << 32) && (int64_t)a.brt * KS * KSTEP < ((int64_t)1 << 32), "mvs_gemm_x3p: a packed operand exceeds 4 GiB");
-    const unsigned grid = (unsigned)(((a.nbm + 7) / 8) * 8 * a.nbn);
-    if (mode == 0) hipLaunchKernelGGL(gemm_x3p_kernel<0>, dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(gemm_x3p_kernel<1>, dim3(grid), dim3(256), 0, s, a);
-    return mvs::finish_launch("mvs_gemm_x3p");
+    PCfg c = mode == 0 ? e0 : e1;
+    // measured at the ViT-small shapes (profiles/r06_bench_x3p.txt): eight wavefronts on a 128 x 128 tile (two per SIMD: one's barrier / LDS-DMA
+    // issue under the other's MFMAs) for the plain epilogues; the GELU + packed epilogue of fc1 prefers 128 x 64 tiles, two blocks per CU
+    // (a block's epilogue under the other block's main loop)
+    if (c.ti == 0) c = (mode == 0 && ((a.act == 1 && a.Op) || a.N <= 64)) ? PCfg{64, 4, 2} : PCfg{128, 8, 2};
+    if (mode == 1) c.ti = 128;
+    a.nbm = (a.M + GT - 1) / GT, a.nbn = (a.N + c.ti - 1) / c.ti;
+#define X3P_CASE(M_, TI_, NW_, NS_) if (mode == M_ && c.ti == TI_ && c.nw == NW_ && c.ns == NS_) { launch_one<M_, TI_, NW_, NS_>(a, s); return mvs::finish_launch("mvs_gemm_x3p"); }
+    X3P_CASE(0, 128, 4, 2) X3P_CASE(0, 128, 8, 2) X3P_CASE(0, 128, 8, 3) X3P_CASE(0, 128, 4, 3) X3P_CASE(0, 64, 4, 2)
+    X3P_CASE(1, 128, 4, 2) X3P_CASE(1, 128, 8, 2) X3P_CASE(1, 128, 8, 3) X3P_CASE(1, 128, 4, 3)
+#undef X3P_CASE
+    mvs::set_error("mvs_gemm_x3p: no kernel instance for TI=%d NW=%d NS=%d", c.ti, c.nw, c.ns);
+    return MVS_EINVAL;
 }
 }  // namespace
 
@@ -617,6 +767,21 @@ extern "C" int mvs_gemm_x3p(const void* Ap, const void* Bp, int M, int N, int K,
     PGemmArgs a{};
     a.Ap = Ap, a.Bp = Bp, a.M = M, a.N = N, a.K = K, a.C = C, a.ldc = ldc, a.scale = scale, a.shift = shift, a.act = act, a.res = res, a.Op = Op;
     return launch_pgemm(a, 0, a_rows_alloc, b_rows_alloc, MVS_STREAM(stream));
+}
+
+extern "C" int mvs_conv_x3p(const void* Xp, int64_t x_rows_alloc, int zero_row, const void* Wp, int64_t w_rows_alloc, int mode, int images, int H, int W,
+                            int Cp, int N, float* C, int ldc, const float* scale, const float* shift, int act, const float* mul, void* Op, mvs_stream_t stream) {
+    MVS_REQUIRE(Xp && Wp && (mode == 1 || mode == 2) && images >= 1 && H >= 1 && W >= 1 && Cp >= 32 && Cp % 32 == 0 && N >= 4 && N % 4 == 0,
+                "mvs_conv_x3p: mode 1 (3x3) / 2 (transposed 4x4 stride 2), Cp %% 32 == 0, N %% 4 == 0");
+    const int64_t M = (int64_t)images * H * W;
+    MVS_REQUIRE(M < ((int64_t)1 << 29) && x_rows_alloc % 16 == 0 && x_rows_alloc >= M && zero_row >= 0 && zero_row < x_rows_alloc && w_rows_alloc % 16 == 0 && w_rows_alloc >= N,
+                "mvs_conv_x3p: the packed map holds fewer rows than pixels, or zero_row outside it");
+    MVS_REQUIRE((C || Op) && (!C || (ldc >= N && ldc % 4 == 0)) && (!mul || C || Op) && act >= 0 && act <= 3 && (!Op || N % 32 == 0), "mvs_conv_x3p: bad outputs");
+    PGemmArgs a{};
+    a.Ap = Xp, a.Bp = Wp, a.M = (int)M, a.N = N, a.K = (mode == 1 ? 9 : 4) * Cp, a.C = C, a.ldc = C ? ldc : N, a.scale = scale, a.shift = shift, a.act = act, a.mul = mul, a.Op = Op;
+    a.a_mode = mode, a.cH = H, a.cW = W, a.Cp = Cp, a.zero_row = zero_row;
+    a.b_class_bytes = mode == 2 ? (long long)(w_rows_alloc / 16) * (a.K / 32) * KSTEP : 0;
+    return launch_pgemm(a, 0, x_rows_alloc, w_rows_alloc, MVS_STREAM(stream));
 }
 
 extern "C" int mvs_gemm_x3p_qkv(const void* Ap, const void* Bp, int images, int Np, int C, int heads, int64_t a_rows_alloc, int64_t b_rows_alloc,

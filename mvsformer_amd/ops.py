@@ -1632,6 +1632,35 @@ def x3p_pack(x: torch.Tensor, rows_alloc: Optional[int] = None) -> Packed:
     return out
 
 
+def x3p_pack_classes(w: torch.Tensor, rows_alloc: int) -> Packed:
+    """``[classes, R, K]`` -> one buffer of ``classes`` packed matrices, ``rows_alloc`` rows each (the transposed convolution's parity classes)."""
+    _chk(w, "w")
+    ncls, R, K = w.shape
+    out = Packed(ncls * rows_alloc, K, w.device, rows_alloc=ncls * rows_alloc)
+    per = int(_lib.load().mvs_x3p_bytes(rows_alloc, K))
+    for c in range(ncls):
+        _call("mvs_x3p_pack", "x3p_pack", w[c].data_ptr(), out.ptr() + c * per, R, K, K, rows_alloc, _stream())
+    out.rows, out.rows_alloc = R, rows_alloc                  # per class
+    return out
+
+
+def conv_x3p(X: Packed, W: Packed, mode: int, images: int, H: int, Wd: int, N: int, C: Optional[torch.Tensor] = None, scale=None, shift=None,
+             act: int = 0, mul=None, out: Optional[Packed] = None) -> None:
+    """Implicit 3x3 (``mode`` 1) / transposed 4x4 stride-2 (``mode`` 2) convolution over the packed channel-last map ``X`` ``[images*H*Wd, Cp]``
+    (see ``mvs_conv_x3p``); ``X`` must hold at least one padding row beyond its pixels, all zeros (row ``X.rows``)."""
+    M = images * H * Wd
+    if X.rows != M or X.rows_alloc <= M:
+        raise _lib.MvsHipError("conv_x3p: map of %d rows (%d allocated) for %d pixels + a zero row" % (X.rows, X.rows_alloc, M))
+    taps = 9 if mode == 1 else 4
+    if W.K != taps * X.K:
+        raise _lib.MvsHipError("conv_x3p: weights K = %d for %d taps x %d channels" % (W.K, taps, X.K))
+    if C is not None:
+        _chk(C, "C")
+    _opt(scale, "scale"), _opt(shift, "shift"), _opt(mul, "mul")
+    _call("mvs_conv_x3p", ("x3p_gemm", "flops", 2.0 * M * N * W.K * (4 if mode == 2 else 1)), X.ptr(), X.rows_alloc, M, W.ptr(), W.rows_alloc, int(mode), images, H, Wd,
+          X.K, N, _ptr(C), C.shape[-1] if C is not None else 0, _ptr(scale), _ptr(shift), int(act), _ptr(mul), out.ptr() if out is not None else None, _stream())
+
+
 def x3p_unpack(p: Packed) -> torch.Tensor:
     x = torch.empty(p.rows, p.K, device=p.buf.device, dtype=torch.float32)
     _call("mvs_x3p_unpack", "x3p_unpack", p.ptr(), _ptr(x), p.rows, p.K, p.K, p.rows_alloc, _stream())

@@ -299,9 +299,43 @@ class VITDecoderStage4Single(nn.Module):
                         wp=_f(a.proj.weight).reshape(a.proj.out_channels, -1), bp=_f(a.proj.bias),
                         w1=_convT_matrices(self.decoder[0].weight), f1=_fold(self.decoder[0], self.decoder[1]),
                         w2=_convT_matrices(self.decoder[3].weight), f2=_fold(self.decoder[3], self.decoder[4]))
+            if self._packed_ok():
+                # the same matrices split once into MFMA fragments (csrc/vit_packed.hip; channels of the [x | att] map padded to a multiple of 32)
+                cpp = (cl_in + 31) // 32 * 32
+                prep.update(cpp=cpp, wl_p=ops.x3p_pack(_conv3_matrix(a.conv_l[0].weight, cpp)), wr_p=ops.x3p_pack(prep["wr"]), wp_p=ops.x3p_pack(prep["wp"]),
+                            w1_p=ops.x3p_pack_classes(prep["w1"], 128), w2_p=ops.x3p_pack_classes(prep["w2"], 128))
             _publish_cache()
             self._cache = (key, prep)
         return self._cache[1]
+
+    def _packed_ok(self) -> bool:
+        a, d = self.attn, self.decoder
+        chans = (a.conv_r[0].in_channels, a.proj.out_channels, d[0].out_channels)
+        return all(c % 32 == 0 for c in chans) and d[3].out_channels % 4 == 0 and os.environ.get("MVS_VIT_PACKED", "1") != "0"
+
+    def _forward_packed(self, p, xc, ac):
+        """The decoder on pre-split operands: every convolution is an implicit GEMM whose A operand is gathered from a packed channel-last map
+        by LDS-DMA (``mvs_conv_x3p``); intermediate maps are written packed by the producing epilogue."""
+        B, h, w, C = xc.shape
+        M, nh, dev = B * h * w, ac.shape[-1], xc.device
+        ra = (M + 128) // 128 * 128                           # rows allocated: the pixels + at least one zero row (taps outside the image)
+        cat = torch.zeros(M, p["cpp"], device=dev, dtype=torch.float32)
+        cat[:, :C] = xc.reshape(M, C)
+        cat[:, C:C + nh] = ac.reshape(M, nh)
+        x1 = torch.empty(M, C, device=dev, dtype=torch.float32)
+        ops.conv_x3p(ops.x3p_pack(cat, ra), p["wl_p"], 1, B, h, w, C, C=x1, scale=p["fl"][0], shift=p["fl"][1], act=2)
+        xr = (xc * ac.mean(dim=-1, keepdim=True)).reshape(M, C).contiguous()
+        x12 = ops.Packed(M, C, dev)
+        ops.conv_x3p(ops.x3p_pack(xr, ra), p["wr_p"], 1, B, h, w, C, scale=p["fr"][0], shift=p["fr"][1], act=2, mul=x1, out=x12)
+        co = p["wp"].shape[0]
+        y = ops.Packed(M, co, dev, rows_alloc=ra, zero=True)
+        ops.gemm_x3p(x12, p["wp_p"], co, shift=p["bp"], out=y)
+        c1, c2 = p["w1"].shape[1], p["w2"].shape[1]
+        y1 = ops.Packed(4 * M, c1, dev, rows_alloc=(4 * M + 128) // 128 * 128, zero=True)
+        ops.conv_x3p(y, p["w1_p"], 2, B, h, w, c1, scale=p["f1"][0], shift=p["f1"][1], act=1, out=y1)
+        out = torch.empty(B, 4 * h, 4 * w, c2, device=dev, dtype=torch.float32)
+        ops.conv_x3p(y1, p["w2_p"], 2, B, 2 * h, 2 * w, c2, C=out.view(16 * M, c2), scale=p["f2"][0], shift=p["f2"][1], act=1)
+        return out.permute(0, 3, 1, 2)
 
     @staticmethod
     def _up(x_cl, wm, fold, act):
@@ -323,6 +357,8 @@ class VITDecoderStage4Single(nn.Module):
             xc = x.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous()
             ac = att.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous()
             nh = ac.shape[-1]
+            if "wl_p" in p:
+                return self._forward_packed(p, xc, ac)
             cat = torch.zeros(B, h, w, p["cp"], device=x.device, dtype=torch.float32)
             cat[..., :C] = xc
             cat[..., C:C + nh] = ac

@@ -237,3 +237,45 @@ def test_vit_packed_path_matches_split_on_the_fly_path(dev, monkeypatch):
     assert tok.shape == tok0.shape == (2, 36, 384) and att.shape == att0.shape == (2, 6, 36)
     assert _rel(tok, tok0.cpu()) < 2e-5 and _rel(att, att0.cpu()) < 2e-5
     assert _rel(full_tok, tok0.cpu()) < 2e-5 and _rel(full_att[:, :, 0], att0.cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("cfg", [None, "128,4,2", "64,4,2"])
+def test_conv_x3p_implicit_convs(dev, cfg):
+    """The implicit 3x3 / transposed 4x4 convolutions on packed channel-last maps (taps gathered per lane by LDS-DMA, out-of-image taps from the
+    map's zero row) against torch's convolutions in fp64; ragged: 2 images of 7 x 9 pixels (row tiles straddle the images)."""
+    import subprocess, sys, os
+    if cfg is not None:                                    # the tile configuration is read once per process: check it in a child
+        env = dict(os.environ, MVS_X3P_CFG=cfg)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "test_conv_x3p_implicit_convs and None"], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+        return
+    from mvsformer_amd import ops
+    from mvsformer_amd.vit import _conv3_matrix, _convT_matrices
+    gen = torch.Generator().manual_seed(5)
+    B, h, w, cin, cout = 2, 7, 9, 44, 72
+    cp = 64
+    M = B * h * w
+    x = torch.randn(B, cin, h, w, generator=gen)
+    w3 = torch.randn(cout, cin, 3, 3, generator=gen) * 0.2
+    xcl = torch.zeros(M, cp)
+    xcl[:, :cin] = x.permute(0, 2, 3, 1).reshape(M, cin)
+    ra = (M + 128) // 128 * 128
+    xp = ops.x3p_pack(xcl.to(dev), ra)
+    scale, shift = torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen)
+    mul = torch.randn(M, cout, generator=gen)
+    out = torch.empty(M, cout, device=dev)
+    ops.conv_x3p(xp, ops.x3p_pack(_conv3_matrix(w3.to(dev), cp)), 1, B, h, w, cout, C=out, scale=scale.to(dev), shift=shift.to(dev), act=2, mul=mul.to(dev))
+    want = F.conv2d(x.double(), w3.double(), padding=1).permute(0, 2, 3, 1).reshape(M, cout) * scale.double() + shift.double()
+    want = want * torch.sigmoid(want) * mul.double()
+    assert _rel(out, want) < 2e-6
+    # transposed convolution: the output rows interleave the four parity classes; fp32 and packed outputs
+    cout2 = 64
+    wt = torch.randn(cp, cout2, 4, 4, generator=gen) * 0.2
+    wt[cin:] = 0
+    wtp = ops.x3p_pack_classes(_convT_matrices(wt.to(dev)), 128)
+    o2 = torch.empty(B, 2 * h, 2 * w, cout2, device=dev)
+    o2p = ops.Packed(4 * M, cout2, dev, zero=True)
+    ops.conv_x3p(xp, wtp, 2, B, h, w, cout2, C=o2.view(4 * M, cout2), act=3, out=o2p)
+    want = torch.relu(F.conv_transpose2d(x.double(), wt[:cin].double(), stride=2, padding=1).permute(0, 2, 3, 1))
+    assert _rel(o2, want) < 2e-6
+    assert torch.equal(ops.x3p_unpack(o2p).reshape(B, 2 * h, 2 * w, cout2), o2)
