@@ -650,11 +650,12 @@ int mvs_bicubic_resize(const float* in, float* out, int planes, int H, int W, in
  *       epi(v) = act(v*scale[n] + shift[n]) + res (act 0 none, 1 GELU(erf)); written as fp32 C [M][ldc] and / or packed Op [M][N]
  *       (the next GEMM's A operand; Op needs a_rows_alloc rows allocated).  N % 4 == 0.
  *   mvs_gemm_x3p_qkv: attn.qkv (vision_transformer.py:139): rows = [images][Np] tokens, columns q | k | v of `heads` heads of 64; writes
- *       Qp = (q + bias) * qscale and Kp packed [image][head][Np rows][64], and Vtp = V^T packed [image][head][64 rows][Np] with the 32 keys of
+ *       Qp = (q + bias) * qscale (qscale = softmax scale * log2(e): the attention kernels exponentiate in base 2) and Kp packed [image][head][Np rows][64], and Vtp = V^T packed [image][head][64 rows][Np] with the 32 keys of
  *       a k step permuted (element e of chunk c <-> key (e < 4 ? 4c + e : 16 + 4c + e - 4)): the order mvs_attention_x3p's accumulators
  *       produce P in.  C = heads * 64, C % 128 == 0, Np % 32 == 0.
- *   mvs_attention_x3p: softmax(Q K^T) V per (image, head), flash form, keys >= N masked; output packed [images * Np][heads * 64].
- *   mvs_cls_attention_x3p: att [image][head][N] = softmax(q_cls . K^T): the one attention row the model reads (mvsformer_model.py:257).
+ *   mvs_attention_x3p: P V with P = 2^(Q K^T - reference) / row sum = softmax(scale * q k^T) for Qp as above, per (image, head), flash form,
+ *       keys >= N masked; output packed [images * Np][heads * 64].
+ *   mvs_cls_attention_x3p: att [image][head][N] = that softmax's CLS row: the one attention row the model reads (mvsformer_model.py:257).
  * ------------------------------------------------------------------------------------------------------- */
 int64_t mvs_x3p_bytes(int64_t rows_alloc, int K);
 int mvs_x3p_pack(const float* x, void* out, int64_t R, int K, int ld, int64_t rows_alloc, mvs_stream_t stream);

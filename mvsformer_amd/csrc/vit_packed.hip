@@ -44,6 +44,17 @@ __device__ __forceinline__ rsrc_t rsrc_of(const void* base, unsigned bytes) {
 __device__ __forceinline__ void dma16(rsrc_t src, unsigned char* lds_dst, unsigned voff_bytes, unsigned soff_bytes) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_ptr_t)lds_dst, 16, voff_bytes, soff_bytes, 0, 0);
 }
+// the three terms of one (row tile, k step): 3 KiB contiguous in memory AND in LDS.  The instruction's immediate offset is added to both
+// addresses, so one M0 (LDS base) write serves the three pieces
+__device__ __forceinline__ void dma16x3(rsrc_t src, unsigned char* lds_dst, unsigned voff_bytes, unsigned soff_bytes) {
+#ifdef X3P_NO_IMM
+    for (int t = 0; t < 3; ++t) dma16(src, lds_dst + t * PIECE, voff_bytes, soff_bytes + t * PIECE);
+#else
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_ptr_t)lds_dst, 16, voff_bytes, soff_bytes, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_ptr_t)lds_dst, 16, voff_bytes, soff_bytes, PIECE, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_ptr_t)lds_dst, 16, voff_bytes, soff_bytes, 2 * PIECE, 0);
+#endif
+}
 __device__ __forceinline__ bf16x8 ldfrag(rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0));
 }
@@ -175,27 +186,25 @@ struct PGemmArgs {
     const float* mul;         // [M][ldc] or null: v *= mul after the activation (before res)
 };
 
-constexpr int GT = 128;                                      // rows of activations per block (the j side by default)
-
-// MODE 0: fp32 C and / or plain packed output.  MODE 1: the qkv form (TI = 128 only).
+// MODE 0: fp32 C and / or plain packed output (and the implicit convolutions).  MODE 1: the qkv form.
 // The MFMA's first operand supplies the accumulator's ROW index i (a lane holds four consecutive i), the second the column j (lane & 15).
-// T1 = the operand in the first slot, T2 = the second.  Default T1 = weights (i = n, TI columns per block), T2 = activations (j = m, 128
-// rows): a lane holds FOUR CONSECUTIVE n of ONE row m - 16-byte fp32 stores, 8-byte packed stores (half a lane's 8-k chunk of the next
-// GEMM's A operand).  The v columns of the qkv form swap the slots (i = token, j = d): four consecutive TOKENS of one d, which is what
-// V^T's pieces want.
-//   TI  columns per block (128 or 64): 128 x 64 blocks have 36 KiB stages -> two blocks per CU, whose epilogues / barriers / LDS-DMA waits
-//       overlap the other block's MFMAs; 128 x 128 blocks move 2/3 of the bytes per MFMA through L2 -> LDS but own their CU
-//   NW  wavefronts (4 or 8): 2 along i x NW/2 along j
-//   NS  LDS stages (2: the barrier of step k drains the LDS-DMA of step k, issued one step earlier; 3: issued TWO steps earlier, counted
-//       vmcnt waits + raw s_barrier so that a step's DMA flies across the previous step's barrier)
-template <int MODE, int TI, int NW, int NS>
+// First slot = weights (i = n, TI columns per block), second = activations (j = m, GTT * 16 rows per block): a lane holds FOUR CONSECUTIVE n
+// of ONE row m - 16-byte fp32 stores, 8-byte packed stores (half a lane's 8-k chunk of the next GEMM's A operand).
+//   GTT row tiles of 16 per block: 8 (128 rows) or 7 (112 rows: at M = 8800 that is 79 row blocks, and 79 x 3 / 9 / 12 column blocks fill
+//       92.6 % of the 256 CUs' rounds where 69 x 3 / 9 / 12 fill 81 %)
+//   TI  columns per block (128 or 64): 64 -> 33-36 KiB stages -> two blocks per CU (a block's epilogue under the other's main loop)
+//   NW  wavefronts (4 or 8) = (NW / WJ) along i x WJ along j; GTT = 7 does not split along j (WJ = 1)
+// Two LDS stages: the barrier of step k drains the LDS-DMA of step k, issued one step earlier, under step k-1's MFMAs.  (Three stages with
+// counted vmcnt waits and a raw s_barrier - step k+2 issued during step k - were built and measured no faster: profiles/r06_bench_x3p.txt.)
+template <int MODE, int GTT, int TI, int NW, int WJ>
 __global__ __launch_bounds__(NW * 64, (TI == 64 || NW == 8) ? 2 : 1) void gemm_x3p_kernel(const PGemmArgs a) {
-    constexpr int RT1 = TI / 16, RTS = RT1 + 8;              // row tiles of T1 / of a stage ([T1 | T2], three terms each)
+    constexpr int GT = GTT * 16;
+    constexpr int RT1 = TI / 16, RTS = RT1 + GTT;            // row tiles of the weights / of a stage ([weights | activations], three terms each)
     constexpr int STAGE = RTS * KSTEP;
-    constexpr int TPW = RTS / NW;                            // row tiles one wavefront fills per K step
-    constexpr int WJ = NW / 2, JT = 8 / WJ, IT = TI / 32;    // the wavefront's tile: IT i tiles x JT j tiles of 16
-    static_assert(RTS % NW == 0 && (MODE == 0 || TI == 128), "tile / wavefront combination");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[NS * STAGE];
+    constexpr int TPW = (RTS + NW - 1) / NW;                 // row tiles one wavefront fills per K step (the last slot may be empty)
+    constexpr int WI = NW / WJ, IT = RT1 / WI, JT = GTT / WJ;  // the wavefront's tile: IT i tiles x JT j tiles of 16
+    static_assert(RT1 % WI == 0 && GTT % WJ == 0 && IT >= 1, "tile / wavefront combination");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware order: block id -> XCD id % 8; the column blocks of one row block run on ONE XCD back to back (its A panel stays in that L2)
@@ -203,7 +212,6 @@ __global__ __launch_bounds__(NW * 64, (TI == 64 || NW == 8) ? 2 : 1) void gemm_x
     const int mb = (slot / a.nbn) * 8 + xcd, nb = slot % a.nbn;
     if (mb >= a.nbm) return;
     const int KS = a.K >> 5;
-    const bool vsec = MODE == 1 && nb * TI >= 2 * a.Cd;
     const rsrc_t rA = rsrc_of(a.Ap, (unsigned)((size_t)a.art * (MODE == 0 && a.a_mode ? a.Cp >> 5 : KS) * KSTEP));
     const rsrc_t rB = rsrc_of(reinterpret_cast<const unsigned char*>(a.Bp) + (MODE == 0 ? (size_t)blockIdx.y * a.b_class_bytes : 0), (unsigned)((size_t)a.brt * KS * KSTEP));
     // LDS-DMA roles: the stage's RTS row tiles are dealt to the wavefronts TPW at a time
@@ -226,8 +234,8 @@ __global__ __launch_bounds__(NW * 64, (TI == 64 || NW == 8) ? 2 : 1) void gemm_x
 #pragma unroll
         for (int r = 0; r < TPW; ++r) {
             const int g = wave * TPW + r;                    // row tile of the stage (scalar)
-            const bool first = g < RT1;                      // belongs to T1
-            const bool fromA = first == vsec;                // T1 = weights unless the slots are swapped
+            if (RTS % NW != 0 && g >= RTS) continue;
+            const bool first = g < RT1;                      // a weight tile
             if (MODE == 0 && a.a_mode && !first) {           // gathered rows of the map: per-lane source rows
                 const int tap = ks / CB, cb = ks - tap * CB;
                 int dy, dx;
@@ -241,16 +249,11 @@ __global__ __launch_bounds__(NW * 64, (TI == 64 || NW == 8) ? 2 : 1) void gemm_x
                 const bool inb = pix_base[r] >= 0 && (unsigned)iy < (unsigned)a.cH && (unsigned)ix < (unsigned)a.cW;
                 const int row = inb ? pix_base[r] + iy * a.cW + ix : a.zero_row;
                 const unsigned vo = (unsigned)((row >> 4) * CB) * (unsigned)KSTEP + (unsigned)(((lane >> 4) << 8) + ((row & 15) << 4));
-                const unsigned soff = (unsigned)(cb * KSTEP);
-#pragma unroll
-                for (int t = 0; t < 3; ++t) dma16(rA, lds + stage * STAGE + (g * 3 + t) * PIECE, vo, soff + t * PIECE);
+                dma16x3(rA, lds + stage * STAGE + g * KSTEP, vo, (unsigned)(cb * KSTEP));
                 continue;
             }
-            const int rt = (fromA ? mb * 8 : nb * RT1) + (first ? g : g - RT1);
-            const unsigned soff = (unsigned)((rt * KS + ks) * KSTEP);
-            const rsrc_t rs = fromA ? rA : rB;
-#pragma unroll
-            for (int t = 0; t < 3; ++t) dma16(rs, lds + stage * STAGE + (g * 3 + t) * PIECE, voff, soff + t * PIECE);
+            const int rt = first ? nb * RT1 + g : mb * GTT + (g - RT1);
+            dma16x3(first ? rB : rA, lds + stage * STAGE + g * KSTEP, voff, (unsigned)((rt * KS + ks) * KSTEP));
         }
     };
     const int wi = wave / WJ, wj = wave % WJ;
@@ -304,167 +307,141 @@ __global__ __launch_bounds__(NW * 64, (TI == 64 || NW == 8) ? 2 : 1) void gemm_x
 #undef X3P_SWEEP
     };
 
-    if constexpr (NS == 2) {
-        fill(0, 0);
-        int ks = 0;
-        for (; ks + 2 <= KS; ks += 2) {                      // two K steps per trip: the stage index is a literal
-            if (X3P_ABLATE < 3 || ks == 0) __syncthreads();  // stage 0 has landed (the barrier drains the LDS-DMA queue); stage 1's readers are done
-            if (X3P_ABLATE == 0 || X3P_ABLATE == 2) fill(1, ks + 1);
-            if (X3P_ABLATE != 2 || ks == 0) compute(0);
-            if (X3P_ABLATE < 3) __syncthreads();
-            if ((X3P_ABLATE == 0 || X3P_ABLATE == 2) && ks + 2 < KS) fill(0, ks + 2);
-            if (X3P_ABLATE != 2) compute(1);
-        }
-        if (ks < KS) {
-            __syncthreads();
-            compute(0);
-        }
-    } else {
-        // three stages: step k's pieces are issued during step k-2.  Before step k's barrier a wavefront waits for ITS pieces of step k only
-        // (vmcnt = the pieces of step k+1 it has in flight); the raw s_barrier (no fence: __syncthreads() would drain the queue) then says
-        // everybody's pieces of step k are in LDS and everybody has read step k-1's stage, which step k+2's pieces may now overwrite.
-        constexpr int PW = TPW * 3;                          // LDS-DMA instructions per wavefront per step
-        auto wait_own = [&](bool younger_in_flight) {
-            __builtin_amdgcn_sched_barrier(0);               // (the previous step's MFMAs stay above the waits: hipcc otherwise sinks them across the asm statements and the barrier)
-            if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        fill(0, 0);
-        if (KS > 1) fill(1, 1);
-        int ks = 0;
-        for (; ks + 3 <= KS; ks += 3) {
-            wait_own(ks + 1 < KS);
-            if (ks + 2 < KS) fill(2, ks + 2);
-            compute(0);
-            wait_own(ks + 2 < KS);
-            if (ks + 3 < KS) fill(0, ks + 3);
-            compute(1);
-            wait_own(ks + 3 < KS);
-            if (ks + 4 < KS) fill(1, ks + 4);
-            compute(2);
-        }
-        if (ks < KS) {                                       // one or two steps left: stages 0 (and 1)
-            wait_own(ks + 1 < KS);
-            compute(0);
-            if (ks + 1 < KS) {
-                wait_own(false);
-                compute(1);
-            }
-        }
+    fill(0, 0);
+    int ks = 0;
+    for (; ks + 2 <= KS; ks += 2) {                          // two K steps per trip: the stage index is a literal
+        if (X3P_ABLATE < 3 || ks == 0) __syncthreads();      // stage 0 has landed (the barrier drains the LDS-DMA queue); stage 1's readers are done
+        if (X3P_ABLATE == 0 || X3P_ABLATE == 2) fill(1, ks + 1);
+        if (X3P_ABLATE != 2 || ks == 0) compute(0);
+        if (X3P_ABLATE < 3) __syncthreads();
+        if ((X3P_ABLATE == 0 || X3P_ABLATE == 2) && ks + 2 < KS) fill(0, ks + 2);
+        if (X3P_ABLATE != 2) compute(1);
+    }
+    if (ks < KS) {
+        __syncthreads();
+        compute(0);
     }
 
-    // ---- epilogue: lane (jl = lane & 15, kb = lane >> 4) holds acc[jt][it][r] = D[i = i0 + it*16 + 4 kb + r][j = j0 + jt*16 + jl]
+    // ---- epilogue: lane (jl = lane & 15, kb = lane >> 4) holds acc[jt][it][r] = D[n = n0 + it*16 + 4 kb + r][m = m0 + jt*16 + jl]
     const int jl = lane & 15, kb = lane >> 4;
-    if (!vsec) {
-        const int n0 = nb * TI + wi * (TI / 2), m0 = mb * GT + wj * (GT / WJ);      // i = n, j = m
-        int img = 0, tok0 = 0, head = 0, sec = 0;
-        if (MODE == 1) {
-            sec = n0 / a.Cd;
-            head = (n0 - sec * a.Cd) >> 6;
-        }
-        const bool has_sc = a.scale != nullptr, has_sh = a.shift != nullptr;
-        int orow[JT];                                         // output row of the lane's row m (the transposed convolution interleaves its parity classes)
+    const int n0 = nb * TI + wi * (IT * 16), m0 = mb * GT + wj * (JT * 16);
+    int sec = 0, head = 0, dt0 = 0;
+    if (MODE == 1) {                                          // the block's columns lie in ONE of q | k | v (Cd % 128 == 0), the wavefront's in one head
+        sec = n0 / a.Cd;
+        head = (n0 - sec * a.Cd) >> 6;
+        dt0 = (n0 & 63) >> 4;                                 // first d tile (of the head's four) of this wavefront
+    }
+    const bool has_sc = a.scale != nullptr, has_sh = a.shift != nullptr;
+    if (MODE == 1 && sec == 2) {
+        // v columns -> V^T pieces [image][head][d tile][key step][term]: lane (kb', jl' = d % 16) element e <-> key pi(kb', e) =
+        // (e < 4 ? 4 kb' + e : 16 + 4 kb' + e - 4) of the step.  A lane holds four d of one token; V^T wants four TOKENS of one d: each
+        // 16 x 16 accumulator tile goes through a wavefront-private LDS tile (written [token][d], read [d][token]) - the stages are free now.
+        __syncthreads();                                      // every wavefront's last fragment reads are done
+        float* tile = reinterpret_cast<float*>(lds + wave * 2048);       // 16 rows of 20 floats: rows 4 kb' + r land 16 banks apart
+        const int KSV = a.Np >> 5;
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
-            const int m = m0 + jt * 16 + jl;
-            orow[jt] = m;
-            if (MODE == 0 && a.a_mode == 2) {
-                const int hw = a.cH * a.cW, img = m / hw, rem = m - img * hw, y = rem / a.cW, x = rem - y * a.cW;
-                orow[jt] = img * 4 * hw + (2 * y + ((int)blockIdx.y >> 1)) * 2 * a.cW + 2 * x + ((int)blockIdx.y & 1);
-            }
-        }
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            const int m = m0 + jt * 16 + jl;
-            if (m >= a.M) continue;
-            if (MODE == 1) {
-                img = (m0 + jt * 16) / a.Np;
-                tok0 = (m0 + jt * 16) - img * a.Np;               // first token of this 16-row tile (Np % 16 == 0: the tile stays in one image)
-            }
+            const int mt = m0 + jt * 16;                      // first row of the token tile (scalar)
+            if (mt >= a.M) continue;
+            const int img = mt / a.Np, tok = mt - img * a.Np; // (Np % 16 == 0: the tile stays in one image)
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 const int n = n0 + it * 16 + 4 * kb;
-                if (n >= a.N) continue;
-                float v[4];
-                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-                if (has_sc) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+                f32x4 sh = {0.f, 0.f, 0.f, 0.f};
                 if (has_sh) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+                f32x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = fmaf(acc[jt][it][r], sc[r], sh[r]);
-                    if (MODE == 0) {
-                        if (a.act == 1) v[r] = gelu_erf(v[r]);
-                        else if (a.act == 2) v[r] = v[r] / (1.0f + __expf(-v[r]));
-                        else if (a.act == 3) v[r] = fmaxf(v[r], 0.0f);
-                    }
-                }
+                for (int r = 0; r < 4; ++r) v[r] = acc[jt][it][r] + sh[r];
+                *reinterpret_cast<f32x4*>(tile + jl * 20 + 4 * kb) = v;
+                __builtin_amdgcn_wave_barrier();              // a wavefront's LDS operations execute in order
+                float t4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t4[r] = tile[(4 * kb + r) * 20 + jl];
+                __builtin_amdgcn_wave_barrier();
+                u32x2 h, mm, l;
+                split4(t4, h, mm, l);
+                unsigned char* d = reinterpret_cast<unsigned char*>(a.Vp) + ((((size_t)img * a.NH + head) * 4 + dt0 + it) * KSV + (tok >> 5)) * KSTEP +
+                                   lane * 16 + ((tok >> 4) & 1) * 8;
+                *reinterpret_cast<u32x2*>(d) = h;
+                *reinterpret_cast<u32x2*>(d + PIECE) = mm;
+                *reinterpret_cast<u32x2*>(d + 2 * PIECE) = l;
+            }
+        }
+        return;
+    }
+    int orow[JT];                                             // output row of the lane's row m (the transposed convolution interleaves its parity classes)
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        const int m = m0 + jt * 16 + jl;
+        orow[jt] = m;
+        if (MODE == 0 && a.a_mode == 2) {
+            const int hw = a.cH * a.cW, img = m / hw, rem = m - img * hw, y = rem / a.cW, x = rem - y * a.cW;
+            orow[jt] = img * 4 * hw + (2 * y + ((int)blockIdx.y >> 1)) * 2 * a.cW + 2 * x + ((int)blockIdx.y & 1);
+        }
+    }
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        const int m = m0 + jt * 16 + jl;
+        if (m >= a.M) continue;
+        int img = 0, tok0 = 0;
+        if (MODE == 1) {
+            img = (m0 + jt * 16) / a.Np;
+            tok0 = (m0 + jt * 16) - img * a.Np;               // first token of this 16-row tile (Np % 16 == 0: the tile stays in one image)
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int n = n0 + it * 16 + 4 * kb;
+            if (n >= a.N) continue;
+            float v[4];
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (has_sc) sc = *reinterpret_cast<const f32x4*>(a.scale + n);
+            if (has_sh) sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = fmaf(acc[jt][it][r], sc[r], sh[r]);
                 if (MODE == 0) {
-                    const size_t o = (size_t)orow[jt] * a.ldc + n;
-                    if (a.mul) {
-                        const f32x4 mm = *reinterpret_cast<const f32x4*>(a.mul + o);
+                    if (a.act == 1) v[r] = gelu_erf(v[r]);
+                    else if (a.act == 2) v[r] = v[r] / (1.0f + __expf(-v[r]));
+                    else if (a.act == 3) v[r] = fmaxf(v[r], 0.0f);
+                }
+            }
+            if (MODE == 0) {
+                const size_t o = (size_t)orow[jt] * a.ldc + n;
+                if (a.mul) {
+                    const f32x4 mm = *reinterpret_cast<const f32x4*>(a.mul + o);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] *= mm[r];
-                    }
-                    if (a.res) {
-                        const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + o);
+                    for (int r = 0; r < 4; ++r) v[r] *= mm[r];
+                }
+                if (a.res) {
+                    const f32x4 rr = *reinterpret_cast<const f32x4*>(a.res + o);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += rr[r];
-                    }
-                    if (a.C) *reinterpret_cast<f32x4*>(a.C + o) = f32x4{v[0], v[1], v[2], v[3]};
-                    if (a.Op) {
-                        u32x2 h, mm, l;
-                        split4(v, h, mm, l);
-                        const int KSo = a.N >> 5;
-                        unsigned char* d = reinterpret_cast<unsigned char*>(a.Op) + ((size_t)(orow[jt] >> 4) * KSo + (n >> 5)) * KSTEP +
-                                           ((((n >> 3) & 3) * 16 + (orow[jt] & 15)) * 16) + ((n >> 2) & 1) * 8;
-                        *reinterpret_cast<u32x2*>(d) = h;
-                        *reinterpret_cast<u32x2*>(d + PIECE) = mm;
-                        *reinterpret_cast<u32x2*>(d + 2 * PIECE) = l;
-                    }
-                } else {                                      // q (scaled) or k of head `head`: packed [image][head][token tile][2 k steps]
-                    if (sec == 0) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] *= a.qscale;
-                    }
+                    for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                }
+                if (a.C) *reinterpret_cast<f32x4*>(a.C + o) = f32x4{v[0], v[1], v[2], v[3]};
+                if (a.Op) {
                     u32x2 h, mm, l;
                     split4(v, h, mm, l);
-                    const int dd = it * 16 + 4 * kb;           // first of the lane's four head dimensions
-                    unsigned char* base = reinterpret_cast<unsigned char*>(sec == 0 ? a.Qp : a.Kp);
-                    unsigned char* d = base + ((((size_t)img * a.NH + head) * (a.Np >> 4) + (tok0 >> 4)) * 2 + (dd >> 5)) * KSTEP +
-                                       ((((dd >> 3) & 3) * 16 + jl) * 16) + ((dd >> 2) & 1) * 8;
+                    const int KSo = a.N >> 5;
+                    unsigned char* d = reinterpret_cast<unsigned char*>(a.Op) + ((size_t)(orow[jt] >> 4) * KSo + (n >> 5)) * KSTEP +
+                                       ((((n >> 3) & 3) * 16 + (orow[jt] & 15)) * 16) + ((n >> 2) & 1) * 8;
                     *reinterpret_cast<u32x2*>(d) = h;
                     *reinterpret_cast<u32x2*>(d + PIECE) = mm;
                     *reinterpret_cast<u32x2*>(d + 2 * PIECE) = l;
                 }
-            }
-        }
-    } else if constexpr (MODE == 1) {
-        // v columns, slots swapped: i = token (m), j = d (n).  acc[jt][it]: d = dt0*16 + jt*16 + jl of head `head`, tokens m0 + it*16 + 4 kb + r.
-        // V^T piece (d tile, key step of 32 tokens): lane (kb, jl) element e <-> key pi(kb, e) = (e < 4 ? 4 kb + e : 16 + 4 kb + e - 4) of the
-        // step - exactly the four tokens this lane holds in the step's first (e < 4) and second (e >= 4) 16-token tile: one 16-byte store.
-        const int m0 = mb * GT + wi * 64, n0 = nb * TI + wj * (GT / WJ);
-        const int head = (n0 - 2 * a.Cd) >> 6, dt0 = (n0 & 63) >> 4;
-        const int KSV = a.Np >> 5;
+            } else {                                          // q (scaled) or k of head `head`: packed [image][head][token tile][2 k steps]
+                if (sec == 0) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {                // the 64 tokens = two key steps
-            const int ms = m0 + half * 32;
-            if (ms >= a.M) continue;                          // (M = images * Np is a multiple of 32: a step is all rows or none)
-            const int img = ms / a.Np, step = (ms - img * a.Np) >> 5;
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt) {
-                const int n = n0 + jt * 16 + jl;
-                const float sc = a.scale ? a.scale[n] : 1.0f, sh = a.shift ? a.shift[n] : 0.0f;
-                float v[8];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[jt][2 * half][r], sc, sh), v[4 + r] = fmaf(acc[jt][2 * half + 1][r], sc, sh);
-                const mvsx3::Split3 sp = mvsx3::split3(v);
-                unsigned char* d = reinterpret_cast<unsigned char*>(a.Vp) + ((((size_t)img * a.NH + head) * 4 + dt0 + jt) * KSV + step) * KSTEP + lane * 16;
-                *reinterpret_cast<bf16x8*>(d) = sp.h;
-                *reinterpret_cast<bf16x8*>(d + PIECE) = sp.m;
-                *reinterpret_cast<bf16x8*>(d + 2 * PIECE) = sp.l;
+                    for (int r = 0; r < 4; ++r) v[r] *= a.qscale;
+                }
+                u32x2 h, mm, l;
+                split4(v, h, mm, l);
+                const int dd = (dt0 + it) * 16 + 4 * kb;      // first of the lane's four head dimensions
+                unsigned char* base = reinterpret_cast<unsigned char*>(sec == 0 ? a.Qp : a.Kp);
+                unsigned char* d = base + ((((size_t)img * a.NH + head) * (a.Np >> 4) + (tok0 >> 4)) * 2 + (dd >> 5)) * KSTEP +
+                                   ((((dd >> 3) & 3) * 16 + jl) * 16) + ((dd >> 2) & 1) * 8;
+                *reinterpret_cast<u32x2*>(d) = h;
+                *reinterpret_cast<u32x2*>(d + PIECE) = mm;
+                *reinterpret_cast<u32x2*>(d + 2 * PIECE) = l;
             }
         }
     }
@@ -523,10 +500,8 @@ __global__ __launch_bounds__(256, 2) void attention_x3p_kernel(const void* __res
     auto fill = [&](int stage, int kt) {
         unsigned char* dk = lds + stage * ASTAGE + wave * KSTEP;
         const unsigned ko = (unsigned)((kt * 4 + wave) * KSTEP), vo = (unsigned)((wave * KSV + kt) * KSTEP);
-#pragma unroll
-        for (int t = 0; t < 3; ++t) dma16(rk, dk + t * PIECE, voff, ko + t * PIECE);
-#pragma unroll
-        for (int t = 0; t < 3; ++t) dma16(rv, dk + 12 * PIECE + t * PIECE, voff, vo + t * PIECE);
+        dma16x3(rk, dk, voff, ko);
+        dma16x3(rv, dk + 12 * PIECE, voff, vo);
     };
     const int kb = lane >> 4;
     auto step = [&](int stage, int kt) {
@@ -557,24 +532,37 @@ __global__ __launch_bounds__(256, 2) void attention_x3p_kernel(const void* __res
                         if (kt * 32 + nt * 16 + 4 * kb + r >= N) s[qt][nt][r] = -INFINITY;
         }
         bf16x8 ph[2], pm[2], pl[2];
+#ifdef X3P_ATT_ABLATE                                         // experiment build: no softmax arithmetic (the MFMA + LDS-DMA + barrier skeleton alone)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            float mx = fmaxf(fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), fmaxf(s[qt][0][2], s[qt][0][3])),
-                             fmaxf(fmaxf(s[qt][1][0], s[qt][1][1]), fmaxf(s[qt][1][2], s[qt][1][3])));
-            mx = xmax32(xmax16(mx));
-            const float mnew = fmaxf(mrow[qt], mx);
-            const float alpha = __expf(mrow[qt] - mnew);
-            mrow[qt] = mnew;
-            float p[8];
+            ph[qt] = __builtin_bit_cast(bf16x8, u32x4{__builtin_bit_cast(unsigned, s[qt][0][0]), __builtin_bit_cast(unsigned, s[qt][0][1]), __builtin_bit_cast(unsigned, s[qt][0][2]), __builtin_bit_cast(unsigned, s[qt][0][3])});
+            pm[qt] = __builtin_bit_cast(bf16x8, u32x4{__builtin_bit_cast(unsigned, s[qt][1][0]), __builtin_bit_cast(unsigned, s[qt][1][1]), __builtin_bit_cast(unsigned, s[qt][1][2]), __builtin_bit_cast(unsigned, s[qt][1][3])});
+            pl[qt] = ph[qt];
+            lrow[qt] = 1.0f;
+        }
+#else
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p[r] = __expf(s[qt][0][r] - mnew), p[4 + r] = __expf(s[qt][1][r] - mnew);
-            lrow[qt] = fmaf(lrow[qt], alpha, ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
-            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {    // the running max moved for some query of the wavefront
+        for (int qt = 0; qt < 2; ++qt) {
+            // The reference maximum mrow is shared by the four lanes of a query (their P values meet in one MFMA contraction) but need not be
+            // the exact running maximum: any common reference gives the same softmax.  It is raised only when some lane of the wavefront sees
+            // a score more than 8 (base-2 exponent: a factor 256) above it - after the first few key steps almost never - so the
+            // cross-lane maximum, the rescale of O and their LDS-crossbar waits leave the steady state (P <= 256, exact in the split).
+            const float lmax = fmaxf(fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), fmaxf(s[qt][0][2], s[qt][0][3])),
+                                     fmaxf(fmaxf(s[qt][1][0], s[qt][1][1]), fmaxf(s[qt][1][2], s[qt][1][3])));
+            if (__builtin_amdgcn_ballot_w64(lmax > mrow[qt] + 8.0f) != 0) {
+                const float mnew = fmaxf(mrow[qt], xmax32(xmax16(lmax)));
+                const float alpha = __builtin_amdgcn_exp2f(mrow[qt] - mnew);      // 0 at the first step (mrow = -inf)
+                mrow[qt] = mnew;
+                lrow[qt] *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
             }
+            float p[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[qt][0][r] - mrow[qt]), p[4 + r] = __builtin_amdgcn_exp2f(s[qt][1][r] - mrow[qt]);
+            lrow[qt] += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
             u32x4 h, m, l;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -584,6 +572,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3p_kernel(const void* __res
             }
             ph[qt] = __builtin_bit_cast(bf16x8, h), pm[qt] = __builtin_bit_cast(bf16x8, m), pl[qt] = __builtin_bit_cast(bf16x8, l);
         }
+#endif
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             const unsigned char* p = sv + dt * KSTEP;
@@ -677,7 +666,7 @@ __global__ __launch_bounds__(256) void cls_attention_kernel(const unsigned char*
     float sum = 0.0f;
 #pragma unroll 1
     for (int key = tid; key < N; key += 256) {                 // (a thread re-reads only its own scores)
-        const float e = __expf(sc[key] - mx);
+        const float e = __builtin_amdgcn_exp2f(sc[key] - mx);
         sc[key] = e;
         sum += e;
     }
@@ -725,17 +714,17 @@ extern "C" int mvs_layernorm_x3p(const float* x, const float* gamma, const float
 }
 
 namespace {
-// MVS_X3P_CFG / MVS_X3P_CFG_QKV (diagnostics, read once): "TI,NW,NS" of the plain GEMM / of the qkv form instead of the choice below
-struct PCfg { int ti, nw, ns; };
+// MVS_X3P_CFG / MVS_X3P_CFG_QKV (diagnostics, read once): "GTT,TI,NW,WJ" of the plain GEMM / of the qkv form instead of the choice below
+struct PCfg { int gtt, ti, nw, wj; };
 PCfg env_cfg(const char* name) {
-    PCfg c{0, 0, 0};
-    if (const char* e = getenv(name)) sscanf(e, "%d,%d,%d", &c.ti, &c.nw, &c.ns);
+    PCfg c{0, 0, 0, 0};
+    if (const char* e = getenv(name)) sscanf(e, "%d,%d,%d,%d", &c.gtt, &c.ti, &c.nw, &c.wj);
     return c;
 }
-template <int MODE, int TI, int NW, int NS>
+template <int MODE, int GTT, int TI, int NW, int WJ>
 void launch_one(const PGemmArgs& a, hipStream_t s) {
     const unsigned grid = (unsigned)(((a.nbm + 7) / 8) * 8 * a.nbn);
-    hipLaunchKernelGGL((gemm_x3p_kernel<MODE, TI, NW, NS>), dim3(grid, a.a_mode == 2 ? 4 : 1), dim3(NW * 64), 0, s, a);
+    hipLaunchKernelGGL((gemm_x3p_kernel<MODE, GTT, TI, NW, WJ>), dim3(grid, a.a_mode == 2 ? 4 : 1), dim3(NW * 64), 0, s, a);
 }
 int launch_pgemm(PGemmArgs& a, int mode, int64_t a_rows_alloc, int64_t b_rows_alloc, hipStream_t s) {
     static const PCfg e0 = env_cfg("MVS_X3P_CFG"), e1 = env_cfg("MVS_X3P_CFG_QKV");
@@ -744,16 +733,25 @@ int launch_pgemm(PGemmArgs& a, int mode, int64_t a_rows_alloc, int64_t b_rows_al
     MVS_REQUIRE((int64_t)a.art * KS * KSTEP < ((int64_t)1 << 32) && (int64_t)a.brt * KS * KSTEP < ((int64_t)1 << 32), "mvs_gemm_x3p: a packed operand exceeds 4 GiB");
     PCfg c = mode == 0 ? e0 : e1;
     // measured at the ViT-small shapes (profiles/r06_bench_x3p.txt): eight wavefronts on a 128 x 128 tile (two per SIMD: one's barrier / LDS-DMA
-    // issue under the other's MFMAs) for the plain epilogues; the GELU + packed epilogue of fc1 prefers 128 x 64 tiles, two blocks per CU
+    // issue under the other's MFMAs) for the plain epilogues; the GELU + packed epilogue of fc1 prefers 64-column tiles, two blocks per CU
     // (a block's epilogue under the other block's main loop)
-    if (c.ti == 0) c = (mode == 0 && ((a.act == 1 && a.Op) || a.N <= 64)) ? PCfg{64, 4, 2} : PCfg{128, 8, 2};
-    if (mode == 1) c.ti = 128;
-    a.nbm = (a.M + GT - 1) / GT, a.nbn = (a.N + c.ti - 1) / c.ti;
-#define X3P_CASE(M_, TI_, NW_, NS_) if (mode == M_ && c.ti == TI_ && c.nw == NW_ && c.ns == NS_) { launch_one<M_, TI_, NW_, NS_>(a, s); return mvs::finish_launch("mvs_gemm_x3p"); }
-    X3P_CASE(0, 128, 4, 2) X3P_CASE(0, 128, 8, 2) X3P_CASE(0, 128, 8, 3) X3P_CASE(0, 128, 4, 3) X3P_CASE(0, 64, 4, 2)
-    X3P_CASE(1, 128, 4, 2) X3P_CASE(1, 128, 8, 2) X3P_CASE(1, 128, 8, 3) X3P_CASE(1, 128, 4, 3)
+    if (c.gtt == 0) {
+        c = (mode == 0 && ((a.act == 1 && a.Op) || a.N <= 64)) ? PCfg{8, 64, 4, 2} : PCfg{8, 128, 8, 4};
+        if (c.ti == 128) {                                   // 112-row blocks when they fill the CUs' rounds better (M = 8800: 79 x nbn against 69 x nbn blocks)
+            const auto fill = [&](int rows) {
+                const long long t = (long long)((a.M + rows - 1) / rows) * ((a.N + 127) / 128);
+                return (double)t / (double)((t + 255) / 256 * 256);
+            };
+            if (fill(112) > fill(128) + 0.05) c = PCfg{7, 128, 8, 1};
+        }
+    }
+    a.nbm = (a.M + c.gtt * 16 - 1) / (c.gtt * 16), a.nbn = (a.N + c.ti - 1) / c.ti;
+#define X3P_CASE(M_, G_, TI_, NW_, WJ_) if (mode == M_ && c.gtt == G_ && c.ti == TI_ && c.nw == NW_ && c.wj == WJ_) { launch_one<M_, G_, TI_, NW_, WJ_>(a, s); return mvs::finish_launch("mvs_gemm_x3p"); }
+    X3P_CASE(0, 8, 128, 8, 4) X3P_CASE(0, 8, 128, 4, 2) X3P_CASE(0, 8, 64, 4, 2) X3P_CASE(0, 8, 128, 8, 1) X3P_CASE(0, 8, 64, 4, 1)
+    X3P_CASE(0, 7, 128, 8, 1) X3P_CASE(0, 7, 128, 4, 1) X3P_CASE(0, 7, 64, 4, 1)
+    X3P_CASE(1, 8, 128, 8, 4) X3P_CASE(1, 8, 128, 4, 2) X3P_CASE(1, 7, 128, 8, 1) X3P_CASE(1, 7, 128, 4, 1) X3P_CASE(1, 8, 128, 8, 1)
 #undef X3P_CASE
-    mvs::set_error("mvs_gemm_x3p: no kernel instance for TI=%d NW=%d NS=%d", c.ti, c.nw, c.ns);
+    mvs::set_error("mvs_gemm_x3p: no kernel instance for GTT=%d TI=%d NW=%d WJ=%d", c.gtt, c.ti, c.nw, c.wj);
     return MVS_EINVAL;
 }
 }  // namespace

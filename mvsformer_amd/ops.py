@@ -1703,7 +1703,10 @@ class QkvPacked:
         self.vt = torch.empty(n, device=device, dtype=torch.uint8)
 
 
-def gemm_x3p_qkv(A: Packed, W: Packed, bias: Optional[torch.Tensor], images: int, Np: int, heads: int, qscale: float, out: Optional[QkvPacked] = None) -> QkvPacked:
+def gemm_x3p_qkv(A: Packed, W: Packed, bias: Optional[torch.Tensor], images: int, Np: int, heads: int, scale: float, out: Optional[QkvPacked] = None) -> QkvPacked:
+    """``attn.qkv`` -> packed Q, K, V^T.  ``scale`` = the softmax scale (``head_dim ** -0.5``); Q is stored times ``scale * log2(e)`` because
+    :func:`attention_x3p` / :func:`cls_attention_x3p` exponentiate in base 2 (one v_exp_f32 per score, no multiply)."""
+    qscale = scale * 1.4426950408889634
     C = heads * 64
     if A.K != C or W.K != C or A.rows != images * Np:
         raise _lib.MvsHipError("gemm_x3p_qkv: A [%d][%d], W [%d][%d] for %d images x %d rows, %d heads" % (A.rows, A.K, W.rows, W.K, images, Np, heads))
