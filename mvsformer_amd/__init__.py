@@ -13,7 +13,7 @@ from . import synth  # noqa: F401
 __all__ = ["synth", "StageNet", "DepthNet", "CostRegNet", "CostRegNet3D", "CascadeMVS", "homo_warping_3D_with_mask",
            "homo_warping_3D", "homo_warping", "depth_regression", "conf_regression", "init_inverse_range",
            "schedule_inverse_range", "install", "fusion", "FPNDecoder", "FPNDecoderV2", "FPNEncoder", "vit_small", "VisionTransformer",
-           "VITDecoderStage4Single"]
+           "VITDecoderStage4Single", "DINOMVSNet"]
 
 
 def __getattr__(name):
@@ -36,6 +36,9 @@ def __getattr__(name):
     if name in ("vit_small", "VisionTransformer", "VITDecoderStage4Single"):
         from . import vit
         return getattr(vit, name)
+    if name == "DINOMVSNet":
+        from . import mvsformer_model
+        return mvsformer_model.DINOMVSNet
     if name == "fusion":
         import importlib
         return importlib.import_module(".fusion", __name__)

@@ -58,6 +58,14 @@ def install(model_module: str = "models.mvsformer_model", also=("models.module",
                 hit.append(sym)
         done[name] = hit
     if features:
+        try:                                                 # the whole model too: its forward uses the CLS-row attention path (forward_with_cls_att)
+            from .mvsformer_model import DINOMVSNet
+            mod = importlib.import_module(model_module)
+            if hasattr(mod, "DINOMVSNet"):
+                mod.DINOMVSNet = DINOMVSNet
+                done.setdefault(model_module, []).append("DINOMVSNet")
+        except ImportError:
+            pass
         try:
             vmod = importlib.import_module(_VIT_MODULE)
             for sym, obj in _VIT_FACTORIES.items():

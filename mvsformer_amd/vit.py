@@ -387,4 +387,4 @@ def vit_branch(vit: VisionTransformer, dec: VITDecoderStage4Single, img: torch.T
     hp, wp = vh // P, vw // P
     feat = tok[:, 1:].reshape(B, hp, wp, vit.embed_dim).permute(0, 3, 1, 2)
     att_cls = att[:, :, 1:].reshape(B, -1, hp, wp)
-    return {"vit_imgs": x, "vit_feat": tok, "att_cls": att[:, :, 1:], "vit_out": dec(feat, att_cls)}
+    return {"vit_imgs": x, "vit_feat": tok, "att_cls": att[:, :, 1:], "vit_out": dec(feat, att_cls) if dec is not None else None}

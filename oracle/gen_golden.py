@@ -24,6 +24,8 @@ float16-exact values to halve the files):
   fpn_decoder.npz          FPNDecoder (the step before the path), eval BatchNorm: state_dict, encoder outputs, the 4 feature maps
   fpn_decoder_v2.npz       FPNDecoderV2 (TwinMVSNet's decoder), eval BatchNorm: state_dict (conv weights float16-exact), 7 input maps, 4 outputs
   fpn_encoder.npz          FPNEncoder, eval BatchNorm: state_dict (conv weights float16-exact), image, the 4 encoder outputs
+  dinomvsnet_e2e.npz       the REAL DINOMVSNet (configs/config_mvsformer-p.json) in eval mode, images -> depth: 3 views of 128x192
+  dinomvsnet_shapes.json   key -> shape of its state_dict() (weights are rebuilt from a seed: oracle/weights.make_model_state_dict)
 """
 import json
 import os
@@ -736,3 +738,49 @@ def gen_fpn_train():
 
 if __name__ == "__main__" and os.environ.get("GEN_FPN_TRAIN", "1") == "1":
     gen_fpn_train()
+
+
+def gen_end_to_end():
+    """The whole MVSFormer-P model, images -> depth map: the reference's own ``DINOMVSNet`` (models/mvsformer_model.py:163-308) built from the
+    shipped ``configs/config_mvsformer-p.json`` arguments, ``eval()``, one reference + two source views of 128 x 192 (the smallest size every
+    stage accepts: H/8 x W/8 = 16 x 24 halves three times in CostRegNet, the ViT sees 64 x 96 = 4 x 6 patches), photo-consistent images
+    rendered by mvsformer_amd.synth, tmp = [5, 5, 5, 1].  Weights from a seed (oracle/weights.make_model_state_dict, strict load)."""
+    from oracle.weights import make_model_state_dict
+    args = json.load(open(os.path.join(REF, "configs", "config_mvsformer-p.json")))["arch"]["args"]
+    cwd = os.getcwd()
+    os.chdir("/tmp")                                        # the constructor probes ./pretrained_weights (absent: it only prints a notice)
+    net = ref_mm.DINOMVSNet(args)
+    os.chdir(cwd)
+    shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+    with open(os.path.join(OUT, "dinomvsnet_shapes.json"), "w") as f:
+        json.dump(shapes, f, indent=0)
+    seed = 31
+    net.load_state_dict(make_model_state_dict(shapes, seed), strict=True)
+    net.eval()
+    V, H, W = 3, 128, 192
+    _, proj, dv, scene = synth.make_inputs(V, H, W, seed=32)
+    imgs = f16exact(synth.render_features(scene, 1, 3, noise=0.02))          # [1, V, 3, H, W]: the plane-induced warp of one texture
+    tmp = [5.0, 5.0, 5.0, 1.0]
+    feats = {}
+    real_forward = net.decoder.forward                      # (the model calls decoder.forward(...) directly: a forward hook would not fire)
+
+    def recording(*a):
+        o = real_forward(*a)
+        feats.setdefault("calls", []).append([t.detach().clone() for t in o])
+        return o
+    net.decoder.forward = recording
+    with torch.no_grad():
+        out = net(imgs, proj, dv, tmp=tmp)
+    arrs = dict(imgs=np32(imgs).astype(np.float16), depth_range=np32(dv), seed=np.int64(seed), scene_seed=np.int64(32), tmps=np.array(tmp, dtype=np.float32),
+                refined_depth=np32(out["refined_depth"]), photometric_confidence=np32(out["photometric_confidence"]),
+                features_stage1=np32(torch.stack([c[0] for c in feats["calls"]], dim=1)))      # [1, V, 64, 16, 24]: FPN + ViT, before the path
+    for k, v in proj.items():
+        arrs["proj_" + k] = np32(v)
+    for i in range(4):
+        arrs["s%d_depth" % (i + 1)] = np32(out["stage%d" % (i + 1)]["depth"])
+    save("dinomvsnet_e2e.npz", **arrs)
+    print("DINOMVSNet params %.1f M, depth range %.1f .. %.1f" % (sum(p.numel() for p in net.parameters()) / 1e6, out["refined_depth"].min(), out["refined_depth"].max()))
+
+
+if __name__ == "__main__" and os.environ.get("GEN_E2E", "1") == "1":
+    gen_end_to_end()

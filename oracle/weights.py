@@ -94,3 +94,34 @@ def make_vit_state_dict(shapes: Dict[str, list], seed: int) -> Dict[str, torch.T
             gain = 2.0 if key.endswith("attn.qkv.weight") else 1.0
             sd[key] = torch.randn(shp, generator=g) * (gain / math.sqrt(max(fan, 1.0)))
     return sd
+
+
+_MODEL_SHAPES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "dinomvsnet_shapes.json")
+
+
+def load_model_shapes() -> Dict[str, list]:
+    """key -> shape of the reference's ``DINOMVSNet(configs/config_mvsformer-p.json).state_dict()`` (582 keys, 26.5 M parameters), dumped by
+    ``oracle/gen_golden.py::gen_end_to_end`` from the real class."""
+    with open(_MODEL_SHAPES) as f:
+        return json.load(f)
+
+
+def make_model_state_dict(shapes: Dict[str, list], seed: int) -> Dict[str, torch.Tensor]:
+    """Seeded weights for the whole MVSFormer-P model: each sub-module's keys go through the generator its own goldens use (``vit.`` /
+    ``decoder_vit.`` -> :func:`make_vit_state_dict`, everything else -> :func:`make_state_dict`), with a seed per prefix."""
+    groups: Dict[str, Dict[str, list]] = {}
+    for key, shp in shapes.items():                      # prefix = first component, "fusions.<i>" for the stage networks
+        parts = key.split(".")
+        prefix = ".".join(parts[:2]) if parts[0] == "fusions" else parts[0]
+        groups.setdefault(prefix, {})[key[len(prefix) + 1:]] = shp
+    sd = {}
+    for n, (prefix, sub) in enumerate(groups.items()):
+        if prefix == "decoder_vit":                      # make_vit_state_dict recognises the transposed convolutions by the name "decoder."
+            part = make_vit_state_dict(sub, seed + n)
+        elif prefix == "vit":
+            part = make_vit_state_dict(sub, seed + n)
+        else:
+            part = make_state_dict(sub, seed + n)
+        for k, v in part.items():
+            sd[prefix + "." + k] = v
+    return sd

@@ -279,3 +279,40 @@ def test_conv_x3p_implicit_convs(dev, cfg):
     want = torch.relu(F.conv_transpose2d(x.double(), wt[:cin].double(), stride=2, padding=1).permute(0, 2, 3, 1))
     assert _rel(o2, want) < 2e-6
     assert torch.equal(ops.x3p_unpack(o2p).reshape(B, 2 * h, 2 * w, cout2), o2)
+
+
+def _mvsformer_p_args():
+    return dict(fix=True, depth_type="ce", fusion_type="cnn", inverse_depth=True, attn_temp=2.0, base_ch=8, ndepths=[32, 16, 8, 4], feat_chs=[8, 16, 32, 64],
+                depth_interals_ratio=[4.0, 2.67, 1.5, 1.0], multi_scale=False,
+                vit_args=dict(twin=False, rescale=0.5, do_vit=True, patch_size=16, qk_scale="default", vit_arch="vit_small", vit_ch=384, out_ch=64,
+                              att_fusion=True, nhead=6))
+
+
+def test_dinomvsnet_images_to_depth_vs_reference_golden(dev):
+    """The composed model, images -> depth map: ``mvsformer_amd.DINOMVSNet`` (FPN encoder -> DINO ViT branch -> FPN decoder -> 4-stage cascade,
+    every piece a HIP kernel) against the REAL reference ``DINOMVSNet`` of configs/config_mvsformer-p.json run on the same images, cameras and
+    seeded weights (tests/golden/dinomvsnet_e2e.npz, oracle/gen_golden.py::gen_end_to_end).  Depth within the north star's 1e-3 relative."""
+    import mvsformer_amd as m
+    from oracle.weights import load_model_shapes, make_model_state_dict
+    g = load_golden("dinomvsnet_e2e.npz")
+    net = m.DINOMVSNet(_mvsformer_p_args())
+    sd = make_model_state_dict(load_model_shapes(), int(g["seed"]))
+    net.load_state_dict(sd, strict=True)
+    assert list(net.state_dict().keys()) == list(sd.keys())          # the reference's keys in the reference's order
+    net = net.to(dev).eval()
+    imgs = torch.from_numpy(g["imgs"].astype(np.float32)).to(dev)
+    proj = {"stage%d" % i: torch.from_numpy(g["proj_stage%d" % i]).to(dev) for i in range(1, 5)}
+    dv = torch.from_numpy(g["depth_range"]).to(dev)
+    feats = net.extract_features(imgs)
+    f1 = torch.from_numpy(g["features_stage1"])
+    assert _rel(feats["stage1"], f1) < 1e-4
+    out = net(imgs, proj, dv, tmp=[float(t) for t in g["tmps"]])
+    torch.cuda.synchronize()
+    for i in range(1, 5):
+        want = torch.from_numpy(g["s%d_depth" % i])
+        rel = ((out["stage%d" % i]["depth"].cpu() - want).abs() / want.abs()).max().item()
+        assert rel < 1e-3, (i, rel)
+    want = torch.from_numpy(g["refined_depth"])
+    rel = ((out["refined_depth"].cpu() - want).abs() / want.abs()).max().item()
+    assert rel < 1e-3, rel
+    assert (out["photometric_confidence"].cpu() - torch.from_numpy(g["photometric_confidence"])).abs().max() < 2e-3

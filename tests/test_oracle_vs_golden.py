@@ -309,3 +309,23 @@ def test_vit_branch_oracle_vs_reference_golden():
     # the attention the decoder consumes is a real distribution, not the uniform one of a default-initialised ViT
     att = torch.from_numpy(g["att_cls"])
     assert att.max() > 4.0 / att.shape[-1] and (att.sum(-1) < 1.0).all()
+
+
+def test_dinomvsnet_oracle_vs_reference():
+    """oracle/ref_model.py (FPN encoder -> ViT branch -> FPN decoder -> 4-stage cascade) against the REAL ``DINOMVSNet`` of the shipped
+    MVSFormer-P config in eval mode (tests/golden/dinomvsnet_e2e.npz: images -> depth map, 3 views of 128 x 192)."""
+    from oracle import ref_model
+    from oracle.weights import load_model_shapes, make_model_state_dict
+    g = load_golden("dinomvsnet_e2e.npz")
+    sd = make_model_state_dict(load_model_shapes(), int(g["seed"]))
+    imgs = torch.from_numpy(g["imgs"].astype(np.float32))
+    proj = {"stage%d" % i: torch.from_numpy(g["proj_stage%d" % i]) for i in range(1, 5)}
+    out = ref_model.dinomvsnet_forward(sd, imgs, proj, torch.from_numpy(g["depth_range"]), tmp=[float(t) for t in g["tmps"]])
+    f1 = torch.from_numpy(g["features_stage1"])
+    assert (out["features"]["stage1"] - f1).abs().max() < 2e-5 * f1.abs().max()
+    for i in range(1, 5):
+        want = torch.from_numpy(g["s%d_depth" % i])
+        assert ((out["stage%d" % i]["depth"] - want).abs() / want.abs()).max() < 1e-4, i
+    want = torch.from_numpy(g["refined_depth"])
+    assert ((out["refined_depth"] - want).abs() / want.abs()).max() < 1e-4
+    assert (out["photometric_confidence"] - torch.from_numpy(g["photometric_confidence"])).abs().max() < 1e-4
