@@ -454,7 +454,7 @@ def main(args):
             torch.cuda.empty_cache()
 
     # ---- the row before the path: FPN decoder emitting channel-last features, timed beside the path (extra key) ----
-    before = None
+    before, end_to_end = None, None
     if rank == 0 and world == 1 and not args.no_other_configs:
         from mvsformer_amd import FPNDecoder, FPNEncoder
         torch.manual_seed(0)
@@ -511,7 +511,36 @@ def main(args):
                       vit_peak_tflops_split_form=round(BF16_MFMA_PEAK_TF / 6.0, 1),
                       vit_note="vits.vit_small(patch 16) + VITDecoderStage4Single on %d views at %dx%d (half size), random weights; fp32-equivalent "
                                "split-form GEMMs (csrc/vit.hip); not in `value`" % (args.views, args.width // 2, args.height // 2))
-        del vnet, vdec, vo, img
+        del vnet, vdec, vo
+        torch.cuda.empty_cache()
+        # ---- images -> depth map: the whole MVSFormer-P model composed as models/mvsformer_model.py:205-308 does (FPN encoder -> ViT branch ->
+        # FPN decoder -> the judged cascade), single stream = the reference's own timed region (test.py:233-249 includes feature extraction)
+        from mvsformer_amd import DINOMVSNet
+        from mvsformer_amd.cascade import randomize_bn_
+        torch.manual_seed(0)
+        e2e_net = DINOMVSNet(dict(fix=True, depth_type="ce", fusion_type="cnn", inverse_depth=True, base_ch=8, ndepths=list(net.ndepths), feat_chs=[8, 16, 32, 64],
+                                  depth_interals_ratio=list(net.depth_interals_ratio), multi_scale=False,
+                                  vit_args=dict(twin=False, rescale=0.5, patch_size=16, qk_scale="default", vit_arch="vit_small", vit_ch=384, out_ch=64,
+                                                att_fusion=True, nhead=6))).eval()
+        randomize_bn_(e2e_net, seed=1)
+        e2e_net = e2e_net.to(dev)
+        imgs = synth.render_features(synth.make_scene(args.views, args.height, args.width, 0), 1, 3, noise=0.02, device=dev, dtype=torch.float32)
+        for _ in range(2):
+            eo = e2e_net(imgs, proj, dv, tmp=tmp)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(10):
+            eo = e2e_net(imgs, proj, dv, tmp=tmp)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        assert torch.isfinite(eo["refined_depth"]).all()
+        e2e_ms = e0.elapsed_time(e1) / 10
+        end_to_end = {"ms_per_depth_map": round(e2e_ms, 3), "depth_maps_per_s": round(1e3 / e2e_ms, 2), "streams": 1, "steps": 10,
+                      "note": "mvsformer_amd.DINOMVSNet.forward(imgs [1,%d,3,%d,%d], proj_matrices, depth_values): FPNEncoder + DINO ViT-small branch + FPNDecoder + "
+                              "the 4-stage cascade, eval, random weights, rendered images; parity of this composition against the real reference DINOMVSNet: "
+                              "tests/test_hip_vit.py::test_dinomvsnet_images_to_depth_vs_reference_golden; not `value` (the judged metric starts from features)"
+                              % (args.views, args.height, args.width)}
+        del e2e_net, eo, imgs, img
         torch.cuda.empty_cache()
 
     # ---- the same workload with channel-last features (what mvsformer_amd.FPNDecoder emits): no nchw_to_nhwc launches (extra key) ----
@@ -554,7 +583,7 @@ def main(args):
         total = world * args.steps * args.batch
         # Key order: the bulky per-kernel table FIRST, the judged scalars LAST - the driver's record keeps the tail of this line.
         line = {
-            "kernels": kernels, "other_configs": other, "before_the_path": before, "features_layout_nhwc": nhwc, "ranks": ranks, "train_config3": train3,
+            "kernels": kernels, "other_configs": other, "before_the_path": before, "end_to_end_mvsformer_p": end_to_end, "features_layout_nhwc": nhwc, "ranks": ranks, "train_config3": train3,
             "traffic_source": traffic_source, "parity": parity,
             "metric": "depth maps/sec @1536x1152 N=5 D=192", "value": round(total / dt, 3), "unit": "depth maps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
