@@ -136,15 +136,12 @@ def depth_parity(net, feats, proj, dv, tmp, ref, dev):
             "reference": "oracle/ref_torch.cascade_forward (the reference's formulation on torch CPU) on the timed inputs, full size"}
 
 
-def csrc_digest():
-    """sha256[:16] over the kernel sources: profiles/traffic_by_kernel.json records the digest it was collected at, and the per-kernel
-    `traffic` is only reported while the sources are still those."""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(REPO, "mvsformer_amd", "csrc", "*.hip")) + glob.glob(os.path.join(REPO, "mvsformer_amd", "csrc", "*.h"))):
-        h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+def kernel_sources_current(recorded):
+    """kernel name -> True while the source files THAT kernel is built from still have the digests the counter passes recorded
+    (mvsformer_amd/_sources.py): an edit to an unrelated kernel does not void this kernel's traffic evidence."""
+    from mvsformer_amd import _sources
+    now = _sources.file_digests()
+    return lambda name: _sources.current(name, recorded or {}, now)
 
 
 def time_steps(run, steps, world, dev):
@@ -308,11 +305,13 @@ def main(args):
     if os.path.exists(TRAFFIC_FILE):
         with open(TRAFFIC_FILE) as f:
             tj = json.load(f)
-        if tj.get("csrc_digest") == csrc_digest():
-            traffic_db = tj.get("kernels", {})
-            traffic_source = "profiles/traffic_by_kernel.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_traffic.py) at kernel sources %s = the sources of this run; not re-measured in this run" % tj["csrc_digest"]
-        else:
-            traffic_source = "none: profiles/traffic_by_kernel.json was collected at kernel sources %s, this run has %s" % (tj.get("csrc_digest"), csrc_digest())
+        is_current = kernel_sources_current(tj.get("source_digests"))
+        traffic_db = {k: v for k, v in tj.get("kernels", {}).items() if is_current(k)}
+        stale = sorted(k for k in tj.get("kernels", {}) if k not in traffic_db)
+        traffic_source = ("profiles/traffic_by_kernel.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_traffic.py) collected at HEAD %s; a kernel's "
+                          "traffic is reported while the source files it is built from have the digests recorded then (mvsformer_amd/_sources.py): "
+                          "%d kernels current, %d stale%s; not re-measured in this run"
+                          % (tj.get("collected_at_head"), len(traffic_db), len(stale), (" (" + ", ".join(stale[:6]) + ")") if stale else ""))
     kernels = []
     for name, s in ksum.items():
         w = work.get(name)

@@ -1483,16 +1483,18 @@ extern "C" int mvs_bf16_conv3d_bn_fwd(const void* x, const void* wpacked, void* 
     if (gather == 0) Do = (Di - 1) / sd + 1, Ho = (Hi - 1) / shw + 1, Wo = (Wi - 1) / shw + 1;
     else Do = Di * sd, Ho = Hi * shw, Wo = Wi * shw;
     const int64_t ips = (gather == 1 && shw == 2) ? (int64_t)Do * Ho * ((Wo + 127) / 128) * 2 : (int64_t)Do * Ho * ((Wo + 63) / 64);   // work items per sample
-    MVS_REQUIRE(B == 1 || ips % 4 == 0, "mvs_bf16_conv3d_bn_fwd: %lld work items per sample are not a multiple of 4 (block rows would straddle samples)",
-                (long long)ips);
+    const bool ks = conv_ksplit(Cin, (int)(ips * B), taps);                  // one work item per block then: four times the rows
+    // (one statistics group: every row belongs to it, a block may straddle samples; the K-split form has one work item per row anyway)
+    MVS_REQUIRE(B == 1 || groups == 1 || ks || ips % 4 == 0,
+                "mvs_bf16_conv3d_bn_fwd: %lld work items per sample are not a multiple of 4 (block rows would straddle samples of different groups)", (long long)ips);
     if (int rc = bf16_conv3d_impl(x, wpacked, nullptr, nullptr, nullptr, y, B, Cin, Cout, Di, Hi, Wi, gather, sd, shw, 0,
                                   reinterpret_cast<float*>(workspace), groups, nullptr, stream, true, taps))
         return rc;
     hipStream_t s = MVS_STREAM(stream);
-    const bool ks = conv_ksplit(Cin, (int)(ips * B), taps);                  // one work item per block then: four times the rows
-    const int nrows = ks ? (int)(ips * B) : (int)((ips * B + 3) / 4), rps = B == 1 ? nrows : (int)(ks ? ips : ips / 4);
+    const bool one = B == 1 || groups == 1;                                  // all rows are one group's
+    const int nrows = ks ? (int)(ips * B) : (int)((ips * B + 3) / 4), rps = one ? nrows : (int)(ks ? ips : ips / 4);
     const int64_t R = (int64_t)B * Do * Ho * Wo;
-    hipLaunchKernelGGL(bf16_bn_rows_finalize_kernel, dim3(Cout), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), nrows, rps, B, groups,
+    hipLaunchKernelGGL(bf16_bn_rows_finalize_kernel, dim3(Cout), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), nrows, rps, one ? 1 : B, groups,
                        Cout, gamma, beta, running_mean, running_var, momentum, eps, (double)(R / groups), stats4,
                        reinterpret_cast<long long*>(num_batches_tracked));
     const size_t total8 = (size_t)R * (Cout / 8);

@@ -27,6 +27,16 @@
 #include "conv_common.h"
 #include "split3.h"
 
+// the ablation switches of the timeline experiments exist only in experiment builds (make exp EXPFLAGS=-DX3_ABLATE): the shipped kernel has no
+// environment-dependent path (as tail_x3.hip)
+#ifdef X3_ABLATE
+#define VIS_ABLATE(a, bit) (((a) & (bit)) != 0)
+static int vis_ablate_bits() { const char* e = getenv("MVS_VIS_ABLATE"); return e ? atoi(e) : 0; }
+#else
+#define VIS_ABLATE(a, bit) false
+static constexpr int vis_ablate_bits() { return 0; }
+#endif
+
 namespace {
 using namespace mvsconv;
 using mvsx3::bf16x4;
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
         auto layer1 = [&](auto inner) {
             constexpr bool INNER = decltype(inner)::value;
 #pragma unroll 1
-            for (int t = wave; t < L1_TILES && !(ablate & 1); t += 4) {
+            for (int t = wave; t < L1_TILES && !VIS_ABLATE(ablate, 1); t += 4) {
                 const int p = t * 16 + n;
                 const unsigned ix = s_idx[p];
                 const float* src = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(s_in) + (ix & 0xffffu));
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(ablate & 2)) {
+                if (!VIS_ABLATE(ablate, 2)) {
                     c0 = mfma6(w2[s], x0f[s & 1], c0);
                     c1 = mfma6(w2[s], x1f[s & 1], c1);
                 }
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
                     store_split<A2_OCT, A2_TERM>(s_a2, oy * A2W + ox, kb, v);
                 }
             };
-            if (!(ablate & 4)) {
+            if (!VIS_ABLATE(ablate, 4)) {
                 finish(t, c0);
                 if (two) finish(t + 4, c1);
             }
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(ablate & 8)) {
+                if (!VIS_ABLATE(ablate, 8)) {
                     c0 = mfma6(w3[s], x0f[s & 1], c0);
                     c1 = mfma6(w3[s], x1f[s & 1], c1);
                 }
@@ -339,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void vis_x3_kernel(const float* __restrict_
                 for (int r = 0; r < 4; ++r) part = fmaf(wl[r], fmaxf(c[r], 0.0f), part);
                 return part + __shfl_xor(part, 16, 64);      // both channel halves now hold the pixel's sum
             };
-            if (!(ablate & 16)) {
+            if (!VIS_ABLATE(ablate, 16)) {
                 // the even channel-half lanes finish row pair `wave`, the odd ones row pair `wave + 4`: one sigmoid per lane instead of two
                 const float p0 = reduce(c0), p1 = reduce(c1);
                 const bool second = (kb & 1) != 0;
@@ -377,6 +387,6 @@ extern "C" int mvs_vis_x3_fwd(const float* entropy, const float* params, const v
         if (rc != MVS_OK) return rc;
     }
     hipLaunchKernelGGL(vis_x3_kernel, dim3(blocks), dim3(256), LDS_BYTES, MVS_STREAM(stream), entropy, params, static_cast<const bf16x8*>(prepared), N,
-                       H, W, ntx, nty, weight, getenv("MVS_VIS_ABLATE") ? atoi(getenv("MVS_VIS_ABLATE")) : 0);
+                       H, W, ntx, nty, weight, vis_ablate_bits());
     return mvs::finish_launch("mvs_vis_x3_fwd");
 }

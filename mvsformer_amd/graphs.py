@@ -69,4 +69,6 @@ class CapturedStep:
     def __call__(self):
         """Replay; returns the (static) output tensors of the captured step - clone them if they must outlive the next replay."""
         self.graph.replay()
+        from . import ops
+        ops.bump_weights_epoch()                             # the replay updates parameters / running statistics without passing through Python
         return self.outputs

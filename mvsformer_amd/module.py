@@ -40,7 +40,9 @@ def _bn_fold(bn: nn.modules.batchnorm._BatchNorm) -> Tuple[torch.Tensor, torch.T
 
 
 def _versions(mod: nn.Module) -> tuple:
-    return tuple((t.data_ptr(), t._version) for t in list(mod.parameters()) + list(mod.buffers()))
+    """Cache key of everything derived from a module's parameters / buffers: torch's (data_ptr, _version) per tensor + the epoch of
+    raw-pointer writes (``ops.bump_weights_epoch``: FusedAdamW, training-mode BatchNorm kernels, replayed hipGraphs)."""
+    return (ops.weights_epoch(),) + tuple((t.data_ptr(), t._version) for t in list(mod.parameters()) + list(mod.buffers()))
 
 
 def _publish_cache() -> None:

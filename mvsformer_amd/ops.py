@@ -47,6 +47,23 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# ----------------------------------------------------------------------------------------------- weights epoch
+# Kernels that write parameters or BatchNorm buffers THROUGH RAW POINTERS (mvs_adamw_step, the training-mode BatchNorm kernels' running
+# statistics, a replayed hipGraph of a whole step) do not advance torch's per-tensor ``_version``, which the eval-path caches (packed
+# weights, folded BatchNorm; module._versions) are keyed on.  Every such write advances this process-wide epoch instead, and the cache keys
+# carry it: an eval after a training step re-packs, consecutive evals do not.
+_weights_epoch = 0
+
+
+def bump_weights_epoch() -> None:
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def weights_epoch() -> int:
+    return _weights_epoch
+
+
 # ----------------------------------------------------------------------------------------------- timing hook
 class KernelTimer:
     """Collects (start, end) HIP events per C-ABI launch, on the stream the kernels are launched on."""
@@ -798,6 +815,8 @@ def bn_finalize(sums, gamma, beta, running_mean, running_var, momentum, eps, cou
     C = sums.numel() // 2
     dev = sums.device
     scale, shift, mean, invstd = (torch.empty(C, device=dev, dtype=torch.float32) for _ in range(4))
+    if running_mean is not None:
+        bump_weights_epoch()                                 # running statistics are written through raw pointers
     _call("mvs_bn_finalize", None, _ptr(sums), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), float(momentum),
           float(eps), float(count), _ptr(count_dev), C, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _stream())
     return scale, shift, mean, invstd
@@ -810,6 +829,8 @@ def bn_finalize_grouped(sums, gamma, beta, running_mean, running_var, momentum, 
     C = CT // groups
     dev = sums.device
     scale, shift, mean, invstd = (torch.empty(CT, device=dev, dtype=torch.float32) for _ in range(4))
+    if running_mean is not None:
+        bump_weights_epoch()                                 # running statistics are written through raw pointers
     _call("mvs_bn_finalize_grouped", None, _ptr(sums), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), float(momentum),
           float(eps), float(count), _ptr(count_dev), C, int(groups), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _stream())
     return scale, shift, mean, invstd
@@ -1193,6 +1214,8 @@ class PackTable:
 
     def run(self):
         _call("mvs_bf16_pack_table_run", "mvs_bf16_pack_weights", _ptr(self.table), self.n, self.blocks, _stream())
+        for o in self.outs:                                  # written through raw pointers: tell autograd, so that a graph that SAVED an earlier
+            torch.autograd.graph.increment_version(o)        # packing (retain_graph / interleaved forwards) raises instead of using new weights
         return self.outs
 
 
@@ -1386,6 +1409,8 @@ def bf16_bn_train_fwd(x, residual, relu, gamma, beta, running_mean, running_var,
     y = torch.empty_like(x)
     st = torch.empty(5, groups * C, device=x.device, dtype=torch.float32)      # scale | shift | mean | invstd | gamma per (group, channel)
     ws = _reduce_ws("mvs_bf16_bn_reduce_workspace_bytes", x.device, C, R, groups, rps)
+    if running_mean is not None:
+        bump_weights_epoch()                                 # running statistics are written through raw pointers
     _call("mvs_bf16_bn_train_fwd", "bf16_bn_train_fwd", _ptr(x), _ptr(residual), int(relu), C, R, groups, rps, _ptr(gamma), _ptr(beta),
           _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), _ptr(num_batches_tracked), _ptr(st), _ptr(y), _ptr(ws), _stream())
     return y, st[0], st[1], st[2], st[3]
@@ -1439,6 +1464,8 @@ def bf16_conv3d_bn_fwd(x, wpacked, cin, cout, gather: int, stride, residual, rel
     ws = _reduce_ws("mvs_bf16_conv3d_bn_fwd_workspace_bytes", x.device, B, cout, Do, Ho, Wo)
     flops = 2.0 * taps * cin * cout * B * (Do * Ho * Wo if gather == 0 else Di * Hi * Wi)
     tag = ("bf16_conv_bn_fwd<%d,%d,g%d,s%d%d%s>" % (cin, cout, gather, sd, shw, ",2d" if taps == 9 else ""), "flops", flops)
+    if running_mean is not None:
+        bump_weights_epoch()                                 # running statistics are written through raw pointers
     _call("mvs_bf16_conv3d_bn_fwd", tag, _ptr(x), _ptr(wpacked), _ptr(y), _ptr(z), _ptr(residual), int(relu), B, cin, cout, Di, Hi, Wi,
           int(gather), sd, shw, int(taps), int(groups), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), float(momentum), float(eps),
           _ptr(num_batches_tracked), _ptr(st), _ptr(ws), _stream())

@@ -98,14 +98,17 @@ def main():
     cal_bytes = 4.0 * 5 * 8 * 1152 * 1536
     ffac = cal_bytes / fetch[calk] if fetch.get(calk) else 2.0
     wfac = cal_bytes / write[calk] if write.get(calk) else 1.0
-    import glob as _g
-    import hashlib
     import os
+    import subprocess
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    h = hashlib.sha256()
-    for f in sorted(_g.glob(os.path.join(repo, "mvsformer_amd", "csrc", "*.hip")) + _g.glob(os.path.join(repo, "mvsformer_amd", "csrc", "*.h"))):
-        h.update(open(f, "rb").read())
-    out = {"csrc_digest": h.hexdigest()[:16], "_units": "bytes per launch (mean over launches)", "_calibration": {"kernel": calk, "known_bytes_each_way": cal_bytes,
+    sys.path.insert(0, repo)
+    from mvsformer_amd import _sources
+    try:
+        head = subprocess.check_output(["git", "-C", repo, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL, text=True).strip()
+    except Exception:                                       # noqa: BLE001 - the GPU box has no .git
+        head = os.environ.get("MVS_HEAD", "unknown (no .git on the GPU box)")
+    # per-FILE digests: bench.py reports a kernel's traffic while the files that kernel is built from are unchanged (mvsformer_amd/_sources.py)
+    out = {"source_digests": _sources.file_digests(), "collected_at_head": head, "_units": "bytes per launch (mean over launches)", "_calibration": {"kernel": calk, "known_bytes_each_way": cal_bytes,
            "fetch_raw": fetch.get(calk), "write_raw": write.get(calk), "fetch_factor": ffac, "write_factor": wfac},
            "_note": "hbm_bytes_per_launch = FETCH_SIZE*1024*fetch_factor + WRITE_SIZE*1024*write_factor; factors from the float4 copy "
                     "of the same run (exact for 16 B/lane streams; 'narrow' kernels load dwords and are only indicative)", "kernels": {}}
