@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 30
+#define MVS_ABI_VERSION 31
 
 typedef void* mvs_stream_t;
 
@@ -437,6 +437,8 @@ int mvs_prob1_bwd(const float* x, const float* w, const float* dlogits, int B, i
                   mvs_stream_t stream);
 int mvs_sigmoid_fwd(const float* x, int64_t n, float* y, mvs_stream_t stream);
 int mvs_sigmoid_bwd(const float* y, const float* dy, int64_t n, float* dx, mvs_stream_t stream);
+/* out = a * b elementwise (models/module.py:464 x1 * x2 of AttentionFusionSimple in training; backward = the same call twice) */
+int mvs_ewise_mul(const float* a, const float* b, int64_t n, float* out, mvs_stream_t stream);
 int mvs_nhwc_to_nchw(const float* in, float* out, int N, int C, int64_t HW, mvs_stream_t stream);
 
 /* Stand-alone heads for callers that use the ops directly.
@@ -678,14 +680,15 @@ int mvs_attention_x3p(const void* Qp, const void* Kp, const void* Vtp, void* Op,
 int mvs_cls_attention_x3p(const void* Qp, const void* Kp, float* att, int images, int N, int Np, int heads, mvs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
- * training mode of the FPN encoder / decoder (models/module.py:208-270 under train(); csrc/vit.hip, csrc/fpn_train.hip).
- * fp32 NCHW like the reference; convolutions as split-form GEMMs with an implicit patch matrix, any odd kernel size, stride 1 / 2:
+ * training mode of the FPN encoder / decoder (models/module.py:208-270 under train(); csrc/vit.hip, csrc/fpn_train.hip) and of
+ * the ViT decoder (models/module.py:353-368,450-466: a ConvTranspose2d's forward / data gradient / weight gradient are modes 2 / 1 / 3 with the
+ * tensors' roles swapped).  fp32 NCHW like the reference; convolutions as split-form GEMMs with an implicit patch matrix, any kernel size, stride 1 / 2:
  *   mvs_conv2d_gemm_x3 mode 1: y [nb1][Cout][Ho*Wo] = w [Cout][Cin*KS*KS] . patches(x [nb1][Cin][H][W])          (A = w, Bmap = x)
  *                      mode 2: dx [nb1][Cin][H*W]   = wT [Cin][Cout*KS*KS] . gather(dy [nb1][Cout][Ho][Wo])     (A = w.permute(1,0,2,3), Bmap = dy)
  *                      mode 3: part [nb1][nsplit][Cout][Cin*KS*KS] = dy . patches(x)^T over ksplit output pixels per split (A = dy, Bmap = x;
  *                              ksplit % 32 == 0, nsplit = ceil(Ho*Wo / ksplit)); the caller adds the partial matrices in a fixed order.
  *   The BatchNorm kernels' `relu` argument (mvs_affine_act, mvs_bn_bwd_reduce, mvs_bn_bwd_apply) is an activation code: 0 none, 1 ReLU,
- *   2 leaky ReLU(0.1) (FPNEncoder), 3 Swish (FPNDecoder).
+ *   2 leaky ReLU(0.1) (FPNEncoder), 3 Swish (FPNDecoder), 4 GELU(erf) (VITDecoderStage4Single).
  *   mvs_upsample2x_add: y = bilinear_x2(x, align_corners = True) (+ lateral); mvs_upsample2x_bwd: its adjoint (a gather: no atomics).
  * ------------------------------------------------------------------------------------------------------- */
 int mvs_conv2d_gemm_x3(int mode, const float* A, const float* Bmap, float* C, int nb1, int Cin, int Cout, int H, int W, int Ho, int Wo, int KS,

@@ -18,7 +18,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVS_HIP_LIB: diagnostics only - another BUILD of the same library (tests/test_hip_multistream.py's variants); never a fallback
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 from ctypes import c_double  # noqa: E402
 
@@ -124,6 +124,7 @@ SIGNATURES = {
     "mvs_prob1_bwd": (I, [P, P, P, I, I, L, P, P, P]),
     "mvs_sigmoid_fwd": (I, [P, L, P, P]),
     "mvs_sigmoid_bwd": (I, [P, P, L, P, P]),
+    "mvs_ewise_mul": (I, [P, P, L, P, P]),
     "mvs_nhwc_to_nchw": (I, [P, P, I, I, L, P]),
     "mvs_depth_regression": (I, [P, P, I, I, I, I, I, P, P]),
     "mvs_conf_regression": (I, [P, I, I, I, I, I, P, P]),

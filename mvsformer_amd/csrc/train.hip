@@ -14,11 +14,13 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int CHUNK = 4096;            // elements of one (b, c) row handled by a block (256 threads x 4 x 4)
 
 // Activation codes of the BatchNorm kernels' `relu` argument (0 / 1 keep their old meaning): 0 none, 1 ReLU (the 3-D regularizer and the
-// visibility CNN), 2 leaky ReLU with slope 0.1 (FPNEncoder's Conv2d, models/module.py:66-67), 3 Swish x*sigmoid(x) (FPNDecoder, :200-206).
+// visibility CNN), 2 leaky ReLU with slope 0.1 (FPNEncoder's Conv2d, models/module.py:66-67), 3 Swish x*sigmoid(x) (FPNDecoder, :200-206),
+// 4 GELU in its erf form (VITDecoderStage4Single's nn.GELU(), models/module.py:361-364).
 __device__ __forceinline__ float act_fwd(float z, int act) {
     if (act == 1) return fmaxf(z, 0.0f);
     if (act == 2) return z > 0.0f ? z : 0.1f * z;
     if (act == 3) return z / (1.0f + __expf(-z));
+    if (act == 4) return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f));          // GELU (erf form, nn.GELU()'s default)
     return z;
 }
 __device__ __forceinline__ float act_grad(float z, int act) {          // d act(z) / dz
@@ -28,6 +30,7 @@ __device__ __forceinline__ float act_grad(float z, int act) {          // d act(
         const float sg = 1.0f / (1.0f + __expf(-z));
         return sg * (1.0f + z * (1.0f - sg));
     }
+    if (act == 4) return 0.5f * (1.0f + erff(z * 0.70710678118654752440f)) + z * 0.39894228040143267794f * expf(-0.5f * z * z);   // Phi(z) + z phi(z)
     return 1.0f;
 }
 
@@ -369,6 +372,24 @@ extern "C" int mvs_sigmoid_bwd(const float* y, const float* dy, int64_t n, float
     MVS_REQUIRE(y && dy && dx && n >= 1, "mvs_sigmoid_bwd: bad arguments");
     hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, MVS_STREAM(stream), y, dy, (size_t)n, dx);
     return mvs::finish_launch("mvs_sigmoid_bwd");
+}
+
+// out = a * b elementwise (AttentionFusionSimple's x1 * x2, models/module.py:464; its backward is the same kernel twice: da = dy * b, db = dy * a)
+__global__ __launch_bounds__(256) void ewise_mul_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, float* __restrict__ out) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 4 <= n) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(a + i), y = *reinterpret_cast<const f32x4*>(b + i);
+        *reinterpret_cast<f32x4*>(out + i) = f32x4{x[0] * y[0], x[1] * y[1], x[2] * y[2], x[3] * y[3]};
+    } else {
+        for (size_t k = i; k < n; ++k) out[k] = a[k] * b[k];
+    }
+}
+
+extern "C" int mvs_ewise_mul(const float* a, const float* b, int64_t n, float* out, mvs_stream_t stream) {
+    MVS_REQUIRE(a && b && out && n >= 1 && (reinterpret_cast<uintptr_t>(a) & 15) == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+                "mvs_ewise_mul: 16-byte aligned tensors");
+    hipLaunchKernelGGL(ewise_mul_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, MVS_STREAM(stream), a, b, (size_t)n, out);
+    return mvs::finish_launch("mvs_ewise_mul");
 }
 
 extern "C" int mvs_nhwc_to_nchw(const float* in, float* out, int N, int C, int64_t HW, mvs_stream_t stream) {

@@ -698,7 +698,8 @@ extern "C" int mvs_gemm_x3(const float* A, const float* B, float* C, int M, int 
     return mvs::finish_launch("mvs_gemm_x3");
 }
 
-// The FPN's 2-D convolutions in training (fp32 NCHW, any odd kernel size / stride 1 or 2 / padding): forward, data gradient and weight
+// The FPN's / ViT decoder's 2-D convolutions in training (fp32 NCHW, any kernel size / stride 1 or 2 / padding; a ConvTranspose2d is the same three
+// GEMMs with the roles swapped: its forward is mode 2, its data gradient mode 1): forward, data gradient and weight
 // gradient as the same split-form GEMM with an implicit patch matrix (mode = 1 / 2 / 3, see GemmArgs).  Per batch item b1:
 //   mode 1: y [Cout][Ho*Wo]      = w [Cout][Cin*KS*KS] . patches(x [Cin][H][W])
 //   mode 2: dx [Cin][H*W]        = wT [Cin][Cout*KS*KS] . gather(dy [Cout][Ho][Wo])         (wT = w.permute(1,0,2,3), made by the caller)
@@ -706,7 +707,7 @@ extern "C" int mvs_gemm_x3(const float* A, const float* B, float* C, int M, int 
 //           a multiple of 32); the caller adds the nb1 * nsplit partial matrices (mvs::launch_partials_reduce order)
 extern "C" int mvs_conv2d_gemm_x3(int mode, const float* A, const float* Bmap, float* C, int nb1, int Cin, int Cout, int H, int W, int Ho, int Wo,
                                   int KS, int S, int P, int ksplit, mvs_stream_t stream) {
-    MVS_REQUIRE(A && Bmap && C && nb1 >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1 && Ho >= 1 && Wo >= 1 && KS >= 1 && (KS & 1) && (S == 1 || S == 2) && P >= 0,
+    MVS_REQUIRE(A && Bmap && C && nb1 >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1 && Ho >= 1 && Wo >= 1 && KS >= 1 && (S == 1 || S == 2) && P >= 0,
                 "mvs_conv2d_gemm_x3: bad shape");
     MVS_REQUIRE(mode >= 1 && mode <= 3 && (mode != 3 || (ksplit >= 32 && ksplit % 32 == 0)), "mvs_conv2d_gemm_x3: mode 1..3 (mode 3 needs ksplit %% 32 == 0)");
     GemmArgs a{};

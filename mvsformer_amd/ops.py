@@ -1809,6 +1809,16 @@ def conv2d_wgrad_x3(dy: torch.Tensor, x: torch.Tensor, KS: int, stride: int, pad
     return dw
 
 
+def ewise_mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """``a * b`` elementwise (same shape, fp32)."""
+    _chk(a, "a"), _chk(b, "b")
+    if a.shape != b.shape:
+        raise _lib.MvsHipError("ewise_mul: %s * %s" % (tuple(a.shape), tuple(b.shape)))
+    out = torch.empty_like(a)
+    _call("mvs_ewise_mul", "ewise_mul", _ptr(a), _ptr(b), a.numel(), _ptr(out), _stream())
+    return out
+
+
 def upsample2x_add(x: torch.Tensor, lateral: Optional[torch.Tensor]) -> torch.Tensor:
     """``F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True) (+ lateral)``, fp32 NCHW."""
     _chk(x, "x"), _opt(lateral, "lateral")

@@ -1,7 +1,8 @@
 """The DINO ViT-small feature branch of MVSFormer-P on the MI355X path: ``vit_small`` / ``VisionTransformer`` with the
 interface and the ``state_dict`` keys of the reference's ``models/vision_transformer.py`` (:340-451, ``vit_small`` :610-614) and
 ``VITDecoderStage4Single`` / ``AttentionFusionSimple`` of ``models/module.py`` (:353-368, :450-466), so the checkpoint of the shipped
-``configs/config_mvsformer-p.json`` loads with ``strict=True``.  Eval mode (the reference freezes the ViT: ``"fix": true``); every
+``configs/config_mvsformer-p.json`` loads with ``strict=True``.  The ViT itself is eval-only (the reference freezes it: ``"fix": true``); the
+decoder also runs in training mode (batch-statistics BatchNorm, every gradient; ``_forward_train``).  In eval every
 matrix product - patch embedding, QKV, attention scores, attention x V, projections, MLP, the decoder's 3x3 convolutions and transposed
 convolutions as implicit GEMMs - runs in ``csrc/vit.hip`` on the bf16 matrix cores in three-term split form (fp32-equivalent), LayerNorm,
 softmax and the bicubic resizes are HIP kernels too; torch only reshapes / concatenates / slices (no arithmetic beyond one broadcast
@@ -276,6 +277,50 @@ def _convT_matrices(w: torch.Tensor) -> torch.Tensor:
     return out.reshape(4, cout, 4 * cin).contiguous()
 
 
+class ConvT2dFn(torch.autograd.Function):
+    """Raw ``ConvTranspose2d`` (weight ``[Cin,Cout,KS,KS]``, no bias) in training, fp32 NCHW: the transposed convolution IS the data gradient of
+    the convolution with the same weight read as ``[Cout_conv = Cin][Cin_conv = Cout]`` - forward = ``mvs_conv2d_gemm_x3`` mode 2, data
+    gradient = mode 1, weight gradient = mode 3 with ``x`` in the role of the convolution's output gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        x = x.to(torch.float32).contiguous()
+        w = weight.detach().to(torch.float32).contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (int(stride), int(pad))
+        KS = w.shape[2]
+        Ho, Wo = (x.shape[2] - 1) * stride - 2 * pad + KS, (x.shape[3] - 1) * stride - 2 * pad + KS
+        return ops.conv2d_dgrad_x3(x, w, int(stride), int(pad), Ho, Wo)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.cfg
+        dy = dy.contiguous()
+        dx = ops.conv2d_fwd_x3(dy, w, stride, pad) if ctx.needs_input_grad[0] else None
+        dw = ops.conv2d_wgrad_x3(x, dy, w.shape[2], stride, pad) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None
+
+
+class MulFn(torch.autograd.Function):
+    """``a * b`` (models/module.py:464) with both gradients through ``mvs_ewise_mul``."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a, b)
+        return ops.ewise_mul(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        dy = dy.contiguous()
+        return (ops.ewise_mul(dy, b) if ctx.needs_input_grad[0] else None), (ops.ewise_mul(dy, a) if ctx.needs_input_grad[1] else None)
+
+
+ACT_GELU_BN = 4                          # GELU(erf) in the fp32 BatchNorm kernels (csrc/train.hip); 3 = Swish
+
+
 class VITDecoderStage4Single(nn.Module):
     """models/module.py:353-368: ``forward(x [B,vit_ch,h,w], att [B,nhead,h,w]) -> [B,out_ch,4h,4w]`` (added to ``conv31``)."""
 
@@ -347,9 +392,32 @@ class VITDecoderStage4Single(nn.Module):
                     a_mode=2, H=h, W=w, Cp=C, scale=fold[0], shift=fold[1], act=act)
         return tmp.view(B, 2, 2, h, w, cout).permute(0, 3, 1, 4, 2, 5).reshape(B, 2 * h, 2 * w, cout).contiguous()
 
+    def _forward_train(self, x, att):
+        """models/module.py:365-368 + :459-466 with batch statistics, every op an autograd-tracked HIP kernel (fp32 NCHW like the FPN's training
+        path): conv_l / conv_r / proj through ``Conv2dFn`` + ``BiasFn``, BatchNorm + Swish / GELU through ``BnActFn`` (SyncBatchNorm-aware), the
+        gated product through ``MulFn``, the two ``ConvTranspose2d`` through ``ConvT2dFn``."""
+        from .autograd import BnActFn
+        from .fpn import ACT_SWISH, BiasFn, Conv2dFn
+        a, d = self.attn, self.decoder
+        x = x.to(torch.float32).contiguous()
+        att = att.to(torch.float32).contiguous()
+
+        def conv_bn(t, seq):
+            y = BiasFn.apply(Conv2dFn.apply(t, seq[0].weight, 1, 1), seq[0].bias)
+            return BnActFn.apply(y, seq[1].weight, seq[1].bias, None, seq[1], ACT_SWISH)
+
+        x1 = conv_bn(torch.cat([x, att], dim=1), a.conv_l)
+        gate = att.mean(dim=1, keepdim=True)                  # inputs come from the frozen ViT: no gradient flows through these two torch ops
+        x2 = conv_bn(x * gate if not (x.requires_grad or att.requires_grad) else MulFn.apply(x, gate.expand_as(x)), a.conv_r)
+        y = BiasFn.apply(Conv2dFn.apply(MulFn.apply(x1, x2), a.proj.weight, 1, 0), a.proj.bias)
+        for conv, bn in ((d[0], d[1]), (d[3], d[4])):
+            y = BiasFn.apply(ConvT2dFn.apply(y, conv.weight, conv.stride[0], conv.padding[0]), conv.bias)
+            y = BnActFn.apply(y, bn.weight, bn.bias, None, bn, ACT_GELU_BN)
+        return y
+
     def forward(self, x, att):
         if self.training:
-            raise _lib.MvsHipError("VITDecoderStage4Single: only eval mode is built on the HIP path")
+            return self._forward_train(x, att)
         p = self._prepared()
         with torch.no_grad():
             B, C, h, w = x.shape

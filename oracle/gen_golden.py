@@ -784,3 +784,46 @@ def gen_end_to_end():
 
 if __name__ == "__main__" and os.environ.get("GEN_E2E", "1") == "1":
     gen_end_to_end()
+
+
+GRAD_SAMPLE = 4096
+
+
+def grad_sample(t, seed):
+    """A fixed random subset of a (large) gradient + its L2 norm: what the goldens of the 3.4 M-parameter ViT decoder store per tensor."""
+    flat = t.detach().reshape(-1)
+    if flat.numel() <= GRAD_SAMPLE:
+        return np32(flat), np.arange(flat.numel(), dtype=np.int64), np.float32(flat.double().norm())
+    idx = torch.randperm(flat.numel(), generator=torch.Generator().manual_seed(seed))[:GRAD_SAMPLE].sort().values
+    return np32(flat[idx]), idx.numpy().astype(np.int64), np.float32(flat.double().norm())
+
+
+def gen_vit_decoder_train():
+    """``VITDecoderStage4Single`` (+ ``AttentionFusionSimple``) of the shipped MVSFormer-P config in TRAINING mode (models/module.py:353-368,
+    450-466 under train(); DINOMVSNet trains it, mvsformer_model.py:196-201,225-228): the real module on two 8 x 10 token maps, batch-statistics
+    BatchNorm, loss = <out, R> with seeded R, every parameter gradient (the big ones as a fixed 4096-element sample + their L2 norm), the
+    gradient of the inputs and the updated running statistics.  Weights: oracle/weights.make_vit_state_dict, seed 41."""
+    from models.module import VITDecoderStage4Single
+    from oracle.weights import load_vit_shapes, make_vit_state_dict
+    vit_args = dict(rescale=0.5, patch_size=16, qk_scale="default", vit_arch="vit_small", vit_ch=384, out_ch=64, att_fusion=True, nhead=6)
+    dec = VITDecoderStage4Single(vit_args)
+    dec.load_state_dict(make_vit_state_dict(load_vit_shapes("vit_decoder"), 41), strict=True)
+    dec.train()
+    g = torch.Generator().manual_seed(42)
+    feat = f16exact(torch.randn(2, 384, 8, 10, generator=g)).requires_grad_(True)
+    att = f16exact(torch.rand(2, 6, 8, 10, generator=g) * 0.05).requires_grad_(True)
+    out = dec(feat, att)
+    R = torch.randn(out.shape, generator=g)
+    loss = (out * R).sum()
+    loss.backward()
+    arrs = dict(feat=np32(feat).astype(np.float16), att=np32(att).astype(np.float16), out=np32(out), loss=np32(loss), seeds=np.array([41, 42]))
+    arrs["dfeat"], arrs["datt"] = np32(feat.grad), np32(att.grad)
+    for n, (k, p) in enumerate(dec.named_parameters()):
+        v, idx, nrm = grad_sample(p.grad, 100 + n)
+        arrs["grad." + k], arrs["idx." + k], arrs["norm." + k] = v, idx, nrm
+    arrs.update({"buf." + k: np32(b) for k, b in dec.named_buffers() if b.dtype.is_floating_point})
+    save("vit_decoder_train.npz", **arrs)
+
+
+if __name__ == "__main__" and os.environ.get("GEN_VIT_TRAIN", "1") == "1":
+    gen_vit_decoder_train()

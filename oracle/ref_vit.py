@@ -66,18 +66,19 @@ def vit_forward_with_last_att(sd: Dict[str, torch.Tensor], x: torch.Tensor) -> T
     return F.layer_norm(t, (EMBED,), sd["norm.weight"], sd["norm.bias"], LN_EPS), att
 
 
-def _bn(x, sd, p):
-    return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"], False, 0.0, 1e-5)
+def _bn(x, sd, p, training=False):
+    """eval: running statistics; training: batch statistics, the running statistics in ``sd`` updated in place (momentum 0.1), as nn.BatchNorm2d."""
+    return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"], training, 0.1 if training else 0.0, 1e-5)
 
 
-def vit_decoder(sd: Dict[str, torch.Tensor], feat: torch.Tensor, att: torch.Tensor) -> torch.Tensor:
-    """VITDecoderStage4Single in eval mode: ``feat [B,384,h,w]``, ``att [B,6,h,w]`` -> ``[B,64,4h,4w]`` (added to conv31)."""
+def vit_decoder(sd: Dict[str, torch.Tensor], feat: torch.Tensor, att: torch.Tensor, training: bool = False) -> torch.Tensor:
+    """VITDecoderStage4Single (models/module.py:353-368,450-466): ``feat [B,384,h,w]``, ``att [B,6,h,w]`` -> ``[B,64,4h,4w]`` (added to conv31)."""
     swish = lambda v: v * torch.sigmoid(v)                                                   # models/module.py Swish
-    x1 = swish(_bn(F.conv2d(torch.cat([feat, att], 1), sd["attn.conv_l.0.weight"], sd["attn.conv_l.0.bias"], padding=1), sd, "attn.conv_l.1."))
-    x2 = swish(_bn(F.conv2d(feat * att.mean(1, keepdim=True), sd["attn.conv_r.0.weight"], sd["attn.conv_r.0.bias"], padding=1), sd, "attn.conv_r.1."))
+    x1 = swish(_bn(F.conv2d(torch.cat([feat, att], 1), sd["attn.conv_l.0.weight"], sd["attn.conv_l.0.bias"], padding=1), sd, "attn.conv_l.1.", training))
+    x2 = swish(_bn(F.conv2d(feat * att.mean(1, keepdim=True), sd["attn.conv_r.0.weight"], sd["attn.conv_r.0.bias"], padding=1), sd, "attn.conv_r.1.", training))
     x = F.conv2d(x1 * x2, sd["attn.proj.weight"], sd["attn.proj.bias"])
-    x = F.gelu(_bn(F.conv_transpose2d(x, sd["decoder.0.weight"], sd["decoder.0.bias"], stride=2, padding=1), sd, "decoder.1."))
-    return F.gelu(_bn(F.conv_transpose2d(x, sd["decoder.3.weight"], sd["decoder.3.bias"], stride=2, padding=1), sd, "decoder.4."))
+    x = F.gelu(_bn(F.conv_transpose2d(x, sd["decoder.0.weight"], sd["decoder.0.bias"], stride=2, padding=1), sd, "decoder.1.", training))
+    return F.gelu(_bn(F.conv_transpose2d(x, sd["decoder.3.weight"], sd["decoder.3.bias"], stride=2, padding=1), sd, "decoder.4.", training))
 
 
 def vit_branch(sd_vit, sd_dec, img: torch.Tensor, rescale: float = 0.5):

@@ -316,3 +316,42 @@ def test_dinomvsnet_images_to_depth_vs_reference_golden(dev):
     rel = ((out["refined_depth"].cpu() - want).abs() / want.abs()).max().item()
     assert rel < 1e-3, rel
     assert (out["photometric_confidence"].cpu() - torch.from_numpy(g["photometric_confidence"])).abs().max() < 2e-3
+
+
+def test_vit_decoder_training_mode_vs_reference_gradients(dev):
+    """``VITDecoderStage4Single`` in TRAINING mode on the HIP path (batch-statistics BatchNorm, Swish / GELU, the gated product, both transposed
+    convolutions; forward and backward are HIP kernels) against the real reference module in train(): output, loss, input gradients, every
+    parameter gradient (the big tensors by a fixed 4096-element sample + their norm) and the updated running statistics."""
+    import mvsformer_amd as m
+    from oracle.weights import load_vit_shapes, make_vit_state_dict
+    g = load_golden("vit_decoder_train.npz")
+    dec = m.VITDecoderStage4Single(dict(out_ch=64, vit_ch=384, att_fusion=True, nhead=6))
+    dec.load_state_dict(make_vit_state_dict(load_vit_shapes("vit_decoder"), int(g["seeds"][0])), strict=True)
+    dec = dec.to(dev).train()
+    feat = torch.from_numpy(g["feat"].astype(np.float32)).to(dev).requires_grad_(True)
+    att = torch.from_numpy(g["att"].astype(np.float32)).to(dev).requires_grad_(True)
+    out = dec(feat, att)
+    gen = torch.Generator().manual_seed(int(g["seeds"][1]))
+    torch.randn(2, 384, 8, 10, generator=gen), torch.rand(2, 6, 8, 10, generator=gen)
+    R = torch.randn(out.shape, generator=gen).to(dev)
+    loss = (out * R).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert _rel(out, torch.from_numpy(g["out"])) < 2e-5
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    assert _rel(feat.grad, torch.from_numpy(g["dfeat"])) < 2e-4 and _rel(att.grad, torch.from_numpy(g["datt"])) < 2e-4
+    worst = 0.0
+    for k, p in dec.named_parameters():
+        want, idx = torch.from_numpy(g["grad." + k]), torch.from_numpy(g["idx." + k])
+        got = p.grad.detach().cpu().reshape(-1)[idx]
+        if want.abs().max() < 1e-2:                        # a conv bias in front of a batch-statistics BatchNorm: exactly zero in exact arithmetic,
+            assert got.abs().max().item() < 1e-2, k        # rounding noise on both sides (the neighbouring gradients are ~1e2)
+            continue
+        e = (got - want).abs().max().item() / max(1e-12, want.abs().max().item())
+        worst = max(worst, e)
+        assert e < 2e-4, (k, e)
+        assert abs(float(p.grad.double().norm()) - float(g["norm." + k])) < 2e-4 * float(g["norm." + k]) + 1e-7, k
+    for k, b in dec.named_buffers():
+        if b.dtype.is_floating_point:
+            assert (b.cpu() - torch.from_numpy(g["buf." + k])).abs().max() < 1e-5, k
+    print("worst parameter-gradient error %.2e" % worst)

@@ -329,3 +329,44 @@ def test_dinomvsnet_oracle_vs_reference():
     want = torch.from_numpy(g["refined_depth"])
     assert ((out["refined_depth"] - want).abs() / want.abs()).max() < 1e-4
     assert (out["photometric_confidence"] - torch.from_numpy(g["photometric_confidence"])).abs().max() < 1e-4
+
+
+def test_vit_decoder_training_oracle_vs_reference():
+    """oracle/ref_vit.vit_decoder(training=True) under torch autograd against the REAL ``VITDecoderStage4Single`` in train() (tests/golden/
+    vit_decoder_train.npz): output, loss, the input gradients, every parameter gradient (sampled for the big tensors) and the running statistics."""
+    from oracle import ref_vit
+    from oracle.weights import load_vit_shapes, make_vit_state_dict
+    g = load_golden("vit_decoder_train.npz")
+    sd = make_vit_state_dict(load_vit_shapes("vit_decoder"), int(g["seeds"][0]))
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    run = {k: (params[k] if k in params else v.clone()) for k, v in sd.items()}
+    feat = torch.from_numpy(g["feat"].astype(np.float32)).requires_grad_(True)
+    att = torch.from_numpy(g["att"].astype(np.float32)).requires_grad_(True)
+    out = ref_vit.vit_decoder(run, feat, att, training=True)
+    R = torch.randn(out.shape, generator=_gen_after(int(g["seeds"][1]), [(2, 384, 8, 10), (2, 6, 8, 10)]))
+    loss = (out * R).sum()
+    loss.backward()
+    assert (out - torch.from_numpy(g["out"])).abs().max() < 2e-5 * float(np.abs(g["out"]).max())
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    for name, got in (("dfeat", feat.grad), ("datt", att.grad)):
+        want = torch.from_numpy(g[name])
+        assert (got - want).abs().max() < 1e-4 * want.abs().max(), name
+    for k, p in params.items():
+        want, idx = torch.from_numpy(g["grad." + k]), torch.from_numpy(g["idx." + k])
+        got = p.grad.reshape(-1)[idx]
+        if want.abs().max() < 1e-2:                        # conv bias in front of a batch-statistics BatchNorm: zero up to rounding noise
+            assert got.abs().max() < 1e-2, k
+            continue
+        assert (got - want).abs().max() < 2e-4 * want.abs().max() + 1e-7, k
+        assert abs(float(p.grad.double().norm()) - float(g["norm." + k])) < 2e-4 * float(g["norm." + k]) + 1e-7, k
+    for k, v in run.items():
+        if "running" in k:
+            assert (v - torch.from_numpy(g["buf." + k])).abs().max() < 1e-5, k
+
+
+def _gen_after(seed, shapes_rand):
+    """The generator of oracle/gen_golden.py::gen_vit_decoder_train after it drew the inputs (randn for feat, rand for att): R comes next."""
+    gen = torch.Generator().manual_seed(seed)
+    torch.randn(shapes_rand[0], generator=gen)
+    torch.rand(shapes_rand[1], generator=gen)
+    return gen
