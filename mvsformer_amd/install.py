@@ -28,7 +28,7 @@ _SYMBOLS = {
     "schedule_inverse_range": _m.schedule_inverse_range,
     "homo_warping_3D_with_mask": _w.homo_warping_3D_with_mask,
 }
-# the rows before the path: eval-only on the HIP path, so they are rebound only on request
+# the rows before the path: rebound on request (eval and training mode are both built; the ViT itself is frozen / eval-only)
 _FEATURE_SYMBOLS = {"FPNDecoder": _f.FPNDecoder, "FPNDecoderV2": _f.FPNDecoderV2, "FPNEncoder": _f.FPNEncoder,
                     "VITDecoderStage4Single": _v.VITDecoderStage4Single}
 # DINOMVSNet builds its backbone as ``vits.__dict__[vit_arch](...)`` (mvsformer_model.py:180): the factory is rebound in that module
@@ -37,9 +37,9 @@ _VIT_MODULE, _VIT_FACTORIES = "models.vision_transformer", {"vit_small": _v.vit_
 
 def install(model_module: str = "models.mvsformer_model", also=("models.module", "models.warping"), features: bool = False) -> dict:
     """Rebind the hot-path names inside the reference's modules.  Returns ``{module: [names rebound]}``.
-    ``features=True`` (inference deployments) also rebinds ``FPNEncoder`` / ``FPNDecoder`` / ``VITDecoderStage4Single`` and the
-    ``vit_small`` factory of ``models.vision_transformer`` (the DINO branch of MVSFormer-P), which are eval-only here: their ``forward``
-    raises in training mode, so leave it off for a model that will be trained."""
+    ``features=True`` also rebinds ``FPNEncoder`` / ``FPNDecoder`` / ``VITDecoderStage4Single``, the ``vit_small`` factory of
+    ``models.vision_transformer`` (the DINO branch of MVSFormer-P) and ``DINOMVSNet`` itself.  The FPN and the ViT decoder run in eval AND
+    training mode; the ViT is eval-only (MVSFormer-P freezes it, ``"fix": true``; a model that fine-tunes the ViT must keep the reference's)."""
     done = {}
     symbols = dict(_SYMBOLS, **(_FEATURE_SYMBOLS if features else {}))
     for name in (model_module,) + tuple(also):

@@ -827,3 +827,52 @@ def gen_vit_decoder_train():
 
 if __name__ == "__main__" and os.environ.get("GEN_VIT_TRAIN", "1") == "1":
     gen_vit_decoder_train()
+
+
+def gen_train_step():
+    """One TRAINING step of the whole MVSFormer-P model as trainer/mvsformer_trainer.py:104-135 runs it (without AMP: fp32), from the real classes:
+    ``DINOMVSNet(config_mvsformer-p)`` in train() ("fix": true - the ViT runs under no_grad), 1 sample x 3 views of 256 x 320,
+    ``ce_loss_stage4`` (models/losses.py:304-350) against the scene's true plane depth, ``backward()``.  Stored: the four stage losses, per
+    trainable tensor a 512-element gradient sample + index + L2 norm, the stage depths.  Weights: make_model_state_dict(seed 51)."""
+    from models.losses import ce_loss_stage4
+    from oracle.weights import load_model_shapes, make_model_state_dict
+    args = json.load(open(os.path.join(REF, "configs", "config_mvsformer-p.json")))["arch"]["args"]
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    net = ref_mm.DINOMVSNet(args)
+    os.chdir(cwd)
+    seed = 51
+    net.load_state_dict(make_model_state_dict(load_model_shapes(), seed), strict=True)
+    net.train()
+    V, H, W = 3, 256, 320
+    _, proj, dv, scene = synth.make_inputs(V, H, W, seed=52)
+    imgs = f16exact(synth.render_features(scene, 1, 3, noise=0.02))
+    tmp = [5.0, 5.0, 5.0, 1.0]
+    gts = {"stage%d" % (i + 1): synth.plane_depth(scene, s).to(torch.float32).unsqueeze(0) for i, s in enumerate((8, 4, 2, 1))}
+    masks = {k: torch.ones_like(v) for k, v in gts.items()}
+    dlossw = [1.0, 1.0, 1.0, 1.0]
+    out = net(imgs, proj, dv, tmp=tmp)
+    losses = ce_loss_stage4(out, gts, masks, dlossw, focal=False, gamma=0.0, inverse_depth=True)
+    sum(losses.values()).backward()
+    arrs = dict(imgs=np32(imgs).astype(np.float16), depth_range=np32(dv), seed=np.int64(seed), scene_seed=np.int64(52), tmps=np.array(tmp, dtype=np.float32),
+                dlossw=np.array(dlossw, dtype=np.float32), losses=np.array([losses["stage%d" % i].item() for i in range(1, 5)], dtype=np.float64))
+    for k, v in proj.items():
+        arrs["proj_" + k] = np32(v)
+    for i in range(1, 5):                                   # (the ground truth is synth.plane_depth(make_scene(V, H, W, scene_seed), scale): not stored)
+        arrs["s%d_depth" % i] = np32(out["stage%d" % i]["depth"])
+    n = 0
+    global GRAD_SAMPLE
+    keep, GRAD_SAMPLE = GRAD_SAMPLE, 512
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        v, idx, nrm = grad_sample(p.grad, 1000 + n)
+        arrs["grad." + k], arrs["idx." + k], arrs["norm." + k] = v, idx.astype(np.int32), nrm
+        n += 1
+    GRAD_SAMPLE = keep
+    save("train_step_mvsformer_p.npz", **arrs)
+    print("train step: losses", arrs["losses"], "tensors with gradients:", n)
+
+
+if __name__ == "__main__" and os.environ.get("GEN_TRAIN_STEP", "1") == "1":
+    gen_train_step()
