@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 31
+#define MVS_ABI_VERSION 32
 
 typedef void* mvs_stream_t;
 
@@ -606,6 +606,14 @@ int mvs_mixup_ce_loss_fwd(const float* logits, const float* depth_values, const 
  * grad_unscaled [B][HW] = d(sum)/d depth (may be NULL), acc >= mvs_ce_loss_acc_floats(B, HW) floats. */
 int mvs_reg_loss_fwd(const float* depth, const float* depth_gt, const float* mask, const float* depth_values, const float* interval, int B, int D,
                      int64_t HW, int inverse_depth, float weight, float* grad_unscaled, float* acc, float* loss, mvs_stream_t stream);
+/* models/losses.py:88-162 (wasserstein_loss -> sinkhorn with continuous = False, the form trainer/mvsformer_trainer.py:114-117 uses), one stage:
+ * weight * mean over {mask > 0.5} of sum_ij T_ij |i - j|, T the Sinkhorn plan after ot_iter log-domain iterations between the prob_volume column
+ * and the one-hot of the hypothesis nearest to depth_gt (cost |i - j| / ot_eps, the reference's signs).  prob_volume, depth_values [B][D][HW],
+ * D <= 32, ot_iter <= 16; grad_unscaled [B][D][HW] = d(sum of the selected pixels' losses) / d prob_volume THROUGH all iterations (may be
+ * NULL); acc >= mvs_was_loss_acc_floats(B, HW) floats; the 1 / N of the mean is applied by mvs_ce_loss_bwd_scale. */
+int64_t mvs_was_loss_acc_floats(int B, int64_t HW);
+int mvs_was_loss_fwd(const float* prob_volume, const float* depth_values, const float* depth_gt, const float* mask, int B, int D, int64_t HW,
+                     int ot_iter, float ot_eps, float weight, float* grad_unscaled, float* acc, float* loss, mvs_stream_t stream);
 int mvs_ce_loss_bwd_scale(const float* grad_unscaled, float* grad, int64_t numel, const float* acc, const float* grad_out, float weight,
                           mvs_stream_t stream);
 

@@ -18,7 +18,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVS_HIP_LIB: diagnostics only - another BUILD of the same library (tests/test_hip_multistream.py's variants); never a fallback
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 from ctypes import c_double  # noqa: E402
 
@@ -138,6 +138,8 @@ SIGNATURES = {
     "mvs_ce_loss_fwd": (I, [P, P, P, P, I, I, L, I, F, P, P, P, P, P, P]),
     "mvs_mixup_ce_loss_fwd": (I, [P, P, P, P, I, I, L, I, F, P, P, P, P]),
     "mvs_reg_loss_fwd": (I, [P, P, P, P, P, I, I, L, I, F, P, P, P, P]),
+    "mvs_was_loss_acc_floats": (L, [I, L]),
+    "mvs_was_loss_fwd": (I, [P, P, P, P, I, I, L, I, F, F, P, P, P, P]),
     "mvs_ce_loss_bwd_scale": (I, [P, P, L, P, P, F, P]),
     "mvs_ce_loss_acc_floats": (L, [I, L]),
     "mvs_bf16_embed_ch0": (I, [P, P, L, P]),

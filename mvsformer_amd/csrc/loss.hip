@@ -192,6 +192,127 @@ __global__ __launch_bounds__(256) void reg_loss_kernel(const float* __restrict__
             (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
+// models/losses.py:88-162 (wasserstein_loss -> sinkhorn, continuous = False: what trainer/mvsformer_trainer.py:114-117 passes), one stage.
+// Per pixel: nu = prob_volume column (D), mu = one-hot at the hypothesis nearest to the ground truth, cost M_ij = |i - j| / eps;
+//   for k = 1..iters:  b_k[j] = log(mu_j + 1e-12) - LSE_i(M_ij + a_{k-1}[i]);   a_k[i] = log(nu_i + 1e-12) - LSE_j(M_ij + b_k[j])      (a_0 = 0)
+//   T_ij = exp(M_ij + a_K[i] + b_K[j]);  pixel loss = sum_ij T_ij |i - j|  (the reference's signs: + M in the exponent), mean over mask > 0.5.
+// The gradient with respect to prob_volume runs through all iterations (the reference's autograd does): reverse sweep
+//   ga[i] = dL/da_K[i] = sum_j T_ij |i-j|, gb[j] likewise;  for k = K..1:  g_lognu += ga;  gb[j] -= sum_i ga[i] P^k_ij;  ga[i] = - sum_j gb[j] Q^k_ij
+//   with P^k_ij = softmax_j(M_ij + b_k[j]) = exp(M_ij + b_k[j] + a_k[i] - lognu_i), Q^k_ij = softmax_i(M_ij + a_{k-1}[i]) = exp(M_ij + a_{k-1}[i] + b_k[j] - logmu_j);
+//   d loss / d nu_i = g_lognu[i] / (nu_i + 1e-12).
+// One wavefront per pixel (lane = (index l & 31, half l >> 5): a lane sums 16 terms of its row / column, the halves meet through one xor-32
+// shuffle), a_k / b_k of all iterations in LDS (the backward needs them), D <= 32, iters <= 16.  grad = unnormalized (mvs_ce_loss_bwd_scale).
+constexpr int WAS_MAXD = 32, WAS_MAXIT = 16;
+__global__ __launch_bounds__(256) void was_loss_kernel(const float* __restrict__ prob, const float* __restrict__ hyp, const float* __restrict__ gt,
+                                                       const float* __restrict__ mask, int D, size_t HW, int iters, float inv_eps,
+                                                       float* __restrict__ grad, float* __restrict__ rows) {
+    __shared__ float A[4][WAS_MAXIT + 1][WAS_MAXD], Bv[4][WAS_MAXIT + 1][WAS_MAXD], V[4][4][WAS_MAXD];      // V: lognu | ga | gb | g_lognu
+    __shared__ float red[2][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, idx = lane & 31, half = lane >> 5;
+    const size_t pix = (size_t)blockIdx.x * 4 + wave;
+    const int b = blockIdx.y;
+    float lsum = 0.0f, cnt = 0.0f;
+    const bool inside = pix < HW;
+    const bool valid = inside && mask[(size_t)b * HW + pix] > 0.5f;                 // wave-uniform
+    if (inside && !valid && grad && lane < D) grad[((size_t)b * D + lane) * HW + pix] = 0.0f;
+    if (valid) {
+        float (*a)[WAS_MAXD] = A[wave];
+        float (*bb)[WAS_MAXD] = Bv[wave];
+        float* lognu = V[wave][0];
+        float* ga = V[wave][1];
+        float* gb = V[wave][2];
+        float* gl = V[wave][3];
+        const float gv = gt[(size_t)b * HW + pix];
+        // nearest hypothesis (first index on ties, as torch.min): lanes 0..D-1 hold |hyp - gt|, butterfly on (distance, index)
+        float dist = INFINITY;
+        int gi = idx;
+        float p = 0.0f;
+        if (lane < D) {
+            dist = fabsf(hyp[((size_t)b * D + lane) * HW + pix] - gv);
+            p = prob[((size_t)b * D + lane) * HW + pix];
+        }
+        for (int m = 16; m >= 1; m >>= 1) {
+            const float od = __shfl_xor(dist, m, 64);
+            const int oi = __shfl_xor(gi, m, 64);
+            if (od < dist || (od == dist && oi < gi)) dist = od, gi = oi;
+        }
+        gi = __shfl(gi, 0, 64);                              // (lanes 32..63 ran the same butterfly on +inf: take the low half's answer)
+        const float logmu_hit = logf(1.0f + 1e-12f), logmu_miss = logf(1e-12f);
+        if (lane < D) {
+            lognu[lane] = logf(p + 1e-12f);
+            a[0][lane] = 0.0f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int lo = half * 16, hi = min(D, lo + 16);       // the half of the other index this lane sums over
+        auto lse = [&](const float* vec) {                    // log sum_t exp(|idx - t| * inv_eps + vec[t]) over t < D (both halves combined)
+            float mx = -INFINITY;
+            for (int t = lo; t < hi; ++t) mx = fmaxf(mx, fabsf((float)(idx - t)) * inv_eps + vec[t]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sm = 0.0f;
+            for (int t = lo; t < hi; ++t) sm += expf(fabsf((float)(idx - t)) * inv_eps + vec[t] - mx);
+            sm += __shfl_xor(sm, 32, 64);
+            return mx + logf(sm);
+        };
+        for (int k = 1; k <= iters; ++k) {
+            const float vb = (idx == gi ? logmu_hit : logmu_miss) - lse(a[k - 1]);
+            if (lane < D) bb[k][lane] = vb;
+            __builtin_amdgcn_wave_barrier();
+            const float va = (idx < D ? lognu[idx] : 0.0f) - lse(bb[k]);
+            if (lane < D) a[k][lane] = va;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // T_ij |i-j| summed over the lane's half row (ga) and half column (gb)
+        float sa = 0.0f, sb = 0.0f;
+        if (idx < D) {
+            for (int t = lo; t < hi; ++t) {
+                const float d = fabsf((float)(idx - t));
+                sa += expf(d * inv_eps + a[iters][idx] + bb[iters][t]) * d;       // row idx, column t
+                sb += expf(d * inv_eps + a[iters][t] + bb[iters][idx]) * d;       // row t, column idx
+            }
+        }
+        sa += __shfl_xor(sa, 32, 64);
+        sb += __shfl_xor(sb, 32, 64);
+        float tot = lane < D ? sa : 0.0f;
+        for (int m = 16; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, 64);
+        lsum = tot, cnt = 1.0f;                               // (every lane of the low half holds the pixel's loss; lane 0 reports it)
+        if (grad) {
+            if (lane < D) ga[lane] = sa, gb[lane] = sb, gl[lane] = 0.0f;
+            __builtin_amdgcn_wave_barrier();
+            for (int k = iters; k >= 1; --k) {
+                if (lane < D) gl[lane] += ga[lane];
+                // gb[j] -= sum_i ga[i] * exp(M_ij + b_k[j] + a_k[i] - lognu[i])        (this lane: column j = idx, rows i = t)
+                float acc = 0.0f;
+                if (idx < D)
+                    for (int t = lo; t < hi; ++t) acc += ga[t] * expf(fabsf((float)(idx - t)) * inv_eps + bb[k][idx] + a[k][t] - lognu[t]);
+                acc += __shfl_xor(acc, 32, 64);
+                __builtin_amdgcn_wave_barrier();
+                if (lane < D) gb[lane] -= acc;
+                __builtin_amdgcn_wave_barrier();
+                // ga_prev[i] = - sum_j gb[j] * exp(M_ij + a_{k-1}[i] + b_k[j] - logmu[j])   (this lane: row i = idx, columns j = t)
+                float acc2 = 0.0f;
+                if (idx < D)
+                    for (int t = lo; t < hi; ++t)
+                        acc2 += gb[t] * expf(fabsf((float)(idx - t)) * inv_eps + a[k - 1][idx] + bb[k][t] - (t == gi ? logmu_hit : logmu_miss));
+                acc2 += __shfl_xor(acc2, 32, 64);
+                __builtin_amdgcn_wave_barrier();
+                if (lane < D) ga[lane] = -acc2;
+                // d b_k / d a_{k-1} only: b_k's own gradient restarts from zero for iteration k-1 (gb accumulates into b_{k-1} below)
+                if (lane < D) gb[lane] = 0.0f;
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (lane < D) grad[((size_t)b * D + lane) * HW + pix] = gl[lane] / (p + 1e-12f);
+        }
+    }
+    if (lane == 0) {
+        red[0][wave] = lsum;
+        red[1][wave] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        rows[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + threadIdx.x] =
+            (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
 // acc[0..1] = the rows (acc + 2) added in a fixed order, acc[1] + eps = the denominator; loss = weight * acc[0] / acc[1]
 __global__ __launch_bounds__(256) void ce_finalize_kernel(float* __restrict__ acc, int nrows, float weight, float eps, float* __restrict__ loss) {
     __shared__ float red[2][4];
@@ -278,6 +399,22 @@ extern "C" int mvs_reg_loss_fwd(const float* depth, const float* depth_gt, const
         hipLaunchKernelGGL(reg_loss_kernel<false>, grid, dim3(256), 0, s, depth, depth_gt, mask, depth_values, interval, D, (size_t)HW, grad_unscaled, acc + 2);
     hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, acc, (int)(grid.x * grid.y), weight, 0.0f, loss);
     return mvs::finish_launch("mvs_reg_loss_fwd");
+}
+
+extern "C" int64_t mvs_was_loss_acc_floats(int B, int64_t HW) {
+    return (B < 1 || HW < 1) ? -1 : 2 + 2 * (int64_t)B * ((HW + 3) / 4);
+}
+
+extern "C" int mvs_was_loss_fwd(const float* prob_volume, const float* depth_values, const float* depth_gt, const float* mask, int B, int D, int64_t HW,
+                                int ot_iter, float ot_eps, float weight, float* grad_unscaled, float* acc, float* loss, mvs_stream_t stream) {
+    MVS_REQUIRE(prob_volume && depth_values && depth_gt && mask && acc && loss, "mvs_was_loss_fwd: null pointer");
+    MVS_REQUIRE(B >= 1 && B <= 65535 && D >= 1 && D <= WAS_MAXD && HW >= 1 && ot_iter >= 1 && ot_iter <= WAS_MAXIT && ot_eps > 0.0f,
+                "mvs_was_loss_fwd: D <= %d, 1 <= ot_iter <= %d (got D=%d iters=%d)", WAS_MAXD, WAS_MAXIT, D, ot_iter);
+    hipStream_t s = MVS_STREAM(stream);
+    dim3 grid((unsigned)mvs::ceil_div((long long)HW, 4LL), B);
+    hipLaunchKernelGGL(was_loss_kernel, grid, dim3(256), 0, s, prob_volume, depth_values, depth_gt, mask, D, (size_t)HW, ot_iter, 1.0f / ot_eps, grad_unscaled, acc + 2);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, acc, (int)(grid.x * grid.y), weight, 0.0f, loss);
+    return mvs::finish_launch("mvs_was_loss_fwd");
 }
 
 extern "C" int mvs_ce_loss_bwd_scale(const float* grad_unscaled, float* grad, int64_t numel, const float* acc, const float* grad_out,

@@ -170,7 +170,8 @@ class FPNDecoderV2(nn.Module):
     maps added.  Eval mode on the split-form implicit GEMMs of csrc/vit.hip (``mvs_gemm_x3``: 3x3 convolution = A rows gathered from the
     channel-last map, the transposed convolution = four output-parity classes of 2x2 taps; BatchNorm folded, activation in the epilogue):
     fp32-equivalent.  ``forward(conv01, conv11, conv21, conv31, vit1, vit2, vit3) -> [out1 (1/8), out2 (1/4), out3 (1/2), out4 (full)]``,
-    logical NCHW over channel-last memory.  Training mode is not built (Twins itself cannot be pinned here: models/gvt.py needs timm)."""
+    logical NCHW over channel-last memory.  Training mode (``_forward_train``): batch-statistics BatchNorm, every gradient, fp32 NCHW.  (Twins
+    itself cannot be pinned here: models/gvt.py needs timm.)"""
 
     def __init__(self, feat_chs):
         super().__init__()
@@ -211,9 +212,30 @@ class FPNDecoderV2(nn.Module):
                     scale=fold[0], shift=fold[1], act=ACT_SWISH_GEMM)
         return out
 
+    def _forward_train(self, conv01, conv11, conv21, conv31, vit1, vit2, vit3):
+        """models/module.py:290-302 with batch statistics: autograd-tracked HIP ops, fp32 NCHW (as the FPNDecoder's training path): 3x3
+        convolutions through ``Conv2dFn``, the transposed ones through ``vit.ConvT2dFn``, BatchNorm + Swish / ReLU (+ the encoder map as the
+        residual) through ``BnActFn``; ``torch.cat`` only moves data."""
+        from .autograd import BnActFn
+        from .vit import ConvT2dFn
+
+        def out(x, seq):
+            return BnActFn.apply(BiasFn.apply(Conv2dFn.apply(x, seq[0].weight, 1, 1), seq[0].bias), seq[1].weight, seq[1].bias, None, seq[1], ACT_SWISH)
+
+        def up(x, seq, skip):                                 # ReLU(BatchNorm(ConvTranspose2d(x))) + skip
+            y = BiasFn.apply(ConvT2dFn.apply(x, seq[0].weight, 2, 1), seq[0].bias)
+            return BnActFn.apply(y, seq[1].weight, seq[1].bias, skip.to(torch.float32), seq[1], 1)
+
+        f = lambda t: t.to(torch.float32)
+        out1 = out(torch.cat([f(conv31), f(vit1)], dim=1), self.out1)
+        out2 = out(torch.cat([up(out1, self.upsample1, conv21), f(vit2)], dim=1), self.out2)
+        out3 = out(torch.cat([up(out2, self.upsample2, conv11), f(vit3)], dim=1), self.out3)
+        out4 = out(up(out3, self.upsample3, conv01), self.out4)
+        return [out1, out2, out3, out4]
+
     def forward(self, conv01, conv11, conv21, conv31, vit1, vit2, vit3):
         if self.training:
-            raise _lib.MvsHipError("FPNDecoderV2: only eval mode is built on the HIP path")
+            return self._forward_train(conv01, conv11, conv21, conv31, vit1, vit2, vit3)
         from .vit import VITDecoderStage4Single
         p = self._prepared()
 

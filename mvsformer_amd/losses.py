@@ -1,6 +1,7 @@
 """Training losses of the cascade on the HIP path — the reference's ``models/losses.py`` interface: ``ce_loss_stage4`` (every shipped
-config), ``mixup_ce_loss_stage4`` (``depth_type='mixup_ce'``) and ``reg_loss_stage4`` (``depth_type='regression'``).
-``wasserstein_loss`` (Sinkhorn iterations on a D x D plan per pixel, losses.py:88-162) is not built.
+config), ``mixup_ce_loss_stage4`` (``depth_type='mixup_ce'``), ``reg_loss_stage4`` (``depth_type='regression'``) and ``wasserstein_loss``
+(``depth_type='was'``: Sinkhorn iterations on a D x D plan per pixel, losses.py:88-162, one wavefront per pixel, the gradient through all
+iterations).
 
 ``ce_loss_stage4`` (losses.py:304-350) keeps its name, arguments and return value (dict stage -> weighted scalar loss).
 Per stage ONE kernel finds every pixel's ground-truth depth bin in the (flipped) hypothesis column, applies the range
@@ -114,4 +115,37 @@ def reg_loss_stage4(inputs, depth_gt_ms, mask_ms, dlossw, depth_interval, mask_o
         dv = st["depth_values"].detach().to(torch.float32) if mask_out_range else None
         out[key] = RegLossFn.apply(st["depth"].to(torch.float32), depth_gt_ms[key].to(torch.float32), mask_ms[key].to(torch.float32), itv, dv,
                                    inverse_depth, w)
+    return out
+
+
+class WasLossFn(torch.autograd.Function):
+    """losses.py:88-128 for one stage: ``(prob_volume [B,D,H,W], depth_values, depth_gt [B,H,W], mask) -> scalar`` (discrete Sinkhorn)."""
+
+    @staticmethod
+    def forward(ctx, prob, depth_values, depth_gt, mask, ot_iter, ot_eps, weight):
+        need_grad = bool(ctx.needs_input_grad[0])
+        loss, acc, grad = ops.was_loss(prob.contiguous(), depth_values.contiguous(), depth_gt.contiguous(), mask.contiguous(), int(ot_iter), float(ot_eps),
+                                       float(weight), want_grad=need_grad)
+        ctx.weight, ctx.has_grad = float(weight), need_grad
+        ctx.save_for_backward(acc, grad if need_grad else acc)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        acc, grad = ctx.saved_tensors
+        if not ctx.has_grad:
+            return (None,) * 7
+        return (ops.ce_loss_bwd_scale(grad, acc, gout.contiguous().reshape(1), ctx.weight),) + (None,) * 6
+
+
+def wasserstein_loss(inputs, depth_gt_ms, mask_ms, dlossw, ot_iter=10, ot_eps=1, ot_continous=False, inverse=True):
+    """losses.py:131-162: per stage ``dlossw[i] * sinkhorn(depth_gt, depth_values, prob_volume, mask > 0.5, ot_iter, ot_eps)[1]``.  Only the
+    discrete plan (``ot_continous=False``, what the trainer passes, mvsformer_trainer.py:114-117) is built."""
+    if ot_continous:
+        raise ops._lib.MvsHipError("wasserstein_loss: ot_continous=True is not built (the reference's trainer always passes False)")
+    out = {}
+    for i, key in enumerate(k for k in inputs.keys() if "stage" in k):
+        st = inputs[key]
+        out[key] = WasLossFn.apply(st["prob_volume"].to(torch.float32), st["depth_values"].detach().to(torch.float32), depth_gt_ms[key].to(torch.float32),
+                                   mask_ms[key].to(torch.float32), ot_iter, ot_eps, float(dlossw[i]))
     return out

@@ -1100,6 +1100,22 @@ def reg_loss(depth, depth_gt, mask, interval, depth_values=None, inverse_depth: 
     return loss, acc, grad
 
 
+def was_loss(prob, depth_values, depth_gt, mask, ot_iter: int = 10, ot_eps: float = 1.0, weight: float = 1.0, want_grad: bool = True):
+    """models/losses.py:88-162 (Sinkhorn, discrete form) for one stage: ``prob``, ``depth_values [B,D,H,W]``, ``depth_gt``, ``mask [B,H,W]`` ->
+    ``(loss [], acc, grad_unscaled [B,D,H,W] or None)``."""
+    _chk(prob, "prob_volume"), _chk(depth_values, "depth_values"), _chk(depth_gt, "depth_gt"), _chk(mask, "mask")
+    B, D, H, W = prob.shape
+    if depth_values.shape != prob.shape or depth_gt.shape != (B, H, W) or mask.shape != (B, H, W):
+        raise _lib.MvsHipError("was_loss: shapes %s %s %s %s" % (tuple(prob.shape), tuple(depth_values.shape), tuple(depth_gt.shape), tuple(mask.shape)))
+    dev = prob.device
+    acc = torch.empty(_lib.load().mvs_was_loss_acc_floats(B, H * W), device=dev, dtype=torch.float32)
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    grad = torch.empty_like(prob) if want_grad else None
+    _call("mvs_was_loss_fwd", "was_loss", _ptr(prob), _ptr(depth_values), _ptr(depth_gt), _ptr(mask), B, D, H * W, int(ot_iter), float(ot_eps), float(weight),
+          _ptr(grad), _ptr(acc), _ptr(loss), _stream())
+    return loss, acc, grad
+
+
 def ce_loss_bwd_scale(grad, acc, gout, weight: float) -> torch.Tensor:
     """-> ``grad * weight * gout / count`` as a NEW tensor (the saved unscaled gradient stays intact for a second backward)."""
     _chk(grad, "grad"), _chk(acc, "acc"), _chk(gout, "grad_out")

@@ -876,3 +876,60 @@ def gen_train_step():
 
 if __name__ == "__main__" and os.environ.get("GEN_TRAIN_STEP", "1") == "1":
     gen_train_step()
+
+
+def gen_fpn_decoder_v2_train():
+    """``FPNDecoderV2`` (TwinMVSNet's decoder, models/module.py:273-302) in TRAINING mode: the real module on two 32 x 40 pyramids, loss =
+    sum_i <out_i, R_i>, every gradient (parameters: 4096-element samples + norms; all seven inputs in full), updated running statistics."""
+    from models.module import FPNDecoderV2
+    dec = FPNDecoderV2([8, 16, 32, 64])
+    shapes = {k: list(v.shape) for k, v in dec.state_dict().items()}
+    with open(os.path.join(OUT, "fpn_v2_shapes.json"), "w") as f:
+        json.dump(shapes, f, indent=0)
+    dec.load_state_dict(make_state_dict(shapes, 61), strict=True)
+    dec.train()
+    g = torch.Generator().manual_seed(62)
+    dims = dict(conv01=(8, 32, 40), conv11=(16, 16, 20), conv21=(32, 8, 10), conv31=(64, 4, 5), vit1=(64, 4, 5), vit2=(32, 8, 10), vit3=(16, 16, 20))
+    ins = {k: f16exact(torch.randn(2, *d, generator=g)).requires_grad_(True) for k, d in dims.items()}
+    outs = dec(*[ins[k] for k in ("conv01", "conv11", "conv21", "conv31", "vit1", "vit2", "vit3")])
+    R = [torch.randn(o.shape, generator=g) for o in outs]
+    loss = sum((o * r).sum() for o, r in zip(outs, R))
+    loss.backward()
+    arrs = {"loss": np32(loss), "seeds": np.array([61, 62])}
+    for k, v in ins.items():
+        arrs["in." + k], arrs["din." + k] = np32(v).astype(np.float16), np32(v.grad)
+    arrs.update({"out%d" % i: np32(o) for i, o in enumerate(outs)})
+    for n, (k, p) in enumerate(dec.named_parameters()):
+        v, idx, nrm = grad_sample(p.grad, 200 + n)
+        arrs["grad." + k], arrs["idx." + k], arrs["norm." + k] = v, idx.astype(np.int32), nrm
+    arrs.update({"buf." + k: np32(b) for k, b in dec.named_buffers() if b.dtype.is_floating_point})
+    save("fpn_decoder_v2_train.npz", **arrs)
+
+
+if __name__ == "__main__" and os.environ.get("GEN_FPN_V2_TRAIN", "1") == "1":
+    gen_fpn_decoder_v2_train()
+
+
+def gen_was_loss():
+    """was_loss.npz: models/losses.py wasserstein_loss (ot_iter 10, ot_eps 1, ot_continous False: the trainer's arguments) on the seeded cases of
+    ce_loss.npz (oracle/ref_losses.make_loss_case seed 3; the tests read depth_values / logits / gt / mask from that file), prob_volume =
+    softmax(logits): the four weighted stage losses and d loss / d prob_volume."""
+    from models.losses import wasserstein_loss
+    from oracle import ref_losses
+    out = {}
+    w = [1.0, 0.5, 2.0, 1.0]
+    inputs, gts, masks = ref_losses.make_loss_case(seed=3, inverse_depth=True)
+    for k in inputs:
+        inputs[k]["prob_volume"] = torch.softmax(inputs[k]["prob_volume_pre"], 1).detach().requires_grad_(True)
+    losses = wasserstein_loss(inputs, gts, masks, w, ot_iter=10, ot_eps=1, ot_continous=False, inverse=True)
+    sum(losses.values()).backward()
+    for k in inputs:
+        out[k + "_loss"] = np.float64(losses[k].item())
+        out[k + "_grad"] = np32(inputs[k]["prob_volume"].grad)
+        print(k, "wasserstein %.6f" % losses[k].item())
+    out["dlossw"] = np.asarray(w, np.float32)
+    save("was_loss.npz", **out)
+
+
+if __name__ == "__main__" and os.environ.get("GEN_WAS", "1") == "1":
+    gen_was_loss()

@@ -100,3 +100,29 @@ def make_loss_case(seed=0, B=2, sizes=((32, 8, 12), (16, 16, 24), (8, 24, 32), (
         inputs[key] = dict(depth_values=dv.contiguous(), prob_volume_pre=logits.contiguous())
         gts[key], masks[key] = gt.contiguous(), mask.contiguous()
     return inputs, gts, masks
+
+
+def sinkhorn_stage(prob, depth_values, depth_gt, mask, iters=10, eps=1.0, weight=1.0):
+    """models/losses.py:88-128 with ``continuous=False``: the log-domain Sinkhorn plan between each pixel's probability column and the one-hot of
+    the hypothesis nearest to the ground truth, cost |i - j| / eps (the reference's signs: + cost in the exponent), loss = mean over
+    ``mask > 0.5`` of sum_ij T_ij |i - j|.  Plain torch (autograd gives the gradient through all iterations)."""
+    B, D, H, W = prob.shape
+    ar = torch.arange(D, dtype=torch.float32)
+    Dm = (ar[:, None] - ar[None, :]).abs()                                   # [D (i: prediction), D (j: ground truth)]
+    gi = (depth_values - depth_gt[:, None]).abs().min(1)[1].reshape(B * H * W)
+    mu = torch.zeros(B * H * W, D)
+    mu[torch.arange(B * H * W), gi] = 1.0
+    nu = prob.permute(0, 2, 3, 1).reshape(B * H * W, D)
+    log_mu, log_nu = (mu + 1e-12).log(), (nu + 1e-12).log()
+    u, v = torch.zeros_like(log_nu), torch.zeros_like(log_mu)
+    for _ in range(iters):
+        v = log_mu - torch.logsumexp(Dm[None] / eps + u[:, :, None], dim=1)
+        u = log_nu - torch.logsumexp(Dm[None] / eps + v[:, None, :], dim=2)
+    T = (Dm[None] / eps + u[:, :, None] + v[:, None, :]).exp()
+    sel = (mask > 0.5).reshape(-1)
+    return weight * (T * Dm[None]).reshape(B * H * W, -1)[sel].sum(-1).mean()
+
+
+def wasserstein_loss(inputs, depth_gt_ms, mask_ms, dlossw, ot_iter=10, ot_eps=1.0):
+    return {k: sinkhorn_stage(inputs[k]["prob_volume"], inputs[k]["depth_values"], depth_gt_ms[k], mask_ms[k], ot_iter, ot_eps, dlossw[i])
+            for i, k in enumerate(k for k in inputs if "stage" in k)}

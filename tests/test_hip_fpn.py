@@ -265,14 +265,57 @@ def v2_case(seed, N, h, w):
     return ref_fpn.make_case(seed, N, h, w) + tuple(torch.randn(N, c, h * s, w * s, generator=g) for c, s in ((64, 1), (32, 2), (16, 4)))
 
 
-def test_fpn_decoder_v2_is_checkpoint_compatible_and_eval_only():
-    """CPU: the reference's parameter names (the golden state_dict loads strictly up to num_batches_tracked); training mode raises."""
+def test_fpn_decoder_v2_is_checkpoint_compatible_and_has_no_cpu_path():
+    """CPU: the reference's parameter names (the golden state_dict loads strictly up to num_batches_tracked); CPU tensors raise in both modes."""
     g = load_golden("fpn_decoder_v2.npz")
     dec = build_decoder_v2({k[3:]: t(v.astype(np.float32)) for k, v in g.items() if k.startswith("sd.")})
     assert sorted(k for k in dec.state_dict() if not k.endswith("num_batches_tracked")) == sorted(k[3:] for k in g if k.startswith("sd."))
     from mvsformer_amd._lib import MvsHipError
     with pytest.raises(MvsHipError):
         dec.train()(*[t(g[k]) for k in V2_INPUTS])
+    with pytest.raises(MvsHipError):
+        dec.eval()(*[t(g[k]) for k in V2_INPUTS])
+
+
+@pytest.mark.gpu
+def test_fpn_decoder_v2_training_mode_vs_reference_gradients():
+    """``FPNDecoderV2`` in TRAINING mode (batch-statistics BatchNorm + Swish, ConvTranspose2d + BatchNorm + ReLU + the encoder map) against
+    the real module in train() (tests/golden/fpn_decoder_v2_train.npz): outputs, loss, the gradient of all seven inputs, every parameter
+    gradient (sampled + norm) and the updated running statistics."""
+    import mvsformer_amd as m
+    from oracle.weights import make_state_dict
+    import json, os
+    g = load_golden("fpn_decoder_v2_train.npz")
+    shapes = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fpn_v2_shapes.json")))
+    dev = torch.device("cuda:0")
+    dec = m.FPNDecoderV2([8, 16, 32, 64])
+    dec.load_state_dict(make_state_dict(shapes, int(g["seeds"][0])), strict=True)
+    dec = dec.to(dev).train()
+    names = ("conv01", "conv11", "conv21", "conv31", "vit1", "vit2", "vit3")
+    ins = {k: t(g["in." + k].astype(np.float32), dev).requires_grad_(True) for k in names}
+    outs = dec(*[ins[k] for k in names])
+    gen = torch.Generator().manual_seed(int(g["seeds"][1]))
+    for k in names:
+        torch.randn(ins[k].shape, generator=gen)
+    loss = sum((o * torch.randn(o.shape, generator=gen).to(dev)).sum() for o in outs)
+    loss.backward()
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert scale_err(o.detach().cpu(), g["out%d" % i]) < 2e-5, i
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    for k in names:
+        assert scale_err(ins[k].grad.cpu(), g["din." + k]) < 2e-4, k
+    for k, p in dec.named_parameters():
+        want, idx = t(g["grad." + k]), torch.from_numpy(g["idx." + k].astype(np.int64))
+        got = p.grad.detach().cpu().reshape(-1)[idx]
+        if want.abs().max() < 1e-3:                         # conv bias in front of a batch-statistics BatchNorm: zero up to rounding noise
+            assert got.abs().max() < 1e-3, k
+            continue
+        assert (got - want).abs().max() < 2e-4 * want.abs().max(), k
+        assert abs(float(p.grad.double().norm()) - float(g["norm." + k])) < 2e-4 * float(g["norm." + k]), k
+    for k, b in dec.named_buffers():
+        if b.dtype.is_floating_point:
+            assert (b.cpu() - t(g["buf." + k])).abs().max() < 1e-5, k
 
 
 @pytest.mark.gpu

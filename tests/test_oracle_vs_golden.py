@@ -370,3 +370,22 @@ def _gen_after(seed, shapes_rand):
     torch.randn(shapes_rand[0], generator=gen)
     torch.rand(shapes_rand[1], generator=gen)
     return gen
+
+
+def test_wasserstein_loss_oracle_vs_reference():
+    """oracle/ref_losses.sinkhorn_stage (torch autograd through the ten log-domain iterations) against models/losses.py wasserstein_loss
+    (tests/golden/was_loss.npz on the inputs of ce_loss.npz): the four weighted stage losses and d loss / d prob_volume."""
+    from oracle import ref_losses
+    gi, g = load_golden("ce_loss.npz"), load_golden("was_loss.npz")
+    w = [float(x) for x in g["dlossw"]]
+    inputs, gts, masks = {}, {}, {}
+    for k in ("stage1", "stage2", "stage3", "stage4"):
+        prob = torch.softmax(torch.from_numpy(gi["inv_%s_logits" % k]), 1).requires_grad_(True)
+        inputs[k] = dict(depth_values=torch.from_numpy(gi["inv_%s_depth_values" % k]), prob_volume=prob)
+        gts[k], masks[k] = torch.from_numpy(gi["inv_%s_gt" % k]), torch.from_numpy(gi["inv_%s_mask" % k])
+    out = ref_losses.wasserstein_loss(inputs, gts, masks, w)
+    sum(out.values()).backward()
+    for k in inputs:
+        assert abs(float(out[k]) - float(g[k + "_loss"])) < 2e-6 * max(1.0, abs(float(g[k + "_loss"]))), k
+        wg = torch.from_numpy(g[k + "_grad"])
+        assert (inputs[k]["prob_volume"].grad - wg).abs().max() < 2e-5 * wg.abs().max(), k
