@@ -39,21 +39,14 @@ constexpr int KSTEP = 3 * PIECE;                             // the three terms 
 __device__ __forceinline__ rsrc_t rsrc_of(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
-// LDS-DMA: lane l moves 16 bytes from src + voff(l) + soff to lds_dst + 16 l (in a __device__ helper on purpose: with the builtin directly
-// in a __global__ template body hipcc drops the kernel's host stub, tools/probe/gather_probe.hip)
-__device__ __forceinline__ void dma16(rsrc_t src, unsigned char* lds_dst, unsigned voff_bytes, unsigned soff_bytes) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_ptr_t)lds_dst, 16, voff_bytes, soff_bytes, 0, 0);
-}
-// the three terms of one (row tile, k step): 3 KiB contiguous in memory AND in LDS.  The instruction's immediate offset is added to both
-// addresses, so one M0 (LDS base) write serves the three pieces
+// LDS-DMA of the three terms of one (row tile, k step) - 3 KiB contiguous in memory AND in LDS: lane l moves 16 bytes from src + voff(l) +
+// soff (+ immediate) to lds_dst + 16 l (+ immediate).  The instruction's immediate offset is added to BOTH addresses, so one M0 (LDS base)
+// write serves the three pieces.  (In a __device__ helper on purpose: with the builtin directly in a __global__ template body hipcc drops the
+// kernel's host stub, tools/probe/gather_probe.hip.)
 __device__ __forceinline__ void dma16x3(rsrc_t src, unsigned char* lds_dst, unsigned voff_bytes, unsigned soff_bytes) {
-#ifdef X3P_NO_IMM
-    for (int t = 0; t < 3; ++t) dma16(src, lds_dst + t * PIECE, voff_bytes, soff_bytes + t * PIECE);
-#else
     __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_ptr_t)lds_dst, 16, voff_bytes, soff_bytes, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_ptr_t)lds_dst, 16, voff_bytes, soff_bytes, PIECE, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_ptr_t)lds_dst, 16, voff_bytes, soff_bytes, 2 * PIECE, 0);
-#endif
 }
 __device__ __forceinline__ bf16x8 ldfrag(rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0));

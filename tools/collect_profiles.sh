@@ -2,7 +2,8 @@
 # Round-end evidence on the GPU box (run from the repo root through gpurun): gather ceiling, per-stage breakdown, kernel trace of the bench,
 # HBM traffic counters (separate --pmc passes), final bench line.  Everything lands in gpurun_out/, copy what is judged into profiles/.
 set -x
-ROUND=${ROUND:-r05}
+export MVS_HEAD=${MVS_HEAD:-unknown}
+ROUND=${ROUND:-r06}
 mkdir -p gpurun_out
 REPO=$(pwd)
 python tools/gather_bound.py > gpurun_out/gather_bound.log 2>&1
@@ -39,6 +40,9 @@ rm -rf gpurun_out/prof_train_${ROUND}
 # the same step under DistributedDataParallel + SyncBatchNorm over RCCL (one rank), captured whole; the ViT branch's per-kernel table
 python bench_train.py --force-ddp --steps 30 --warmup 3 > gpurun_out/${ROUND}_bench_train_ddp.json 2> gpurun_out/${ROUND}_bench_train_ddp.err
 python tools/prof_vit.py > gpurun_out/${ROUND}_prof_vit.txt 2>&1
+python tools/bench_x3p.py > gpurun_out/${ROUND}_bench_x3p.txt 2>&1
+tools/sweep_x3p.sh > gpurun_out/${ROUND}_sweep_x3p.txt 2>&1
+tools/prof_vit_trace.sh > /dev/null 2>&1          # -> gpurun_out/${ROUND}_vit_kernel_stats.csv (kernel trace of the branch, ATen glue included)
 python tools/exp_small_conv.py > gpurun_out/${ROUND}_bf16_small_conv.txt 2>&1
 python bench.py --steps 200 --warmup 10 > gpurun_out/${ROUND}_final_bench.json 2> gpurun_out/${ROUND}_final_bench.err
 tail -c 400 gpurun_out/${ROUND}_final_bench.err

@@ -6,6 +6,6 @@ rm -rf $REPO/gpurun_out/prof_vit_trace
 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_vit_trace -o v -- python $REPO/tools/prof_vit.py > $REPO/gpurun_out/prof_vit_under_rocprof.txt 2>&1
 cd $REPO
 DB=$(find gpurun_out/prof_vit_trace -name "*.db" | head -1)
-python tools/rocpd_stats.py $DB > gpurun_out/r06_vit_kernel_stats.csv 2> gpurun_out/rocpd_stats_vit.err
-head -40 gpurun_out/r06_vit_kernel_stats.csv | cut -c1-150
+python tools/rocpd_stats.py $DB > gpurun_out/${ROUND:-r06}_vit_kernel_stats.csv 2> gpurun_out/rocpd_stats_vit.err
+head -40 gpurun_out/${ROUND:-r06}_vit_kernel_stats.csv | cut -c1-150
 rm -rf gpurun_out/prof_vit_trace
