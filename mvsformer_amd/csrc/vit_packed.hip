@@ -497,83 +497,100 @@ __global__ __launch_bounds__(256, 2) void attention_x3p_kernel(const void* __res
         dma16x3(rv, dk + 12 * PIECE, voff, vo);
     };
     const int kb = lane >> 4;
-    auto step = [&](int stage, int kt) {
-        const unsigned char* sk = lds + stage * ASTAGE + lane * 16;
-        const unsigned char* sv = sk + 12 * PIECE;
-        f32x4 s[2][2];                                        // [query tile][key tile]
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) s[qt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // One key step: S for both query tiles | reference maxima | P (exponentials, split) | PV.  (Measured and not kept, NOTEBOOK.md round 6:
+    // tile 1's S / tile 0's PV MFMAs placed over the other tile's vector work - 0.1197 against 0.1204 ms, within 1 %; s_setprio around the
+    // MFMA phases - slower; the order below, term pairs swept over independent accumulators, 0.1186.)
+    auto mask_tail = [&](int kt, f32x4 (&s)[2]) {               // the tail step: keys >= N are padding
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int ds = 0; ds < 2; ++ds) {
-                const unsigned char* p = sk + (nt * 2 + ds) * KSTEP;
-                const bf16x8 kh = *reinterpret_cast<const bf16x8*>(p), km = *reinterpret_cast<const bf16x8*>(p + PIECE),
-                             kl = *reinterpret_cast<const bf16x8*>(p + 2 * PIECE);
+            for (int r = 0; r < 4; ++r)
+                if (kt * 32 + nt * 16 + 4 * kb + r >= N) s[nt][r] = -INFINITY;
+    };
+    // The reference maximum mrow is shared by the four lanes of a query (their P values meet in one MFMA contraction) but need not be the
+    // exact running maximum: any common reference gives the same softmax.  It is raised only when some lane of the wavefront sees a score
+    // more than 8 (base-2 exponent: a factor 256) above it - after the first few key steps almost never - so the cross-lane maximum, the
+    // rescale of O and their LDS-crossbar waits leave the steady state (P <= 256, exact in the split).
+    auto raise_ref = [&](int qt, const f32x4 (&s)[2]) {
+        const float lmax = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+        if (__builtin_amdgcn_ballot_w64(lmax > mrow[qt] + 8.0f) != 0) {
+            const float mnew = fmaxf(mrow[qt], xmax32(xmax16(lmax)));
+            const float alpha = __builtin_amdgcn_exp2f(mrow[qt] - mnew);          // 0 at the first step (mrow = -inf)
+            mrow[qt] = mnew;
+            lrow[qt] *= alpha;
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) s[qt][nt] = mvsx3::mfma6(kh, km, kl, qf[qt][ds][0], qf[qt][ds][1], qf[qt][ds][2], s[qt][nt]);
-            }
-        if (kt * 32 + 32 > N) {                               // the tail step: keys >= N are padding
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (kt * 32 + nt * 16 + 4 * kb + r >= N) s[qt][nt][r] = -INFINITY;
+                for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
         }
+    };
+    auto p_tile = [&](int qt, const f32x4 (&s)[2], bf16x8& ph, bf16x8& pm, bf16x8& pl) {
+        float p[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[0][r] - mrow[qt]), p[4 + r] = __builtin_amdgcn_exp2f(s[1][r] - mrow[qt]);
+        lrow[qt] += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        u32x4 h, m, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned a, b, c;
+            mvsx3::split3_pair<false>(p[2 * e], p[2 * e + 1], a, b, c);
+            h[e] = a, m[e] = b, l[e] = c;
+        }
+        ph = __builtin_bit_cast(bf16x8, h), pm = __builtin_bit_cast(bf16x8, m), pl = __builtin_bit_cast(bf16x8, l);
+    };
+    // MFMA order: each term pair is swept over ALL independent accumulators (4 in the S phase: 2 query x 2 key tiles; 8 in the PV phase:
+    // 2 query x 4 d tiles) before the next pair, so no two consecutive MFMAs share an accumulator (a chain of six dependent MFMAs per
+    // accumulator waits out the matrix pipe's latency at every link)
+    auto step = [&](int stage, int kt) {
+        const unsigned char* sk = lds + stage * ASTAGE + lane * 16;
+        const unsigned char* sv = sk + 12 * PIECE;
+        const bool tail = kt * 32 + 32 > N;                   // (block-uniform)
+        f32x4 s0[2], s1[2];
         bf16x8 ph[2], pm[2], pl[2];
-#ifdef X3P_ATT_ABLATE                                         // experiment build: no softmax arithmetic (the MFMA + LDS-DMA + barrier skeleton alone)
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            ph[qt] = __builtin_bit_cast(bf16x8, u32x4{__builtin_bit_cast(unsigned, s[qt][0][0]), __builtin_bit_cast(unsigned, s[qt][0][1]), __builtin_bit_cast(unsigned, s[qt][0][2]), __builtin_bit_cast(unsigned, s[qt][0][3])});
-            pm[qt] = __builtin_bit_cast(bf16x8, u32x4{__builtin_bit_cast(unsigned, s[qt][1][0]), __builtin_bit_cast(unsigned, s[qt][1][1]), __builtin_bit_cast(unsigned, s[qt][1][2]), __builtin_bit_cast(unsigned, s[qt][1][3])});
-            pl[qt] = ph[qt];
-            lrow[qt] = 1.0f;
+        for (int nt = 0; nt < 2; ++nt) s0[nt] = s1[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) {
+            bf16x8 kf[2][3];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) kf[nt][t] = *reinterpret_cast<const bf16x8*>(sk + (nt * 2 + ds) * KSTEP + t * PIECE);
+#define X3P_S_SWEEP(TA, TB)                                                                                                     \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                                           \
+        s0[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[nt][TA], qf[0][ds][TB], s0[nt], 0, 0, 0);                              \
+        s1[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[nt][TA], qf[1][ds][TB], s1[nt], 0, 0, 0);                              \
+    }
+            X3P_S_SWEEP(1, 1)
+            X3P_S_SWEEP(0, 2)
+            X3P_S_SWEEP(2, 0)
+            X3P_S_SWEEP(0, 1)
+            X3P_S_SWEEP(1, 0)
+            X3P_S_SWEEP(0, 0)
+#undef X3P_S_SWEEP
         }
-#else
+        if (tail) mask_tail(kt, s0), mask_tail(kt, s1);
+        raise_ref(0, s0);
+        raise_ref(1, s1);
+        p_tile(0, s0, ph[0], pm[0], pl[0]);
+        p_tile(1, s1, ph[1], pm[1], pl[1]);
+        bf16x8 vf[4][3];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            // The reference maximum mrow is shared by the four lanes of a query (their P values meet in one MFMA contraction) but need not be
-            // the exact running maximum: any common reference gives the same softmax.  It is raised only when some lane of the wavefront sees
-            // a score more than 8 (base-2 exponent: a factor 256) above it - after the first few key steps almost never - so the
-            // cross-lane maximum, the rescale of O and their LDS-crossbar waits leave the steady state (P <= 256, exact in the split).
-            const float lmax = fmaxf(fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), fmaxf(s[qt][0][2], s[qt][0][3])),
-                                     fmaxf(fmaxf(s[qt][1][0], s[qt][1][1]), fmaxf(s[qt][1][2], s[qt][1][3])));
-            if (__builtin_amdgcn_ballot_w64(lmax > mrow[qt] + 8.0f) != 0) {
-                const float mnew = fmaxf(mrow[qt], xmax32(xmax16(lmax)));
-                const float alpha = __builtin_amdgcn_exp2f(mrow[qt] - mnew);      // 0 at the first step (mrow = -inf)
-                mrow[qt] = mnew;
-                lrow[qt] *= alpha;
+        for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
-            }
-            float p[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(s[qt][0][r] - mrow[qt]), p[4 + r] = __builtin_amdgcn_exp2f(s[qt][1][r] - mrow[qt]);
-            lrow[qt] += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-            u32x4 h, m, l;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                unsigned a, b, c;
-                mvsx3::split3_pair<false>(p[2 * e], p[2 * e + 1], a, b, c);
-                h[e] = a, m[e] = b, l[e] = c;
-            }
-            ph[qt] = __builtin_bit_cast(bf16x8, h), pm[qt] = __builtin_bit_cast(bf16x8, m), pl[qt] = __builtin_bit_cast(bf16x8, l);
-        }
-#endif
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const unsigned char* p = sv + dt * KSTEP;
-            const bf16x8 vh = *reinterpret_cast<const bf16x8*>(p), vm = *reinterpret_cast<const bf16x8*>(p + PIECE),
-                         vl = *reinterpret_cast<const bf16x8*>(p + 2 * PIECE);
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) o[qt][dt] = mvsx3::mfma6(vh, vm, vl, ph[qt], pm[qt], pl[qt], o[qt][dt]);
-        }
+            for (int t = 0; t < 3; ++t) vf[dt][t] = *reinterpret_cast<const bf16x8*>(sv + dt * KSTEP + t * PIECE);
+#define X3P_PV_SWEEP(TA, TB)                                                                                                    \
+    _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) {                                                                           \
+        o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt][TA], (TB == 0 ? ph[0] : TB == 1 ? pm[0] : pl[0]), o[0][dt], 0, 0, 0); \
+        o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt][TA], (TB == 0 ? ph[1] : TB == 1 ? pm[1] : pl[1]), o[1][dt], 0, 0, 0); \
+    }
+        X3P_PV_SWEEP(1, 1)
+        X3P_PV_SWEEP(0, 2)
+        X3P_PV_SWEEP(2, 0)
+        X3P_PV_SWEEP(0, 1)
+        X3P_PV_SWEEP(1, 0)
+        X3P_PV_SWEEP(0, 0)
+#undef X3P_PV_SWEEP
     };
     const int KT = (N + 31) >> 5;
     fill(0, 0);
