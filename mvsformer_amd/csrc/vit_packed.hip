@@ -94,58 +94,77 @@ __global__ __launch_bounds__(256) void x3p_unpack_kernel(const unsigned char* __
 }
 
 // ---------------------------------------------------------------------------------------------------------------- LayerNorm -> packed
-// One wavefront per row, lane l holds features 8 l .. 8 l + 7 (C <= 512, a multiple of 32): statistics as vit.hip's layernorm_kernel
-// (mean, then the centered sum of squares), output split and written as the row's 16-byte chunks of C / 32 pieces.  Rows are laid out
-// [images][Np]: rows t >= N of an image are padding and written as zeros (finite keys / values for the attention's masked tail).
+// A block owns ONE row tile of 16 rows (four wavefronts x four rows each, one row at a time per wavefront: lane l holds features 8 l ..
+// 8 l + 7, C <= 512, a multiple of 32); statistics as vit.hip's layernorm_kernel (mean, then the centered sum of squares).  The split rows
+// are assembled in LDS in the packed layout ([k step][term][lane][8]) and leave as whole 1 KiB pieces, one coalesced 16-byte store per lane
+// (12.8 us per launch at 8800 x 384 = 34 MB: the same as the form that stored each row's 16-byte chunks straight from registers, and as the
+// fp32-output kernel of vit.hip - the launch is bound by its load -> reduce -> reduce -> store chain, not by the store pattern).
+// Rows are laid out [images][Np]: rows t >= N of an image are padding and written as zeros (finite keys / values for the attention's
+// masked tail).
 __global__ __launch_bounds__(256) void layernorm_x3p_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
                                                             unsigned char* __restrict__ out, int rows, int C, int Np, int N, float eps) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= rows) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile[];           // [C / 32][3][64 lanes][16 bytes]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool active = lane * 8 < C;
-    const bool pad = (row % Np) >= N;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = 0.0f;
-    if (active && !pad) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(x + (size_t)row * C + lane * 8), hi = *reinterpret_cast<const f32x4*>(x + (size_t)row * C + lane * 8 + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = lo[e], v[4 + e] = hi[e];
+    const int KS = C >> 5, ks = lane >> 2, kb = lane & 3;
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, b0 = g0, b1 = g0;
+    if (active) {
+        g0 = *reinterpret_cast<const f32x4*>(g + lane * 8), g1 = *reinterpret_cast<const f32x4*>(g + lane * 8 + 4);
+        b0 = *reinterpret_cast<const f32x4*>(b + lane * 8), b1 = *reinterpret_cast<const f32x4*>(b + lane * 8 + 4);
     }
-    float s = 0.0f;
+    // the wavefront's four rows: loads of all four in flight before the first reduction
+    float v[4][8];
+    bool pad[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s += v[e];
+    for (int r = 0; r < 4; ++r) {
+        const int row = blockIdx.x * 16 + wave * 4 + r;
+        pad[r] = row >= rows || (row % Np) >= N;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-    const float mean = s / (float)C;
-    float q = 0.0f;
+        for (int e = 0; e < 8; ++e) v[r][e] = 0.0f;
+        if (active && !pad[r]) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(x + (size_t)row * C + lane * 8), hi = *reinterpret_cast<const f32x4*>(x + (size_t)row * C + lane * 8 + 4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float d = active ? v[e] - mean : 0.0f;
-        q = fmaf(d, d, q);
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
-    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
-    if (!active) return;
-    float y[8];
-    if (pad) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] = 0.0f;
-    } else {
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(g + lane * 8), g1 = *reinterpret_cast<const f32x4*>(g + lane * 8 + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + lane * 8), b1 = *reinterpret_cast<const f32x4*>(b + lane * 8 + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            y[e] = fmaf((v[e] - mean) * rstd, g0[e], b0[e]);
-            y[4 + e] = fmaf((v[4 + e] - mean) * rstd, g1[e], b1[e]);
+            for (int e = 0; e < 4; ++e) v[r][e] = lo[e], v[r][4 + e] = hi[e];
         }
     }
-    const mvsx3::Split3 sp = mvsx3::split3(y);
-    const int KS = C >> 5, ks = lane >> 2, kb = lane & 3;
-    unsigned char* d = out + ((size_t)(row >> 4) * KS + ks) * KSTEP + (kb * 16 + (row & 15)) * 16;
-    *reinterpret_cast<bf16x8*>(d) = sp.h;
-    *reinterpret_cast<bf16x8*>(d + PIECE) = sp.m;
-    *reinterpret_cast<bf16x8*>(d + 2 * PIECE) = sp.l;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float s = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[r][e];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        const float mean = s / (float)C;
+        float q = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = active ? v[r][e] - mean : 0.0f;
+            q = fmaf(d, d, q);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
+        const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+        if (!active) continue;
+        float y[8];
+        if (pad[r]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = 0.0f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = fmaf((v[r][e] - mean) * rstd, g0[e], b0[e]);
+                y[4 + e] = fmaf((v[r][4 + e] - mean) * rstd, g1[e], b1[e]);
+            }
+        }
+        const mvsx3::Split3 sp = mvsx3::split3(y);
+        unsigned char* d = tile + (size_t)ks * KSTEP + (kb * 16 + wave * 4 + r) * 16;
+        *reinterpret_cast<bf16x8*>(d) = sp.h;
+        *reinterpret_cast<bf16x8*>(d + PIECE) = sp.m;
+        *reinterpret_cast<bf16x8*>(d + 2 * PIECE) = sp.l;
+    }
+    __syncthreads();
+    unsigned char* dst = out + (size_t)blockIdx.x * KS * KSTEP;
+    for (int i = threadIdx.x; i < KS * 3 * 64; i += 256) *reinterpret_cast<u32x4*>(dst + (size_t)i * 16) = *reinterpret_cast<const u32x4*>(tile + (size_t)i * 16);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- GEMM
@@ -718,7 +737,8 @@ extern "C" int mvs_layernorm_x3p(const float* x, const float* gamma, const float
     MVS_REQUIRE(x && gamma && beta && out && rows >= 1 && rows < ((int64_t)1 << 31) && C >= 32 && C <= 512 && C % 32 == 0,
                 "mvs_layernorm_x3p: 32 <= C <= 512, a multiple of 32 (got %d)", C);
     MVS_REQUIRE(Np >= 16 && Np % 16 == 0 && N >= 1 && N <= Np && rows % Np == 0, "mvs_layernorm_x3p: rows = images * Np, Np %% 16 == 0, N <= Np");
-    hipLaunchKernelGGL(layernorm_x3p_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, MVS_STREAM(stream), x, gamma, beta,
+    // (the packed buffer holds whole row tiles: rows rounded up to 16 are written - zeros beyond `rows`)
+    hipLaunchKernelGGL(layernorm_x3p_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), (C / 32) * KSTEP, MVS_STREAM(stream), x, gamma, beta,
                        reinterpret_cast<unsigned char*>(out), (int)rows, C, Np, N, eps);
     return mvs::finish_launch("mvs_layernorm_x3p");
 }
