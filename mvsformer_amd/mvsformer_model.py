@@ -38,6 +38,14 @@ class DINOMVSNet(CascadeMVS):
         del self.fusions
         self.fusions = fusions
 
+    def train(self, mode: bool = True):
+        """``"fix": true`` (MVSFormer-P): the ViT runs under ``no_grad`` in the reference (mvsformer_model.py:216-218); it has no dropout and no
+        BatchNorm, so keeping it in eval mode changes nothing and lets it stay on the eval-only HIP path."""
+        super().train(mode)
+        if self.args.get("fix", False):
+            self.vit.eval()
+        return self
+
     def extract_features(self, imgs: torch.Tensor):
         """mvsformer_model.py:209-271 -> ``{stageK: [B,V,C,H/s,W/s]}`` (logical NCHW, channel-last memory in eval)."""
         B, V, _, H, W = imgs.shape
@@ -46,7 +54,6 @@ class DINOMVSNet(CascadeMVS):
         if self.training and not self.args.get("fix", False):
             raise _lib.MvsHipError("DINOMVSNet: training the ViT itself (fix=False) is not built; MVSFormer-P freezes it (\"fix\": true)")
         with torch.no_grad():                                # the frozen ViT (mvsformer_model.py:216-218,248-250)
-            self.vit.eval()
             vb = vit_branch(self.vit, self.decoder_vit if not self.training else None, x, self.vit_args["rescale"])
         if self.training:
             P = self.vit.patch_size
