@@ -266,3 +266,23 @@ def test_fused_adamw_and_queues_have_no_cpu_path():
     q = ag.WgradQueue()
     q.flush(())                                                 # no jobs: no call into the library
     assert q.jobs == []
+
+
+def test_counter_traffic_evidence_matches_the_kernel_sources():
+    """profiles/traffic_by_kernel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/collect_profiles.sh) records a digest per source
+    file; ``bench.py`` reports a kernel's HBM traffic only while the files that kernel is built from are unchanged (the driver's
+    line carried ``traffic: null`` because a late edit had voided the evidence).  This test fails when an eval-path kernel source was edited
+    after the last collection: re-run ``tools/collect_profiles.sh`` as the round's last GPU call and commit its output."""
+    import json
+    from mvsformer_amd import _sources
+    path = os.path.join(REPO, "profiles", "traffic_by_kernel.json")
+    tj = json.load(open(path))
+    rec = tj["source_digests"]
+    assert tj.get("collected_at_head")
+    now = _sources.file_digests()
+    stale = sorted(k for k in tj["kernels"] if not _sources.current(k, rec, now))
+    assert not stale, "counter traffic is stale for %s: re-collect (tools/collect_profiles.sh)" % stale[:5]
+    for k in ("vis_x3_kernel", "cv_aggregate_kernel<2,true>", "cv_entropy_kernel<2>", "nchw_to_nhwc_multi"):      # the bench line's roofline kernels
+        assert k in tj["kernels"], k
+        assert all(os.path.exists(os.path.join(_sources.CSRC, f)) for f in _sources.files_of(k))
+    assert len(_sources.files_of("vis_x3_kernel")) < 6          # a known kernel maps to ITS files, not to all of csrc/
