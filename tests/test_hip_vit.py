@@ -185,7 +185,7 @@ def test_layernorm_x3p(dev):
     assert got[:, N:].abs().max() == 0                     # padding rows: zeros
 
 
-@pytest.mark.parametrize("shape", [(1, 2, 50), (2, 6, 197), (1, 6, 1729), (3, 2, 64)])
+@pytest.mark.parametrize("shape", [(1, 2, 50), (2, 6, 197), (1, 6, 1729), (3, 2, 64), (2, 2, 5), (1, 4, 33)])
 def test_attention_x3p_vs_fp64(dev, shape):
     """qkv GEMM -> packed Q / K / V^T -> flash attention -> packed output, and the CLS row, against fp64 attention on the fp32 qkv values
     the GEMM produced (the split-on-the-fly GEMM gives them as fp32)."""
@@ -482,3 +482,22 @@ def test_mvsformer_p_training_step_vs_reference(dev):
             if float(b.norm()) < 1e-6 * b.numel() ** 0.5:
                 continue                                    # (conv biases in front of a batch-statistics BatchNorm)
             assert float((a - b).norm() / b.norm()) < tol, (k, name, float((a - b).norm() / b.norm()))
+
+
+def test_dinomvsnet_batch_of_two_equals_two_single_samples(dev):
+    """``DINOMVSNet`` in eval batches the B x V views through the 2-D networks: a batch of two samples (different images, same cameras) must give
+    each sample the depth map it gets alone (eval BatchNorm: no coupling between images), bit for bit."""
+    import mvsformer_amd as m
+    from mvsformer_amd import synth
+    torch.manual_seed(1)
+    net = m.DINOMVSNet(_mvsformer_p_args()).eval()
+    m.cascade.randomize_bn_(net, seed=2)
+    net = net.to(dev)
+    V, H, W = 3, 128, 192
+    _, proj, dv, _ = synth.make_inputs(V, H, W, seed=4, device=dev)
+    imgs = torch.stack([synth.render_features(synth.make_scene(V, H, W, s), 1, 3, noise=0.02, device=dev, dtype=torch.float32)[0] for s in (4, 9)])
+    proj2 = {k: v.expand(2, *v.shape[1:]).contiguous() for k, v in proj.items()}
+    both = net(imgs, proj2, dv.expand(2, -1).contiguous(), tmp=[5.0, 5.0, 5.0, 1.0])["refined_depth"]
+    for b in range(2):
+        one = net(imgs[b:b + 1], proj, dv, tmp=[5.0, 5.0, 5.0, 1.0])["refined_depth"]
+        assert torch.equal(both[b:b + 1], one), b
