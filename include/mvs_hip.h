@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 32
+#define MVS_ABI_VERSION 33
 
 typedef void* mvs_stream_t;
 
@@ -544,6 +544,17 @@ int mvs_fpn_out0(const float* x, const float* w, const float* scale, const float
 int mvs_fpn_level(const float* intra_prev, const float* lateral, const float* w_inner_p, const float* b_inner, const float* w_packed,
                   const float* scale, const float* shift, int N, int Ck, int h, int w, float* intra_out, float* out,
                   mvs_stream_t stream);
+/* The full-resolution level (models/module.py:266-268, Ck = 8: out3 = Swish(BN(conv3x3(up2(intra2) + inner3(conv01))))) in three-term bf16
+ * split form (csrc/fpn_x3.hip): fp32 in / out, fp32-equivalent.  The convolution is linear, so the lateral path runs as ONE composed 3x3
+ * convolution: the caller passes wc [Ck,Ck,3,3] = sum_c w3[:,c] * w_inner[c,:] (composed in fp64), shift = the folded BatchNorm shift PLUS
+ * scale * (the response of inner3's bias through all nine taps), and border [9][Ck] = scale * (that response per tap), which the kernel
+ * subtracts for the taps that fall into intra3's zero padding at the image border.
+ *   prepare: w3 [Ck,64,3,3] (out3.0.weight), wc, scale [Ck] -> prepared, mvs_fpn_level_x3_prepared_bytes(Ck) bytes
+ *   level:   intra_prev [N,64,h,w], lateral [N,Ck,2h,2w] -> out [N,2h,2w,Ck] channel-last */
+int64_t mvs_fpn_level_x3_prepared_bytes(int Ck);
+int mvs_fpn_level_x3_prepare(const float* w3, const float* wc, const float* scale, int Ck, void* prepared, mvs_stream_t stream);
+int mvs_fpn_level_x3(const float* intra_prev, const float* lateral, const void* prepared, const float* shift, const float* border, int N,
+                     int Ck, int h, int w, float* out, mvs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Next row after the path: geometric consistency filtering of the depth maps, misc/fusion.py:79-122

@@ -133,8 +133,11 @@ class FPNDecoder(nn.Module):
             for k in (1, 2, 3):
                 inner, seq = getattr(self, "inner%d" % k), getattr(self, "out%d" % k)
                 scale, shift = self._fold(seq)
+                x3 = None
+                if k == 3 and os.environ.get("MVS_FPN_X3", "1") != "0":      # the full-resolution level in split form (csrc/fpn_x3.hip)
+                    x3 = ops.fpn_level_x3_prepare(seq[0].weight.detach().contiguous(), inner.weight.detach(), inner.bias.detach(), scale, shift)
                 levels.append((inner.weight.detach().reshape(ops.FPN_CH // 2, 2, -1).permute(0, 2, 1).contiguous(), inner.bias.detach().contiguous(),
-                               ops.fpn_pack_weights(seq[0].weight.detach().contiguous()), scale, shift))
+                               ops.fpn_pack_weights(seq[0].weight.detach().contiguous()), scale, shift, x3))
             s0, h0 = self._fold(self.out0)
             _publish_cache()
             self._cache = (key, (self.out0[0].weight.detach().reshape(ops.FPN_CH, ops.FPN_CH).contiguous(), s0, h0), levels)
@@ -158,8 +161,11 @@ class FPNDecoder(nn.Module):
             intra = conv31.float().contiguous()
             outs = [ops.fpn_out0(intra, w0, s0, h0)]
             for i, lateral in enumerate((conv21, conv11, conv01)):
-                w_in, b_in, packed, scale, shift = levels[i]
-                intra, out = ops.fpn_level(intra, lateral.float().contiguous(), w_in, b_in, packed, scale, shift, want_intra=(i < 2))
+                w_in, b_in, packed, scale, shift, x3 = levels[i]
+                if x3 is not None:
+                    out = ops.fpn_level_x3(intra, lateral.float().contiguous(), *x3)
+                else:
+                    intra, out = ops.fpn_level(intra, lateral.float().contiguous(), w_in, b_in, packed, scale, shift, want_intra=(i < 2))
                 outs.append(out)
         return [o.permute(0, 3, 1, 2) for o in outs]
 

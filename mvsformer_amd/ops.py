@@ -1553,6 +1553,41 @@ def fpn_level(intra_prev: torch.Tensor, lateral: torch.Tensor, w_inner_p: torch.
     return intra, out
 
 
+def fpn_level_x3_prepare(w3: torch.Tensor, w_inner: torch.Tensor, b_inner: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor):
+    """Operands of ``fpn_level_x3`` from ``out_k.0.weight [Ck,64,3,3]``, ``inner_k.weight [64,Ck]`` / ``.bias [64]`` and the folded BatchNorm
+    ``(scale, shift)``: the pre-split MFMA fragments, the shift including the inner bias' response, and the per-tap border table.  The
+    composition (a [Ck,64,9] x [64,Ck] product, once per weight version) is done in float64."""
+    _chk(w3, "fpn 3x3 weight"), _chk(w_inner, "inner weight"), _chk(b_inner, "inner bias"), _chk(scale, "scale"), _chk(shift, "shift")
+    Ck = w3.shape[0]
+    n = int(_lib.load().mvs_fpn_level_x3_prepared_bytes(Ck))
+    if n <= 0 or w3.shape != (Ck, FPN_CH, 3, 3) or w_inner.numel() != FPN_CH * Ck:
+        raise _lib.MvsHipError("fpn_level_x3_prepare: unsupported Ck=%d / weight %s" % (Ck, tuple(w3.shape)))
+    w3d, wi = w3.double(), w_inner.reshape(FPN_CH, Ck).double()
+    wc = torch.einsum("ochw,ci->oihw", w3d, wi).float().contiguous()                       # [Ck,Ck,3,3]
+    resp = torch.einsum("ochw,c->ohw", w3d, b_inner.double()).reshape(Ck, 9) * scale.double()[:, None]    # scale * bias response per tap
+    shift_x = (shift.double() + resp.sum(1)).float().contiguous()
+    border = resp.t().float().contiguous()                                                  # [9][Ck]
+    prepared = torch.empty(n, device=w3.device, dtype=torch.uint8)
+    _call("mvs_fpn_level_x3_prepare", None, _ptr(w3.contiguous()), _ptr(wc), _ptr(scale), Ck, _ptr(prepared), _stream())
+    return prepared, shift_x, border
+
+
+def fpn_level_x3(intra_prev: torch.Tensor, lateral: torch.Tensor, prepared: torch.Tensor, shift_x: torch.Tensor, border: torch.Tensor) -> torch.Tensor:
+    """The full-resolution top-down level in split form (csrc/fpn_x3.hip): ``out [N,2h,2w,Ck]`` channel-last; the 64-channel
+    ``intra`` map is never written."""
+    _chk(intra_prev, "intra_prev"), _chk(lateral, "lateral"), _chk(prepared, "prepared", torch.uint8), _chk(shift_x, "shift"), _chk(border, "border")
+    N, C, h, w = intra_prev.shape
+    Ck = lateral.shape[1]
+    if C != FPN_CH or lateral.shape != (N, Ck, 2 * h, 2 * w):
+        raise _lib.MvsHipError("fpn_level_x3: intra_prev %s needs a lateral [N,Ck,2h,2w], got %s" % (tuple(intra_prev.shape), tuple(lateral.shape)))
+    if prepared.numel() != int(_lib.load().mvs_fpn_level_x3_prepared_bytes(Ck)) or shift_x.numel() != Ck or border.numel() != 9 * Ck:
+        raise _lib.MvsHipError("fpn_level_x3: operands do not match Ck=%d" % Ck)
+    out = torch.empty(N, 2 * h, 2 * w, Ck, device=lateral.device, dtype=torch.float32)
+    tag = ("fpn8_x3_kernel", "flops", 2.0 * FPN_CH * Ck * 10 * N * 4 * h * w)
+    _call("mvs_fpn_level_x3", tag, _ptr(intra_prev), _ptr(lateral), _ptr(prepared), _ptr(shift_x), _ptr(border), N, Ck, h, w, _ptr(out), _stream())
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- FPN encoder layers
 def conv2d_pack_weights(w: torch.Tensor) -> torch.Tensor:
     """``conv.weight [Cout,Cin,K,K]`` of an FPN encoder layer -> the MFMA-fragment image ``mvs_conv2d_bn_lrelu`` stages through LDS."""
