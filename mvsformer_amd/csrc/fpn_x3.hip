@@ -121,80 +121,52 @@ __global__ __launch_bounds__(256, 2) void fpn8_x3_kernel(const float* __restrict
     const rsrc_t rlat = make_rsrc(lat + (size_t)img * CK * H * W, (unsigned)(CK * H * W) * 4u);
 
     // ---- the coarse window of a batch's four new rows: unit v = 64 i + lane = (channel, window row, column quad), one 16-byte load each
-    //      (4 columns of a row), scattered into [channel quad][row][col][4 channels] ----
-    unsigned wgo[3], wmeta[3];                               // global offset without the row part; LDS offset | valid columns << 16 | row << 20
+    //      (4 columns of a row), scattered into [channel quad][row][col][4 channels].  Nothing is masked: window rows >= h / columns >= w hold
+    //      whatever follows in memory (zero past the tensor's end) and are never referenced (the taps clamp like ATen's) ----
+    unsigned wgo[3], wlds[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int v = 64 * i + lane, ch = v / 12, rem = v % 12, row = rem / 3, col0 = wx0 + 4 * (rem % 3);
-        wgo[i] = (unsigned)((16 * wave + ch) * h * w + col0) * 4u;
-        wmeta[i] = (unsigned)((ch >> 2) * WIN_QUAD + row * WIN_ROWB + 4 * (rem % 3) * 16 + (ch & 3) * 4) | (unsigned)min(max(w - col0, 0), 4) << 16 | (unsigned)row << 20;
+        const int v = 64 * i + lane, ch = v / 12, rem = v % 12, row = rem / 3, cq = rem % 3;
+        wgo[i] = (unsigned)(((16 * wave + ch) * h + row) * w + wx0 + 4 * cq) * 4u;
+        wlds[i] = (unsigned)((ch >> 2) * WIN_QUAD + row * WIN_ROWB + 4 * cq * 16 + (ch & 3) * 4);
     }
     f32x4 wreg[3];
     auto window_issue = [&](int g0) {
         const int wy0 = (int)(sy * (float)min(max(g0, 0), H - 1));
+        const unsigned rowpart = (unsigned)(wy0 * w) * 4u;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int r = wy0 + (int)(wmeta[i] >> 20);
-            const unsigned off = (r < h && (wmeta[i] >> 16 & 15u)) ? wgo[i] + (unsigned)(r * w) * 4u : OOB;
-            wreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rprev, off, 0, 0));
-        }
+        for (int i = 0; i < 3; ++i) wreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rprev, wgo[i] + rowpart, 0, 0));
     };
     auto window_commit = [&]() {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int nv = (int)(wmeta[i] >> 16 & 15u);
-            unsigned char* dst = swin + (wmeta[i] & 0xffffu);
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) *reinterpret_cast<float*>(dst + e * 16) = e < nv ? wreg[i][e] : 0.0f;    // (columns past the row end: the next row's data)
-        }
+            for (int e = 0; e < 4; ++e) *reinterpret_cast<float*>(swin + wlds[i] + e * 16) = wreg[i][e];
     };
-    // ---- the wave's lateral row of each row pair: unit v = 64 i + lane = (channel, row pair, column quad of the 18 halo columns) ----
-    unsigned lgo[2], lmeta[2];                               // global offset without the row part; LDS offset | row pair << 16 | first halo column << 20 | unit valid << 28
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int v = 64 * i + lane, ch = v / 10, rem = v % 10, rp = rem / 5, hc0 = 4 * (rem % 5);
-        const bool ok = v < 80;
-        const bool shifted = x0 == 0 && hc0 == 0;           // halo column -1 of the image's first strip: load columns 0..3, use them one slot later
-        lgo[i] = (unsigned)(ch * H * W + x0 - 1 + hc0 + (shifted ? 1 : 0)) * 4u;
-        lmeta[i] = (unsigned)((rp * HC + hc0) * 16 + ch * 2) | (unsigned)rp << 16 | (unsigned)hc0 << 20 | (ok ? 1u << 28 : 0u) | (shifted ? 1u << 29 : 0u);
-    }
-    f32x4 lreg[2];
+    // ---- the wave's lateral row of each row pair: lane = (row pair, halo column), 8 channel loads (the channel in the scalar offset) ----
+    const int lrp = lane / HC, lgx = x0 - 1 + lane % HC;
+    const unsigned lgo = (lane < 2 * HC && lgx >= 0 && lgx < W) ? (unsigned)((2 * lrp - 1 + wave) * W + lgx) * 4u : OOB;   // (wraps for the row above the image: masked below)
+    const unsigned lchb = (unsigned)(H * W) * 4u;
+    float lreg[8];
     auto lat_issue = [&](int Y) {
+        const int r = Y + 2 * lrp - 1 + wave;
+        const unsigned off = (r >= 0 && r < H) ? lgo + (unsigned)(Y * W) * 4u : OOB;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = Y + 2 * (int)(lmeta[i] >> 16 & 1u) - 1 + wave;
-            const unsigned off = ((lmeta[i] >> 28 & 1u) && r >= 0 && r < H) ? lgo[i] + (unsigned)(r * W) * 4u : OOB;
-            lreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rlat, off, 0, 0));
-        }
+        for (int c = 0; c < 8; ++c) lreg[c] = buf_load(rlat, off, (unsigned)c * lchb);
     };
     auto lat_commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (!(lmeta[i] >> 28 & 1u)) continue;
-            const int hc0 = (int)(lmeta[i] >> 20 & 31u);
-            const bool shifted = (lmeta[i] >> 29 & 1u) != 0;
-            unsigned char* dst = slat + (lmeta[i] & 0xffffu);
-            float v[4];
+        if (lane < 2 * HC) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 th, tm, tl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int gx = x0 - 1 + hc0 + e;
-                const float val = shifted ? (e ? lreg[i][e ? e - 1 : 0] : 0.0f) : lreg[i][e];
-                v[e] = (gx >= 0 && gx < W) ? val : 0.0f;
-            }
-#pragma unroll
-            for (int e2 = 0; e2 < 2; ++e2) {
                 unsigned xh, xm, xl;
-                mvsx3::split3_pair<true>(v[2 * e2], v[2 * e2 + 1], xh, xm, xl);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    if (hc0 + 2 * e2 + q < HC) {
-                        unsigned char* d = dst + (2 * e2 + q) * 16;
-                        *reinterpret_cast<unsigned short*>(d) = (unsigned short)(q ? xh >> 16 : xh & 0xffffu);
-                        *reinterpret_cast<unsigned short*>(d + LAT_TERM) = (unsigned short)(q ? xm >> 16 : xm & 0xffffu);
-                        *reinterpret_cast<unsigned short*>(d + 2 * LAT_TERM) = (unsigned short)(q ? xl >> 16 : xl & 0xffffu);
-                    }
-                }
+                mvsx3::split3_pair<false>(lreg[2 * e], lreg[2 * e + 1], xh, xm, xl);
+                th[e] = xh; tm[e] = xm; tl[e] = xl;
             }
+            *reinterpret_cast<u32x4*>(slat + lane * 16) = th;
+            *reinterpret_cast<u32x4*>(slat + LAT_TERM + lane * 16) = tm;
+            *reinterpret_cast<u32x4*>(slat + 2 * LAT_TERM + lane * 16) = tl;
         }
     };
 
@@ -212,25 +184,36 @@ __global__ __launch_bounds__(256, 2) void fpn8_x3_kernel(const float* __restrict
         const float fx = sx * (float)min(max(gx, 0), W - 1);
         const int ix0 = (int)fx, ix1 = ix0 + (ix0 < w - 1 ? 1 : 0);
         const int rx0 = min(ix0 - wx0, WIN_COLS - 1), rx1 = min(ix1 - wx0, WIN_COLS - 1);
-        bl[p] = fx - (float)ix0;
+        bl[p] = colok ? fx - (float)ix0 : -1.0f;          // (-1: a halo column outside the image - zero padding)
         bA[p] = (unsigned)(quad * WIN_QUAD + rx0 * 16) | (unsigned)(quad * WIN_QUAD + rx1 * 16) << 16;     // (+ the window row * WIN_ROWB per batch)
-        bB[p] = (unsigned)((quad >> 1) * OCT + col * 16 + (quad & 1) * 8) | (unsigned)row << 16 | (colok ? 1u << 20 : 0u) | (ok ? 1u << 21 : 0u);
+        bB[p] = (unsigned)((quad >> 1) * OCT + col * 16 + (quad & 1) * 8) | (unsigned)(row * 4) << 16 | (ok ? 1u << 21 : 0u);
     }
     auto build = [&](int g0, int slot0) {
         const int wy0 = (int)(sy * (float)min(max(g0, 0), H - 1));
-        f32x4 va[2][4];
-        float wv[2][2];                                      // vertical weights (gated)
-        auto taps = [&](int p, f32x4 (&v)[4], float (&ly)[2]) {
-            const int g = g0 + (int)(bB[p] >> 16 & 15u);
+        // vertical taps of the batch's four rows, computed once by lanes 0..3 (every lane evaluates row lane & 3) and fetched per pass by
+        // ds_bpermute (a pass's lanes span all four rows): window row offset | row step << 16, and the two weights (0 for a row outside the image)
+        int vpk;
+        float vl0, vl1;
+        {
+            const int g = g0 + (lane & 3);
             const float fy = sy * (float)min(max(g, 0), H - 1);
             const int iy0 = (int)fy;
             const int ry0 = min(max(iy0 - wy0, 0), WIN_ROWS - 1), ry1 = min(ry0 + (iy0 < h - 1 ? 1 : 0), WIN_ROWS - 1);
-            const float gate = (g >= 0 && g < H && (bB[p] >> 20 & 1u)) ? 1.0f : 0.0f;
-            ly[1] = (fy - (float)iy0) * gate;
-            ly[0] = (1.0f - (fy - (float)iy0)) * gate;
-            const unsigned char* s0 = swin + (bA[p] & 0xffffu) + ry0 * WIN_ROWB;
-            const unsigned char* s1 = swin + (bA[p] >> 16) + ry0 * WIN_ROWB;
-            const int dr = (ry1 - ry0) * WIN_ROWB;
+            const float gate = (g >= 0 && g < H) ? 1.0f : 0.0f;
+            vl1 = (fy - (float)iy0) * gate;
+            vl0 = (1.0f - (fy - (float)iy0)) * gate;
+            vpk = ry0 * WIN_ROWB | ((ry1 - ry0) * WIN_ROWB) << 16;
+        }
+        f32x4 va[2][4];
+        float wv[2][2];
+        auto taps = [&](int p, f32x4 (&v)[4], float (&ly)[2]) {
+            const int sel = (int)(bB[p] >> 16 & 15u);                 // 4 * row = the byte address of lane `row` for ds_bpermute
+            const int pk = __builtin_amdgcn_ds_bpermute(sel, vpk);
+            ly[0] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, vl0)));
+            ly[1] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, __builtin_bit_cast(int, vl1)));
+            const unsigned char* s0 = swin + (bA[p] & 0xffffu) + (pk & 0xffff);
+            const unsigned char* s1 = swin + (bA[p] >> 16) + (pk & 0xffff);
+            const int dr = pk >> 16;
             v[0] = *reinterpret_cast<const f32x4*>(s0);
             v[1] = *reinterpret_cast<const f32x4*>(s1);
             v[2] = *reinterpret_cast<const f32x4*>(s0 + dr);
@@ -243,11 +226,12 @@ __global__ __launch_bounds__(256, 2) void fpn8_x3_kernel(const float* __restrict
             __builtin_amdgcn_sched_barrier(0);
             if (bB[p] >> 21 & 1u) {
                 const f32x4(&v)[4] = va[p & 1];
-                const float lx1 = bl[p], lx0 = 1.0f - lx1;
+                const bool colok = bl[p] >= 0.0f;
+                const float lx1 = colok ? bl[p] : 0.0f, lx0 = colok ? 1.0f - bl[p] : 0.0f;
                 const float w00 = wv[p & 1][0] * lx0, w01 = wv[p & 1][0] * lx1, w10 = wv[p & 1][1] * lx0, w11 = wv[p & 1][1] * lx1;
-                int slot = slot0 + (int)(bB[p] >> 16 & 15u);
-                slot = slot >= RING ? slot - RING : slot;
-                unsigned char* dst = ring + (bB[p] & 0xffffu) + slot * ROWB;
+                int slot4 = 4 * slot0 + (int)(bB[p] >> 16 & 15u);
+                slot4 = slot4 >= 4 * RING ? slot4 - 4 * RING : slot4;
+                unsigned char* dst = ring + (bB[p] & 0xffffu) + slot4 * (ROWB / 4);
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                 u32x2 th, tm, tl;
 #pragma unroll
@@ -255,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void fpn8_x3_kernel(const float* __restrict
                     const float a = fmaf(w11, v[3][2 * r], fmaf(w10, v[2][2 * r], fmaf(w01, v[1][2 * r], w00 * v[0][2 * r])));
                     const float b = fmaf(w11, v[3][2 * r + 1], fmaf(w10, v[2][2 * r + 1], fmaf(w01, v[1][2 * r + 1], w00 * v[0][2 * r + 1])));
                     unsigned xh, xm, xl;
-                    mvsx3::split3_pair<true>(a, b, xh, xm, xl);
+                    mvsx3::split3_pair<false>(a, b, xh, xm, xl);    // convex combinations of finite feature values: no clamp (split3.h)
                     th[r] = xh; tm[r] = xm; tl[r] = xl;
                 }
                 *reinterpret_cast<u32x2*>(dst) = th;
