@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 33
+#define MVS_ABI_VERSION 34
 
 typedef void* mvs_stream_t;
 
@@ -537,6 +537,15 @@ int64_t mvs_conv2d_packed_floats(int Cin, int Cout, int K);
 int mvs_conv2d_pack_weights(const float* w, int Cin, int Cout, int K, float* packed, mvs_stream_t stream);
 int mvs_conv2d_bn_lrelu(const float* x, const float* packed, const float* scale, const float* shift, int N, int Cin, int Cout, int K,
                         int stride, int H, int W, float slope, float* y, mvs_stream_t stream);
+/* conv00 / conv01 (the two full-resolution layers: (Cin,Cout,K,stride) = (3,8,7,1), (8,8,5,1)) in three-term bf16 split form (csrc/conv2d_x3.hip):
+ * same contract as mvs_conv2d_bn_lrelu - fp32 NCHW in and out, fp32-equivalent - with the BatchNorm scale folded into the pre-split weights.
+ *   prepare: w [8,Cin,K,K], scale [8] -> prepared, mvs_conv2d_x3_prepared_bytes(Cin, 8, K) bytes
+ *   x [N,Cin,H,W], shift [8] -> y [N,8,H,W] = leaky_relu(conv(x, w) * scale + shift, slope) */
+int mvs_conv2d_x3_supported(int Cin, int Cout, int K, int stride);
+int64_t mvs_conv2d_x3_prepared_bytes(int Cin, int Cout, int K);
+int mvs_conv2d_x3_prepare(const float* w, const float* scale, int Cin, int Cout, int K, void* prepared, mvs_stream_t stream);
+int mvs_conv2d_x3_bn_lrelu(const float* x, const void* prepared, const float* shift, int N, int Cin, int Cout, int K, int stride, int H, int W,
+                           float slope, float* y, mvs_stream_t stream);
 int64_t mvs_fpn_packed_floats(int Cout);
 int mvs_fpn_pack_weights(const float* w, int Cout, float* packed, mvs_stream_t stream);
 int mvs_fpn_out0(const float* x, const float* w, const float* scale, const float* shift, int N, int h, int wd, float* out,

@@ -316,8 +316,11 @@ class FPNEncoder(nn.Module):
                 m = getattr(self, name)
                 scale = m.bn.weight.detach().double() / torch.sqrt(m.bn.running_var.double() + m.bn.eps)
                 shift = m.bn.bias.detach().double() - m.bn.running_mean.double() * scale
-                layers.append((ops.conv2d_pack_weights(m.conv.weight.detach().contiguous()), scale.float().contiguous(),
-                               shift.float().contiguous(), m.conv.out_channels, k, stride))
+                wt = m.conv.weight.detach().contiguous()
+                x3 = None                                    # conv00 / conv01: the split form (csrc/conv2d_x3.hip)
+                if os.environ.get("MVS_FPN_X3", "1") != "0" and ops.conv2d_x3_supported(wt.shape[1], wt.shape[0], k, stride):
+                    x3 = ops.conv2d_x3_prepare(wt, scale.float().contiguous())
+                layers.append((ops.conv2d_pack_weights(wt), scale.float().contiguous(), shift.float().contiguous(), m.conv.out_channels, k, stride, x3))
             _publish_cache()
             self._cache = (key, layers)
         return self._cache[1]
@@ -334,7 +337,10 @@ class FPNEncoder(nn.Module):
         with torch.no_grad():
             x = x.float().contiguous()
             outs = {}
-            for (name, _, _), (packed, scale, shift, cout, k, stride) in zip(self.LAYERS, self._prepared()):
-                x = ops.conv2d_bn_lrelu(x, packed, scale, shift, cout, k, stride, 0.1)
+            for (name, _, _), (packed, scale, shift, cout, k, stride, x3) in zip(self.LAYERS, self._prepared()):
+                if x3 is not None:
+                    x = ops.conv2d_x3_bn_lrelu(x, x3, shift, cout, k, 0.1)
+                else:
+                    x = ops.conv2d_bn_lrelu(x, packed, scale, shift, cout, k, stride, 0.1)
                 outs[name] = x
         return [outs["conv01"], outs["conv11"], outs["conv21"], outs["conv31"]]

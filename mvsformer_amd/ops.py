@@ -1589,6 +1589,34 @@ def fpn_level_x3(intra_prev: torch.Tensor, lateral: torch.Tensor, prepared: torc
 
 
 # ----------------------------------------------------------------------------------------------- FPN encoder layers
+def conv2d_x3_supported(Cin: int, Cout: int, K: int, stride: int) -> bool:
+    return bool(_lib.load().mvs_conv2d_x3_supported(Cin, Cout, K, stride))
+
+
+def conv2d_x3_prepare(w: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """``conv.weight [8,Cin,K,K]`` of conv00 / conv01 with the folded BatchNorm scale -> the pre-split MFMA fragments of ``conv2d_x3_bn_lrelu``."""
+    _chk(w, "conv2d weight"), _chk(scale, "scale")
+    Cout, Cin, K, K2 = w.shape
+    n = int(_lib.load().mvs_conv2d_x3_prepared_bytes(Cin, Cout, K)) if K == K2 else -1
+    if n <= 0 or scale.numel() != Cout:
+        raise _lib.MvsHipError("conv2d_x3_prepare: %s is not conv00 / conv01 of the FPN encoder" % (tuple(w.shape),))
+    prepared = torch.empty(n, device=w.device, dtype=torch.uint8)
+    _call("mvs_conv2d_x3_prepare", None, _ptr(w), _ptr(scale), Cin, Cout, K, _ptr(prepared), _stream())
+    return prepared
+
+
+def conv2d_x3_bn_lrelu(x: torch.Tensor, prepared: torch.Tensor, shift: torch.Tensor, Cout: int, K: int, slope: float) -> torch.Tensor:
+    """conv00 / conv01 in split form (csrc/conv2d_x3.hip): ``leaky_relu(BatchNorm_eval(conv2d(x)))``, fp32 NCHW, fp32-equivalent."""
+    _chk(x, "x"), _chk(prepared, "prepared", torch.uint8), _chk(shift, "shift")
+    N, Cin, H, W = x.shape
+    if prepared.numel() != int(_lib.load().mvs_conv2d_x3_prepared_bytes(Cin, Cout, K)) or shift.numel() != Cout:
+        raise _lib.MvsHipError("conv2d_x3_bn_lrelu: operands do not match (Cin,Cout,K)=(%d,%d,%d)" % (Cin, Cout, K))
+    y = torch.empty(N, Cout, H, W, device=x.device, dtype=torch.float32)
+    tag = ("enc_x3_kernel<%d,%d,%d>" % (Cin, Cout, K), "flops", 2.0 * K * K * Cin * Cout * N * H * W)
+    _call("mvs_conv2d_x3_bn_lrelu", tag, _ptr(x), _ptr(prepared), _ptr(shift), N, Cin, Cout, K, 1, H, W, float(slope), _ptr(y), _stream())
+    return y
+
+
 def conv2d_pack_weights(w: torch.Tensor) -> torch.Tensor:
     """``conv.weight [Cout,Cin,K,K]`` of an FPN encoder layer -> the MFMA-fragment image ``mvs_conv2d_bn_lrelu`` stages through LDS."""
     _chk(w, "conv2d weight")
