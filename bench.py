@@ -485,8 +485,11 @@ def main(args):
         ems = e1.elapsed_time(e2) / 20
         before = {"fpn_decoder_ms_per_depth_map": round(ms, 3), "algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 1),
                   "fpn_encoder_ms_per_depth_map": round(ems, 3), "encoder_algorithmic_tflops": round(eflops / (ems * 1e-3) / 1e12, 1),
-                  "peak_tflops_fp32_mfma": 157.3, "outputs": "channel-last [N,H,W,C]: consumed by the sweeps without nchw_to_nhwc",
-                  "note": "FPNEncoder / FPNDecoder.forward (models/module.py:226-270), eval BatchNorm, %d views, random inputs; not in `value`" % args.views}
+                  "peak_tflops_fp32_mfma": 157.3, "peak_tflops_split_form": 416.7,
+                  "outputs": "channel-last [N,H,W,C]: consumed by the sweeps without nchw_to_nhwc",
+                  "note": "FPNEncoder / FPNDecoder.forward (models/module.py:226-270), eval BatchNorm, %d views, random inputs; the full-resolution layers "
+                          "(conv00, conv01, the decoder's last level) in three-term bf16 split form (csrc/conv2d_x3.hip, csrc/fpn_x3.hip), the rest on the "
+                          "fp32 matrix cores; not in `value`" % args.views}
         del dec, enc, outs, fenc
         # the DINO ViT-small branch of MVSFormer-P (csrc/vit.hip): half-size bicubic resize, 12 blocks, attention-gated decoder, all views batched
         from mvsformer_amd import vit as V

@@ -44,7 +44,10 @@ def test_fpn_decoder_has_no_cpu_path_and_is_checkpoint_compatible():
 
 
 @pytest.mark.gpu
-def test_fpn_decoder_vs_golden(monkeypatch):
+@pytest.mark.parametrize("x3", ["1", "0"])
+def test_fpn_decoder_vs_golden(monkeypatch, x3):
+    """Both forms of the full-resolution level: the split-form kernel of csrc/fpn_x3.hip (default) and the fp32-MFMA kernel of csrc/fpn.hip."""
+    monkeypatch.setenv("MVS_FPN_X3", x3)
     g = load_golden("fpn_decoder.npz")
     dev = torch.device("cuda:0")
     dec = build_decoder({k[3:]: t(v) for k, v in g.items() if k.startswith("sd.")}).to(dev)
@@ -56,9 +59,10 @@ def test_fpn_decoder_vs_golden(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,h,w", [(3, 7, 9), (1, 1, 1), (2, 2, 17)])
+@pytest.mark.parametrize("N,h,w", [(3, 7, 9), (1, 1, 1), (2, 2, 17), (1, 25, 2)])
 def test_fpn_decoder_vs_oracle(N, h, w, monkeypatch):
-    """Partial tiles in both directions, several images, the degenerate 1x1 coarsest level (upsampling scale 0)."""
+    """Partial tiles in both directions, several images, the degenerate 1x1 coarsest level (upsampling scale 0), a tall narrow image (the
+    full-resolution level's 16-column strip cut into vertical segments: 200 rows)."""
     from oracle import ref_fpn
     dec = build_decoder(seed=3)
     feats = ref_fpn.make_case(4, N, h, w)
@@ -149,7 +153,10 @@ def test_fpn_encoder_has_no_cpu_path_and_is_checkpoint_compatible():
 
 
 @pytest.mark.gpu
-def test_fpn_encoder_vs_golden():
+@pytest.mark.parametrize("x3", ["1", "0"])
+def test_fpn_encoder_vs_golden(monkeypatch, x3):
+    """conv00 / conv01 in split form (csrc/conv2d_x3.hip, default) and on the fp32 matrix cores (csrc/conv2d.hip)."""
+    monkeypatch.setenv("MVS_FPN_X3", x3)
     g = load_golden("fpn_encoder.npz")
     dev = torch.device("cuda:0")
     enc = build_encoder({k[3:]: t(v) for k, v in g.items() if k.startswith("sd.")}).to(dev)
@@ -171,6 +178,21 @@ def test_fpn_encoder_vs_oracle(N, H, W):
     for i, (o, ww) in enumerate(zip(outs, want)):
         assert o.shape == ww.shape
         assert scale_err(o.cpu(), ww) < TOL, i
+
+
+@pytest.mark.gpu
+def test_full_resolution_layers_run_in_split_form_by_default(monkeypatch):
+    """conv00, conv01 and the decoder's last level launch the split-form kernels (csrc/conv2d_x3.hip, csrc/fpn_x3.hip) unless MVS_FPN_X3=0."""
+    from mvsformer_amd import ops
+    monkeypatch.delenv("MVS_FPN_X3", raising=False)
+    dev = torch.device("cuda:0")
+    enc, dec = build_encoder(seed=41).to(dev), build_decoder(seed=42).to(dev)
+    x = torch.randn(1, 3, 64, 96, generator=torch.Generator().manual_seed(43)).to(dev)
+    with ops.kernel_timer() as kt:
+        dec(*enc(x))
+    names = set(kt.events)
+    assert {"enc_x3_kernel<3,8,7>", "enc_x3_kernel<8,8,5>", "fpn8_x3_kernel"} <= names, names
+    assert not any(k.startswith("fpn_level_kernel<8>") or k in ("conv2d_kernel<3,8,7,1>", "conv2d_kernel<8,8,5,1>") for k in names), names
 
 
 @pytest.mark.gpu
