@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 34
+#define MVS_ABI_VERSION 36
 
 typedef void* mvs_stream_t;
 
@@ -537,6 +537,14 @@ int64_t mvs_conv2d_packed_floats(int Cin, int Cout, int K);
 int mvs_conv2d_pack_weights(const float* w, int Cin, int Cout, int K, float* packed, mvs_stream_t stream);
 int mvs_conv2d_bn_lrelu(const float* x, const float* packed, const float* scale, const float* shift, int N, int Cin, int Cout, int K,
                         int stride, int H, int W, float slope, float* y, mvs_stream_t stream);
+/* The same level with the channel contraction IN FRONT of the upsampling (csrc/fpn_cp.hip): P_tap[q] = w3[:, :, tap] . intra_prev[q] on the bf16
+ * matrix cores at the coarse resolution (split form), blended at the fine level with ATen's per-pixel bilinear weights - the same linear map,
+ * a quarter of the matrix work and no per-pixel split.  Same operands (w3, wc, scale -> prepared; shift, border) and contract as
+ * mvs_fpn_level_x3; fp32-equivalent. */
+int64_t mvs_fpn_level_cp_prepared_bytes(int Ck);
+int mvs_fpn_level_cp_prepare(const float* w3, const float* wc, const float* scale, int Ck, void* prepared, mvs_stream_t stream);
+int mvs_fpn_level_cp(const float* intra_prev, const float* lateral, const void* prepared, const float* shift, const float* border, int N,
+                     int Ck, int h, int w, float* out, mvs_stream_t stream);
 /* conv00 / conv01 (the two full-resolution layers: (Cin,Cout,K,stride) = (3,8,7,1), (8,8,5,1)) in three-term bf16 split form (csrc/conv2d_x3.hip):
  * same contract as mvs_conv2d_bn_lrelu - fp32 NCHW in and out, fp32-equivalent - with the BatchNorm scale folded into the pre-split weights.
  *   prepare: w [8,Cin,K,K], scale [8] -> prepared, mvs_conv2d_x3_prepared_bytes(Cin, 8, K) bytes
@@ -546,6 +554,9 @@ int64_t mvs_conv2d_x3_prepared_bytes(int Cin, int Cout, int K);
 int mvs_conv2d_x3_prepare(const float* w, const float* scale, int Cin, int Cout, int K, void* prepared, mvs_stream_t stream);
 int mvs_conv2d_x3_bn_lrelu(const float* x, const void* prepared, const float* shift, int N, int Cin, int Cout, int K, int stride, int H, int W,
                            float slope, float* y, mvs_stream_t stream);
+/* the same, additionally writing y_nhwc [N,H,W,8] (may be NULL): the channel-last companion mvs_fpn_level_cp reads as its lateral */
+int mvs_conv2d_x3_bn_lrelu_nhwc(const float* x, const void* prepared, const float* shift, int N, int Cin, int Cout, int K, int stride, int H,
+                                int W, float slope, float* y, float* y_nhwc, mvs_stream_t stream);
 int64_t mvs_fpn_packed_floats(int Cout);
 int mvs_fpn_pack_weights(const float* w, int Cout, float* packed, mvs_stream_t stream);
 int mvs_fpn_out0(const float* x, const float* w, const float* scale, const float* shift, int N, int h, int wd, float* out,
@@ -553,6 +564,10 @@ int mvs_fpn_out0(const float* x, const float* w, const float* scale, const float
 int mvs_fpn_level(const float* intra_prev, const float* lateral, const float* w_inner_p, const float* b_inner, const float* w_packed,
                   const float* scale, const float* shift, int N, int Ck, int h, int w, float* intra_out, float* out,
                   mvs_stream_t stream);
+/* the same with the layout of intra_out chosen: intra_nhwc = 1 writes [N,2h,2w,64] (what mvs_fpn_level_cp reads as intra_prev) */
+int mvs_fpn_level_layout(const float* intra_prev, const float* lateral, const float* w_inner_p, const float* b_inner, const float* w_packed,
+                         const float* scale, const float* shift, int N, int Ck, int h, int w, float* intra_out, int intra_nhwc, float* out,
+                         mvs_stream_t stream);
 /* The full-resolution level (models/module.py:266-268, Ck = 8: out3 = Swish(BN(conv3x3(up2(intra2) + inner3(conv01))))) in three-term bf16
  * split form (csrc/fpn_x3.hip): fp32 in / out, fp32-equivalent.  The convolution is linear, so the lateral path runs as ONE composed 3x3
  * convolution: the caller passes wc [Ck,Ck,3,3] = sum_c w3[:,c] * w_inner[c,:] (composed in fp64), shift = the folded BatchNorm shift PLUS

@@ -76,7 +76,7 @@ __global__ void enc_x3_prepare_kernel(const float* __restrict__ w /*[8,CIN,KS,KS
 template <int KS>
 __global__ __launch_bounds__(256, 2) void enc_x3_kernel(const float* __restrict__ x /*[N,CIN,H,W]*/, const bf16x8* __restrict__ prep,
                                                         const float* __restrict__ shift /*[8]*/, int H, int W, int ngroups, int nseg, int seg_rows,
-                                                        float slope, float* __restrict__ y /*[N,8,H,W]*/) {
+                                                        float slope, float* __restrict__ y /*[N,8,H,W]*/, float* __restrict__ ycl /*[N,H,W,8] or null*/) {
     using E = Enc<KS>;
     constexpr int P = E::P, HC = E::HC, RINGN = E::RINGN, ROWB = E::ROWB, TERM = E::TERM, CIN = E::CIN;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
@@ -235,18 +235,22 @@ __global__ __launch_bounds__(256, 2) void enc_x3_kernel(const float* __restrict_
             const f32x4& c = rp ? c1 : c0;
             const int gy = Y + 2 * rp + (kb >> 1);
             if (gy < yend && gx < W) {
+                f32x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = c[r];
-                    y_img[(size_t)((kb & 1) * 4 + r) * H * W + (size_t)gy * W + gx] = v > 0.0f ? v : v * slope;
+                    o[r] = v > 0.0f ? v : v * slope;
+                    y_img[(size_t)((kb & 1) * 4 + r) * H * W + (size_t)gy * W + gx] = o[r];
                 }
+                // the channel-last companion (what the decoder's last level stages with 16-byte loads): this lane's 4 channels are 16 contiguous bytes
+                if (ycl) *reinterpret_cast<f32x4*>(ycl + (((size_t)img * H + gy) * W + gx) * CO + (kb & 1) * 4) = o;
             }
         }
     }
 }
 
 template <int KS>
-int launch_enc(const float* x, const void* prepared, const float* shift, int N, int H, int W, float slope, float* y, hipStream_t s) {
+int launch_enc(const float* x, const void* prepared, const float* shift, int N, int H, int W, float slope, float* y, float* ycl, hipStream_t s) {
     using E = Enc<KS>;
     const int ngroups = mvs::ceil_div(W, 4 * TW), slots = 2 * mvs::device_cus();
     int nseg = 1;
@@ -268,7 +272,7 @@ int launch_enc(const float* x, const void* prepared, const float* shift, int N, 
         if (rc != MVS_OK) return rc;
     }
     hipLaunchKernelGGL((enc_x3_kernel<KS>), dim3((unsigned)items), dim3(256), LDS, s, x, static_cast<const bf16x8*>(prepared), shift, H, W, ngroups, nseg,
-                       seg_rows, slope, y);
+                       seg_rows, slope, y, ycl);
     return mvs::finish_launch("mvs_conv2d_x3_bn_lrelu");
 }
 
@@ -293,13 +297,21 @@ extern "C" int mvs_conv2d_x3_prepare(const float* w, const float* scale, int Cin
     return mvs::finish_launch("mvs_conv2d_x3_prepare");
 }
 
+extern "C" int mvs_conv2d_x3_bn_lrelu_nhwc(const float* x, const void* prepared, const float* shift, int N, int Cin, int Cout, int KS, int stride,
+                                           int H, int W, float slope, float* y, float* y_nhwc, mvs_stream_t stream);
+
 extern "C" int mvs_conv2d_x3_bn_lrelu(const float* x, const void* prepared, const float* shift, int N, int Cin, int Cout, int KS, int stride, int H,
                                       int W, float slope, float* y, mvs_stream_t stream) {
+    return mvs_conv2d_x3_bn_lrelu_nhwc(x, prepared, shift, N, Cin, Cout, KS, stride, H, W, slope, y, nullptr, stream);
+}
+
+extern "C" int mvs_conv2d_x3_bn_lrelu_nhwc(const float* x, const void* prepared, const float* shift, int N, int Cin, int Cout, int KS, int stride,
+                                           int H, int W, float slope, float* y, float* y_nhwc, mvs_stream_t stream) {
     MVS_REQUIRE(x && prepared && shift && y, "mvs_conv2d_x3_bn_lrelu: null pointer");
     MVS_REQUIRE(mvs_conv2d_x3_supported(Cin, Cout, KS, stride), "mvs_conv2d_x3_bn_lrelu: (Cin,Cout,K,stride)=(%d,%d,%d,%d) is not conv00 / conv01 of the FPN encoder",
                 Cin, Cout, KS, stride);
     MVS_REQUIRE(N >= 1 && H >= 1 && W >= 1, "mvs_conv2d_x3_bn_lrelu: bad shape N=%d H=%d W=%d", N, H, W);
     MVS_REQUIRE((int64_t)8 * H * W * 4 < ((int64_t)1 << 30), "mvs_conv2d_x3_bn_lrelu: one image exceeds 1 GiB");
     hipStream_t s = MVS_STREAM(stream);
-    return KS == 7 ? launch_enc<7>(x, prepared, shift, N, H, W, slope, y, s) : launch_enc<5>(x, prepared, shift, N, H, W, slope, y, s);
+    return KS == 7 ? launch_enc<7>(x, prepared, shift, N, H, W, slope, y, y_nhwc, s) : launch_enc<5>(x, prepared, shift, N, H, W, slope, y, y_nhwc, s);
 }

@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256, (CK == 32 ? 2 : (CK == 16 ? 3 : 4))) void fpn_
                                                         const float* __restrict__ w_in_p /*[32,CK,2]*/, const float* __restrict__ b_in /*[64]*/,
                                                         const float* __restrict__ wp, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int h, int w,
-                                                        float* __restrict__ intra_out /*[N,64,2h,2w] or null*/,
-                                                        float* __restrict__ out /*[N,2h,2w,CK]*/) {
+                                                        float* __restrict__ intra_out /*[N,64,2h,2w] ([N,2h,2w,64] with intra_nhwc) or null*/,
+                                                        float* __restrict__ out /*[N,2h,2w,CK]*/, int intra_nhwc) {
     constexpr bool ROWS2 = (CK == 8);
     constexpr int NT = fpn_nt(CK), NP = np_of(NT), T = fpn_taps(CK), WCH = fpn_chunk_floats(CK);
     constexpr int MT = ROWS2 ? 1 : 2;        // M tiles (16 pixels) per wavefront
@@ -210,7 +210,16 @@ __global__ __launch_bounds__(256, (CK == 32 ? 2 : (CK == 16 ? 3 : 4))) void fpn_
             }
         }
         __syncthreads();
-        if (intra_out) {                                    // interior of the tile -> NCHW, 128-byte row segments
+        if (intra_out && intra_nhwc) {                      // interior of the tile -> channel-last (what fpn_cp.hip stages with 16-byte loads): 64-byte pixel segments
+#pragma unroll
+            for (int i = 0; i < CCH * TH * TW / 256; ++i) {
+                const int idx = tid + i * 256;
+                const int c = idx % CCH, col = (idx / CCH) % TW, row = idx / (CCH * TW);
+                const int yy = y0 + row, xx = x0 + col;
+                if (yy < H && xx < W)
+                    intra_out[((size_t)img * H * W + (unsigned)(yy * W + xx)) * FC + cc * CCH + c] = s_tile[c * CS + (row + 1) * HC + col + 1];
+            }
+        } else if (intra_out) {                             // interior of the tile -> NCHW, 128-byte row segments
 #pragma unroll
             for (int i = 0; i < CCH * TH * TW / 256; ++i) {
                 const int idx = tid + i * 256;
@@ -305,9 +314,19 @@ extern "C" int mvs_fpn_out0(const float* x, const float* w, const float* scale, 
     return mvs::finish_launch("mvs_fpn_out0");
 }
 
+extern "C" int mvs_fpn_level_layout(const float* intra_prev, const float* lateral, const float* w_inner_p, const float* b_inner,
+                                    const float* w_packed, const float* scale, const float* shift, int N, int Ck, int h, int w,
+                                    float* intra_out, int intra_nhwc, float* out, mvs_stream_t stream);
+
 extern "C" int mvs_fpn_level(const float* intra_prev, const float* lateral, const float* w_inner_p, const float* b_inner,
                              const float* w_packed, const float* scale, const float* shift, int N, int Ck, int h, int w,
                              float* intra_out, float* out, mvs_stream_t stream) {
+    return mvs_fpn_level_layout(intra_prev, lateral, w_inner_p, b_inner, w_packed, scale, shift, N, Ck, h, w, intra_out, 0, out, stream);
+}
+
+extern "C" int mvs_fpn_level_layout(const float* intra_prev, const float* lateral, const float* w_inner_p, const float* b_inner,
+                                    const float* w_packed, const float* scale, const float* shift, int N, int Ck, int h, int w,
+                                    float* intra_out, int intra_nhwc, float* out, mvs_stream_t stream) {
     MVS_REQUIRE(intra_prev && lateral && w_inner_p && b_inner && w_packed && scale && shift && out, "mvs_fpn_level: null pointer");
     MVS_REQUIRE(Ck == 8 || Ck == 16 || Ck == 32, "mvs_fpn_level: lateral channels must be 8, 16 or 32 (got %d)", Ck);
     MVS_REQUIRE(N >= 1 && N <= 65535 && h >= 1 && w >= 1 && (int64_t)2 * h <= 4 * 65535, "mvs_fpn_level: bad shape N=%d h=%d w=%d", N, h, w);
@@ -315,10 +334,10 @@ extern "C" int mvs_fpn_level(const float* intra_prev, const float* lateral, cons
     const dim3 grid(mvs::ceil_div(2 * w, TW), mvs::ceil_div(2 * h, TH), N), block(256);
     hipStream_t s = MVS_STREAM(stream);
     if (Ck == 8)
-        hipLaunchKernelGGL(fpn_level_kernel<8>, grid, block, 0, s, intra_prev, lateral, w_inner_p, b_inner, w_packed, scale, shift, h, w, intra_out, out);
+        hipLaunchKernelGGL(fpn_level_kernel<8>, grid, block, 0, s, intra_prev, lateral, w_inner_p, b_inner, w_packed, scale, shift, h, w, intra_out, out, intra_nhwc);
     else if (Ck == 16)
-        hipLaunchKernelGGL(fpn_level_kernel<16>, grid, block, 0, s, intra_prev, lateral, w_inner_p, b_inner, w_packed, scale, shift, h, w, intra_out, out);
+        hipLaunchKernelGGL(fpn_level_kernel<16>, grid, block, 0, s, intra_prev, lateral, w_inner_p, b_inner, w_packed, scale, shift, h, w, intra_out, out, intra_nhwc);
     else
-        hipLaunchKernelGGL(fpn_level_kernel<32>, grid, block, 0, s, intra_prev, lateral, w_inner_p, b_inner, w_packed, scale, shift, h, w, intra_out, out);
+        hipLaunchKernelGGL(fpn_level_kernel<32>, grid, block, 0, s, intra_prev, lateral, w_inner_p, b_inner, w_packed, scale, shift, h, w, intra_out, out, intra_nhwc);
     return mvs::finish_launch("mvs_fpn_level");
 }

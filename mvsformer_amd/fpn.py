@@ -102,6 +102,15 @@ class Swish(nn.Module):
         raise _lib.MvsHipError("Swish is a structural placeholder of FPNDecoder: call the decoder")
 
 
+def _channels_last(t: torch.Tensor) -> torch.Tensor:
+    """``[N,C,H,W]`` (logical) -> a contiguous ``[N,H,W,C]`` tensor: free when the producer already wrote channel-last memory (the level kernels'
+    ``intra`` with ``intra_nhwc``, the encoder's ``conv01`` companion, any ``permute`` view of an NHWC buffer), one copy otherwise."""
+    tag = getattr(t, "_mvs_nhwc", None)
+    if tag is not None and tag[1] == t._version and tag[0].shape == (t.shape[0], t.shape[2], t.shape[3], t.shape[1]):
+        return tag[0]                                        # (a companion is dropped as soon as its tensor was written to)
+    return t.float().permute(0, 2, 3, 1).contiguous()
+
+
 class FPNDecoder(nn.Module):
     def __init__(self, feat_chs):
         super().__init__()
@@ -162,10 +171,20 @@ class FPNDecoder(nn.Module):
             outs = [ops.fpn_out0(intra, w0, s0, h0)]
             for i, lateral in enumerate((conv21, conv11, conv01)):
                 w_in, b_in, packed, scale, shift, x3 = levels[i]
-                if x3 is not None:
-                    out = ops.fpn_level_x3(intra, lateral.float().contiguous(), *x3)
+                if x3 is not None:                           # MVS_FPN_X3: 1 (default) = csrc/fpn_cp.hip, strip = csrc/fpn_x3.hip, 0 = csrc/fpn.hip
+                    prepared, shift_x, border, prepared_cp = x3
+                    if os.environ.get("MVS_FPN_X3", "1") == "strip":
+                        out = ops.fpn_level_x3(intra, lateral.float().contiguous(), prepared, shift_x, border)
+                    else:
+                        out = ops.fpn_level_cp(_channels_last(intra), _channels_last(lateral), prepared_cp, shift_x, border)
                 else:
-                    intra, out = ops.fpn_level(intra, lateral.float().contiguous(), w_in, b_in, packed, scale, shift, want_intra=(i < 2))
+                    # the level below the full-resolution one hands its intra map over channel-last when csrc/fpn_cp.hip will read it
+                    nhwc = i == 1 and levels[2][5] is not None and os.environ.get("MVS_FPN_X3", "1") != "strip"
+                    intra, out = ops.fpn_level(intra, lateral.float().contiguous(), w_in, b_in, packed, scale, shift, want_intra=(i < 2), intra_nhwc=nhwc)
+                    if nhwc:                                 # logical NCHW view over the channel-last memory, the memory itself riding along
+                        cl = intra
+                        intra = cl.permute(0, 3, 1, 2)
+                        intra._mvs_nhwc = (cl, intra._version)
                 outs.append(out)
         return [o.permute(0, 3, 1, 2) for o in outs]
 
@@ -338,7 +357,10 @@ class FPNEncoder(nn.Module):
             x = x.float().contiguous()
             outs = {}
             for (name, _, _), (packed, scale, shift, cout, k, stride, x3) in zip(self.LAYERS, self._prepared()):
-                if x3 is not None:
+                if x3 is not None and name == "conv01":     # + the channel-last companion the decoder's last level stages with 16-byte loads
+                    x, cl = ops.conv2d_x3_bn_lrelu(x, x3, shift, cout, k, 0.1, nhwc_companion=True)
+                    x._mvs_nhwc = (cl, x._version)
+                elif x3 is not None:
                     x = ops.conv2d_x3_bn_lrelu(x, x3, shift, cout, k, 0.1)
                 else:
                     x = ops.conv2d_bn_lrelu(x, packed, scale, shift, cout, k, stride, 0.1)

@@ -1532,7 +1532,7 @@ def fpn_out0(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift: torch
 
 
 def fpn_level(intra_prev: torch.Tensor, lateral: torch.Tensor, w_inner_p: torch.Tensor, b_inner: torch.Tensor, packed: torch.Tensor,
-              scale: torch.Tensor, shift: torch.Tensor, want_intra: bool):
+              scale: torch.Tensor, shift: torch.Tensor, want_intra: bool, intra_nhwc: bool = False):
     """One top-down level (models/module.py:262-268): ``(intra_out [N,64,2h,2w] | None, out [N,2h,2w,Ck] channel-last)``.
     ``w_inner_p`` is ``inner_k.weight [64,Ck]`` regrouped by output-channel pair: ``[32,Ck,2]`` (include/mvs_hip.h)."""
     _chk(intra_prev, "intra_prev"), _chk(lateral, "lateral"), _chk(w_inner_p, "inner weight"), _chk(b_inner, "inner bias")
@@ -1545,11 +1545,13 @@ def fpn_level(intra_prev: torch.Tensor, lateral: torch.Tensor, w_inner_p: torch.
         raise _lib.MvsHipError("fpn_level: parameter sizes do not match Ck=%d" % Ck)
     if Ck not in (8, 16, 32) or packed.numel() != int(_lib.load().mvs_fpn_packed_floats(Ck)):
         raise _lib.MvsHipError("fpn_level: Ck=%d / packed weights of %d floats are not a supported pair" % (Ck, packed.numel()))
-    intra = torch.empty(N, FPN_CH, 2 * h, 2 * w, device=lateral.device, dtype=torch.float32) if want_intra else None
+    intra = None
+    if want_intra:                                           # ``intra_nhwc``: [N,2h,2w,64] memory (what ``fpn_level_cp`` reads), else the reference's [N,64,2h,2w]
+        intra = torch.empty((N, 2 * h, 2 * w, FPN_CH) if intra_nhwc else (N, FPN_CH, 2 * h, 2 * w), device=lateral.device, dtype=torch.float32)
     out = torch.empty(N, 2 * h, 2 * w, Ck, device=lateral.device, dtype=torch.float32)
     tag = ("fpn_level_kernel<%d>" % Ck, "flops", 2.0 * FPN_CH * Ck * 10 * N * 4 * h * w)
-    _call("mvs_fpn_level", tag, _ptr(intra_prev), _ptr(lateral), _ptr(w_inner_p), _ptr(b_inner), _ptr(packed), _ptr(scale), _ptr(shift),
-          N, Ck, h, w, _ptr(intra), _ptr(out), _stream())
+    _call("mvs_fpn_level_layout", tag, _ptr(intra_prev), _ptr(lateral), _ptr(w_inner_p), _ptr(b_inner), _ptr(packed), _ptr(scale), _ptr(shift),
+          N, Ck, h, w, _ptr(intra), 1 if (want_intra and intra_nhwc) else 0, _ptr(out), _stream())
     return intra, out
 
 
@@ -1569,12 +1571,14 @@ def fpn_level_x3_prepare(w3: torch.Tensor, w_inner: torch.Tensor, b_inner: torch
     border = resp.t().float().contiguous()                                                  # [9][Ck]
     prepared = torch.empty(n, device=w3.device, dtype=torch.uint8)
     _call("mvs_fpn_level_x3_prepare", None, _ptr(w3.contiguous()), _ptr(wc), _ptr(scale), Ck, _ptr(prepared), _stream())
-    return prepared, shift_x, border
+    prepared_cp = torch.empty(int(_lib.load().mvs_fpn_level_cp_prepared_bytes(Ck)), device=w3.device, dtype=torch.uint8)
+    _call("mvs_fpn_level_cp_prepare", None, _ptr(w3.contiguous()), _ptr(wc), _ptr(scale), Ck, _ptr(prepared_cp), _stream())
+    return prepared, shift_x, border, prepared_cp
 
 
 def fpn_level_x3(intra_prev: torch.Tensor, lateral: torch.Tensor, prepared: torch.Tensor, shift_x: torch.Tensor, border: torch.Tensor) -> torch.Tensor:
-    """The full-resolution top-down level in split form (csrc/fpn_x3.hip): ``out [N,2h,2w,Ck]`` channel-last; the 64-channel
-    ``intra`` map is never written."""
+    """The full-resolution top-down level in split form, strip kernel (csrc/fpn_x3.hip): NCHW sources, ``out [N,2h,2w,Ck]`` channel-last; the
+    64-channel ``intra`` map is never written."""
     _chk(intra_prev, "intra_prev"), _chk(lateral, "lateral"), _chk(prepared, "prepared", torch.uint8), _chk(shift_x, "shift"), _chk(border, "border")
     N, C, h, w = intra_prev.shape
     Ck = lateral.shape[1]
@@ -1585,6 +1589,22 @@ def fpn_level_x3(intra_prev: torch.Tensor, lateral: torch.Tensor, prepared: torc
     out = torch.empty(N, 2 * h, 2 * w, Ck, device=lateral.device, dtype=torch.float32)
     tag = ("fpn8_x3_kernel", "flops", 2.0 * FPN_CH * Ck * 10 * N * 4 * h * w)
     _call("mvs_fpn_level_x3", tag, _ptr(intra_prev), _ptr(lateral), _ptr(prepared), _ptr(shift_x), _ptr(border), N, Ck, h, w, _ptr(out), _stream())
+    return out
+
+
+def fpn_level_cp(intra_prev_cl: torch.Tensor, lateral_cl: torch.Tensor, prepared_cp: torch.Tensor, shift_x: torch.Tensor, border: torch.Tensor) -> torch.Tensor:
+    """The same level with the channel contraction in front of the upsampling (csrc/fpn_cp.hip).  Both sources CHANNEL-LAST:
+    ``intra_prev_cl [N,h,w,64]``, ``lateral_cl [N,2h,2w,Ck]`` -> ``out [N,2h,2w,Ck]``."""
+    _chk(intra_prev_cl, "intra_prev"), _chk(lateral_cl, "lateral"), _chk(prepared_cp, "prepared", torch.uint8), _chk(shift_x, "shift"), _chk(border, "border")
+    N, h, w, C = intra_prev_cl.shape
+    Ck = lateral_cl.shape[3]
+    if C != FPN_CH or lateral_cl.shape != (N, 2 * h, 2 * w, Ck):
+        raise _lib.MvsHipError("fpn_level_cp: intra_prev [N,h,w,64] %s needs a lateral [N,2h,2w,Ck], got %s" % (tuple(intra_prev_cl.shape), tuple(lateral_cl.shape)))
+    if prepared_cp.numel() != int(_lib.load().mvs_fpn_level_cp_prepared_bytes(Ck)) or shift_x.numel() != Ck or border.numel() != 9 * Ck:
+        raise _lib.MvsHipError("fpn_level_cp: operands do not match Ck=%d" % Ck)
+    out = torch.empty(N, 2 * h, 2 * w, Ck, device=lateral_cl.device, dtype=torch.float32)
+    tag = ("fpn8_cp_kernel", "flops", 2.0 * FPN_CH * Ck * 10 * N * 4 * h * w)
+    _call("mvs_fpn_level_cp", tag, _ptr(intra_prev_cl), _ptr(lateral_cl), _ptr(prepared_cp), _ptr(shift_x), _ptr(border), N, Ck, h, w, _ptr(out), _stream())
     return out
 
 
@@ -1605,16 +1625,17 @@ def conv2d_x3_prepare(w: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
     return prepared
 
 
-def conv2d_x3_bn_lrelu(x: torch.Tensor, prepared: torch.Tensor, shift: torch.Tensor, Cout: int, K: int, slope: float) -> torch.Tensor:
+def conv2d_x3_bn_lrelu(x: torch.Tensor, prepared: torch.Tensor, shift: torch.Tensor, Cout: int, K: int, slope: float, nhwc_companion: bool = False):
     """conv00 / conv01 in split form (csrc/conv2d_x3.hip): ``leaky_relu(BatchNorm_eval(conv2d(x)))``, fp32 NCHW, fp32-equivalent."""
     _chk(x, "x"), _chk(prepared, "prepared", torch.uint8), _chk(shift, "shift")
     N, Cin, H, W = x.shape
     if prepared.numel() != int(_lib.load().mvs_conv2d_x3_prepared_bytes(Cin, Cout, K)) or shift.numel() != Cout:
         raise _lib.MvsHipError("conv2d_x3_bn_lrelu: operands do not match (Cin,Cout,K)=(%d,%d,%d)" % (Cin, Cout, K))
     y = torch.empty(N, Cout, H, W, device=x.device, dtype=torch.float32)
+    ycl = torch.empty(N, H, W, Cout, device=x.device, dtype=torch.float32) if nhwc_companion else None
     tag = ("enc_x3_kernel<%d,%d,%d>" % (Cin, Cout, K), "flops", 2.0 * K * K * Cin * Cout * N * H * W)
-    _call("mvs_conv2d_x3_bn_lrelu", tag, _ptr(x), _ptr(prepared), _ptr(shift), N, Cin, Cout, K, 1, H, W, float(slope), _ptr(y), _stream())
-    return y
+    _call("mvs_conv2d_x3_bn_lrelu_nhwc", tag, _ptr(x), _ptr(prepared), _ptr(shift), N, Cin, Cout, K, 1, H, W, float(slope), _ptr(y), _ptr(ycl), _stream())
+    return (y, ycl) if nhwc_companion else y
 
 
 def conv2d_pack_weights(w: torch.Tensor) -> torch.Tensor:

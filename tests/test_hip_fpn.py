@@ -44,9 +44,10 @@ def test_fpn_decoder_has_no_cpu_path_and_is_checkpoint_compatible():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("x3", ["1", "0"])
+@pytest.mark.parametrize("x3", ["1", "strip", "0"])
 def test_fpn_decoder_vs_golden(monkeypatch, x3):
-    """Both forms of the full-resolution level: the split-form kernel of csrc/fpn_x3.hip (default) and the fp32-MFMA kernel of csrc/fpn.hip."""
+    """All three forms of the full-resolution level: contraction before the upsampling (csrc/fpn_cp.hip, default), the split-form strip kernel
+    (csrc/fpn_x3.hip) and the fp32-MFMA kernel (csrc/fpn.hip)."""
     monkeypatch.setenv("MVS_FPN_X3", x3)
     g = load_golden("fpn_decoder.npz")
     dev = torch.device("cuda:0")
@@ -60,10 +61,12 @@ def test_fpn_decoder_vs_golden(monkeypatch, x3):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,h,w", [(3, 7, 9), (1, 1, 1), (2, 2, 17), (1, 25, 2)])
-def test_fpn_decoder_vs_oracle(N, h, w, monkeypatch):
+@pytest.mark.parametrize("x3", ["1", "strip"])
+def test_fpn_decoder_vs_oracle(N, h, w, x3, monkeypatch):
     """Partial tiles in both directions, several images, the degenerate 1x1 coarsest level (upsampling scale 0), a tall narrow image (the
     full-resolution level's 16-column strip cut into vertical segments: 200 rows)."""
     from oracle import ref_fpn
+    monkeypatch.setenv("MVS_FPN_X3", x3)
     dec = build_decoder(seed=3)
     feats = ref_fpn.make_case(4, N, h, w)
     want = ref_fpn.fpn_decoder_forward({k: v.detach() for k, v in dec.state_dict().items()}, *feats)
@@ -182,7 +185,8 @@ def test_fpn_encoder_vs_oracle(N, H, W):
 
 @pytest.mark.gpu
 def test_full_resolution_layers_run_in_split_form_by_default(monkeypatch):
-    """conv00, conv01 and the decoder's last level launch the split-form kernels (csrc/conv2d_x3.hip, csrc/fpn_x3.hip) unless MVS_FPN_X3=0."""
+    """conv00, conv01 and the decoder's last level launch the split-form kernels (csrc/conv2d_x3.hip, csrc/fpn_cp.hip) unless MVS_FPN_X3 says
+    otherwise, and the decoder takes both of its channel-last sources from their producers (no torch copy kernel in between)."""
     from mvsformer_amd import ops
     monkeypatch.delenv("MVS_FPN_X3", raising=False)
     dev = torch.device("cuda:0")
@@ -191,8 +195,16 @@ def test_full_resolution_layers_run_in_split_form_by_default(monkeypatch):
     with ops.kernel_timer() as kt:
         dec(*enc(x))
     names = set(kt.events)
-    assert {"enc_x3_kernel<3,8,7>", "enc_x3_kernel<8,8,5>", "fpn8_x3_kernel"} <= names, names
-    assert not any(k.startswith("fpn_level_kernel<8>") or k in ("conv2d_kernel<3,8,7,1>", "conv2d_kernel<8,8,5,1>") for k in names), names
+    assert {"enc_x3_kernel<3,8,7>", "enc_x3_kernel<8,8,5>", "fpn8_cp_kernel"} <= names, names
+    assert not any(k.startswith("fpn_level_kernel<8>") or k in ("conv2d_kernel<3,8,7,1>", "conv2d_kernel<8,8,5,1>", "fpn8_x3_kernel") for k in names), names
+    feats = enc(x)
+    assert feats[0]._mvs_nhwc[0].shape == (1, 64, 96, 8)     # conv01's channel-last companion rides on the tensor ...
+    assert torch.equal(feats[0]._mvs_nhwc[0].permute(0, 3, 1, 2), feats[0])
+    from mvsformer_amd.fpn import _channels_last
+    assert _channels_last(feats[0]).data_ptr() == feats[0]._mvs_nhwc[0].data_ptr()
+    feats[0].mul_(2.0)                                       # ... and is dropped once the tensor was written to
+    assert _channels_last(feats[0]).data_ptr() != feats[0]._mvs_nhwc[0].data_ptr()
+    assert torch.equal(_channels_last(feats[0]).permute(0, 3, 1, 2), feats[0])
 
 
 @pytest.mark.gpu

@@ -52,8 +52,14 @@ def main():
         med, mn = timeit(lambda: ops.fpn_level(prev, lat, w_in, b_in, packed, scale, shift, want_intra=(k < 3)))
         print("level %d (Ck %2d) fp32-MFMA kernel   %.4f ms (min %.4f)  %6.1f TFLOP/s" % (k, ck, med, mn, flops / med / 1e9))
         if x3 is not None:
-            med, mn = timeit(lambda: ops.fpn_level_x3(prev, lat, *x3))
-            print("level %d (Ck %2d) split-form kernel  %.4f ms (min %.4f)  %6.1f TFLOP/s  [%s]" % (k, ck, med, mn, flops / med / 1e9, os.environ.get("MVS_HIP_LIB", "shipped")))
+            prepared, shift_x, border, prepared_cp = x3
+            med, mn = timeit(lambda: ops.fpn_level_x3(prev, lat, prepared, shift_x, border))
+            print("level %d (Ck %2d) split form, strips   %.4f ms (min %.4f)  %6.1f TFLOP/s  [%s]" % (k, ck, med, mn, flops / med / 1e9, os.environ.get("MVS_HIP_LIB", "shipped")))
+            prev_cl, lat_cl = prev.permute(0, 2, 3, 1).contiguous(), lat.permute(0, 2, 3, 1).contiguous()
+            med, mn = timeit(lambda: ops.fpn_level_cp(prev_cl, lat_cl, prepared_cp, shift_x, border))
+            print("level %d (Ck %2d) split form, contraction first (channel-last sources)  %.4f ms (min %.4f)  %6.1f TFLOP/s  [%s]" % (k, ck, med, mn, flops / med / 1e9, os.environ.get("MVS_HIP_LIB", "shipped")))
+            a, b = ops.fpn_level_x3(prev, lat, prepared, shift_x, border), ops.fpn_level_cp(prev_cl, lat_cl, prepared_cp, shift_x, border)
+            print("   the two forms differ by %.2e of scale" % float((a - b).abs().max() / a.abs().max()))
 
 
 if __name__ == "__main__":
