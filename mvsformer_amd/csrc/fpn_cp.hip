@@ -274,9 +274,7 @@ __global__ __launch_bounds__(256, 2) void fpn8_cp_kernel(const float* __restrict
         __builtin_amdgcn_sched_barrier(0);
         // ---- the next tile's loads fly during phase 2 ----
         const int next = tile + tstep;
-#ifndef FPNCP_NOISSUE
         if (next < tend) issue(next);
-#endif
 
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase 2: blend the partials at this thread's pixel ----
@@ -291,8 +289,22 @@ __global__ __launch_bounds__(256, 2) void fpn8_cp_kernel(const float* __restrict
                     o[4 + r] = b[r] + sborder[9 * CK + 4 + r];
                 }
             }
-            // rolled loops on purpose: fully unrolled, the 36 (tap, corner) terms of this phase cost > 100 registers and everything else spills
-#ifndef FPNCP_NOTAPS
+            // the row loop stays rolled on purpose: fully unrolled, the 36 (tap, corner) terms of this phase cost > 100 registers and everything else
+            // spills; the three columns' taps are computed once and unrolled with a scheduling fence between them
+            unsigned cx0[3], cx1[3];
+            float wxa[3], wxb[3];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int xx = gx + kw - 1;
+                const float fx = sx * (float)min(max(xx, 0), W - 1);
+                const int ix0 = (int)fx;
+                const float gx_ = (xx >= 0 && xx < W) ? 1.0f : 0.0f;
+                wxb[kw] = (fx - (float)ix0) * gx_;
+                wxa[kw] = (1.0f - (fx - (float)ix0)) * gx_;
+                const int rx0 = min(max(ix0 - wx0, 0), WQ - 1), rx1 = min(rx0 + (ix0 < w - 1 ? 1 : 0), WQ - 1);
+                cx0[kw] = (unsigned)(rx0 * PST + kw * 32);
+                cx1[kw] = (unsigned)(rx1 * PST + kw * 32);
+            }
 #pragma unroll 1
             for (int kh = 0; kh < 3; ++kh) {
                 const int yy = gy + kh - 1;
@@ -303,28 +315,21 @@ __global__ __launch_bounds__(256, 2) void fpn8_cp_kernel(const float* __restrict
                 const int ry0 = min(max(iy0 - wy0, 0), WQ - 1), ry1 = min(ry0 + (iy0 < h - 1 ? 1 : 0), WQ - 1);
                 const unsigned char* row0 = sB + ry0 * (WQ * PST) + kh * 96;
                 const unsigned char* row1 = sB + ry1 * (WQ * PST) + kh * 96;
-#pragma unroll 1
+#pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    const int xx = gx + kw - 1;
-                    const float fx = sx * (float)min(max(xx, 0), W - 1);
-                    const int ix0 = (int)fx;
-                    const float gx_ = (xx >= 0 && xx < W) ? 1.0f : 0.0f;
-                    const float wx1 = (fx - (float)ix0) * gx_, wx0_ = (1.0f - (fx - (float)ix0)) * gx_;
-                    const int rx0 = min(max(ix0 - wx0, 0), WQ - 1), rx1 = min(rx0 + (ix0 < w - 1 ? 1 : 0), WQ - 1);
-                    const int c0 = rx0 * PST + kw * 32, c1 = rx1 * PST + kw * 32;
-                    const f32x4 a00 = *reinterpret_cast<const f32x4*>(row0 + c0), b00 = *reinterpret_cast<const f32x4*>(row0 + c0 + 16);
-                    const f32x4 a01 = *reinterpret_cast<const f32x4*>(row0 + c1), b01 = *reinterpret_cast<const f32x4*>(row0 + c1 + 16);
-                    const f32x4 a10 = *reinterpret_cast<const f32x4*>(row1 + c0), b10 = *reinterpret_cast<const f32x4*>(row1 + c0 + 16);
-                    const f32x4 a11 = *reinterpret_cast<const f32x4*>(row1 + c1), b11 = *reinterpret_cast<const f32x4*>(row1 + c1 + 16);
-                    const float w00 = wy0_ * wx0_, w01 = wy0_ * wx1, w10 = wy1 * wx0_, w11 = wy1 * wx1;
+                    const f32x4 a00 = *reinterpret_cast<const f32x4*>(row0 + cx0[kw]), b00 = *reinterpret_cast<const f32x4*>(row0 + cx0[kw] + 16);
+                    const f32x4 a01 = *reinterpret_cast<const f32x4*>(row0 + cx1[kw]), b01 = *reinterpret_cast<const f32x4*>(row0 + cx1[kw] + 16);
+                    const f32x4 a10 = *reinterpret_cast<const f32x4*>(row1 + cx0[kw]), b10 = *reinterpret_cast<const f32x4*>(row1 + cx0[kw] + 16);
+                    const f32x4 a11 = *reinterpret_cast<const f32x4*>(row1 + cx1[kw]), b11 = *reinterpret_cast<const f32x4*>(row1 + cx1[kw] + 16);
+                    const float w00 = wy0_ * wxa[kw], w01 = wy0_ * wxb[kw], w10 = wy1 * wxa[kw], w11 = wy1 * wxb[kw];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         o[r] = fmaf(w11, a11[r], fmaf(w10, a10[r], fmaf(w01, a01[r], fmaf(w00, a00[r], o[r]))));
                         o[4 + r] = fmaf(w11, b11[r], fmaf(w10, b10[r], fmaf(w01, b01[r], fmaf(w00, b00[r], o[4 + r]))));
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-#endif
             if (gy < H && gx < W) {
                 if (gy == 0 || gy == H - 1 || gx == 0 || gx == W - 1) {   // the bias' response loses the taps that fall into the zero padding
 #pragma unroll

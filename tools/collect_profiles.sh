@@ -44,6 +44,11 @@ python tools/bench_x3p.py > gpurun_out/${ROUND}_bench_x3p.txt 2>&1
 tools/sweep_x3p.sh > gpurun_out/${ROUND}_sweep_x3p.txt 2>&1
 tools/prof_vit_trace.sh > /dev/null 2>&1          # -> gpurun_out/${ROUND}_vit_kernel_stats.csv (kernel trace of the branch, ATen glue included)
 python tools/exp_small_conv.py > gpurun_out/${ROUND}_bf16_small_conv.txt 2>&1
+# the FPN (before the path): encoder / decoder per kernel with the split-form full-resolution layers and with the fp32-MFMA kernels, the last level's three forms, its SQ counters
+python tools/bench_fpn.py --iters 20 2>/dev/null > gpurun_out/${ROUND}_fpn_encoder_decoder.json
+MVS_FPN_X3=0 python tools/bench_fpn.py --iters 20 2>/dev/null > gpurun_out/${ROUND}_fpn_encoder_decoder_fp32mfma.json
+python tools/bench_fpn_level.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${ROUND}_bench_fpn_level.txt
+bash tools/pmc_fpn.sh; cp gpurun_out/pmc_fpn_level.txt gpurun_out/${ROUND}_pmc_fpn_level.txt
 python bench.py --steps 200 --warmup 10 > gpurun_out/${ROUND}_final_bench.json 2> gpurun_out/${ROUND}_final_bench.err
 tail -c 400 gpurun_out/${ROUND}_final_bench.err
 ls -la gpurun_out | tail -20
