@@ -211,13 +211,16 @@ __global__ __launch_bounds__(256, (CK == 32 ? 2 : (CK == 16 ? 3 : 4))) void fpn_
         }
         __syncthreads();
         if (intra_out && intra_nhwc) {                      // interior of the tile -> channel-last (what fpn_cp.hip stages with 16-byte loads): 64-byte pixel segments
+            // a thread takes 4 channels of one pixel (LDS reads: consecutive lanes = consecutive pixels, conflict-free) -> one 16-byte store
 #pragma unroll
-            for (int i = 0; i < CCH * TH * TW / 256; ++i) {
+            for (int i = 0; i < CCH * TH * TW / 1024; ++i) {
                 const int idx = tid + i * 256;
-                const int c = idx % CCH, col = (idx / CCH) % TW, row = idx / (CCH * TW);
+                const int pix = idx % (TH * TW), g = idx / (TH * TW), col = pix % TW, row = pix / TW;
                 const int yy = y0 + row, xx = x0 + col;
+                const float* src = s_tile + (4 * g) * CS + (row + 1) * HC + col + 1;
+                const f32x4 v = {src[0], src[CS], src[2 * CS], src[3 * CS]};
                 if (yy < H && xx < W)
-                    intra_out[((size_t)img * H * W + (unsigned)(yy * W + xx)) * FC + cc * CCH + c] = s_tile[c * CS + (row + 1) * HC + col + 1];
+                    *reinterpret_cast<f32x4*>(intra_out + ((size_t)img * H * W + (unsigned)(yy * W + xx)) * FC + cc * CCH + 4 * g) = v;
             }
         } else if (intra_out) {                             // interior of the tile -> NCHW, 128-byte row segments
 #pragma unroll
