@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 36
+#define MVS_ABI_VERSION 37
 
 typedef void* mvs_stream_t;
 
@@ -554,9 +554,11 @@ int64_t mvs_conv2d_x3_prepared_bytes(int Cin, int Cout, int K);
 int mvs_conv2d_x3_prepare(const float* w, const float* scale, int Cin, int Cout, int K, void* prepared, mvs_stream_t stream);
 int mvs_conv2d_x3_bn_lrelu(const float* x, const void* prepared, const float* shift, int N, int Cin, int Cout, int K, int stride, int H, int W,
                            float slope, float* y, mvs_stream_t stream);
-/* the same, additionally writing y_nhwc [N,H,W,8] (may be NULL): the channel-last companion mvs_fpn_level_cp reads as its lateral */
-int mvs_conv2d_x3_bn_lrelu_nhwc(const float* x, const void* prepared, const float* shift, int N, int Cin, int Cout, int K, int stride, int H,
-                                int W, float slope, float* y, float* y_nhwc, mvs_stream_t stream);
+/* the same with the layouts chosen: x_nhwc = 1 reads x as [N,H,W,8] (Cin = 8: conv01 after a channel-last conv00); y [N,8,H,W] and / or
+ * y_nhwc [N,H,W,8] are written (either may be NULL): conv00 -> conv01 hand over channel-last (16-byte stores and loads instead of scattered
+ * dwords), conv01's y_nhwc is the lateral mvs_fpn_level_cp reads */
+int mvs_conv2d_x3_bn_lrelu_layout(const float* x, int x_nhwc, const void* prepared, const float* shift, int N, int Cin, int Cout, int K,
+                                  int stride, int H, int W, float slope, float* y, float* y_nhwc, mvs_stream_t stream);
 int64_t mvs_fpn_packed_floats(int Cout);
 int mvs_fpn_pack_weights(const float* w, int Cout, float* packed, mvs_stream_t stream);
 int mvs_fpn_out0(const float* x, const float* w, const float* scale, const float* shift, int N, int h, int wd, float* out,

@@ -76,7 +76,7 @@ __global__ void enc_x3_prepare_kernel(const float* __restrict__ w /*[8,CIN,KS,KS
 template <int KS>
 __global__ __launch_bounds__(256, 2) void enc_x3_kernel(const float* __restrict__ x /*[N,CIN,H,W]*/, const bf16x8* __restrict__ prep,
                                                         const float* __restrict__ shift /*[8]*/, int H, int W, int ngroups, int nseg, int seg_rows,
-                                                        float slope, float* __restrict__ y /*[N,8,H,W]*/, float* __restrict__ ycl /*[N,H,W,8] or null*/) {
+                                                        float slope, float* __restrict__ y /*[N,8,H,W] or null*/, float* __restrict__ ycl /*[N,H,W,8] or null*/, int in_nhwc /*x is [N,H,W,8] (conv01 only)*/) {
     using E = Enc<KS>;
     constexpr int P = E::P, HC = E::HC, RINGN = E::RINGN, ROWB = E::ROWB, TERM = E::TERM, CIN = E::CIN;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
@@ -115,8 +115,19 @@ __global__ __launch_bounds__(256, 2) void enc_x3_kernel(const float* __restrict_
         for (int p = 0; p < E::PASSES; ++p) {
             const int g = g0 + (int)(smeta[p] >> 16 & 15u);
             const unsigned off = (g >= 0 && g < H) ? sgo[p] + (unsigned)(g0 * W) * 4u : OOB;
+            if (CIN == 8 && in_nhwc) {                        // a pixel's 8 channels are 32 contiguous bytes: two 16-byte loads instead of 8 scattered dwords
+                const unsigned off8 = (off & OOB) ? OOB : off * 8u;
+                const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off8, 0, 0));
+                const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off8, 16, 0));
 #pragma unroll
-            for (int c = 0; c < CIN; ++c) sreg[p][c] = buf_load(rx, off, (unsigned)c * chb);
+                for (int c = 0; c < 4; ++c) {
+                    sreg[p][c] = a[c];
+                    sreg[p][(4 + c) % CIN] = b[c];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) sreg[p][c] = buf_load(rx, off, (unsigned)c * chb);
+            }
         }
     };
     auto stage_commit = [&](int slot0) {
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void enc_x3_kernel(const float* __restrict_
                 for (int r = 0; r < 4; ++r) {
                     const float v = c[r];
                     o[r] = v > 0.0f ? v : v * slope;
-                    y_img[(size_t)((kb & 1) * 4 + r) * H * W + (size_t)gy * W + gx] = o[r];
+                    if (y) y_img[(size_t)((kb & 1) * 4 + r) * H * W + (size_t)gy * W + gx] = o[r];
                 }
                 // the channel-last companion (what the decoder's last level stages with 16-byte loads): this lane's 4 channels are 16 contiguous bytes
                 if (ycl) *reinterpret_cast<f32x4*>(ycl + (((size_t)img * H + gy) * W + gx) * CO + (kb & 1) * 4) = o;
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void enc_x3_kernel(const float* __restrict_
 }
 
 template <int KS>
-int launch_enc(const float* x, const void* prepared, const float* shift, int N, int H, int W, float slope, float* y, float* ycl, hipStream_t s) {
+int launch_enc(const float* x, int in_nhwc, const void* prepared, const float* shift, int N, int H, int W, float slope, float* y, float* ycl, hipStream_t s) {
     using E = Enc<KS>;
     const int ngroups = mvs::ceil_div(W, 4 * TW), slots = 2 * mvs::device_cus();
     int nseg = 1;
@@ -272,7 +283,7 @@ int launch_enc(const float* x, const void* prepared, const float* shift, int N, 
         if (rc != MVS_OK) return rc;
     }
     hipLaunchKernelGGL((enc_x3_kernel<KS>), dim3((unsigned)items), dim3(256), LDS, s, x, static_cast<const bf16x8*>(prepared), shift, H, W, ngroups, nseg,
-                       seg_rows, slope, y, ycl);
+                       seg_rows, slope, y, ycl, in_nhwc);
     return mvs::finish_launch("mvs_conv2d_x3_bn_lrelu");
 }
 
@@ -297,21 +308,22 @@ extern "C" int mvs_conv2d_x3_prepare(const float* w, const float* scale, int Cin
     return mvs::finish_launch("mvs_conv2d_x3_prepare");
 }
 
-extern "C" int mvs_conv2d_x3_bn_lrelu_nhwc(const float* x, const void* prepared, const float* shift, int N, int Cin, int Cout, int KS, int stride,
-                                           int H, int W, float slope, float* y, float* y_nhwc, mvs_stream_t stream);
+extern "C" int mvs_conv2d_x3_bn_lrelu_layout(const float* x, int x_nhwc, const void* prepared, const float* shift, int N, int Cin, int Cout, int KS,
+                                             int stride, int H, int W, float slope, float* y, float* y_nhwc, mvs_stream_t stream);
 
 extern "C" int mvs_conv2d_x3_bn_lrelu(const float* x, const void* prepared, const float* shift, int N, int Cin, int Cout, int KS, int stride, int H,
                                       int W, float slope, float* y, mvs_stream_t stream) {
-    return mvs_conv2d_x3_bn_lrelu_nhwc(x, prepared, shift, N, Cin, Cout, KS, stride, H, W, slope, y, nullptr, stream);
+    return mvs_conv2d_x3_bn_lrelu_layout(x, 0, prepared, shift, N, Cin, Cout, KS, stride, H, W, slope, y, nullptr, stream);
 }
 
-extern "C" int mvs_conv2d_x3_bn_lrelu_nhwc(const float* x, const void* prepared, const float* shift, int N, int Cin, int Cout, int KS, int stride,
-                                           int H, int W, float slope, float* y, float* y_nhwc, mvs_stream_t stream) {
-    MVS_REQUIRE(x && prepared && shift && y, "mvs_conv2d_x3_bn_lrelu: null pointer");
+extern "C" int mvs_conv2d_x3_bn_lrelu_layout(const float* x, int x_nhwc, const void* prepared, const float* shift, int N, int Cin, int Cout, int KS,
+                                             int stride, int H, int W, float slope, float* y, float* y_nhwc, mvs_stream_t stream) {
+    MVS_REQUIRE(x && prepared && shift && (y || y_nhwc), "mvs_conv2d_x3_bn_lrelu: null pointer");
     MVS_REQUIRE(mvs_conv2d_x3_supported(Cin, Cout, KS, stride), "mvs_conv2d_x3_bn_lrelu: (Cin,Cout,K,stride)=(%d,%d,%d,%d) is not conv00 / conv01 of the FPN encoder",
                 Cin, Cout, KS, stride);
+    MVS_REQUIRE(!x_nhwc || Cin == 8, "mvs_conv2d_x3_bn_lrelu: a channel-last input needs Cin = 8 (got %d)", Cin);
     MVS_REQUIRE(N >= 1 && H >= 1 && W >= 1, "mvs_conv2d_x3_bn_lrelu: bad shape N=%d H=%d W=%d", N, H, W);
-    MVS_REQUIRE((int64_t)8 * H * W * 4 < ((int64_t)1 << 30), "mvs_conv2d_x3_bn_lrelu: one image exceeds 1 GiB");
+    MVS_REQUIRE((int64_t)8 * H * W * 4 < ((int64_t)1 << 28), "mvs_conv2d_x3_bn_lrelu: one image exceeds 256 MiB");
     hipStream_t s = MVS_STREAM(stream);
-    return KS == 7 ? launch_enc<7>(x, prepared, shift, N, H, W, slope, y, y_nhwc, s) : launch_enc<5>(x, prepared, shift, N, H, W, slope, y, y_nhwc, s);
+    return KS == 7 ? launch_enc<7>(x, 0, prepared, shift, N, H, W, slope, y, y_nhwc, s) : launch_enc<5>(x, x_nhwc ? 1 : 0, prepared, shift, N, H, W, slope, y, y_nhwc, s);
 }

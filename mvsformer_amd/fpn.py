@@ -357,11 +357,13 @@ class FPNEncoder(nn.Module):
             x = x.float().contiguous()
             outs = {}
             for (name, _, _), (packed, scale, shift, cout, k, stride, x3) in zip(self.LAYERS, self._prepared()):
+                if x3 is not None and name == "conv00":     # conv00 -> conv01 channel-last: 16-byte stores / loads instead of scattered dwords
+                    x00 = ops.conv2d_x3_bn_lrelu(x, x3, shift, cout, k, 0.1, out="nhwc")
+                    outs[name] = x00.permute(0, 3, 1, 2)
+                    continue
                 if x3 is not None and name == "conv01":     # + the channel-last companion the decoder's last level stages with 16-byte loads
-                    x, cl = ops.conv2d_x3_bn_lrelu(x, x3, shift, cout, k, 0.1, nhwc_companion=True)
+                    x, cl = ops.conv2d_x3_bn_lrelu(x00, x3, shift, cout, k, 0.1, x_nhwc=True, out="both")
                     x._mvs_nhwc = (cl, x._version)
-                elif x3 is not None:
-                    x = ops.conv2d_x3_bn_lrelu(x, x3, shift, cout, k, 0.1)
                 else:
                     x = ops.conv2d_bn_lrelu(x, packed, scale, shift, cout, k, stride, 0.1)
                 outs[name] = x

@@ -1625,17 +1625,23 @@ def conv2d_x3_prepare(w: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
     return prepared
 
 
-def conv2d_x3_bn_lrelu(x: torch.Tensor, prepared: torch.Tensor, shift: torch.Tensor, Cout: int, K: int, slope: float, nhwc_companion: bool = False):
-    """conv00 / conv01 in split form (csrc/conv2d_x3.hip): ``leaky_relu(BatchNorm_eval(conv2d(x)))``, fp32 NCHW, fp32-equivalent."""
+def conv2d_x3_bn_lrelu(x: torch.Tensor, prepared: torch.Tensor, shift: torch.Tensor, Cout: int, K: int, slope: float, x_nhwc: bool = False,
+                       out: str = "nchw"):
+    """conv00 / conv01 in split form (csrc/conv2d_x3.hip): ``leaky_relu(BatchNorm_eval(conv2d(x)))``, fp32, fp32-equivalent.  ``x`` is
+    ``[N,Cin,H,W]`` or, with ``x_nhwc`` (Cin = 8), ``[N,H,W,8]``; ``out``: "nchw" -> ``y [N,8,H,W]``, "nhwc" -> ``[N,H,W,8]``, "both" -> the pair."""
     _chk(x, "x"), _chk(prepared, "prepared", torch.uint8), _chk(shift, "shift")
-    N, Cin, H, W = x.shape
-    if prepared.numel() != int(_lib.load().mvs_conv2d_x3_prepared_bytes(Cin, Cout, K)) or shift.numel() != Cout:
-        raise _lib.MvsHipError("conv2d_x3_bn_lrelu: operands do not match (Cin,Cout,K)=(%d,%d,%d)" % (Cin, Cout, K))
-    y = torch.empty(N, Cout, H, W, device=x.device, dtype=torch.float32)
-    ycl = torch.empty(N, H, W, Cout, device=x.device, dtype=torch.float32) if nhwc_companion else None
+    if x_nhwc:
+        N, H, W, Cin = x.shape
+    else:
+        N, Cin, H, W = x.shape
+    if prepared.numel() != int(_lib.load().mvs_conv2d_x3_prepared_bytes(Cin, Cout, K)) or shift.numel() != Cout or out not in ("nchw", "nhwc", "both"):
+        raise _lib.MvsHipError("conv2d_x3_bn_lrelu: operands do not match (Cin,Cout,K)=(%d,%d,%d) / out=%r" % (Cin, Cout, K, out))
+    y = torch.empty(N, Cout, H, W, device=x.device, dtype=torch.float32) if out != "nhwc" else None
+    ycl = torch.empty(N, H, W, Cout, device=x.device, dtype=torch.float32) if out != "nchw" else None
     tag = ("enc_x3_kernel<%d,%d,%d>" % (Cin, Cout, K), "flops", 2.0 * K * K * Cin * Cout * N * H * W)
-    _call("mvs_conv2d_x3_bn_lrelu_nhwc", tag, _ptr(x), _ptr(prepared), _ptr(shift), N, Cin, Cout, K, 1, H, W, float(slope), _ptr(y), _ptr(ycl), _stream())
-    return (y, ycl) if nhwc_companion else y
+    _call("mvs_conv2d_x3_bn_lrelu_layout", tag, _ptr(x), 1 if x_nhwc else 0, _ptr(prepared), _ptr(shift), N, Cin, Cout, K, 1, H, W, float(slope),
+          _ptr(y), _ptr(ycl), _stream())
+    return (y, ycl) if out == "both" else (y if out == "nchw" else ycl)
 
 
 def conv2d_pack_weights(w: torch.Tensor) -> torch.Tensor:
