@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 37
+#define MVS_ABI_VERSION 38
 
 typedef void* mvs_stream_t;
 
@@ -570,6 +570,13 @@ int mvs_fpn_level(const float* intra_prev, const float* lateral, const float* w_
 int mvs_fpn_level_layout(const float* intra_prev, const float* lateral, const float* w_inner_p, const float* b_inner, const float* w_packed,
                          const float* scale, const float* shift, int N, int Ck, int h, int w, float* intra_out, int intra_nhwc, float* out,
                          mvs_stream_t stream);
+/* Levels 1 and 2 (Ck = 32 | 16) with the 3x3 convolution in three-term bf16 split form (csrc/fpn_lvl_x3.hip): mvs_fpn_level_layout's contract
+ * (same sources, same intra_out in either layout, same out), the convolution's weights pre-split with the BatchNorm scale folded in.
+ *   prepare: w3 [Ck,64,3,3] (out_k.0.weight), scale [Ck] -> prepared, mvs_fpn_level_x3s_prepared_bytes(Ck) bytes */
+int64_t mvs_fpn_level_x3s_prepared_bytes(int Ck);
+int mvs_fpn_level_x3s_prepare(const float* w3, const float* scale, int Ck, void* prepared, mvs_stream_t stream);
+int mvs_fpn_level_x3s(const float* intra_prev, const float* lateral, const float* w_inner_p, const float* b_inner, const void* prepared,
+                      const float* shift, int N, int Ck, int h, int w, float* intra_out, int intra_nhwc, float* out, mvs_stream_t stream);
 /* The full-resolution level (models/module.py:266-268, Ck = 8: out3 = Swish(BN(conv3x3(up2(intra2) + inner3(conv01))))) in three-term bf16
  * split form (csrc/fpn_x3.hip): fp32 in / out, fp32-equivalent.  The convolution is linear, so the lateral path runs as ONE composed 3x3
  * convolution: the caller passes wc [Ck,Ck,3,3] = sum_c w3[:,c] * w_inner[c,:] (composed in fp64), shift = the folded BatchNorm shift PLUS

@@ -26,6 +26,7 @@ _RULES = [
     (r"^pack_deconv_s1", ["deconv3d_s1.hip", "conv_common.h", "common.h"]),
     (r"^(head_|init_inverse|schedule_inverse|conf_accumulate|mvs_head|mvs_init_inverse|mvs_schedule_inverse|mvs_conf)", ["head.hip", "common.h"]),
     (r"^(proj_|mvs_proj)", ["proj.hip", "common.h"]),
+    (r"^(fpn_level_x3s|fpn_lvl_x3|mvs_fpn_level_x3s)", ["fpn_lvl_x3.hip", "conv_common.h", "common.h", "split3.h"]),
     (r"^(fpn8_cp|mvs_fpn_level_cp)", ["fpn_cp.hip", "conv_common.h", "common.h", "split3.h"]),
     (r"^(enc_x3|mvs_conv2d_x3)", ["conv2d_x3.hip", "conv_common.h", "common.h", "split3.h"]),
     (r"^(fpn8_x3|fpn_level_x3|mvs_fpn_level_x3)", ["fpn_x3.hip", "conv_common.h", "common.h", "split3.h"]),

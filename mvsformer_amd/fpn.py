@@ -143,8 +143,10 @@ class FPNDecoder(nn.Module):
                 inner, seq = getattr(self, "inner%d" % k), getattr(self, "out%d" % k)
                 scale, shift = self._fold(seq)
                 x3 = None
-                if k == 3 and os.environ.get("MVS_FPN_X3", "1") != "0":      # the full-resolution level in split form (csrc/fpn_x3.hip)
+                if k == 3 and os.environ.get("MVS_FPN_X3", "1") != "0":      # the full-resolution level in split form (csrc/fpn_cp.hip, fpn_x3.hip)
                     x3 = ops.fpn_level_x3_prepare(seq[0].weight.detach().contiguous(), inner.weight.detach(), inner.bias.detach(), scale, shift)
+                elif os.environ.get("MVS_FPN_X3", "1") != "0":               # levels 1-2: the 3x3 convolution in split form (csrc/fpn_lvl_x3.hip)
+                    x3 = ops.fpn_level_x3s_prepare(seq[0].weight.detach().contiguous(), scale)
                 levels.append((inner.weight.detach().reshape(ops.FPN_CH // 2, 2, -1).permute(0, 2, 1).contiguous(), inner.bias.detach().contiguous(),
                                ops.fpn_pack_weights(seq[0].weight.detach().contiguous()), scale, shift, x3))
             s0, h0 = self._fold(self.out0)
@@ -171,7 +173,7 @@ class FPNDecoder(nn.Module):
             outs = [ops.fpn_out0(intra, w0, s0, h0)]
             for i, lateral in enumerate((conv21, conv11, conv01)):
                 w_in, b_in, packed, scale, shift, x3 = levels[i]
-                if x3 is not None:                           # MVS_FPN_X3: 1 (default) = csrc/fpn_cp.hip, strip = csrc/fpn_x3.hip, 0 = csrc/fpn.hip
+                if i == 2 and x3 is not None:                # MVS_FPN_X3: 1 (default) = csrc/fpn_cp.hip, strip = csrc/fpn_x3.hip, 0 = csrc/fpn.hip
                     prepared, shift_x, border, prepared_cp = x3
                     if os.environ.get("MVS_FPN_X3", "1") == "strip":
                         out = ops.fpn_level_x3(intra, lateral.float().contiguous(), prepared, shift_x, border)
@@ -180,7 +182,10 @@ class FPNDecoder(nn.Module):
                 else:
                     # the level below the full-resolution one hands its intra map over channel-last when csrc/fpn_cp.hip will read it
                     nhwc = i == 1 and levels[2][5] is not None and os.environ.get("MVS_FPN_X3", "1") != "strip"
-                    intra, out = ops.fpn_level(intra, lateral.float().contiguous(), w_in, b_in, packed, scale, shift, want_intra=(i < 2), intra_nhwc=nhwc)
+                    if x3 is not None:
+                        intra, out = ops.fpn_level_x3s(intra, lateral.float().contiguous(), w_in, b_in, x3, shift, want_intra=True, intra_nhwc=nhwc)
+                    else:
+                        intra, out = ops.fpn_level(intra, lateral.float().contiguous(), w_in, b_in, packed, scale, shift, want_intra=(i < 2), intra_nhwc=nhwc)
                     if nhwc:                                 # logical NCHW view over the channel-last memory, the memory itself riding along
                         cl = intra
                         intra = cl.permute(0, 3, 1, 2)

@@ -1555,6 +1555,39 @@ def fpn_level(intra_prev: torch.Tensor, lateral: torch.Tensor, w_inner_p: torch.
     return intra, out
 
 
+def fpn_level_x3s_prepare(w3: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """``out_k.0.weight [Ck,64,3,3]`` (Ck 16 | 32) with the folded BatchNorm scale -> the pre-split MFMA fragments of ``fpn_level_x3s``."""
+    _chk(w3, "fpn 3x3 weight"), _chk(scale, "scale")
+    Ck = w3.shape[0]
+    n = int(_lib.load().mvs_fpn_level_x3s_prepared_bytes(Ck))
+    if n <= 0 or w3.shape != (Ck, FPN_CH, 3, 3) or scale.numel() != Ck:
+        raise _lib.MvsHipError("fpn_level_x3s_prepare: unsupported weight %s" % (tuple(w3.shape),))
+    prepared = torch.empty(n, device=w3.device, dtype=torch.uint8)
+    _call("mvs_fpn_level_x3s_prepare", None, _ptr(w3.contiguous()), _ptr(scale), Ck, _ptr(prepared), _stream())
+    return prepared
+
+
+def fpn_level_x3s(intra_prev: torch.Tensor, lateral: torch.Tensor, w_inner_p: torch.Tensor, b_inner: torch.Tensor, prepared: torch.Tensor,
+                  shift: torch.Tensor, want_intra: bool, intra_nhwc: bool = False):
+    """``fpn_level`` for the levels with Ck = 16 | 32, the 3x3 convolution in split form (csrc/fpn_lvl_x3.hip): ``(intra | None, out)``."""
+    _chk(intra_prev, "intra_prev"), _chk(lateral, "lateral"), _chk(w_inner_p, "inner weight"), _chk(b_inner, "inner bias")
+    _chk(prepared, "prepared", torch.uint8), _chk(shift, "shift")
+    N, C, h, w = intra_prev.shape
+    Ck = lateral.shape[1]
+    if C != FPN_CH or lateral.shape != (N, Ck, 2 * h, 2 * w) or w_inner_p.shape != (FPN_CH // 2, Ck, 2) or b_inner.numel() != FPN_CH or shift.numel() != Ck:
+        raise _lib.MvsHipError("fpn_level_x3s: shapes do not match (intra_prev %s, lateral %s)" % (tuple(intra_prev.shape), tuple(lateral.shape)))
+    if prepared.numel() != int(_lib.load().mvs_fpn_level_x3s_prepared_bytes(Ck)):
+        raise _lib.MvsHipError("fpn_level_x3s: prepared weights do not match Ck=%d" % Ck)
+    intra = None
+    if want_intra:
+        intra = torch.empty((N, 2 * h, 2 * w, FPN_CH) if intra_nhwc else (N, FPN_CH, 2 * h, 2 * w), device=lateral.device, dtype=torch.float32)
+    out = torch.empty(N, 2 * h, 2 * w, Ck, device=lateral.device, dtype=torch.float32)
+    tag = ("fpn_level_x3s_kernel<%d>" % Ck, "flops", 2.0 * FPN_CH * Ck * 10 * N * 4 * h * w)
+    _call("mvs_fpn_level_x3s", tag, _ptr(intra_prev), _ptr(lateral), _ptr(w_inner_p), _ptr(b_inner), _ptr(prepared), _ptr(shift), N, Ck, h, w,
+          _ptr(intra), 1 if (want_intra and intra_nhwc) else 0, _ptr(out), _stream())
+    return intra, out
+
+
 def fpn_level_x3_prepare(w3: torch.Tensor, w_inner: torch.Tensor, b_inner: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor):
     """Operands of ``fpn_level_x3`` from ``out_k.0.weight [Ck,64,3,3]``, ``inner_k.weight [64,Ck]`` / ``.bias [64]`` and the folded BatchNorm
     ``(scale, shift)``: the pre-split MFMA fragments, the shift including the inner bias' response, and the per-tap border table.  The
