@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 38
+#define MVS_ABI_VERSION 39
 
 typedef void* mvs_stream_t;
 
@@ -559,6 +559,14 @@ int mvs_conv2d_x3_bn_lrelu(const float* x, const void* prepared, const float* sh
  * dwords), conv01's y_nhwc is the lateral mvs_fpn_level_cp reads */
 int mvs_conv2d_x3_bn_lrelu_layout(const float* x, int x_nhwc, const void* prepared, const float* shift, int N, int Cin, int Cout, int K,
                                   int stride, int H, int W, float slope, float* y, float* y_nhwc, mvs_stream_t stream);
+/* The encoder's six 3x3 stride-1 layers below full resolution (Cin = Cout = 16 | 32 | 64) in three-term bf16 split form (csrc/conv2d_x3s.hip): same
+ * contract as mvs_conv2d_bn_lrelu (fp32 NCHW in and out, fp32-equivalent), the BatchNorm scale folded into the pre-split weights.
+ *   prepare: w [C,C,3,3], scale [C] -> prepared, mvs_conv2d_x3s_prepared_bytes(C, C, 3) bytes */
+int mvs_conv2d_x3s_supported(int Cin, int Cout, int K, int stride);
+int64_t mvs_conv2d_x3s_prepared_bytes(int Cin, int Cout, int K);
+int mvs_conv2d_x3s_prepare(const float* w, const float* scale, int Cin, int Cout, int K, void* prepared, mvs_stream_t stream);
+int mvs_conv2d_x3s_bn_lrelu(const float* x, const void* prepared, const float* shift, int N, int Cin, int Cout, int K, int stride, int H, int W,
+                            float slope, float* y, mvs_stream_t stream);
 int64_t mvs_fpn_packed_floats(int Cout);
 int mvs_fpn_pack_weights(const float* w, int Cout, float* packed, mvs_stream_t stream);
 int mvs_fpn_out0(const float* x, const float* w, const float* scale, const float* shift, int N, int h, int wd, float* out,

@@ -28,6 +28,7 @@ _RULES = [
     (r"^(proj_|mvs_proj)", ["proj.hip", "common.h"]),
     (r"^(fpn_level_x3s|fpn_lvl_x3|mvs_fpn_level_x3s)", ["fpn_lvl_x3.hip", "conv_common.h", "common.h", "split3.h"]),
     (r"^(fpn8_cp|mvs_fpn_level_cp)", ["fpn_cp.hip", "conv_common.h", "common.h", "split3.h"]),
+    (r"^(conv2d_x3s|mvs_conv2d_x3s)", ["conv2d_x3s.hip", "conv_common.h", "common.h", "split3.h"]),
     (r"^(enc_x3|mvs_conv2d_x3)", ["conv2d_x3.hip", "conv_common.h", "common.h", "split3.h"]),
     (r"^(fpn8_x3|fpn_level_x3|mvs_fpn_level_x3)", ["fpn_x3.hip", "conv_common.h", "common.h", "split3.h"]),
     (r"^(x3p_|gemm_x3p|attention_x3p|layernorm_x3p|cls_attention)", ["vit_packed.hip", "common.h", "split3.h"]),
