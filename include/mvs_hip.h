@@ -44,7 +44,7 @@ extern "C" {
 
 #define MVS_OK 0
 #define MVS_EINVAL (-22)
-#define MVS_ABI_VERSION 39
+#define MVS_ABI_VERSION 40
 
 typedef void* mvs_stream_t;
 
@@ -559,14 +559,16 @@ int mvs_conv2d_x3_bn_lrelu(const float* x, const void* prepared, const float* sh
  * dwords), conv01's y_nhwc is the lateral mvs_fpn_level_cp reads */
 int mvs_conv2d_x3_bn_lrelu_layout(const float* x, int x_nhwc, const void* prepared, const float* shift, int N, int Cin, int Cout, int K,
                                   int stride, int H, int W, float slope, float* y, float* y_nhwc, mvs_stream_t stream);
-/* The encoder's six 3x3 stride-1 layers below full resolution (Cin = Cout = 16 | 32 | 64) in three-term bf16 split form (csrc/conv2d_x3s.hip): same
- * contract as mvs_conv2d_bn_lrelu (fp32 NCHW in and out, fp32-equivalent), the BatchNorm scale folded into the pre-split weights.
- *   prepare: w [C,C,3,3], scale [C] -> prepared, mvs_conv2d_x3s_prepared_bytes(C, C, 3) bytes */
+/* The encoder's layers below full resolution in three-term bf16 split form (csrc/conv2d_x3s.hip): the six 3x3 stride-1 layers (Cin = Cout = 16 | 32 |
+ * 64) and the three stride-2 layers ((Cin,Cout,K) = (8,16,5), (16,32,5), (32,64,3)); same contract as mvs_conv2d_bn_lrelu (fp32 NCHW in and out,
+ * fp32-equivalent), the BatchNorm scale folded into the pre-split weights.  x_nhwc = 1: x is [N,H,W,8] (the 8-channel stride-2 layer reading
+ * conv01's channel-last companion).
+ *   prepare: w [Cout,Cin,K,K], scale [Cout] -> prepared, mvs_conv2d_x3s_prepared_bytes(Cin, Cout, K, stride) bytes */
 int mvs_conv2d_x3s_supported(int Cin, int Cout, int K, int stride);
-int64_t mvs_conv2d_x3s_prepared_bytes(int Cin, int Cout, int K);
-int mvs_conv2d_x3s_prepare(const float* w, const float* scale, int Cin, int Cout, int K, void* prepared, mvs_stream_t stream);
-int mvs_conv2d_x3s_bn_lrelu(const float* x, const void* prepared, const float* shift, int N, int Cin, int Cout, int K, int stride, int H, int W,
-                            float slope, float* y, mvs_stream_t stream);
+int64_t mvs_conv2d_x3s_prepared_bytes(int Cin, int Cout, int K, int stride);
+int mvs_conv2d_x3s_prepare(const float* w, const float* scale, int Cin, int Cout, int K, int stride, void* prepared, mvs_stream_t stream);
+int mvs_conv2d_x3s_bn_lrelu(const float* x, int x_nhwc, const void* prepared, const float* shift, int N, int Cin, int Cout, int K, int stride, int H,
+                            int W, float slope, float* y, mvs_stream_t stream);
 int64_t mvs_fpn_packed_floats(int Cout);
 int mvs_fpn_pack_weights(const float* w, int Cout, float* packed, mvs_stream_t stream);
 int mvs_fpn_out0(const float* x, const float* w, const float* scale, const float* shift, int N, int h, int wd, float* out,

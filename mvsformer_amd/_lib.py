@@ -18,7 +18,7 @@ import torch  # noqa: F401  (load order, see above)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVS_HIP_LIB: diagnostics only - another BUILD of the same library (tests/test_hip_multistream.py's variants); never a fallback
 LIB_PATH = os.environ.get("MVS_HIP_LIB") or os.path.join(_HERE, "libmvs_hip.so")
-ABI_VERSION = 39
+ABI_VERSION = 40
 
 from ctypes import c_double  # noqa: E402
 
@@ -181,9 +181,9 @@ SIGNATURES = {
     "mvs_fpn_level_cp_prepare": (I, [P, P, P, I, P, P]),
     "mvs_fpn_level_cp": (I, [P, P, P, P, P, I, I, I, I, P, P]),
     "mvs_conv2d_x3s_supported": (I, [I, I, I, I]),
-    "mvs_conv2d_x3s_prepared_bytes": (L, [I, I, I]),
-    "mvs_conv2d_x3s_prepare": (I, [P, P, I, I, I, P, P]),
-    "mvs_conv2d_x3s_bn_lrelu": (I, [P, P, P, I, I, I, I, I, I, I, F, P, P]),
+    "mvs_conv2d_x3s_prepared_bytes": (L, [I, I, I, I]),
+    "mvs_conv2d_x3s_prepare": (I, [P, P, I, I, I, I, P, P]),
+    "mvs_conv2d_x3s_bn_lrelu": (I, [P, I, P, P, I, I, I, I, I, I, I, F, P, P]),
     "mvs_conv2d_x3_supported": (I, [I, I, I, I]),
     "mvs_conv2d_x3_prepared_bytes": (L, [I, I, I]),
     "mvs_conv2d_x3_prepare": (I, [P, P, I, I, I, P, P]),

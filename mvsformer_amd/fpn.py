@@ -345,7 +345,7 @@ class FPNEncoder(nn.Module):
                 if os.environ.get("MVS_FPN_X3", "1") != "0" and ops.conv2d_x3_supported(wt.shape[1], wt.shape[0], k, stride):
                     x3 = ops.conv2d_x3_prepare(wt, scale.float().contiguous())
                 elif os.environ.get("MVS_FPN_X3", "1") != "0" and ops.conv2d_x3s_supported(wt.shape[1], wt.shape[0], k, stride):
-                    x3 = ops.conv2d_x3s_prepare(wt, scale.float().contiguous())      # the 3x3 stride-1 layers below full resolution (csrc/conv2d_x3s.hip)
+                    x3 = ops.conv2d_x3s_prepare(wt, scale.float().contiguous(), stride)      # the layers below full resolution (csrc/conv2d_x3s.hip)
                 layers.append((ops.conv2d_pack_weights(wt), scale.float().contiguous(), shift.float().contiguous(), m.conv.out_channels, k, stride, x3))
             _publish_cache()
             self._cache = (key, layers)
@@ -371,8 +371,12 @@ class FPNEncoder(nn.Module):
                 if x3 is not None and name == "conv01":     # + the channel-last companion the decoder's last level stages with 16-byte loads
                     x, cl = ops.conv2d_x3_bn_lrelu(x00, x3, shift, cout, k, 0.1, x_nhwc=True, out="both")
                     x._mvs_nhwc = (cl, x._version)
-                elif x3 is not None:
-                    x = ops.conv2d_x3s_bn_lrelu(x, x3, shift, 0.1)
+                elif x3 is not None:                        # (downsample1 reads conv01's channel-last companion)
+                    cl = getattr(x, "_mvs_nhwc", None) if name == "downsample1" else None
+                    if cl is not None and cl[1] == x._version:
+                        x = ops.conv2d_x3s_bn_lrelu(cl[0], x3, shift, cout, k, stride, 0.1, x_nhwc=True)
+                    else:
+                        x = ops.conv2d_x3s_bn_lrelu(x, x3, shift, cout, k, stride, 0.1)
                 else:
                     x = ops.conv2d_bn_lrelu(x, packed, scale, shift, cout, k, stride, 0.1)
                 outs[name] = x

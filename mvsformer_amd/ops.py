@@ -1646,27 +1646,31 @@ def conv2d_x3s_supported(Cin: int, Cout: int, K: int, stride: int) -> bool:
     return bool(_lib.load().mvs_conv2d_x3s_supported(Cin, Cout, K, stride))
 
 
-def conv2d_x3s_prepare(w: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
-    """``conv.weight [C,C,3,3]`` (C 16 | 32 | 64) with the folded BatchNorm scale -> the pre-split MFMA fragments of ``conv2d_x3s_bn_lrelu``."""
+def conv2d_x3s_prepare(w: torch.Tensor, scale: torch.Tensor, stride: int) -> torch.Tensor:
+    """``conv.weight`` of an encoder layer below full resolution with the folded BatchNorm scale -> the pre-split MFMA fragments of ``conv2d_x3s_bn_lrelu``."""
     _chk(w, "conv2d weight"), _chk(scale, "scale")
     Cout, Cin, K, K2 = w.shape
-    n = int(_lib.load().mvs_conv2d_x3s_prepared_bytes(Cin, Cout, K)) if K == K2 else -1
+    n = int(_lib.load().mvs_conv2d_x3s_prepared_bytes(Cin, Cout, K, stride)) if K == K2 else -1
     if n <= 0 or scale.numel() != Cout:
-        raise _lib.MvsHipError("conv2d_x3s_prepare: %s is not a 3x3 16|32|64-channel layer of the FPN encoder" % (tuple(w.shape),))
+        raise _lib.MvsHipError("conv2d_x3s_prepare: %s stride %d is not a layer of the FPN encoder below full resolution" % (tuple(w.shape), stride))
     prepared = torch.empty(n, device=w.device, dtype=torch.uint8)
-    _call("mvs_conv2d_x3s_prepare", None, _ptr(w), _ptr(scale), Cin, Cout, K, _ptr(prepared), _stream())
+    _call("mvs_conv2d_x3s_prepare", None, _ptr(w), _ptr(scale), Cin, Cout, K, stride, _ptr(prepared), _stream())
     return prepared
 
 
-def conv2d_x3s_bn_lrelu(x: torch.Tensor, prepared: torch.Tensor, shift: torch.Tensor, slope: float) -> torch.Tensor:
-    """A 3x3 stride-1 encoder layer below full resolution in split form (csrc/conv2d_x3s.hip): fp32 NCHW in and out, fp32-equivalent."""
+def conv2d_x3s_bn_lrelu(x: torch.Tensor, prepared: torch.Tensor, shift: torch.Tensor, Cout: int, K: int, stride: int, slope: float, x_nhwc: bool = False) -> torch.Tensor:
+    """An encoder layer below full resolution in split form (csrc/conv2d_x3s.hip): fp32 in (``[N,Cin,H,W]``, or ``[N,H,W,8]`` with ``x_nhwc``), NCHW out."""
     _chk(x, "x"), _chk(prepared, "prepared", torch.uint8), _chk(shift, "shift")
-    N, C, H, W = x.shape
-    if prepared.numel() != int(_lib.load().mvs_conv2d_x3s_prepared_bytes(C, C, 3)) or shift.numel() != C:
-        raise _lib.MvsHipError("conv2d_x3s_bn_lrelu: operands do not match C=%d" % C)
-    y = torch.empty(N, C, H, W, device=x.device, dtype=torch.float32)
-    tag = ("conv2d_x3s_kernel<%d,%d>" % (C, C), "flops", 2.0 * 9 * C * C * N * H * W)
-    _call("mvs_conv2d_x3s_bn_lrelu", tag, _ptr(x), _ptr(prepared), _ptr(shift), N, C, C, 3, 1, H, W, float(slope), _ptr(y), _stream())
+    if x_nhwc:
+        N, H, W, Cin = x.shape
+    else:
+        N, Cin, H, W = x.shape
+    if prepared.numel() != int(_lib.load().mvs_conv2d_x3s_prepared_bytes(Cin, Cout, K, stride)) or shift.numel() != Cout:
+        raise _lib.MvsHipError("conv2d_x3s_bn_lrelu: operands do not match (Cin,Cout,K,stride)=(%d,%d,%d,%d)" % (Cin, Cout, K, stride))
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty(N, Cout, Ho, Wo, device=x.device, dtype=torch.float32)
+    tag = ("conv2d_x3s_kernel<%d,%d,%d,%d>" % (Cin, Cout, K, stride), "flops", 2.0 * K * K * Cin * Cout * N * Ho * Wo)
+    _call("mvs_conv2d_x3s_bn_lrelu", tag, _ptr(x), 1 if x_nhwc else 0, _ptr(prepared), _ptr(shift), N, Cin, Cout, K, stride, H, W, float(slope), _ptr(y), _stream())
     return y
 
 
