@@ -363,7 +363,9 @@ extern "C" int mvs_conv2d_x3s_bn_lrelu(const float* x, int x_nhwc, const void* p
                 Cin, Cout, KS, stride);
     MVS_REQUIRE(!x_nhwc || (Cin == 8 && stride == 2), "mvs_conv2d_x3s_bn_lrelu: a channel-last input is read by the 8-channel stride-2 layer only");
     MVS_REQUIRE(N >= 1 && N <= 65535 && H >= 1 && W >= 1 && (int64_t)H <= 4 * 65535, "mvs_conv2d_x3s_bn_lrelu: bad shape N=%d H=%d W=%d", N, H, W);
-    MVS_REQUIRE((int64_t)(Cin > 8 ? Cin : 8) * H * W * 4 < ((int64_t)1 << 28) * (Cin > 8 ? 8 : 1), "mvs_conv2d_x3s_bn_lrelu: one image is too large for 32-bit offsets");
+    // 32-bit byte offsets inside one image: Cin * H * W * 4 < 2^31; the channel-last 8-channel input scales a pixel offset by 32: H * W * 32 < 2^28 keeps it exact
+    MVS_REQUIRE((int64_t)Cin * H * W * 4 < ((int64_t)1 << 31) && (!x_nhwc || (int64_t)H * W * 32 < ((int64_t)1 << 28)),
+                "mvs_conv2d_x3s_bn_lrelu: one image is too large for 32-bit offsets");
     hipStream_t s = MVS_STREAM(stream);
     if (stride == 1) {
         if (Cin == 16) return launch<16, 16>(x, prepared, shift, N, H, W, slope, y, s);
