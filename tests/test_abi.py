@@ -268,6 +268,30 @@ def test_fused_adamw_and_queues_have_no_cpu_path():
     assert q.jobs == []
 
 
+def test_fpn_split_form_shape_queries_and_argument_checks():
+    """The FPN split-form entry points' pure host logic (no GPU): which layer shapes each kernel family is built for, the operand sizes, and
+    that a bad call is refused with MVS_EINVAL and a message instead of launching anything."""
+    from mvsformer_amd import _lib
+    lib = _lib.load()
+    enc_full = [(3, 8, 7, 1), (8, 8, 5, 1)]
+    enc_below = [(16, 16, 3, 1), (32, 32, 3, 1), (64, 64, 3, 1), (8, 16, 5, 2), (16, 32, 5, 2), (32, 64, 3, 2)]
+    for cfg in enc_full + enc_below:                          # every FPNEncoder layer shape has exactly one split-form kernel
+        assert bool(lib.mvs_conv2d_x3_supported(*cfg)) == (cfg in enc_full), cfg
+        assert bool(lib.mvs_conv2d_x3s_supported(*cfg)) == (cfg in enc_below), cfg
+    assert not lib.mvs_conv2d_x3s_supported(16, 16, 3, 2) and not lib.mvs_conv2d_x3_supported(8, 8, 5, 2)
+    assert lib.mvs_conv2d_x3_prepared_bytes(3, 8, 7) == lib.mvs_conv2d_x3_prepared_bytes(8, 8, 5) == 8 * 3 * 64 * 16
+    assert lib.mvs_conv2d_x3s_prepared_bytes(64, 64, 3, 1) == 4 * 5 * 4 * 3 * 64 * 16 and lib.mvs_conv2d_x3s_prepared_bytes(8, 16, 5, 2) == 1 * 7 * 1 * 3 * 64 * 16
+    assert lib.mvs_conv2d_x3s_prepared_bytes(8, 16, 5, 1) == -1
+    assert lib.mvs_fpn_level_x3_prepared_bytes(8) == 4 * 7 * 3 * 64 * 16 and lib.mvs_fpn_level_x3_prepared_bytes(16) == -1
+    assert lib.mvs_fpn_level_cp_prepared_bytes(8) == 39 * 64 * 16 and lib.mvs_fpn_level_cp_prepared_bytes(32) == -1
+    assert lib.mvs_fpn_level_x3s_prepared_bytes(16) == 4 * 5 * 1 * 3 * 64 * 16 and lib.mvs_fpn_level_x3s_prepared_bytes(32) == 2 * lib.mvs_fpn_level_x3s_prepared_bytes(16)
+    assert lib.mvs_fpn_level_x3s_prepared_bytes(8) == -1
+    # null pointers / unsupported shapes: refused before any launch (MVS_EINVAL = a negative code, the message names the entry point)
+    assert lib.mvs_fpn_level_cp(None, None, None, None, None, 1, 8, 4, 4, None, None) < 0 and b"mvs_fpn_level_cp" in lib.mvs_last_error()
+    assert lib.mvs_conv2d_x3s_bn_lrelu(None, 0, None, None, 1, 16, 16, 3, 1, 8, 8, 0.1, None, None) < 0 and b"mvs_conv2d_x3s_bn_lrelu" in lib.mvs_last_error()
+    assert lib.mvs_fpn_level_x3s(None, None, None, None, None, None, 1, 16, 4, 4, None, 0, None, None) < 0 and b"mvs_fpn_level_x3s" in lib.mvs_last_error()
+
+
 def test_counter_traffic_evidence_matches_the_kernel_sources():
     """profiles/traffic_by_kernel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/collect_profiles.sh) records a digest per source
     file; ``bench.py`` reports a kernel's HBM traffic only while the files that kernel is built from are unchanged (the driver's
