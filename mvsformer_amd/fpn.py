@@ -351,7 +351,9 @@ class FPNEncoder(nn.Module):
             self._cache = (key, layers)
         return self._cache[1]
 
-    def forward(self, x):
+    def forward(self, x, conv01_channels_last: bool = False):
+        """``conv01_channels_last`` (eval): return ``conv01`` as a logical-NCHW VIEW of its channel-last buffer and skip writing the NCHW copy no kernel
+        of the eval path reads (downsample1 and the decoder's last level take the channel-last map) - what ``DINOMVSNet`` asks for."""
         if self.training:                                    # models/module.py:226-240 with batch statistics
             outs = {}
             x = x.to(torch.float32)
@@ -369,7 +371,11 @@ class FPNEncoder(nn.Module):
                     outs[name] = x00.permute(0, 3, 1, 2)
                     continue
                 if x3 is not None and name == "conv01":     # + the channel-last companion the decoder's last level stages with 16-byte loads
-                    x, cl = ops.conv2d_x3_bn_lrelu(x00, x3, shift, cout, k, 0.1, x_nhwc=True, out="both")
+                    if conv01_channels_last:
+                        cl = ops.conv2d_x3_bn_lrelu(x00, x3, shift, cout, k, 0.1, x_nhwc=True, out="nhwc")
+                        x = cl.permute(0, 3, 1, 2)
+                    else:
+                        x, cl = ops.conv2d_x3_bn_lrelu(x00, x3, shift, cout, k, 0.1, x_nhwc=True, out="both")
                     x._mvs_nhwc = (cl, x._version)
                 elif x3 is not None:                        # (downsample1 reads conv01's channel-last companion)
                     cl = getattr(x, "_mvs_nhwc", None) if name == "downsample1" else None

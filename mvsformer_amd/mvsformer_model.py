@@ -50,7 +50,7 @@ class DINOMVSNet(CascadeMVS):
         """mvsformer_model.py:209-271 -> ``{stageK: [B,V,C,H/s,W/s]}`` (logical NCHW, channel-last memory in eval)."""
         B, V, _, H, W = imgs.shape
         x = imgs.reshape(B * V, 3, H, W)
-        conv01, conv11, conv21, conv31 = self.encoder(x)
+        conv01, conv11, conv21, conv31 = self.encoder(x) if self.training else self.encoder(x, conv01_channels_last=True)
         if self.training and not self.args.get("fix", False):
             raise _lib.MvsHipError("DINOMVSNet: training the ViT itself (fix=False) is not built; MVSFormer-P freezes it (\"fix\": true)")
         with torch.no_grad():                                # the frozen ViT (mvsformer_model.py:216-218,248-250)

@@ -202,6 +202,10 @@ def test_full_resolution_layers_run_in_split_form_by_default(monkeypatch):
     assert torch.equal(feats[0]._mvs_nhwc[0].permute(0, 3, 1, 2), feats[0])
     from mvsformer_amd.fpn import _channels_last
     assert _channels_last(feats[0]).data_ptr() == feats[0]._mvs_nhwc[0].data_ptr()
+    lean = enc(x, conv01_channels_last=True)                 # what DINOMVSNet asks for: conv01 as a view of its channel-last buffer, no NCHW copy
+    assert not lean[0].is_contiguous() and lean[0].permute(0, 2, 3, 1).is_contiguous()
+    assert all(torch.equal(a, b) for a, b in zip(lean, feats))
+    assert all(torch.equal(a, b) for a, b in zip(dec(*lean), dec(*feats)))
     feats[0].mul_(2.0)                                       # ... and is dropped once the tensor was written to
     assert _channels_last(feats[0]).data_ptr() != feats[0]._mvs_nhwc[0].data_ptr()
     assert torch.equal(_channels_last(feats[0]).permute(0, 3, 1, 2), feats[0])
